@@ -1,0 +1,111 @@
+/*
+ * rumi_orb.h — C ABI of the MI355X-native ORB front-end (librumi_hip.so).
+ *
+ * Drop-in boundary for the reference class ORB_SLAM3::ORBextractor
+ * (R/ = /root/reference/src/rumi-slam/):
+ *   R/include/cloud_edge_slam_lib/ORBextractor.h:42-111   class surface
+ *   R/lib_src/ORBextractor.cc:405-461                      constructor tables
+ *   R/lib_src/ORBextractor.cc:1014-1091                    operator()
+ * The reference has no FFI layer; the C++ facade in rumi-slam_amd/facade/ keeps the reference's
+ * class signature and marshals cv::Mat / std::vector<cv::KeyPoint> into these calls
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions: every function returns an int status (RUMI_OK = 0, < 0 = error); no exceptions
+ * cross the ABI; all buffers are caller-owned; a handle may be used from any host thread but not
+ * concurrently (same rule as the reference object, which mutates mvImagePyramid).  There is no CPU
+ * fallback: without a gfx950 device every entry point that computes returns RUMI_E_NO_DEVICE.
+ */
+#ifndef RUMI_ORB_H
+#define RUMI_ORB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUMI_OK 0
+#define RUMI_E_INVALID (-1)     /* bad argument / unsupported geometry */
+#define RUMI_E_NO_DEVICE (-2)   /* no HIP device, or a HIP call failed (see rumi_last_error) */
+#define RUMI_E_CAPACITY (-3)    /* caller buffer or handle capacity too small */
+#define RUMI_E_EMPTY (-4)       /* empty image: the reference's operator() returns -1 here */
+
+/* Same 28-byte layout as cv::KeyPoint: pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct RumiKeyPoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} RumiKeyPoint;
+
+/* ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+ * (ORBextractor.h:47-48) plus the arena sizes the handle pre-allocates in HBM. */
+typedef struct RumiOrbConfig {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;        /* 1..16 */
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t max_width;      /* largest image the handle will see */
+    int32_t max_height;
+    int32_t max_batch;      /* largest number of frames per batched call (>= 1) */
+    int32_t device;         /* HIP device ordinal, -1 = current */
+    int32_t host_threads;   /* reserved (0) */
+} RumiOrbConfig;
+
+typedef struct RumiOrb RumiOrb;
+
+const char *rumi_last_error(void);          /* thread-local message of the last failing call */
+int rumi_device_count(void);                /* HIP devices visible to the process (0 if none) */
+
+/* ORBextractor::ORBextractor — ORBextractor.cc:405-461 */
+int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out);
+void rumi_orb_destroy(RumiOrb *h);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (ORBextractor.h:62-84) plus mnFeaturesPerLevel and umax; each array has nlevels entries
+ * (umax16: 16).  Any pointer may be NULL.  Host-only: works without a device. */
+int rumi_orb_tables(const RumiOrbConfig *cfg, float *scale, float *inv_scale, float *sigma2,
+                    float *inv_sigma2, int32_t *features_per_level, int32_t *umax16);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea) — ORBextractor.cc:1014-1091.
+ * Host image in (8-bit grey, `stride` bytes per row), host key-points / descriptors out.
+ * *n_out = number of key-points, *mono_out = the reference's return value (monoIndex).
+ * Returns RUMI_E_EMPTY (and *mono_out = -1) for an empty image, RUMI_E_CAPACITY if n > cap
+ * (*n_out still holds n). */
+int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int32_t stride,
+                     int32_t lap0, int32_t lap1, RumiKeyPoint *kp_out, uint8_t *desc_out, int32_t cap,
+                     int32_t *n_out, int32_t *mono_out);
+
+/* Batched form for the rumination queue (CloudImageSampler.cc:148-170 collects the frames; KFDSample.cc:113
+ * runs the same extractor on them).  All pointers are DEVICE pointers; frames are `frame_stride`
+ * bytes apart.  Outputs: d_kp [nframes][cap], d_desc [nframes][cap][32], d_counts [nframes][2] =
+ * {n, monoIndex}; slots >= n are left untouched.  Work is enqueued on `hip_stream` (a hipStream_t, NULL =
+ * default stream); the call returns after the last kernel is enqueued, except while the quadtree
+ * stage runs on the host (RUMI_ORB_OCTREE_HOST), where it synchronises the stream internally. */
+int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                  int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                  void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream);
+
+/* Backs the public member mvImagePyramid (ORBextractor.h:86): copies level `level` of frame `frame`
+ * of the last call to host memory, with `border` replicated pixels of BORDER_REFLECT_101 on each side
+ * (the reference uses 19); which = 0 pyramid, 1 Gaussian-blurred working image (ORBextractor.cc:1057-1058).
+ * out may be NULL to query *w_out / *h_out (sizes without border). */
+int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, int32_t which, int32_t border,
+                           uint8_t *out, int32_t out_stride, int32_t *w_out, int32_t *h_out);
+
+/* Stage taps for parity tests (results of the last call):
+ * stage 0 = FAST candidates of (frame, level) before the quadtree, in the reference's emission order,
+ *           coordinates relative to (16,16) as at ORBextractor.cc:796-803;
+ * stage 1 = key-points of the level after DistributeOctTree + IC_Angle, level coordinates. */
+int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level, int32_t stage, RumiKeyPoint *out,
+                             int32_t cap, int32_t *n_out);
+
+/* Average device time per stage of the last batched call, in milliseconds (HIP events on the call's
+ * stream): [0] pyramid, [1] FAST+NMS cells, [2] candidate compaction, [3] blur, [4] quadtree,
+ * [5] orientation+descriptors, [6] total.  Only filled when rumi_orb_set_profiling(h, 1) was called. */
+int rumi_orb_set_profiling(RumiOrb *h, int32_t on);
+int rumi_orb_stage_ms(RumiOrb *h, float ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUMI_ORB_H */
