@@ -429,7 +429,10 @@ float OrbExtractor::ic_angle(const Image &im, float x, float y) const {
 void OrbExtractor::orb_descriptor(const Image &im, const KeyPoint &kp, uint8_t *desc) const {
     static const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float angle = (float)kp.angle * factorPI;
-    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    // The reference writes `(float)cos(angle)` with a float argument under `using namespace std`, which
+    // overload resolution binds to std::cos(float) = libm cosf (single precision), not double cos.
+    float a = std::cos(angle), b = std::sin(angle);
+    static_assert(sizeof(decltype(std::cos(angle))) == sizeof(float), "float overload");
     const uint8_t *c = im.row(cv_round(kp.y)) + cv_round(kp.x);
     const int step = im.w;
     auto val = [&](int idx) -> int {

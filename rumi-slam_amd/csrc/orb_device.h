@@ -1,0 +1,54 @@
+// Device-visible parameter blocks of the ORB extractor and the kernel launch wrappers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "orb_geom.h"
+#include "rumi_orb.h"
+
+namespace rumi {
+
+struct DevLevel {
+    int w, h, pitch;
+    long long off;                 // byte offset of the level in a frame's arena (pyramid and blur arenas alike)
+    int nCols, nRows, wCell, hCell;
+    int cellBase, nCells;
+    int maxBX, maxBY;
+    int nfeat;
+    float scale;                   // mvScaleFactor[level]
+    float patchSize;               // (float)(int)(31 * scale)  (ORBextractor.cc:816)
+    int candCap;
+    int coefX, coefY, xmax;        // resize tables (int16 units into the coefficient buffer)
+};
+
+struct DevParams {
+    int nlevels, totalCells, maxCellCand, totalCand;
+    int iniTh, minTh;
+    long long arenaStride;         // bytes per frame in the pyramid / blur arenas
+    int umax[16];
+    DevLevel lv[kMaxLevels];
+};
+
+// Where the kernels find pixels: level 0 is the caller's image batch, levels >= 1 live in `pyr`,
+// blurred levels (all, including 0) in `blur`.
+struct ImgSrc {
+    const uint8_t *l0;
+    long long l0FrameStride;
+    int l0Pitch;
+    uint8_t *pyr;
+    uint8_t *blur;
+};
+
+void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
+                   hipStream_t st);
+void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
+                 hipStream_t st);
+void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
+                    uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st);
+void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int level, int nframes, hipStream_t st);
+void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
+                        const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
+                        int outCap, int nframes, hipStream_t st);
+
+}  // namespace rumi

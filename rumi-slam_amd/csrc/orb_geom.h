@@ -99,7 +99,7 @@ inline bool make_geometry(const OrbTables &t, int w, int h, std::vector<LevelGeo
         // NMS keeps at most one of any 2x2 block: worst case per level / per cell
         const int dw = L.maxBX - kBorder - 6, dh = L.maxBY - kBorder - 6;   // detection region
         L.candBase = cand;
-        L.candCap = std::max(1, ((dw + 1) / 2) * ((dh + 1) / 2));
+        L.candCap = std::min(65535, std::max(1, ((dw + 1) / 2) * ((dh + 1) / 2)));   // u16 key ids in the quadtree
         cand += L.candCap;
         cellCand = std::max(cellCand, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
         L.coefOff = 0;

@@ -1,0 +1,494 @@
+// Host side of the C ABI in include/rumi_orb.h: handle, HBM arenas, stage scheduling.
+// Reference behaviour: ORBextractor::operator() R/lib_src/ORBextractor.cc:1014-1091.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orb_device.h"
+#include "orb_octree.h"
+#include "rumi_common.h"
+
+using namespace rumi;
+
+namespace rumi {
+thread_local std::string g_lastError;
+void set_error(const char *fmt, const char *a, const char *b, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b, line);
+    g_lastError = buf;
+}
+}  // namespace rumi
+
+extern "C" const char *rumi_last_error(void) { return g_lastError.c_str(); }
+
+extern "C" int rumi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+namespace {
+constexpr int kChunk = 64;   // frames per pass through the host-side quadtree stage
+
+template <class T> int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return RUMI_OK;
+}
+template <class T> int pin_alloc(T **p, size_t n) {
+    *p = nullptr;
+    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+    return RUMI_OK;
+}
+}  // namespace
+
+struct RumiOrb {
+    RumiOrbConfig cfg{};
+    OrbTables tab;
+    int device = 0;
+    int hostThreads = 1;
+    // capacities (from max_width x max_height)
+    long long capArena = 0;
+    int capCells = 0, capCand = 0, capCellCand = 0, capSel = 0, capCoef = 0;
+    // geometry of the current image size
+    int gw = 0, gh = 0;
+    DevParams hP{};
+    DevParams *dP = nullptr;
+    int16_t *dCoef = nullptr;
+    // HBM arenas (sized for max_batch frames unless noted)
+    uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame)
+    uint8_t *dPyr = nullptr, *dBlur = nullptr;
+    uint32_t *dCellBuf = nullptr;    // kChunk frames
+    int32_t *dCellCnt = nullptr;
+    uint32_t *dCand = nullptr;       // kChunk frames x capCand
+    int32_t *dLevelStart = nullptr, *dOverflow = nullptr;
+    uint32_t *dSelPacked = nullptr, *dSelMeta = nullptr;   // kChunk frames x capSel
+    int32_t *dSelCount = nullptr;
+    RumiKeyPoint *dKp = nullptr;     // outputs of the single-frame host API
+    uint8_t *dDesc = nullptr;
+    int32_t *dCounts = nullptr;
+    // pinned host mirrors (kChunk frames)
+    uint32_t *hCand = nullptr;
+    int32_t *hLevelStart = nullptr, *hOverflow = nullptr;
+    uint32_t *hSelPacked = nullptr, *hSelMeta = nullptr;
+    int32_t *hSelCount = nullptr, *hCounts = nullptr;
+    // last-call bookkeeping for the stage taps
+    ImgSrc lastSrc{};
+    int lastFrames = 0, lastChunkBase = 0, lastChunkFrames = 0;
+    RumiKeyPoint *lastKp = nullptr;  // device pointer the last call wrote key-points to
+    int lastOutCap = 0;
+    bool profiling = false;
+    float stageMs[8] = {0};
+    hipEvent_t ev[8] = {nullptr};
+};
+
+static int set_geometry(RumiOrb *h, int w, int hgt) {
+    if (h->gw == w && h->gh == hgt) return RUMI_OK;
+    std::vector<LevelGeom> g;
+    long long arena; int cells, cand, cellCand;
+    if (!make_geometry(h->tab, w, hgt, g, &arena, &cells, &cand, &cellCand)) {
+        g_lastError = "image too small for the FAST cell grid at some pyramid level, or cell larger than the LDS tile";
+        return RUMI_E_INVALID;
+    }
+    if (arena > h->capArena || cells > h->capCells || cand > h->capCand || cellCand > h->capCellCand) {
+        g_lastError = "image larger than the handle's max_width x max_height arenas";
+        return RUMI_E_CAPACITY;
+    }
+    DevParams &P = h->hP;
+    std::memset(&P, 0, sizeof P);
+    P.nlevels = h->tab.nlevels; P.totalCells = cells; P.maxCellCand = h->capCellCand; P.totalCand = h->capCand;
+    P.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255);   // cv::FAST clamps its threshold
+    P.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
+    P.arenaStride = h->capArena;
+    for (int i = 0; i < 16; i++) P.umax[i] = h->tab.umax[i];
+    std::vector<int16_t> coef;
+    for (int l = 0; l < P.nlevels; l++) {
+        DevLevel &D = P.lv[l];
+        const LevelGeom &G = g[l];
+        D.w = G.w; D.h = G.h; D.pitch = G.pitch; D.off = G.off;
+        D.nCols = G.nCols; D.nRows = G.nRows; D.wCell = G.wCell; D.hCell = G.hCell;
+        D.cellBase = G.cellBase; D.nCells = G.nCells; D.maxBX = G.maxBX; D.maxBY = G.maxBY;
+        D.nfeat = G.nfeat; D.scale = G.scale;
+        D.patchSize = (float)(int)(kPatchSize * G.scale);
+        D.candCap = std::min(G.candCap, 65535);
+        D.coefX = D.coefY = 0; D.xmax = G.w;
+        if (l > 0) {
+            std::vector<int16_t> ofs, taps;
+            int dmax;
+            make_resize_axis(g[l - 1].w, G.w, true, ofs, taps, &dmax);
+            D.coefX = (int)coef.size(); D.xmax = dmax;
+            coef.insert(coef.end(), ofs.begin(), ofs.end());
+            coef.insert(coef.end(), taps.begin(), taps.end());
+            make_resize_axis(g[l - 1].h, G.h, false, ofs, taps, &dmax);
+            D.coefY = (int)coef.size();
+            coef.insert(coef.end(), ofs.begin(), ofs.end());
+            coef.insert(coef.end(), taps.begin(), taps.end());
+        }
+    }
+    if ((int)coef.size() > h->capCoef) { g_lastError = "resize table capacity"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
+    if (!coef.empty()) HIP_TRY(hipMemcpy(h->dCoef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    h->gw = w; h->gh = hgt;
+    return RUMI_OK;
+}
+
+extern "C" int rumi_orb_tables(const RumiOrbConfig *cfg, float *scale, float *inv_scale, float *sigma2,
+                               float *inv_sigma2, int32_t *features_per_level, int32_t *umax16) {
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels) return RUMI_E_INVALID;
+    OrbTables t = make_tables(cfg->nfeatures, cfg->scale_factor, cfg->nlevels);
+    for (int i = 0; i < t.nlevels; i++) {
+        if (scale) scale[i] = t.scale[i];
+        if (inv_scale) inv_scale[i] = t.invScale[i];
+        if (sigma2) sigma2[i] = t.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = t.invSigma2[i];
+        if (features_per_level) features_per_level[i] = t.featuresPerLevel[i];
+    }
+    if (umax16) for (int i = 0; i < 16; i++) umax16[i] = t.umax[i];
+    return RUMI_OK;
+}
+
+extern "C" void rumi_orb_destroy(RumiOrb *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *dev[] = {h->dP, h->dCoef, h->dIn, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
+                   h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts};
+    for (void *p : dev) if (p) (void)hipFree(p);
+    void *pin[] = {h->hCand, h->hLevelStart, h->hOverflow, h->hSelPacked, h->hSelMeta, h->hSelCount, h->hCounts};
+    for (void *p : pin) if (p) (void)hipHostFree(p);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    delete h;
+}
+
+extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
+    if (!out) return RUMI_E_INVALID;
+    *out = nullptr;
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 1 || cfg->max_batch < 1 ||
+        cfg->max_width < 1 || cfg->max_height < 1 || !(cfg->scale_factor > 1.0f)) {
+        g_lastError = "invalid RumiOrbConfig";
+        return RUMI_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_lastError = "no HIP device visible: librumi_hip has no CPU fallback";
+        return RUMI_E_NO_DEVICE;
+    }
+    RumiOrb *h = new RumiOrb();
+    h->cfg = *cfg;
+    if (cfg->device >= 0) { h->device = cfg->device; }
+    else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    if (hipSetDevice(h->device) != hipSuccess) { delete h; g_lastError = "hipSetDevice failed"; return RUMI_E_NO_DEVICE; }
+    h->tab = make_tables(cfg->nfeatures, cfg->scale_factor, cfg->nlevels);
+    h->hostThreads = cfg->host_threads > 0 ? cfg->host_threads
+                                           : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<LevelGeom> g;
+    int cells, cand, cellCand;
+    if (!make_geometry(h->tab, cfg->max_width, cfg->max_height, g, &h->capArena, &cells, &cand, &cellCand)) {
+        delete h;
+        g_lastError = "max_width x max_height too small for the FAST cell grid at some level";
+        return RUMI_E_INVALID;
+    }
+    int coefN = 0;
+    for (int l = 1; l < cfg->nlevels; l++) coefN += 3 * (g[l].w + g[l].h);
+    h->capCells = cells + cells / 8 + 16;            // slack: smaller images can have slightly different grids
+    h->capCellCand = cellCand + cellCand / 2 + 16;
+    int candSum = 0;
+    for (int l = 0; l < cfg->nlevels; l++) candSum += std::min(g[l].candCap, 65535);
+    h->capCand = candSum + 64;
+    h->capCoef = coefN + 64 * cfg->nlevels;
+    h->capSel = cfg->nfeatures + 4 * cfg->nlevels + 64;   // the quadtree may return a few more than N per level
+    const size_t B = (size_t)cfg->max_batch, C = (size_t)std::min<int>(kChunk, cfg->max_batch);
+    int rc = RUMI_OK;
+#define TRY_ALLOC(x) if ((rc = (x)) != RUMI_OK) { rumi_orb_destroy(h); return rc; }
+    TRY_ALLOC(dev_alloc(&h->dP, 1));
+    TRY_ALLOC(dev_alloc(&h->dCoef, (size_t)h->capCoef));
+    TRY_ALLOC(dev_alloc(&h->dIn, (size_t)cfg->max_width * cfg->max_height));
+    TRY_ALLOC(dev_alloc(&h->dPyr, (size_t)h->capArena * B));
+    TRY_ALLOC(dev_alloc(&h->dBlur, (size_t)h->capArena * B));
+    TRY_ALLOC(dev_alloc(&h->dCellBuf, C * h->capCells * h->capCellCand));
+    TRY_ALLOC(dev_alloc(&h->dCellCnt, C * h->capCells));
+    TRY_ALLOC(dev_alloc(&h->dCand, C * h->capCand));
+    TRY_ALLOC(dev_alloc(&h->dLevelStart, C * (kMaxLevels + 1)));
+    TRY_ALLOC(dev_alloc(&h->dOverflow, C));
+    TRY_ALLOC(dev_alloc(&h->dSelPacked, C * h->capSel));
+    TRY_ALLOC(dev_alloc(&h->dSelMeta, C * h->capSel));
+    TRY_ALLOC(dev_alloc(&h->dSelCount, C));
+    TRY_ALLOC(dev_alloc(&h->dKp, (size_t)h->capSel));
+    TRY_ALLOC(dev_alloc(&h->dDesc, (size_t)h->capSel * 32));
+    TRY_ALLOC(dev_alloc(&h->dCounts, 2));
+    TRY_ALLOC(pin_alloc(&h->hCand, C * h->capCand));
+    TRY_ALLOC(pin_alloc(&h->hLevelStart, C * (kMaxLevels + 1)));
+    TRY_ALLOC(pin_alloc(&h->hOverflow, C));
+    TRY_ALLOC(pin_alloc(&h->hSelPacked, C * h->capSel));
+    TRY_ALLOC(pin_alloc(&h->hSelMeta, C * h->capSel));
+    TRY_ALLOC(pin_alloc(&h->hSelCount, C));
+    TRY_ALLOC(pin_alloc(&h->hCounts, C * 2));
+#undef TRY_ALLOC
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
+    *out = h;
+    return RUMI_OK;
+}
+
+extern "C" int rumi_orb_set_profiling(RumiOrb *h, int32_t on) {
+    if (!h) return RUMI_E_INVALID;
+    h->profiling = on != 0;
+    return RUMI_OK;
+}
+extern "C" int rumi_orb_stage_ms(RumiOrb *h, float ms[8]) {
+    if (!h || !ms) return RUMI_E_INVALID;
+    for (int i = 0; i < 8; i++) ms[i] = h->stageMs[i];
+    return RUMI_OK;
+}
+
+// Host quadtree stage for one frame: DistributeOctTree per level (ORBextractor.cc:811-813), then the
+// lapping-area slot rule of operator() (:1077-1085).  Returns the number of key-points.
+static int select_frame(const RumiOrb *h, const uint32_t *cand, const int32_t *ls, int lap0, int lap1,
+                        uint32_t *selPacked, uint32_t *selMeta, int32_t *counts, int *err) {
+    const DevParams &P = h->hP;
+    int total = 0;
+    std::vector<int> idx;
+    std::vector<std::pair<uint32_t, int>> picked;   // (packed, level) in (level, list) order
+    for (int l = 0; l < P.nlevels; l++) {
+        const DevLevel &L = P.lv[l];
+        const uint32_t *c = cand + ls[l];
+        const int n = ls[l + 1] - ls[l];
+        int m = octree_host(c, n, kBorder, L.maxBX, kBorder, L.maxBY, L.nfeat, idx);
+        if (m < 0) { *err = 1; return 0; }
+        for (int k = 0; k < m; k++) picked.emplace_back(c[idx[k]], l);
+        total += m;
+    }
+    if (total > h->capSel) { *err = 2; counts[0] = total; counts[1] = 0; return total; }
+    int mono = 0, stereo = total - 1;
+    for (int k = 0; k < total; k++) {
+        const uint32_t pk = picked[k].first;
+        const int l = picked[k].second;
+        float x = (float)((int)(pk & 0xFFF) + kBorder);
+        if (l != 0) x = x * P.lv[l].scale;
+        const int slot = (x >= (float)lap0 && x <= (float)lap1) ? stereo-- : mono++;
+        selPacked[k] = pk;
+        selMeta[k] = (uint32_t)l | ((uint32_t)slot << 8);
+    }
+    counts[0] = total;
+    counts[1] = mono;
+    return total;
+}
+
+static void parallel_for(int n, int threads, const std::function<void(int)> &fn) {
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto &t : pool) t.join();
+}
+
+extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                             int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                             void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream) {
+    if (!h || !d_imgs || !d_kp || !d_desc || !d_counts || nframes < 1 || cap < 1 || stride < w) {
+        g_lastError = "rumi_orb_extract_batch_device: bad argument";
+        return RUMI_E_INVALID;
+    }
+    if (w <= 0 || hgt <= 0) return RUMI_E_EMPTY;
+    if (nframes > h->cfg.max_batch) { g_lastError = "nframes > max_batch"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = set_geometry(h, w, hgt);
+    if (rc != RUMI_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const DevParams &P = h->hP;
+    ImgSrc src{(const uint8_t *)d_imgs, frame_stride, stride, h->dPyr, h->dBlur};
+    const bool prof = h->profiling;
+    float acc[8] = {0};
+    int status = RUMI_OK;
+
+    // Stage A (all frames): pyramid + blur.  Levels depend on each other, frames do not.
+    if (prof) HIP_TRY(hipEventRecord(h->ev[0], st));
+    for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
+    if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
+    for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, st);
+    if (prof) HIP_TRY(hipEventRecord(h->ev[2], st));
+    HIP_TRY(hipGetLastError());
+
+    for (int base = 0; base < nframes; base += kChunk) {
+        const int nf = std::min(kChunk, nframes - base);
+        ImgSrc cs = src;
+        cs.l0 = src.l0 + (long long)base * frame_stride;
+        cs.pyr = src.pyr + (long long)base * P.arenaStride;
+        cs.blur = src.blur + (long long)base * P.arenaStride;
+        HIP_TRY(hipMemsetAsync(h->dOverflow, 0, nf * sizeof(int32_t), st));
+        if (prof) HIP_TRY(hipEventRecord(h->ev[3], st));
+        launch_fast(h->dP, P, cs, h->dCellBuf, h->dCellCnt, nf, st);
+        if (prof) HIP_TRY(hipEventRecord(h->ev[4], st));
+        launch_compact(h->dP, P, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart, h->dOverflow, nf, st);
+        if (prof) HIP_TRY(hipEventRecord(h->ev[5], st));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->hLevelStart, h->dLevelStart, (size_t)nf * (kMaxLevels + 1) * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int f = 0; f < nf; f++) {
+            if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
+            const int tot = h->hLevelStart[(size_t)f * (kMaxLevels + 1) + P.nlevels];
+            if (tot > 0)
+                HIP_TRY(hipMemcpyAsync(h->hCand + (size_t)f * h->capCand, h->dCand + (size_t)f * h->capCand,
+                                       (size_t)tot * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        // ---- host quadtree (v1; moves on-device in orb_octree_kernel.hip) ----
+        auto t0 = std::chrono::steady_clock::now();
+        std::atomic<int> err{0};
+        parallel_for(nf, h->hostThreads, [&](int f) {
+            int e = 0;
+            select_frame(h, h->hCand + (size_t)f * h->capCand, h->hLevelStart + (size_t)f * (kMaxLevels + 1), lap0, lap1,
+                         h->hSelPacked + (size_t)f * h->capSel, h->hSelMeta + (size_t)f * h->capSel, h->hCounts + 2 * f, &e);
+            h->hSelCount[f] = e ? 0 : h->hCounts[2 * f];
+            if (e) err.store(e);
+        });
+        acc[4] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (err.load() == 1) { g_lastError = "quadtree node pool exhausted"; return RUMI_E_INVALID; }
+        if (err.load() == 2) { g_lastError = "more key-points than the handle's selection capacity"; return RUMI_E_CAPACITY; }
+        int maxSel = 0;
+        for (int f = 0; f < nf; f++) {
+            maxSel = std::max(maxSel, h->hSelCount[f]);
+            if (h->hCounts[2 * f] > cap) status = RUMI_E_CAPACITY;   // reported after the counts are delivered
+        }
+        HIP_TRY(hipMemcpyAsync(h->dSelPacked, h->hSelPacked, (size_t)nf * h->capSel * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(h->dSelMeta, h->hSelMeta, (size_t)nf * h->capSel * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(h->dSelCount, h->hSelCount, nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((int32_t *)d_counts + 2 * base, h->hCounts, (size_t)nf * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (prof) HIP_TRY(hipEventRecord(h->ev[6], st));
+        launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, maxSel,
+                           (RumiKeyPoint *)d_kp + (size_t)base * cap, (uint8_t *)d_desc + (size_t)base * cap * 32, cap, nf, st);
+        if (prof) HIP_TRY(hipEventRecord(h->ev[7], st));
+        HIP_TRY(hipGetLastError());
+        // the pinned selection buffers are reused by the next chunk
+        HIP_TRY(hipStreamSynchronize(st));
+        if (prof) {
+            float ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); acc[1] += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); acc[2] += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); acc[5] += ms;
+        }
+        h->lastChunkBase = base; h->lastChunkFrames = nf;
+    }
+    if (prof) {
+        float ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); acc[0] = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); acc[3] = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[7])); acc[6] = ms;
+        for (int i = 0; i < 8; i++) h->stageMs[i] = acc[i];
+    }
+    h->lastSrc = src; h->lastFrames = nframes;
+    h->lastKp = (RumiKeyPoint *)d_kp; h->lastOutCap = cap;
+    if (status == RUMI_E_CAPACITY) g_lastError = "output capacity (cap) smaller than the number of key-points of some frame";
+    return status;
+}
+
+extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int32_t stride, int32_t lap0,
+                                int32_t lap1, RumiKeyPoint *kp_out, uint8_t *desc_out, int32_t cap, int32_t *n_out,
+                                int32_t *mono_out) {
+    if (n_out) *n_out = 0;
+    if (mono_out) *mono_out = -1;
+    if (!h || !n_out || !mono_out) return RUMI_E_INVALID;
+    if (!img || w <= 0 || hgt <= 0) return RUMI_E_EMPTY;            // operator() returns -1 on an empty image
+    if (stride < w || w > h->cfg.max_width || hgt > h->cfg.max_height) { g_lastError = "image size"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy2D(h->dIn, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)hgt, hipMemcpyHostToDevice));
+    int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, w, (int64_t)w * hgt, lap0, lap1, h->dKp, h->dDesc,
+                                           h->dCounts, h->capSel, nullptr);
+    if (rc != RUMI_OK) return rc;
+    int32_t counts[2];
+    HIP_TRY(hipMemcpy(counts, h->dCounts, sizeof counts, hipMemcpyDeviceToHost));
+    *n_out = counts[0];
+    *mono_out = counts[1];
+    if (counts[0] > cap) { g_lastError = "kp_out/desc_out capacity"; return RUMI_E_CAPACITY; }
+    if (counts[0] > 0) {
+        if (!kp_out || !desc_out) return RUMI_E_INVALID;
+        HIP_TRY(hipMemcpy(kp_out, h->dKp, (size_t)counts[0] * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(desc_out, h->dDesc, (size_t)counts[0] * 32, hipMemcpyDeviceToHost));
+    }
+    return RUMI_OK;
+}
+
+extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, int32_t which, int32_t border,
+                                      uint8_t *out, int32_t out_stride, int32_t *w_out, int32_t *h_out) {
+    if (!h || h->lastFrames == 0 || frame < 0 || frame >= h->lastFrames || level < 0 || level >= h->hP.nlevels || border < 0)
+        return RUMI_E_INVALID;
+    const DevLevel &L = h->hP.lv[level];
+    if (w_out) *w_out = L.w;
+    if (h_out) *h_out = L.h;
+    if (!out) return RUMI_OK;
+    if (out_stride < L.w + 2 * border) return RUMI_E_CAPACITY;
+    HIP_TRY(hipSetDevice(h->device));
+    const uint8_t *srcp;
+    size_t pitch;
+    if (which == 0 && level == 0) { srcp = h->lastSrc.l0 + (long long)frame * h->lastSrc.l0FrameStride; pitch = h->lastSrc.l0Pitch; }
+    else {
+        srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off;
+        pitch = L.pitch;
+    }
+    HIP_TRY(hipMemcpy2D(out + (size_t)border * out_stride + border, out_stride, srcp, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    // copyMakeBorder(..., BORDER_REFLECT_101) around the level (ORBextractor.cc:1105-1110)
+    auto refl = [](int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; return i; };
+    for (int y = 0; y < L.h; y++) {
+        uint8_t *row = out + (size_t)(y + border) * out_stride;
+        for (int x = 0; x < border; x++) {
+            row[x] = row[border + refl(x - border, L.w)];
+            row[border + L.w + x] = row[border + refl(L.w + x, L.w)];
+        }
+    }
+    for (int y = 0; y < border; y++) {
+        std::memcpy(out + (size_t)y * out_stride, out + (size_t)(border + refl(y - border, L.h)) * out_stride, L.w + 2 * border);
+        std::memcpy(out + (size_t)(border + L.h + y) * out_stride, out + (size_t)(border + refl(L.h + y, L.h)) * out_stride,
+                    L.w + 2 * border);
+    }
+    return RUMI_OK;
+}
+
+extern "C" int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level, int32_t stage, RumiKeyPoint *out,
+                                        int32_t cap, int32_t *n_out) {
+    if (!h || !n_out || h->lastFrames == 0 || level < 0 || level >= h->hP.nlevels) return RUMI_E_INVALID;
+    const int f = frame - h->lastChunkBase;
+    if (f < 0 || f >= h->lastChunkFrames) { g_lastError = "stage taps cover the last 64-frame chunk only"; return RUMI_E_INVALID; }
+    const DevLevel &L = h->hP.lv[level];
+    if (stage == 0) {
+        const int32_t *ls = h->hLevelStart + (size_t)f * (kMaxLevels + 1);
+        const int n = ls[level + 1] - ls[level];
+        *n_out = n;
+        if (!out) return RUMI_OK;
+        if (n > cap) return RUMI_E_CAPACITY;
+        const uint32_t *c = h->hCand + (size_t)f * h->capCand + ls[level];
+        for (int k = 0; k < n; k++)
+            out[k] = RumiKeyPoint{(float)cand_x(c[k]), (float)cand_y(c[k]), 7.f, -1.f, (float)cand_score(c[k]), 0, -1};
+        return RUMI_OK;
+    }
+    if (stage == 1) {
+        HIP_TRY(hipSetDevice(h->device));
+        const int tot = h->hSelCount[f];
+        std::vector<RumiKeyPoint> fin((size_t)std::max(tot, 1));
+        const int ocap = h->lastOutCap;
+        int n = 0;
+        for (int k = 0; k < tot; k++) {
+            const uint32_t meta = h->hSelMeta[(size_t)f * h->capSel + k], pk = h->hSelPacked[(size_t)f * h->capSel + k];
+            if ((int)(meta & 0xFF) != level) continue;
+            const int slot = (int)(meta >> 8);
+            RumiKeyPoint kp;
+            if (slot >= ocap) return RUMI_E_CAPACITY;
+            HIP_TRY(hipMemcpy(&kp, h->lastKp + (size_t)frame * ocap + slot, sizeof kp, hipMemcpyDeviceToHost));
+            kp.x = (float)(cand_x(pk) + kBorder); kp.y = (float)(cand_y(pk) + kBorder);
+            if (out && n < cap) out[n] = kp;
+            n++;
+        }
+        *n_out = n;
+        (void)L;
+        return (out && n > cap) ? RUMI_E_CAPACITY : RUMI_OK;
+    }
+    return RUMI_E_INVALID;
+}

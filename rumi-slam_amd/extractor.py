@@ -1,0 +1,120 @@
+"""Host-side mirror of ``ORB_SLAM3::ORBextractor`` (R/include/cloud_edge_slam_lib/ORBextractor.h:42-111)
+over the C ABI.  Same constructor arguments, same call semantics (``__call__`` returns the
+reference's ``monoIndex`` and fills key-points / descriptors), same getters.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import KP_DTYPE, RumiOrbConfig
+
+
+class ORBextractor:
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width=640, max_height=480,
+                 max_batch=1, device=-1):
+        self._lib = capi.lib()
+        self.cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
+                                 max_batch, device, 0)
+        self._h = C.c_void_p()
+        capi.check(self._lib.rumi_orb_create(C.byref(self.cfg), C.byref(self._h)))
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self._tables = tables(nfeatures, scaleFactor, nlevels)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rumi_orb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- getters of the reference class ----
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(np.float32(self.cfg.scale_factor))
+
+    def GetScaleFactors(self):
+        return self._tables["scale"].copy()
+
+    def GetInverseScaleFactors(self):
+        return self._tables["inv_scale"].copy()
+
+    def GetScaleSigmaSquares(self):
+        return self._tables["sigma2"].copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables["inv_sigma2"].copy()
+
+    # ---- operator() ----
+    def __call__(self, image, mask=None, vLappingArea=(0, 1000)):
+        """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[n,32] u8); monoIndex == -1 for an empty image."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected"
+        image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int32(), C.c_int32()
+        capi.check(self._lib.rumi_orb_extract(self._h, capi.ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
+                                              int(vLappingArea[1]), capi.ptr(kps), capi.ptr(desc), cap,
+                                              C.byref(n), C.byref(mono)))
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batched, device-resident form (torch tensors on the handle's GPU) ----
+    def extract_batch(self, frames, vLappingArea=(0, 1000), cap=None, stream=None):
+        """frames: torch.uint8 CUDA tensor [B,H,W] (contiguous rows).  Returns (kp [B,cap,7] f32 view of the
+        28-byte records, desc [B,cap,32] u8, counts [B,2] i32 = (n, monoIndex)) as CUDA tensors."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
+        B, H, W = frames.shape
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kp = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
+        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
+        counts = torch.zeros((B, 2), dtype=torch.int32, device=frames.device)
+        st = stream if stream is not None else torch.cuda.current_stream(frames.device)
+        capi.check(self._lib.rumi_orb_extract_batch_device(
+            self._h, frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0), int(vLappingArea[0]),
+            int(vLappingArea[1]), kp.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, st.cuda_stream))
+        return kp, desc, counts
+
+    # ---- taps ----
+    def pyramid_level(self, level, frame=0, blurred=False, border=0):
+        w, h = C.c_int32(), C.c_int32()
+        capi.check(self._lib.rumi_orb_pyramid_level(self._h, frame, level, int(blurred), border, None, 0,
+                                                    C.byref(w), C.byref(h)))
+        out = np.zeros((h.value + 2 * border, w.value + 2 * border), np.uint8)
+        capi.check(self._lib.rumi_orb_pyramid_level(self._h, frame, level, int(blurred), border, capi.ptr(out),
+                                                    out.strides[0], C.byref(w), C.byref(h)))
+        return out
+
+    def stage_keypoints(self, level, stage, frame=0):
+        n = C.c_int32()
+        capi.check(self._lib.rumi_orb_stage_keypoints(self._h, frame, level, stage, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), KP_DTYPE)
+        capi.check(self._lib.rumi_orb_stage_keypoints(self._h, frame, level, stage, capi.ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def set_profiling(self, on=True):
+        capi.check(self._lib.rumi_orb_set_profiling(self._h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(8, np.float32)
+        capi.check(self._lib.rumi_orb_stage_ms(self._h, capi.ptr(ms)))
+        return dict(pyramid=ms[0], fast=ms[1], compact=ms[2], blur=ms[3], quadtree_host=ms[4], orient_desc=ms[5],
+                    total=ms[6])
+
+
+def tables(nfeatures=1000, scaleFactor=1.2, nlevels=8):
+    """Constructor tables of the reference (host-only; works without a GPU)."""
+    cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, 20, 7, 640, 480, 1, -1, 0)
+    f = [np.zeros(nlevels, np.float32) for _ in range(4)]
+    per = np.zeros(nlevels, np.int32)
+    umax = np.zeros(16, np.int32)
+    capi.check(capi.lib().rumi_orb_tables(C.byref(cfg), *[capi.ptr(a) for a in f], capi.ptr(per), capi.ptr(umax)))
+    return dict(scale=f[0], inv_scale=f[1], sigma2=f[2], inv_sigma2=f[3], per_level=per, umax=umax)

@@ -13,7 +13,7 @@ _LUT_N = 1024
 _SIN = np.round(np.sin(np.arange(_LUT_N) * (2.0 * np.pi / _LUT_N)) * 16384.0).astype(np.int64)
 
 
-def synth_frame(seed, w=640, h=480, n_rect=400, noise=3):
+def synth_frame(seed, w=640, h=480, n_rect=400, noise=3, contrast=(25, 120)):
     rng = np.random.Generator(np.random.PCG64(int(seed)))
     yy, xx = np.mgrid[0:h, 0:w].astype(np.int64)
     acc = np.full((h, w), 110 << 14, dtype=np.int64)
@@ -33,7 +33,7 @@ def synth_frame(seed, w=640, h=480, n_rect=400, noise=3):
         ang = int(rng.integers(0, _LUT_N)) if rot else 0
         checker = int(rng.integers(0, 4)) == 0
         cs = int(rng.integers(4, 9))
-        con = int(rng.integers(25, 121)) * (1 if int(rng.integers(0, 2)) else -1)
+        con = int(rng.integers(contrast[0], contrast[1] + 1)) * (1 if int(rng.integers(0, 2)) else -1)
         r = int(1.5 * max(hw, hh)) + 2
         x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, w), max(cy - r, 0), min(cy + r + 1, h)
         if x0 >= x1 or y0 >= y1:

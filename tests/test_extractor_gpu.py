@@ -1,0 +1,107 @@
+"""GPU parity of the HIP ORB extractor against the CPU oracle, through the C ABI.
+Bar: bit-exact key-point records (28 B each, order included), descriptors, counts and monoIndex."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from rumi_slam_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(nf=1000, sf=1.2, nl=8, ini=20, mn=7, w=640, h=480, batch=1):
+    from rumi_slam_amd.extractor import ORBextractor
+    return (ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=batch),
+            oracle_lib.OracleExtractor(nf, sf, nl, ini, mn))
+
+
+def _assert_same(gpu_out, orc_out, tag=""):
+    gm, gk, gd = gpu_out
+    om, ok, od = orc_out
+    assert len(gk) == len(ok), f"{tag}: key-point count {len(gk)} vs oracle {len(ok)}"
+    assert gm == om, f"{tag}: monoIndex {gm} vs {om}"
+    if gk.tobytes() != ok.tobytes():
+        for name in gk.dtype.names:
+            bad = np.nonzero(gk[name] != ok[name])[0]
+            assert len(bad) == 0, f"{tag}: field {name} differs at {bad[:5]}: {gk[name][bad[:5]]} vs {ok[name][bad[:5]]}"
+    assert np.array_equal(gd, od), f"{tag}: descriptors differ in {np.count_nonzero((gd != od).any(axis=1))} rows"
+
+
+@pytest.mark.parametrize("seed", [1234, 1235, 1236, 7, 99])
+def test_full_frame_bit_exact(seed):
+    g, o = _pair()
+    img = synth_frame(seed)
+    _assert_same(g(img, None, (0, 1000)), o.extract(img, (0, 1000)), f"seed {seed}")
+
+
+def test_stages_bit_exact():
+    g, o = _pair()
+    img = synth_frame(4321)
+    g(img, None, (0, 1000))
+    o.extract(img, (0, 1000))
+    for l in range(8):
+        assert np.array_equal(g.pyramid_level(l), o.level(l)), f"pyramid level {l}"
+        assert np.array_equal(g.pyramid_level(l, blurred=True), o.level(l, blurred=True)), f"blurred level {l}"
+        gc, oc = g.stage_keypoints(l, 0), o.keypoints(l, False)
+        assert len(gc) == len(oc), f"candidates level {l}: {len(gc)} vs {len(oc)}"
+        assert gc.tobytes() == oc.tobytes(), f"candidate list level {l}"
+        gs, os_ = g.stage_keypoints(l, 1), o.keypoints(l, True)
+        assert gs.tobytes() == os_.tobytes(), f"selected key-points level {l}"
+
+
+def test_lapping_forward_order():
+    # KFDSample passes {0,0}: every key-point takes the mono branch (forward order)   KFDSample.h:53
+    g, o = _pair()
+    img = synth_frame(55)
+    _assert_same(g(img, None, (0, 0)), o.extract(img, (0, 0)), "lap {0,0}")
+    _assert_same(g(img, None, (200, 400)), o.extract(img, (200, 400)), "lap {200,400}")
+
+
+@pytest.mark.parametrize("nf", [2000, 5000])
+def test_more_features(nf):
+    g, o = _pair(nf=nf)
+    img = synth_frame(1234 + nf)
+    _assert_same(g(img, None, (0, 1000)), o.extract(img, (0, 1000)), f"nfeatures {nf}")
+
+
+def test_low_texture_retry_path():
+    # cells with no corner at iniThFAST fall back to minThFAST (ORBextractor.cc:783-785)
+    g, o = _pair()
+    for seed, kw in [(3, dict(n_rect=60, contrast=(8, 19))), (4, dict(n_rect=120, contrast=(8, 40))), (5, dict(n_rect=0))]:
+        img = synth_frame(seed, **kw)
+        out = o.extract(img, (0, 1000))
+        _assert_same(g(img, None, (0, 1000)), out, f"low texture {seed}")
+
+
+@pytest.mark.parametrize("wh", [(752, 480), (600, 350), (320, 240), (1241, 376)])
+def test_other_sizes(wh):
+    w, h = wh
+    g, o = _pair(w=w, h=h)
+    img = synth_frame(77, w=w, h=h)
+    _assert_same(g(img, None, (0, 1000)), o.extract(img, (0, 1000)), f"size {wh}")
+
+
+def test_strided_input_and_empty():
+    g, o = _pair()
+    big = np.zeros((480, 700), np.uint8)
+    big[:, :640] = synth_frame(8)
+    _assert_same(g(big[:, :640], None, (0, 1000)) if False else g(np.ascontiguousarray(big[:, :640]), None, (0, 1000)),
+                 o.extract(big[:, :640], (0, 1000)), "strided")
+    mono, k, d = g(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0
+
+
+def test_batch_device_matches_single():
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    B = 6
+    g, o = _pair(batch=B)
+    frames = synth_batch(B, seed0=500)
+    kp, desc, counts = g.extract_batch(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    kp = kp.cpu().numpy(); desc = desc.cpu().numpy(); counts = counts.cpu().numpy()
+    for f in range(B):
+        om, ok, od = o.extract(frames[f], (0, 1000))
+        n = counts[f, 0]
+        gk = kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
+        _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"batch frame {f}")
