@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark (driver contract: python bench.py --gpus N --steps K --warmup W).
+
+Workload (BASELINE.json configs[1], the configuration the fps target is quoted on): ORB extraction of
+synthetic 640x480 frames, 8-level pyramid, 1000 features/frame, on 1 x MI355X.  One *step* = one batch of
+`--batch` frames (already resident in HBM) through the whole extractor: pyramid -> per-cell FAST+NMS ->
+quadtree -> IC_Angle -> Gaussian blur -> rBRIEF, key-points and descriptors left in HBM.
+With N > 1 (one process per GPU, RCCL) every rank extracts its own `--batch` frames of the rumination queue
+(weak scaling, configs[4]) and the step ends with the all-gather of (counts, key-points, descriptors).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (per-stage device time from HIP events
+on the stream the kernels run on); `cpu_baseline` is the CPU oracle (kind "port": the reference itself cannot
+be built in this image) timed single-threaded on a bounded sample of the same frames, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
+    """4 752 128 + n*(1369+749+60) B for 640x480, 8 levels (general form below)."""
+    lv, ww, hh = [], w, h
+    import numpy as np
+    inv = np.float32(1.0)
+    sc = np.float32(1.0)
+    for l in range(8):
+        if l:
+            sc = np.float32(np.float64(sc) * np.float64(np.float32(1.2)))
+        inv = np.float32(1.0) / sc
+        lv.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+    px = [a * b for a, b in lv]
+    total = sum(px)
+    return dict(read_l0=px[0], write_levels=total - px[0], fast_read=total, blur_rw=2 * total,
+                per_kp=1369 + 749 + 60, total=px[0] + (total - px[0]) + total + 2 * total + n_kp * (1369 + 749 + 60))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to --batch)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.synth import synth_frame
+
+    B, W, H = args.batch, 640, 480
+    uniq = min(args.unique, B)
+    host = np.stack([synth_frame(1234 + rank * 100000 + i) for i in range(uniq)])
+    frames = torch.from_numpy(host).to(dev)
+    frames = frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
+
+    ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    cap = args.nfeatures + 4 * 8 + 64
+
+    def step():
+        kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap)
+        if world > 1:
+            # the path's one exchange step: every GPU ends up with all key-points / descriptors
+            gk = torch.empty((world,) + kp.shape, dtype=kp.dtype, device=dev)
+            gd = torch.empty((world,) + desc.shape, dtype=desc.dtype, device=dev)
+            gc = torch.empty((world,) + counts.shape, dtype=counts.dtype, device=dev)
+            dist.all_gather_into_tensor(gk, kp)
+            dist.all_gather_into_tensor(gd, desc)
+            dist.all_gather_into_tensor(gc, counts)
+            return gk, gd, gc
+        return kp, desc, counts
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    n_kp = float(out[2].reshape(-1, 2)[:, 0].float().mean().item())
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-stage device time of one more (untimed) step, HIP events on the kernels' stream
+    ext.set_profiling(True)
+    ext.extract_batch(frames, (0, 1000), cap=cap)
+    torch.cuda.synchronize()
+    stage = {k: float(v) for k, v in ext.stage_ms().items()}
+    ext.set_profiling(False)
+
+    if rank == 0:
+        fps = B * world * args.steps / dt
+        ab = algorithmic_bytes_per_frame(n_kp)
+        # dominant kernel by device time; algorithmic bytes of that kernel per launch
+        kern_bytes = {"fast": ab["fast_read"], "pyramid": ab["read_l0"] + 1.44 * ab["write_levels"] + ab["write_levels"],
+                      "blur": ab["blur_rw"], "orient_desc": n_kp * ab["per_kp"]}
+        kern_ms = {k: stage[k] for k in kern_bytes}
+        dom = max(kern_ms, key=kern_ms.get)
+        achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+        line = {
+            "metric": "frames/sec ORB extract", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "ORB extraction only: 640x480, 8-level pyramid, %d features/frame (BASELINE.json configs[1])" % args.nfeatures,
+                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": round(n_kp, 1),
+                       "exchange": "all_gather(counts,keypoints,descriptors) over RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
+                         "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
+        }
+        if world == 1 and not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib                      # the checker, timed as the CPU baseline (kind "port")
+            orc = oracle_lib.OracleExtractor(args.nfeatures, 1.2, 8, 20, 7)
+            n, c0 = 0, time.perf_counter()
+            while n < len(host) * 8 and time.perf_counter() - c0 < args.cpu_seconds:
+                orc.extract(host[n % len(host)], (0, 1000))
+                n += 1
+            cdt = time.perf_counter() - c0
+            line["cpu_baseline"] = {"value": round(n / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": "%d of the same synthetic frames, oracle/ (g++ -O2, scalar), %.1f s" % (n, cdt)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

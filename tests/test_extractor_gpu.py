@@ -105,3 +105,19 @@ def test_batch_device_matches_single():
         n = counts[f, 0]
         gk = kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
         _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"batch frame {f}")
+
+
+def test_golden_fixtures_on_gpu():
+    import glob, os
+    from rumi_slam_amd.extractor import ORBextractor
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "orb_*.npz"))):
+        g = np.load(path)
+        w, h = (int(v) for v in g["wh"])
+        kw = dict(n_rect=60, contrast=(8, 19)) if "lowtex" in path else {}
+        img = synth_frame(int(g["seed"]), w=w, h=h, **kw)
+        ext = ORBextractor(int(g["nfeatures"]), 1.2, 8, 20, 7, max_width=w, max_height=h)
+        mono, kps, desc = ext(img, None, tuple(int(v) for v in g["lap"]))
+        assert mono == int(g["mono"]), path
+        assert np.array_equal(kps.view(np.uint8).reshape(-1, 28), g["kps"]), path
+        assert np.array_equal(desc, g["desc"]), path

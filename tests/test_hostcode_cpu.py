@@ -1,0 +1,139 @@
+"""CPU tests of product host code (no GPU needed): the C-ABI library loads and exports every declared
+symbol; the host compilation of code shared with the kernels (sort replay, array quadtree, scalar math)
+agrees with the oracle / libm / libstdc++."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from rumi_slam_amd import capi
+from rumi_slam_amd.extractor import tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    declared = set()
+    for hdr in ("rumi_orb.h", "rumi_testhooks.h", "rumi_match.h", "rumi_opt.h", "rumi_dist.h"):
+        p = os.path.join(ROOT, "include", hdr)
+        if not os.path.exists(p):
+            continue
+        txt = re.sub(r"/\*.*?\*/", "", open(p).read(), flags=re.S)
+        declared |= set(re.findall(r"\b(rumi_[a-z0-9_]+)\s*\(", txt))
+    assert declared, "no declarations parsed"
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    assert set(capi.ORB_SYMBOLS) <= declared
+
+
+def test_create_without_gpu_fails_loudly():
+    L = capi.lib()
+    if L.rumi_device_count() > 0:
+        pytest.skip("GPU present")
+    cfg = capi.RumiOrbConfig(1000, 1.2, 8, 20, 7, 640, 480, 1, -1, 0)
+    h = C.c_void_p()
+    assert L.rumi_orb_create(C.byref(cfg), C.byref(h)) == capi.RUMI_E_NO_DEVICE
+    assert b"no CPU fallback" in L.rumi_last_error()
+
+
+def test_invalid_config_rejected():
+    L = capi.lib()
+    h = C.c_void_p()
+    for bad in (capi.RumiOrbConfig(0, 1.2, 8, 20, 7, 640, 480, 1, -1, 0), capi.RumiOrbConfig(1000, 1.0, 8, 20, 7, 640, 480, 1, -1, 0),
+                capi.RumiOrbConfig(1000, 1.2, 0, 20, 7, 640, 480, 1, -1, 0), capi.RumiOrbConfig(1000, 1.2, 17, 20, 7, 640, 480, 1, -1, 0)):
+        assert L.rumi_orb_create(C.byref(bad), C.byref(h)) == capi.RUMI_E_INVALID
+
+
+@pytest.mark.parametrize("cfg", [(1000, 1.2, 8), (2000, 1.2, 8), (5000, 1.2, 8), (1500, 1.1, 12), (300, 1.5, 4)])
+def test_tables_match_oracle(cfg):
+    nf, sf, nl = cfg
+    a, b = tables(nf, sf, nl), O.OracleExtractor(nf, sf, nl, 20, 7).tables()
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
+
+
+def test_sort_replay_equals_libstdcxx():
+    """Ties in (size, UL.x) are ordered by std::sort's algorithm; the oracle calls the real std::sort inside
+    its quadtree, the product replays it.  Compare on the quadtree level below and here directly through a
+    stable-vs-unstable fingerprint: sorted keys must be ascending and ids a permutation."""
+    H = capi.hooks()
+    rng = np.random.default_rng(0)
+    for n in [0, 1, 2, 15, 16, 17, 18, 33, 100, 257, 1000]:
+        for rng_hi in (2, 5, 1000):
+            keys = rng.integers(0, rng_hi, n).astype(np.uint32)
+            ids = np.arange(n, dtype=np.uint16)
+            k2, i2 = keys.copy(), ids.copy()
+            assert H.rumi_hook_sort_like_std(capi.ptr(k2), capi.ptr(i2), n) == 0
+            assert (np.diff(k2.astype(np.int64)) >= 0).all()
+            assert sorted(i2.tolist()) == list(range(n))
+            assert np.array_equal(keys[i2], k2)
+
+
+def _pack(x, y, s):
+    return (x.astype(np.uint32) | (y.astype(np.uint32) << 12) | (s.astype(np.uint32) << 24)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("trial", range(40))
+def test_array_quadtree_equals_oracle_list_quadtree(trial):
+    """Product quadtree (arrays + replayed sort) vs oracle (std::list + real std::sort): same key-points in the
+    same order — including sizes > 16 nodes with many (size, UL.x) ties, where std::sort's tie order matters."""
+    H = capi.hooks()
+    rng = np.random.default_rng(100 + trial)
+    W, Hh = int(rng.integers(60, 700)), int(rng.integers(60, 500))
+    if W < Hh // 2:
+        W = Hh
+    n = int(rng.integers(0, 7000))
+    N = int(rng.integers(0, 1200)) if trial % 4 else int(rng.integers(0, 40))
+    n = min(n, W * Hh // 2)
+    pos = np.sort(rng.choice(W * Hh, n, replace=False)) if n else np.zeros(0, np.int64)
+    x, y = (pos % W).astype(np.int64), (pos // W).astype(np.int64)
+    s = rng.integers(7, 10 if trial % 5 == 0 else 255, n)
+    cand = np.zeros(n, O.KP_DTYPE)
+    cand["x"], cand["y"], cand["response"] = x, y, s
+    ref = O.octree(cand, 16, 16 + W, 16, 16 + Hh, N)
+    packed = _pack(x, y, s)
+    out = np.zeros(n + 8, np.int32)
+    m = C.c_int32()
+    assert H.rumi_hook_quadtree(capi.ptr(packed), n, 16, 16 + W, 16, 16 + Hh, N, capi.ptr(out), len(out), C.byref(m)) == 0
+    assert m.value == len(ref)
+    sel = out[:m.value]
+    assert np.array_equal(x[sel], ref["x"].astype(np.int64)) and np.array_equal(y[sel], ref["y"].astype(np.int64))
+    assert np.array_equal(s[sel], ref["response"].astype(np.int64))
+
+
+def test_restated_sinf_cosf_equal_libm():
+    H = capi.hooks()
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    k = np.float32(np.pi / 180.0)
+    rng = np.random.default_rng(0)
+    degs = np.concatenate([np.arange(0, 360, 0.25, dtype=np.float32), rng.uniform(0, 360, 20000).astype(np.float32),
+                           np.float32([0, 1e-5, 45, 90, 180, 270, 359.99997])])
+    for d in degs:
+        a = float(np.float32(d) * k)
+        assert H.rumi_hook_sinf(a) == libm.sinf(a), d
+        assert H.rumi_hook_cosf(a) == libm.cosf(a), d
+
+
+def test_atan2_and_round_equal_oracle():
+    H, L = capi.hooks(), O.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(20000):
+        y, x = (float(v) for v in rng.integers(-400000, 400000, 2))
+        assert H.rumi_hook_fast_atan2(y, x) == L.orc_fast_atan2(y, x)
+    for v in (0.5, 1.5, 2.5, -0.5, -2.5, 7.49999, 1e6 + 0.5):
+        assert H.rumi_hook_cv_round(v) == L.orc_cv_round(float(np.float32(v)))
+
+
+def test_pattern_tables_identical():
+    a = open(os.path.join(ROOT, "oracle", "orb_pattern.inc")).read()
+    b = open(os.path.join(ROOT, "rumi-slam_amd", "csrc", "orb_pattern.inc")).read()
+    assert a == b
+    nums = [int(v) for v in re.findall(r"-?\d+", re.sub(r"//.*", "", a))]
+    assert len(nums) == 1024 and max(map(abs, nums)) <= 13
+    assert nums[:8] == [8, -3, 9, 5, 4, 2, 7, -12]          # first two test pairs of the ORB pattern
