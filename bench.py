@@ -125,7 +125,7 @@ def main():
         ab = algorithmic_bytes_per_frame(n_kp)
         # dominant kernel by device time; algorithmic bytes of that kernel per launch
         kern_bytes = {"fast": ab["fast_read"], "pyramid": ab["read_l0"] + 1.44 * ab["write_levels"] + ab["write_levels"],
-                      "blur": ab["blur_rw"], "orient_desc": n_kp * ab["per_kp"]}
+                      "blur": ab["blur_rw"], "orient_desc": n_kp * ab["per_kp"], "quadtree": 0.0}
         kern_ms = {k: stage[k] for k in kern_bytes}
         dom = max(kern_ms, key=kern_ms.get)
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0

@@ -51,4 +51,12 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
                         int outCap, int nframes, hipStream_t st);
 
+void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *cand, const int32_t *levelStart,
+                   uint16_t *owner, uint32_t *selLevel, int32_t *selLevelCnt, int selLevelCap, int32_t *errFlag,
+                   int nframes, size_t ldsBytes, hipStream_t st);
+void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,
+                     int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts,
+                     int32_t *errFlag, int nframes, hipStream_t st);
+size_t octree_lds_for(const DevParams &hP);
+
 }  // namespace rumi

@@ -34,7 +34,7 @@ extern "C" int rumi_device_count(void) {
 }
 
 namespace {
-constexpr int kChunk = 64;   // frames per pass through the host-side quadtree stage
+constexpr int kChunk = 256;  // frames per pass through the candidate / quadtree scratch arenas
 
 template <class T> int dev_alloc(T **p, size_t n) {
     *p = nullptr;
@@ -73,15 +73,23 @@ struct RumiOrb {
     RumiKeyPoint *dKp = nullptr;     // outputs of the single-frame host API
     uint8_t *dDesc = nullptr;
     int32_t *dCounts = nullptr;
-    // pinned host mirrors (kChunk frames)
-    uint32_t *hCand = nullptr;
-    int32_t *hLevelStart = nullptr, *hOverflow = nullptr;
-    uint32_t *hSelPacked = nullptr, *hSelMeta = nullptr;
-    int32_t *hSelCount = nullptr, *hCounts = nullptr;
+    uint16_t *dOwner = nullptr;      // kChunk frames x capCand: quadtree node id of every candidate
+    uint32_t *dSelLevel = nullptr;   // kChunk frames x nlevels x selLevelCap: quadtree output per level
+    int32_t *dSelLevelCnt = nullptr;
+    int32_t *dErr = nullptr;         // device error word (bit 0/1/2/3: roots, node pool, level cap, selection cap)
+    int selLevelCap = 0;
+    size_t octLds = 0;
+    // pinned host words
+    int32_t *hOverflow = nullptr, *hErr = nullptr;
+    // host copies fetched lazily by the stage taps
+    std::vector<uint32_t> tapCand, tapSelPacked, tapSelMeta;
+    std::vector<int32_t> tapLevelStart, tapSelCount;
+    bool tapValid = false;
     // last-call bookkeeping for the stage taps
     ImgSrc lastSrc{};
     int lastFrames = 0, lastChunkBase = 0, lastChunkFrames = 0;
     RumiKeyPoint *lastKp = nullptr;  // device pointer the last call wrote key-points to
+    int32_t *lastCounts = nullptr;
     int lastOutCap = 0;
     bool profiling = false;
     float stageMs[8] = {0};
@@ -134,6 +142,8 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
     if ((int)coef.size() > h->capCoef) { g_lastError = "resize table capacity"; return RUMI_E_CAPACITY; }
     HIP_TRY(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
     if (!coef.empty()) HIP_TRY(hipMemcpy(h->dCoef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    h->octLds = octree_lds_for(P);
+    if (h->octLds > 160 * 1024) { g_lastError = "nfeatures too large for the LDS-resident quadtree node pool"; return RUMI_E_INVALID; }
     h->gw = w; h->gh = hgt;
     return RUMI_OK;
 }
@@ -157,9 +167,10 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *dev[] = {h->dP, h->dCoef, h->dIn, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
-                   h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts};
+                   h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
+                   h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *pin[] = {h->hCand, h->hLevelStart, h->hOverflow, h->hSelPacked, h->hSelMeta, h->hSelCount, h->hCounts};
+    void *pin[] = {h->hOverflow, h->hErr};
     for (void *p : pin) if (p) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -221,13 +232,15 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dKp, (size_t)h->capSel));
     TRY_ALLOC(dev_alloc(&h->dDesc, (size_t)h->capSel * 32));
     TRY_ALLOC(dev_alloc(&h->dCounts, 2));
-    TRY_ALLOC(pin_alloc(&h->hCand, C * h->capCand));
-    TRY_ALLOC(pin_alloc(&h->hLevelStart, C * (kMaxLevels + 1)));
+    int maxN = 0;
+    for (int l = 0; l < cfg->nlevels; l++) maxN = std::max(maxN, h->tab.featuresPerLevel[l]);
+    h->selLevelCap = maxN + 4 * 16 + 8;
+    TRY_ALLOC(dev_alloc(&h->dOwner, C * h->capCand));
+    TRY_ALLOC(dev_alloc(&h->dSelLevel, C * cfg->nlevels * h->selLevelCap));
+    TRY_ALLOC(dev_alloc(&h->dSelLevelCnt, C * cfg->nlevels));
+    TRY_ALLOC(dev_alloc(&h->dErr, 1));
     TRY_ALLOC(pin_alloc(&h->hOverflow, C));
-    TRY_ALLOC(pin_alloc(&h->hSelPacked, C * h->capSel));
-    TRY_ALLOC(pin_alloc(&h->hSelMeta, C * h->capSel));
-    TRY_ALLOC(pin_alloc(&h->hSelCount, C));
-    TRY_ALLOC(pin_alloc(&h->hCounts, C * 2));
+    TRY_ALLOC(pin_alloc(&h->hErr, 1));
 #undef TRY_ALLOC
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
@@ -244,49 +257,6 @@ extern "C" int rumi_orb_stage_ms(RumiOrb *h, float ms[8]) {
     if (!h || !ms) return RUMI_E_INVALID;
     for (int i = 0; i < 8; i++) ms[i] = h->stageMs[i];
     return RUMI_OK;
-}
-
-// Host quadtree stage for one frame: DistributeOctTree per level (ORBextractor.cc:811-813), then the
-// lapping-area slot rule of operator() (:1077-1085).  Returns the number of key-points.
-static int select_frame(const RumiOrb *h, const uint32_t *cand, const int32_t *ls, int lap0, int lap1,
-                        uint32_t *selPacked, uint32_t *selMeta, int32_t *counts, int *err) {
-    const DevParams &P = h->hP;
-    int total = 0;
-    std::vector<int> idx;
-    std::vector<std::pair<uint32_t, int>> picked;   // (packed, level) in (level, list) order
-    for (int l = 0; l < P.nlevels; l++) {
-        const DevLevel &L = P.lv[l];
-        const uint32_t *c = cand + ls[l];
-        const int n = ls[l + 1] - ls[l];
-        int m = octree_host(c, n, kBorder, L.maxBX, kBorder, L.maxBY, L.nfeat, idx);
-        if (m < 0) { *err = 1; return 0; }
-        for (int k = 0; k < m; k++) picked.emplace_back(c[idx[k]], l);
-        total += m;
-    }
-    if (total > h->capSel) { *err = 2; counts[0] = total; counts[1] = 0; return total; }
-    int mono = 0, stereo = total - 1;
-    for (int k = 0; k < total; k++) {
-        const uint32_t pk = picked[k].first;
-        const int l = picked[k].second;
-        float x = (float)((int)(pk & 0xFFF) + kBorder);
-        if (l != 0) x = x * P.lv[l].scale;
-        const int slot = (x >= (float)lap0 && x <= (float)lap1) ? stereo-- : mono++;
-        selPacked[k] = pk;
-        selMeta[k] = (uint32_t)l | ((uint32_t)slot << 8);
-    }
-    counts[0] = total;
-    counts[1] = mono;
-    return total;
-}
-
-static void parallel_for(int n, int threads, const std::function<void(int)> &fn) {
-    threads = std::max(1, std::min(threads, n));
-    if (threads == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++)
-        pool.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
-    for (auto &t : pool) t.join();
 }
 
 extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
@@ -306,9 +276,10 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     ImgSrc src{(const uint8_t *)d_imgs, frame_stride, stride, h->dPyr, h->dBlur};
     const bool prof = h->profiling;
     float acc[8] = {0};
-    int status = RUMI_OK;
+    h->tapValid = false;
 
     // Stage A (all frames): pyramid + blur.  Levels depend on each other, frames do not.
+    HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
     if (prof) HIP_TRY(hipEventRecord(h->ev[0], st));
     for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
@@ -316,6 +287,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     if (prof) HIP_TRY(hipEventRecord(h->ev[2], st));
     HIP_TRY(hipGetLastError());
 
+    // Stage B (chunks of kChunk frames share the candidate / quadtree scratch; no host round trip in between)
     for (int base = 0; base < nframes; base += kChunk) {
         const int nf = std::min(kChunk, nframes - base);
         ImgSrc cs = src;
@@ -328,56 +300,34 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         if (prof) HIP_TRY(hipEventRecord(h->ev[4], st));
         launch_compact(h->dP, P, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart, h->dOverflow, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[5], st));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->hLevelStart, h->dLevelStart, (size_t)nf * (kMaxLevels + 1) * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int f = 0; f < nf; f++) {
-            if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
-            const int tot = h->hLevelStart[(size_t)f * (kMaxLevels + 1) + P.nlevels];
-            if (tot > 0)
-                HIP_TRY(hipMemcpyAsync(h->hCand + (size_t)f * h->capCand, h->dCand + (size_t)f * h->capCand,
-                                       (size_t)tot * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(hipStreamSynchronize(st));
-        // ---- host quadtree (v1; moves on-device in orb_octree_kernel.hip) ----
-        auto t0 = std::chrono::steady_clock::now();
-        std::atomic<int> err{0};
-        parallel_for(nf, h->hostThreads, [&](int f) {
-            int e = 0;
-            select_frame(h, h->hCand + (size_t)f * h->capCand, h->hLevelStart + (size_t)f * (kMaxLevels + 1), lap0, lap1,
-                         h->hSelPacked + (size_t)f * h->capSel, h->hSelMeta + (size_t)f * h->capSel, h->hCounts + 2 * f, &e);
-            h->hSelCount[f] = e ? 0 : h->hCounts[2 * f];
-            if (e) err.store(e);
-        });
-        acc[4] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (err.load() == 1) { g_lastError = "quadtree node pool exhausted"; return RUMI_E_INVALID; }
-        if (err.load() == 2) { g_lastError = "more key-points than the handle's selection capacity"; return RUMI_E_CAPACITY; }
-        int maxSel = 0;
-        for (int f = 0; f < nf; f++) {
-            maxSel = std::max(maxSel, h->hSelCount[f]);
-            if (h->hCounts[2 * f] > cap) status = RUMI_E_CAPACITY;   // reported after the counts are delivered
-        }
-        HIP_TRY(hipMemcpyAsync(h->dSelPacked, h->hSelPacked, (size_t)nf * h->capSel * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(h->dSelMeta, h->hSelMeta, (size_t)nf * h->capSel * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(h->dSelCount, h->hSelCount, nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync((int32_t *)d_counts + 2 * base, h->hCounts, (size_t)nf * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        launch_octree(h->dP, P, h->dCand, h->dLevelStart, h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, h->dErr,
+                      nf, h->octLds, st);
+        launch_assemble(h->dP, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, lap0, lap1, h->dSelPacked, h->dSelMeta,
+                        h->dSelCount, h->capSel, (int32_t *)d_counts + 2 * base, h->dErr, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[6], st));
-        launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, maxSel,
+        launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, h->capSel,
                            (RumiKeyPoint *)d_kp + (size_t)base * cap, (uint8_t *)d_desc + (size_t)base * cap * 32, cap, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[7], st));
         HIP_TRY(hipGetLastError());
-        // the pinned selection buffers are reused by the next chunk
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (prof || base + kChunk < nframes) {
+            // scratch arenas are reused by the next chunk; the overflow words are read below
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int f = 0; f < nf; f++)
+                if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
+        }
         if (prof) {
             float ms;
             HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); acc[1] += ms;
             HIP_TRY(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); acc[2] += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev[5], h->ev[6])); acc[4] += ms;
             HIP_TRY(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); acc[5] += ms;
         }
         h->lastChunkBase = base; h->lastChunkFrames = nf;
     }
+    // One synchronisation per call: the error word and the overflow words of the last chunk.
+    HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (prof) {
         float ms;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); acc[0] = ms;
@@ -387,8 +337,14 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     }
     h->lastSrc = src; h->lastFrames = nframes;
     h->lastKp = (RumiKeyPoint *)d_kp; h->lastOutCap = cap;
-    if (status == RUMI_E_CAPACITY) g_lastError = "output capacity (cap) smaller than the number of key-points of some frame";
-    return status;
+    h->lastCounts = (int32_t *)d_counts;
+    for (int f = 0; f < h->lastChunkFrames; f++)
+        if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
+    const int err = *h->hErr;
+    if (err & 1) { g_lastError = "aspect ratio gives 0 or more than 16 quadtree roots"; return RUMI_E_INVALID; }
+    if (err & 2) { g_lastError = "quadtree node pool exhausted"; return RUMI_E_INVALID; }
+    if (err & (4 | 8)) { g_lastError = "more key-points than the handle's selection capacity"; return RUMI_E_CAPACITY; }
+    return RUMI_OK;
 }
 
 extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int32_t stride, int32_t lap0,
@@ -452,31 +408,49 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
     return RUMI_OK;
 }
 
+// Stage taps read the scratch arenas of the LAST chunk (device -> host on first use after a call).
+static int fetch_taps(RumiOrb *h) {
+    if (h->tapValid) return RUMI_OK;
+    const size_t nf = (size_t)h->lastChunkFrames;
+    h->tapLevelStart.resize(nf * (kMaxLevels + 1));
+    h->tapSelCount.resize(nf);
+    h->tapCand.resize(nf * h->capCand);
+    h->tapSelPacked.resize(nf * h->capSel);
+    h->tapSelMeta.resize(nf * h->capSel);
+    HIP_TRY(hipMemcpy(h->tapLevelStart.data(), h->dLevelStart, h->tapLevelStart.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelCount.data(), h->dSelCount, nf * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapCand.data(), h->dCand, h->tapCand.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelPacked.data(), h->dSelPacked, h->tapSelPacked.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelMeta.data(), h->dSelMeta, h->tapSelMeta.size() * 4, hipMemcpyDeviceToHost));
+    h->tapValid = true;
+    return RUMI_OK;
+}
+
 extern "C" int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level, int32_t stage, RumiKeyPoint *out,
                                         int32_t cap, int32_t *n_out) {
     if (!h || !n_out || h->lastFrames == 0 || level < 0 || level >= h->hP.nlevels) return RUMI_E_INVALID;
     const int f = frame - h->lastChunkBase;
-    if (f < 0 || f >= h->lastChunkFrames) { g_lastError = "stage taps cover the last 64-frame chunk only"; return RUMI_E_INVALID; }
-    const DevLevel &L = h->hP.lv[level];
+    if (f < 0 || f >= h->lastChunkFrames) { g_lastError = "stage taps cover the last 256-frame chunk only"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = fetch_taps(h);
+    if (rc != RUMI_OK) return rc;
     if (stage == 0) {
-        const int32_t *ls = h->hLevelStart + (size_t)f * (kMaxLevels + 1);
+        const int32_t *ls = h->tapLevelStart.data() + (size_t)f * (kMaxLevels + 1);
         const int n = ls[level + 1] - ls[level];
         *n_out = n;
         if (!out) return RUMI_OK;
         if (n > cap) return RUMI_E_CAPACITY;
-        const uint32_t *c = h->hCand + (size_t)f * h->capCand + ls[level];
+        const uint32_t *c = h->tapCand.data() + (size_t)f * h->capCand + ls[level];
         for (int k = 0; k < n; k++)
             out[k] = RumiKeyPoint{(float)cand_x(c[k]), (float)cand_y(c[k]), 7.f, -1.f, (float)cand_score(c[k]), 0, -1};
         return RUMI_OK;
     }
     if (stage == 1) {
-        HIP_TRY(hipSetDevice(h->device));
-        const int tot = h->hSelCount[f];
-        std::vector<RumiKeyPoint> fin((size_t)std::max(tot, 1));
+        const int tot = h->tapSelCount[f];
         const int ocap = h->lastOutCap;
         int n = 0;
         for (int k = 0; k < tot; k++) {
-            const uint32_t meta = h->hSelMeta[(size_t)f * h->capSel + k], pk = h->hSelPacked[(size_t)f * h->capSel + k];
+            const uint32_t meta = h->tapSelMeta[(size_t)f * h->capSel + k], pk = h->tapSelPacked[(size_t)f * h->capSel + k];
             if ((int)(meta & 0xFF) != level) continue;
             const int slot = (int)(meta >> 8);
             RumiKeyPoint kp;
@@ -487,7 +461,6 @@ extern "C" int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level
             n++;
         }
         *n_out = n;
-        (void)L;
         return (out && n > cap) ? RUMI_E_CAPACITY : RUMI_OK;
     }
     return RUMI_E_INVALID;

@@ -106,7 +106,7 @@ class ORBextractor:
     def stage_ms(self):
         ms = np.zeros(8, np.float32)
         capi.check(self._lib.rumi_orb_stage_ms(self._h, capi.ptr(ms)))
-        return dict(pyramid=ms[0], fast=ms[1], compact=ms[2], blur=ms[3], quadtree_host=ms[4], orient_desc=ms[5],
+        return dict(pyramid=ms[0], fast=ms[1], compact=ms[2], blur=ms[3], quadtree=ms[4], orient_desc=ms[5],
                     total=ms[6])
 
 
