@@ -1,0 +1,101 @@
+/*
+ * rumi_match.h — C ABI of the MI355X-native Hamming matchers (librumi_hip.so).
+ *
+ * Drop-in boundary for ORB_SLAM3::ORBmatcher (R/ = /root/reference/src/rumi-slam/):
+ *   R/include/cloud_edge_slam_lib/ORBmatcher.h:36-103   class surface (ctor nnratio/checkOri, TH_LOW/TH_HIGH/HISTO_LENGTH)
+ *   R/lib_src/ORBmatcher.cc:39-196      SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+ *   R/lib_src/ORBmatcher.cc:198-370     SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)
+ *   R/lib_src/ORBmatcher.cc:1498-1683   SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)
+ *   R/lib_src/ORBmatcher.cc:1830-1844   DescriptorDistance
+ *   R/lib_src/Frame.cc:441-466,695-761  AssignFeaturesToGrid / GetFeaturesInArea / PosInGrid (candidate order)
+ * The facade marshals Frame / KeyFrame / MapPoint pointers into the flat views below: a MapPoint* becomes an
+ * int32 id into caller-side arrays, NULL becomes -1.  Mono branches only (the node hard-codes MONOCULAR,
+ * R/src/cloud_edge_main.cpp:267).  Results are bit-identical to the reference's sequential loops, including
+ * the "feature already taken by an earlier map point" side effect and the first-candidate-wins tie rule.
+ *
+ * Status codes, error string and threading rules: rumi_orb.h.
+ */
+#ifndef RUMI_MATCH_H
+#define RUMI_MATCH_H
+
+#include <stdint.h>
+
+#include "rumi_orb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUMI_TH_HIGH 100      /* ORBmatcher::TH_HIGH      ORBmatcher.cc:30 */
+#define RUMI_TH_LOW 50        /* ORBmatcher::TH_LOW       ORBmatcher.cc:31 */
+#define RUMI_HISTO_LENGTH 30  /* ORBmatcher::HISTO_LENGTH ORBmatcher.cc:32 */
+
+/* What the matchers read out of a Frame (or KeyFrame): host pointers. */
+typedef struct RumiFrameFeatures {
+    int32_t n;                    /* Frame::N */
+    const RumiKeyPoint *keys_un;  /* Frame::mvKeysUn (pt, angle, octave are used) */
+    const uint8_t *desc;          /* Frame::mDescriptors, n x 32 */
+    float min_x, min_y, max_x, max_y;   /* Frame::mnMinX ... mnMaxY (image bounds) */
+    const float *scale_factors;   /* Frame::mvScaleFactors */
+    int32_t nlevels;
+} RumiFrameFeatures;
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) in CSR form, node ids ascending. */
+typedef struct RumiFeatureVector {
+    int32_t n_nodes;
+    const uint32_t *node_ids;     /* [n_nodes] ascending */
+    const int32_t *offsets;       /* [n_nodes + 1] */
+    const uint32_t *indices;      /* [offsets[n_nodes]] feature indices, in the vectors' order */
+} RumiFeatureVector;
+
+typedef struct RumiMatcher RumiMatcher;
+
+/* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&) — host, no device needed. */
+int rumi_descriptor_distance(const uint8_t *a32, const uint8_t *b32);
+
+/* Scratch arenas for frames of up to max_features features and calls of up to max_queries queries
+ * (map points / last-frame features / key-frame features). */
+int rumi_match_create(int32_t max_features, int32_t max_queries, int32_t device, RumiMatcher **out);
+void rumi_match_destroy(RumiMatcher *m);
+
+/* SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints) — TrackLocalMap.
+ * Per map point i (arrays of length nmp): the fields Frame::isInFrustum left on it (mbTrackInView, mTrackProjX/Y,
+ * mnTrackScaleLevel, mTrackViewCos, mTrackDepth), isBad(), GetDescriptor() (nmp x 32) and Observations().
+ * frame_mp [F->n] in/out = F.mvpMapPoints as ids into the same map-point arrays (-1 = NULL).
+ * *nmatches_out = the reference's return value. */
+int rumi_search_by_projection_mappoints(RumiMatcher *m, const RumiFrameFeatures *F, int32_t nmp,
+                                        const uint8_t *track_in_view, const float *proj_x, const float *proj_y,
+                                        const int32_t *scale_level, const float *view_cos, const float *track_depth,
+                                        const uint8_t *is_bad, const uint8_t *mp_desc, const int32_t *mp_obs, float th,
+                                        int32_t far_points, float th_far_points, float nnratio, int32_t *frame_mp,
+                                        int32_t *nmatches_out);
+
+/* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono = true) — TrackWithMotionModel.
+ * Tcw7 = CurrentFrame.GetPose() as Sophus stores it: unit quaternion (x,y,z,w) then translation; K4 = fx,fy,cx,cy.
+ * last_mp[nlast] = LastFrame.mvpMapPoints as ids (-1 NULL) into mp_pos (nmp x 3, GetWorldPos), mp_desc (nmp x 32),
+ * mp_obs (Observations()); last_outlier = LastFrame.mvbOutlier.  cur_mp [Cur->n] in/out = CurrentFrame.mvpMapPoints. */
+int rumi_search_by_projection_frame(RumiMatcher *m, const RumiFrameFeatures *Cur, const float *Tcw7, const float *K4,
+                                    const RumiKeyPoint *last_keys, int32_t nlast, const int32_t *last_mp,
+                                    const uint8_t *last_outlier, int32_t nmp, const float *mp_pos, const uint8_t *mp_desc,
+                                    const int32_t *mp_obs, float th, int32_t check_orientation, int32_t *cur_mp,
+                                    int32_t *nmatches_out);
+
+/* SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) — TrackReferenceKeyFrame / Relocalization.
+ * kf_mp[KF->n] = pKF->GetMapPointMatches() as ids (-1 NULL); mp_bad[nmp] = isBad().  matches [F->n] out (-1 = NULL). */
+int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, const RumiFeatureVector *kf_fv, const int32_t *kf_mp,
+                       int32_t nmp, const uint8_t *mp_bad, const RumiFrameFeatures *F, const RumiFeatureVector *f_fv,
+                       float nnratio, int32_t check_orientation, int32_t *matches, int32_t *nmatches_out);
+
+/* Brute-force all-pairs 256-bit Hamming (the GPU formulation of BASELINE.json config 3), device pointers:
+ * for each of B frame pairs, every query descriptor against every train descriptor; best index (first train index
+ * wins ties, as in every loop of the reference), best and second-best distance.
+ * d_query/d_train: [B][cap][32] u8; d_nq/d_nt: [B] int32 at stride `count_stride` int32s (pass the extractor's
+ * [B][2] counts with count_stride = 2); outputs [B][cap] int32 each. */
+int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
+                                       int32_t count_stride, int32_t cap, int32_t nbatch, void *d_best_idx,
+                                       void *d_best_dist, void *d_second_dist, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUMI_MATCH_H */

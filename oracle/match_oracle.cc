@@ -1,0 +1,290 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's Hamming matchers on flat arrays
+// (map points / key-frames are integer ids; a NULL MapPoint* is -1).  R/ = /root/reference/src/rumi-slam/.
+//   DescriptorDistance                              R/lib_src/ORBmatcher.cc:1830-1844
+//   Frame::AssignFeaturesToGrid / PosInGrid         R/lib_src/Frame.cc:441-466, 752-761
+//   Frame::GetFeaturesInArea                        R/lib_src/Frame.cc:695-750
+//   SearchByProjection(Frame&, vector<MapPoint*>&)  R/lib_src/ORBmatcher.cc:39-196        (mono branch)
+//   SearchByBoW(KeyFrame*, Frame&, ...)             R/lib_src/ORBmatcher.cc:198-370       (mono branch)
+//   SearchByProjection(Frame& Cur, const Frame& Last) R/lib_src/ORBmatcher.cc:1498-1683   (mono branch)
+//   ComputeThreeMaxima                              R/lib_src/ORBmatcher.cc:1795-1826
+//   Sophus SE3f * point, Pinhole::project           R/Thirdparty/Sophus/sophus/so3.hpp:358-367, R/lib_src/CameraModels/Pinhole.cpp:43-49
+// PARITY STATUS: pinned by source only (the reference has no tests for this path); integer logic is exact,
+// the float projection follows Eigen's expression order (no FMA: build with -ffp-contract=off).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "orb_oracle.h"
+
+namespace orc {
+
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // ORBmatcher.cc:30-32
+static const int GRID_COLS = 64, GRID_ROWS = 48;                  // Frame.h:42-43
+
+int descriptor_distance(const uint8_t *a, const uint8_t *b) {
+    int32_t pa[8], pb[8];
+    std::memcpy(pa, a, 32); std::memcpy(pb, b, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned int v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+struct FrameGrid {
+    int n;
+    const KeyPoint *keys;        // mvKeysUn
+    const uint8_t *desc;         // mDescriptors
+    float minX, minY, maxX, maxY, wInv, hInv;
+    std::vector<int> cell[GRID_COLS][GRID_ROWS];
+
+    FrameGrid(const KeyPoint *k, const uint8_t *d, int n_, float minX_, float minY_, float maxX_, float maxY_)
+        : n(n_), keys(k), desc(d), minX(minX_), minY(minY_), maxX(maxX_), maxY(maxY_) {
+        wInv = (float)GRID_COLS / (float)(maxX - minX);      // Frame.cc:322-323
+        hInv = (float)GRID_ROWS / (float)(maxY - minY);
+        for (int i = 0; i < n; i++) {                          // AssignFeaturesToGrid + PosInGrid
+            int px = (int)std::round((keys[i].x - minX) * wInv);
+            int py = (int)std::round((keys[i].y - minY) * hInv);
+            if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+            cell[px][py].push_back(i);
+        }
+    }
+    // GetFeaturesInArea(x, y, r, minLevel, maxLevel)
+    void in_area(float x, float y, float r, int minLevel, int maxLevel, std::vector<int> &out) const {
+        out.clear();
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * wInv));
+        if (nMinCellX >= GRID_COLS) return;
+        const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - minX + r) * wInv));
+        if (nMaxCellX < 0) return;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * hInv));
+        if (nMinCellY >= GRID_ROWS) return;
+        const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - minY + r) * hInv));
+        if (nMaxCellY < 0) return;
+        const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (int idx : cell[ix][iy]) {
+                    const KeyPoint &kp = keys[idx];
+                    if (checkLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float dx = kp.x - x, dy = kp.y - y;
+                    if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(idx);
+                }
+    }
+};
+
+static void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+
+static int rot_bin(float angleA, float angleB) {
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = angleA - angleB;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Sophus::SE3f * Vector3f with q = (x,y,z,w), t:  p + w*uv + q.vec x uv  (uv = 2 * q.vec x p), then + t
+static void se3_mul(const float *T /*qx qy qz qw tx ty tz*/, const float *p, float *o) {
+    const float qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+    float uv[3] = {qy * p[2] - qz * p[1], qz * p[0] - qx * p[2], qx * p[1] - qy * p[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const float c[3] = {qy * uv[2] - qz * uv[1], qz * uv[0] - qx * uv[2], qx * uv[1] - qy * uv[0]};
+    for (int i = 0; i < 3; i++) o[i] = ((p[i] + qw * uv[i]) + c[i]) + T[4 + i];
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b) { return descriptor_distance(a, b); }
+
+// GetFeaturesInArea on a frame; returns the number of indices written (enumeration order).
+int orc_features_in_area(const KeyPoint *keys, int n, float minX, float minY, float maxX, float maxY, float x, float y,
+                         float r, int minLevel, int maxLevel, int32_t *out, int cap) {
+    static const uint8_t dummy[32] = {0};
+    FrameGrid g(keys, dummy, n, minX, minY, maxX, maxY);
+    std::vector<int> v;
+    g.in_area(x, y, r, minLevel, maxLevel, v);
+    for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+// SearchByProjection(Frame &F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), mono.
+// frame_mp[n]: map point id per feature (-1 = none), updated in place.  Returns nmatches.
+int orc_search_by_projection_mappoints(const KeyPoint *keys, const uint8_t *desc, int n, float minX, float minY, float maxX,
+                                       float maxY, const float *scaleFactors, int nmp, const uint8_t *trackInView,
+                                       const float *projX, const float *projY, const int32_t *scaleLevel,
+                                       const float *viewCos, const float *trackDepth, const uint8_t *isBad,
+                                       const uint8_t *mpDesc, const int32_t *mpObs, float th, int bFarPoints,
+                                       float thFarPoints, float nnratio, int32_t *frame_mp) {
+    FrameGrid F(keys, desc, n, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nmp; iMP++) {
+        if (!trackInView[iMP]) continue;
+        if (bFarPoints && trackDepth[iMP] > thFarPoints) continue;
+        if (isBad[iMP]) continue;
+        const int nPredictedLevel = scaleLevel[iMP];
+        float r = viewCos[iMP] > 0.998 ? 2.5f : 4.0f;     // RadiusByViewingCos
+        if (bFactor) r *= th;
+        F.in_area(projX[iMP], projY[iMP], r * scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t *MPd = mpDesc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (frame_mp[idx] >= 0 && mpObs[frame_mp[idx]] > 0) continue;
+            const int dist = descriptor_distance(MPd, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = keys[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = keys[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                frame_mp[bestIdx] = iMP;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(Frame &Cur, const Frame &Last, th, bMono=true), mono.
+// last_mp[nlast]: map point id of each last-frame feature (-1 none); cur_mp[ncur] in/out.
+int orc_search_by_projection_frame(const KeyPoint *curKeys, const uint8_t *curDesc, int ncur, float minX, float minY,
+                                   float maxX, float maxY, const float *scaleFactors, const float *Tcw7, const float *K4,
+                                   const KeyPoint *lastKeys, int nlast, const int32_t *lastMp, const uint8_t *lastOutlier,
+                                   const float *mpPos, const uint8_t *mpDesc, const int32_t *mpObs, float th, int checkOri,
+                                   int32_t *cur_mp) {
+    FrameGrid C(curKeys, curDesc, ncur, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<int> vIndices2;
+    for (int i = 0; i < nlast; i++) {
+        const int pMP = lastMp[i];
+        if (pMP < 0 || lastOutlier[i]) continue;
+        float x3Dc[3];
+        se3_mul(Tcw7, mpPos + (size_t)pMP * 3, x3Dc);
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (invzc < 0) continue;
+        const float u = K4[0] * x3Dc[0] / x3Dc[2] + K4[2], v = K4[1] * x3Dc[1] / x3Dc[2] + K4[3];
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const int nLastOctave = lastKeys[i].octave;
+        const float radius = th * scaleFactors[nLastOctave];
+        C.in_area(u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);   // mono: neither forward nor backward
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = mpDesc + (size_t)pMP * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (cur_mp[i2] >= 0 && mpObs[cur_mp[i2]] > 0) continue;
+            const int dist = descriptor_distance(dMP, curDesc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_mp[bestIdx2] = pMP;
+            nmatches++;
+            if (checkOri) rotHist[rot_bin(lastKeys[i].angle, curKeys[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { cur_mp[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+// SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), mono.
+// FeatureVectors in CSR form: node ids ascending (std::map order), offsets[nn+1], feature indices.
+int orc_search_by_bow(const KeyPoint *kfKeys, const uint8_t *kfDesc, int nkf, const int32_t *kfMp, const uint8_t *mpBad,
+                      const uint32_t *kfNodes, const int32_t *kfOff, const uint32_t *kfIdx, int nnKF,
+                      const KeyPoint *fKeys, const uint8_t *fDesc, int nf, const uint32_t *fNodes, const int32_t *fOff,
+                      const uint32_t *fIdx, int nnF, float nnratio, int checkOri, int32_t *matches /*[nf]*/) {
+    for (int i = 0; i < nf; i++) matches[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a < nnKF && b < nnF) {
+        if (kfNodes[a] == fNodes[b]) {
+            for (int p = kfOff[a]; p < kfOff[a + 1]; p++) {
+                const unsigned realIdxKF = kfIdx[p];
+                const int pMP = kfMp[realIdxKF];
+                if (pMP < 0) continue;
+                if (mpBad[pMP]) continue;
+                const uint8_t *dKF = kfDesc + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int q = fOff[b]; q < fOff[b + 1]; q++) {
+                    const unsigned realIdxF = fIdx[q];
+                    if (matches[realIdxF] >= 0) continue;
+                    const int dist = descriptor_distance(dKF, fDesc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        matches[bestIdxF] = pMP;
+                        if (checkOri) rotHist[rot_bin(kfKeys[realIdxKF].angle, fKeys[bestIdxF].angle)].push_back(bestIdxF);
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kfNodes[a] < fNodes[b]) {
+            a = (int)(std::lower_bound(kfNodes, kfNodes + nnKF, fNodes[b]) - kfNodes);
+        } else {
+            b = (int)(std::lower_bound(fNodes, fNodes + nnF, kfNodes[a]) - fNodes);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// Brute-force all-pairs best / second-best (the GPU formulation named by BASELINE.json config 3); ties keep the
+// FIRST train index, like every matcher loop of the reference (strict <).
+void orc_bruteforce_match(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *bestIdx, int32_t *bestDist,
+                          int32_t *secondDist) {
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, b2 = 256, bi = -1;
+        for (int j = 0; j < nt; j++) {
+            const int d = descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < b1) { b2 = b1; b1 = d; bi = j; }
+            else if (d < b2) b2 = d;
+        }
+        bestIdx[i] = bi; bestDist[i] = b1; secondDist[i] = b2;
+    }
+}
+
+}  // extern "C"

@@ -81,6 +81,9 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
+                 "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_match_bruteforce_batch_device"]
+
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
                 "rumi_hook_fast_atan2", "rumi_hook_cv_round"]
 

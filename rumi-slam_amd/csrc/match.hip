@@ -1,0 +1,648 @@
+// MI355X-native Hamming matchers behind include/rumi_match.h (kernels + host side).
+//
+// The reference walks map points / key-frame features one after another and lets each one see the
+// assignments of the ones before it (ORBmatcher.cc:80-82, :248-249, :1556-1558).  GPU formulation, exact:
+//   1. k_grid        Frame::AssignFeaturesToGrid as a key sort: (cell << 16 | feature) ascending, cell = ix*48+iy, so
+//                    the cells GetFeaturesInArea visits for one ix are one contiguous range, already in its order.
+//   2. k_queries_*   one query per map point / last-frame feature / key-frame feature (projection, window, levels).
+//   3. k_candidates  one wave per query: enumerate candidates in the reference's order, 256-bit Hamming by
+//                    xor + popcount, ballot-compacted into a per-query list (count pass, scan, fill pass).
+//   4. k_resolve     one workgroup: every query picks its best candidate given "feature f is taken by an earlier
+//                    query" (blockedFrom[f] = smallest blocking query index); iterate to the fix point.  After
+//                    round k queries 0..k-1 hold their sequential result, and a fix point is the sequential result
+//                    (induction on the query index), so the outcome equals the reference's loop bit for bit.
+//                    Then the rotation histogram / ComputeThreeMaxima filter and the result arrays.
+//   k_bruteforce     all-pairs best / second-best, queries in registers, train descriptors broadcast from LDS.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "rumi_common.h"
+#include "rumi_match.h"
+
+namespace rumi {
+
+constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // Frame.h:42-43
+constexpr int kMaxSortN = 8192;
+
+enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2 };
+
+struct Query {           // 48 bytes
+    float u, v, r;       // window centre / half-size (MODE_BOW: unused)
+    int32_t minLevel, maxLevel;
+    int32_t valid;
+    int32_t descId;      // row of the query descriptor in qDesc
+    int32_t mpId;        // map point id this query assigns
+    int32_t blocks;      // Observations() > 0: an assignment hides the feature from later queries
+    int32_t c0, c1;      // MODE_BOW: candidate range in the frame's FeatureVector indices
+    float angle;         // key-point angle on the query side (rotation histogram)
+};
+
+struct FrameDev {
+    int n;
+    const RumiKeyPoint *keys;
+    const uint8_t *desc;
+    float minX, minY, maxX, maxY, wInv, hInv;
+    const uint16_t *sortedIdx;   // features sorted by (cell, index)
+    const int32_t *cellStart;    // [kGridCells + 1]
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t *d) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += __popc(q[k] ^ d[k]);
+    return s;
+}
+
+// ---- 1. grid -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid(int n, const RumiKeyPoint *__restrict__ keys, float minX, float minY, float wInv,
+                                              float hInv, uint16_t *__restrict__ sortedIdx, int32_t *__restrict__ cellStart) {
+    __shared__ uint32_t s[kMaxSortN];
+    const int tid = threadIdx.x;
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = tid; i < m; i += 256) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < n) {
+            // Frame::PosInGrid: round() of the float expression, dropped when outside the grid
+            const int px = (int)__builtin_roundf((keys[i].x - minX) * wInv);
+            const int py = (int)__builtin_roundf((keys[i].y - minY) * hInv);
+            if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) key = ((uint32_t)(px * kGridRows + py) << 16) | (uint32_t)i;
+        }
+        s[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s[i], b = s[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // sorted ascending: valid keys first.  cellStart[c] = first position whose cell >= c.
+    for (int i = tid; i < n; i += 256) sortedIdx[i] = (uint16_t)(s[i] & 0xFFFF);
+    for (int i = tid; i <= n; i += 256) {
+        const int cPrev = i == 0 ? -1 : (s[i - 1] == 0xFFFFFFFFu ? kGridCells : (int)(s[i - 1] >> 16));
+        const int cHere = (i == n || s[i] == 0xFFFFFFFFu) ? kGridCells : (int)(s[i] >> 16);
+        for (int c = cPrev + 1; c <= cHere; c++) cellStart[c] = i;
+    }
+}
+
+// ---- 2. queries ----------------------------------------------------------------------------------------------
+// SearchByProjection(F, map points): ORBmatcher.cc:44-71
+__global__ void k_queries_mappoints(int nmp, const uint8_t *trackInView, const float *projX, const float *projY,
+                                    const int32_t *scaleLevel, const float *viewCos, const float *trackDepth,
+                                    const uint8_t *isBad, const int32_t *mpObs, const float *scaleFactors, float th,
+                                    int farPoints, float thFar, Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nmp) return;
+    Query o{};
+    o.valid = trackInView[i] && !(farPoints && trackDepth[i] > thFar) && !isBad[i];
+    if (o.valid) {
+        const int lvl = scaleLevel[i];
+        float r = (double)viewCos[i] > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos (float vs double literal)
+        if ((double)th != 1.0) r *= th;
+        o.u = projX[i]; o.v = projY[i];
+        o.r = r * scaleFactors[lvl];
+        o.minLevel = lvl - 1; o.maxLevel = lvl;
+    }
+    o.descId = i; o.mpId = i; o.blocks = mpObs[i] > 0;
+    q[i] = o;
+}
+
+// SearchByProjection(Cur, Last): ORBmatcher.cc:1516-1551 (mono: levels nLastOctave-1 .. nLastOctave+1)
+__global__ void k_queries_frame(int nlast, const RumiKeyPoint *lastKeys, const int32_t *lastMp, const uint8_t *lastOutlier,
+                                const float *mpPos, const int32_t *mpObs, const float *Tcw, const float *K,
+                                const float *scaleFactors, float th, float minX, float minY, float maxX, float maxY,
+                                Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlast) return;
+    Query o{};
+    const int mp = lastMp[i];
+    if (mp >= 0 && !lastOutlier[i]) {
+        // Sophus::SE3f * p: p + w*uv + q.vec x uv, uv = 2 (q.vec x p); then + t   (so3.hpp:358-367)
+        const float qx = Tcw[0], qy = Tcw[1], qz = Tcw[2], qw = Tcw[3];
+        const float p0 = mpPos[mp * 3], p1 = mpPos[mp * 3 + 1], p2 = mpPos[mp * 3 + 2];
+        float u0 = qy * p2 - qz * p1, u1 = qz * p0 - qx * p2, u2 = qx * p1 - qy * p0;
+        u0 += u0; u1 += u1; u2 += u2;
+        const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+        const float xc = ((p0 + qw * u0) + c0) + Tcw[4], yc = ((p1 + qw * u1) + c1) + Tcw[5], zc = ((p2 + qw * u2) + c2) + Tcw[6];
+        const float invzc = (float)(1.0 / (double)zc);
+        if (!(invzc < 0)) {
+            const float u = K[0] * xc / zc + K[2], v = K[1] * yc / zc + K[3];      // Pinhole::project
+            if (!(u < minX || u > maxX) && !(v < minY || v > maxY)) {
+                const int oct = lastKeys[i].octave;
+                o.valid = 1; o.u = u; o.v = v; o.r = th * scaleFactors[oct];
+                o.minLevel = oct - 1; o.maxLevel = oct + 1;
+            }
+        }
+        o.descId = mp; o.mpId = mp; o.blocks = mpObs[mp] > 0;
+    }
+    o.angle = lastKeys[i].angle;
+    q[i] = o;
+}
+
+// SearchByBoW: one query per entry of the key-frame's FeatureVector, in (node, entry) order (ORBmatcher.cc:217-232)
+__global__ void k_queries_bow(int nnKF, const uint32_t *kfNodes, const int32_t *kfOff, const uint32_t *kfIdx,
+                              const int32_t *kfMp, const uint8_t *mpBad, const RumiKeyPoint *kfKeys, int nnF,
+                              const uint32_t *fNodes, const int32_t *fOff, Query *q) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nnKF) return;
+    // the merge-walk of the two ordered maps visits exactly the node ids present in both
+    int lo = 0, hi = nnF;
+    const uint32_t id = kfNodes[a];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fNodes[mid] < id) lo = mid + 1; else hi = mid; }
+    const bool hit = lo < nnF && fNodes[lo] == id;
+    for (int p = kfOff[a]; p < kfOff[a + 1]; p++) {
+        Query o{};
+        const int feat = (int)kfIdx[p];
+        const int mp = kfMp[feat];
+        o.valid = hit && mp >= 0 && !mpBad[mp];
+        o.descId = feat; o.mpId = mp; o.blocks = 1;
+        if (o.valid) { o.c0 = fOff[lo]; o.c1 = fOff[lo + 1]; }
+        o.angle = kfKeys[feat].angle;
+        q[p] = o;
+    }
+}
+
+// ---- 3. candidates: one wave per query -----------------------------------------------------------------------------
+// list entry: feature (16 bit) | distance (9 bit) << 16 | octave (4 bit) << 25
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Query *__restrict__ q, FrameDev F,
+                                                    const uint8_t *__restrict__ qDesc, const uint32_t *__restrict__ fvIdx,
+                                                    int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                                                    uint32_t *__restrict__ lists) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const Query Q = q[qi];
+    if (!Q.valid) {
+        if (!FILL && lane == 0) counts[qi] = 0;
+        return;
+    }
+    uint32_t qd[8];
+    if (FILL) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(qDesc + (size_t)Q.descId * 32);
+        const uint32_t mine = src[lane & 7];
+#pragma unroll
+        for (int k = 0; k < 8; k++) qd[k] = __shfl(mine, k);
+    }
+    uint32_t *out = FILL ? lists + offsets[qi] : nullptr;
+    int count = 0;
+    if (mode == MODE_BOW) {
+        for (int p = Q.c0 + lane; p - lane < Q.c1; p += 64) {
+            const bool ok = p < Q.c1;
+            if (FILL && ok) {
+                const int idx = (int)fvIdx[p];
+                const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
+                out[p - Q.c0] = (uint32_t)idx | ((uint32_t)d << 16);
+            }
+        }
+        count = Q.c1 - Q.c0;
+    } else {
+        // Frame::GetFeaturesInArea (Frame.cc:695-750)
+        const int nMinCellX = max(0, (int)floorf((Q.u - F.minX - Q.r) * F.wInv));
+        const int nMaxCellX = min(kGridCols - 1, (int)ceilf((Q.u - F.minX + Q.r) * F.wInv));
+        const int nMinCellY = max(0, (int)floorf((Q.v - F.minY - Q.r) * F.hInv));
+        const int nMaxCellY = min(kGridRows - 1, (int)ceilf((Q.v - F.minY + Q.r) * F.hInv));
+        if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0) {
+            const bool checkLevels = Q.minLevel > 0 || Q.maxLevel >= 0;
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                const int p0 = F.cellStart[ix * kGridRows + nMinCellY], p1 = F.cellStart[ix * kGridRows + nMaxCellY + 1];
+                for (int base = p0; base < p1; base += 64) {
+                    const int p = base + lane;
+                    bool pass = false;
+                    int idx = 0, oct = 0;
+                    if (p < p1) {
+                        idx = F.sortedIdx[p];
+                        const RumiKeyPoint kp = F.keys[idx];
+                        oct = kp.octave;
+                        pass = true;
+                        if (checkLevels) {
+                            if (oct < Q.minLevel) pass = false;
+                            if (Q.maxLevel >= 0 && oct > Q.maxLevel) pass = false;
+                        }
+                        const float dx = kp.x - Q.u, dy = kp.y - Q.v;
+                        if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) pass = false;
+                    }
+                    const unsigned long long b = __ballot(pass);
+                    if (FILL && pass) {
+                        const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
+                        out[count + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
+                    }
+                    count += __popcll(b);
+                }
+            }
+        }
+    }
+    if (!FILL && lane == 0) counts[qi] = count;
+}
+
+// exclusive scan of counts -> offsets (single workgroup; nq is a few thousand)
+__global__ __launch_bounds__(256) void k_scan(int n, const int32_t *__restrict__ counts, int32_t *__restrict__ offsets) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x, chunk = (n + 255) / 256;
+    int s = 0;
+    for (int k = 0; k < chunk; k++) { const int i = tid * chunk + k; if (i < n) s += counts[i]; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; } offsets[n] = run; }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = 0; k < chunk; k++) { const int i = tid * chunk + k; if (i < n) { offsets[i] = run; run += counts[i]; } }
+}
+
+// ---- 4. resolve ------------------------------------------------------------------------------------------------
+struct ResolveArgs {
+    int mode, nq, nfeat;
+    const Query *q;
+    const int32_t *counts, *offsets;
+    const uint32_t *lists;
+    const RumiKeyPoint *featKeys;   // angles of the frame's key-points (rotation histogram)
+    const int32_t *mpObs;           // Observations() per map point id (initial occupancy), may be null (BOW)
+    int32_t *featMp;                // in: initial frame_mp (MODE 0/1); out: final ids   [nfeat]
+    int32_t *assign;                // scratch [nq]: feature chosen by each query or -1
+    int32_t *nmatches;              // out
+    float nnratio;
+    int checkOri;
+};
+
+__device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatcher.cc:1592-1599
+    const float factor = 1.0f / RUMI_HISTO_LENGTH;
+    float rot = a - b;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)__builtin_roundf(rot * factor);
+    if (bin == RUMI_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+__global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
+    extern __shared__ int32_t blockedFrom[];      // [nfeat] smallest blocking query index; -1 = taken before the call
+    __shared__ int sChanged, sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH], sCount;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int kFree = 0x7FFFFFFF;
+    for (int i = tid; i < A.nq; i += nt) A.assign[i] = -1;
+    if (tid < RUMI_HISTO_LENGTH) sHist[tid] = 0;
+    if (tid == 0) sCount = 0;
+    for (int round = 0; round <= A.nq + 1; round++) {
+        // occupancy as the previous round's assignments imply it
+        for (int f = tid; f < A.nfeat; f += nt) {
+            int b = kFree;
+            if (A.mode != MODE_BOW) {
+                const int id = A.featMp[f];
+                if (id >= 0 && A.mpObs[id] > 0) b = -1;
+            }
+            blockedFrom[f] = b;
+        }
+        if (tid == 0) sChanged = 0;
+        __syncthreads();
+        for (int i = tid; i < A.nq; i += nt) {
+            const int f = A.assign[i];
+            if (f >= 0 && A.q[i].blocks) atomicMin(&blockedFrom[f], i);
+        }
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < A.nq; i += nt) {
+            const int cnt = A.counts[i];
+            int pick = -1;
+            if (cnt > 0) {
+                const uint32_t *L = A.lists + A.offsets[i];
+                int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
+                for (int k = 0; k < cnt; k++) {
+                    const uint32_t e = L[k];
+                    const int f = (int)(e & 0xFFFF);
+                    if (blockedFrom[f] < i) continue;                  // taken by an earlier query (or before the call)
+                    const int d = (int)((e >> 16) & 0x1FF), lv = (int)((e >> 25) & 15);
+                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = f; }
+                    else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; }
+                }
+                if (A.mode == MODE_MAPPOINTS) {                         // ORBmatcher.cc:106-111
+                    if (bestDist <= RUMI_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) pick = bestIdx;
+                } else if (A.mode == MODE_FRAME) {                      // :1577
+                    if (bestDist <= RUMI_TH_HIGH) pick = bestIdx;
+                } else {                                                // :283-285
+                    if (bestDist <= RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
+                }
+            }
+            if (pick != A.assign[i]) { changed = 1; A.assign[i] = pick; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        const int any = sChanged;
+        __syncthreads();
+        if (!any) break;
+    }
+    // results: a feature keeps the LAST query that assigned it (later assignments overwrite, as in the loop)
+    int32_t *last = blockedFrom;                                        // reuse LDS: last assigning query per feature
+    for (int f = tid; f < A.nfeat; f += nt) last[f] = -1;
+    __syncthreads();
+    const bool useHist = A.checkOri && A.mode != MODE_MAPPOINTS;
+    int local = 0;
+    for (int i = tid; i < A.nq; i += nt) {
+        const int f = A.assign[i];
+        if (f < 0) continue;
+        local++;
+        atomicMax(&last[f], i);
+        if (useHist) atomicAdd(&sHist[rot_bin(A.q[i].angle, A.featKeys[f].angle)], 1);
+    }
+    atomicAdd(&sCount, local);
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = 1;
+        if (useHist) {                                                   // ComputeThreeMaxima, ORBmatcher.cc:1795-1826
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
+                const int s = sHist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            int removed = 0;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
+                sKeep[i] = (i == ind1 || i == ind2 || i == ind3);
+                if (!sKeep[i]) removed += sHist[i];
+            }
+            sCount -= removed;
+        }
+        *A.nmatches = sCount;
+    }
+    __syncthreads();
+    // MODE_BOW starts from an all-NULL vector (ORBmatcher.cc:201); the other modes update the frame's vector in place
+    if (A.mode == MODE_BOW)
+        for (int f = tid; f < A.nfeat; f += nt) A.featMp[f] = -1;
+    __syncthreads();
+    for (int f = tid; f < A.nfeat; f += nt)
+        if (last[f] >= 0) A.featMp[f] = A.q[last[f]].mpId;
+    __syncthreads();
+    if (useHist)                                                        // entries of the rejected bins are set to NULL
+        for (int i = tid; i < A.nq; i += nt) {
+            const int f = A.assign[i];
+            if (f >= 0 && !sKeep[rot_bin(A.q[i].angle, A.featKeys[f].angle)]) A.featMp[f] = -1;
+        }
+}
+
+// ---- brute force ----------------------------------------------------------------------------------------------------
+// grid (ceil(cap/256), B); 256 queries per workgroup in registers; train descriptors staged 256 at a time in LDS and
+// read as broadcasts (every lane reads the same address: conflict-free).
+__global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ qd, const int32_t *__restrict__ nqArr,
+                                                    const uint8_t *__restrict__ td, const int32_t *__restrict__ ntArr,
+                                                    int countStride, int cap, int32_t *__restrict__ bestIdx,
+                                                    int32_t *__restrict__ bestDist, int32_t *__restrict__ secondDist) {
+    __shared__ uint4 tile[256 * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nq = min(nqArr[(size_t)b * countStride], cap), nt = min(ntArr[(size_t)b * countStride], cap);
+    const int qi = blockIdx.x * 256 + tid;
+    if (blockIdx.x * 256 >= nq) return;
+    uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qi < nq) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(qd + ((size_t)b * cap + qi) * 32);
+        const uint4 a = src[0], c = src[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = c.x; q[5] = c.y; q[6] = c.z; q[7] = c.w;
+    }
+    int b1 = 256, b2 = 256, bi = -1;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        const int m = min(256, nt - t0);
+        __syncthreads();
+        if (tid < m) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(td + ((size_t)b * cap + t0 + tid) * 32);
+            tile[tid * 2] = src[0];
+            tile[tid * 2 + 1] = src[1];
+        }
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const uint4 a = tile[j * 2], c = tile[j * 2 + 1];
+            const int d = __popc(q[0] ^ a.x) + __popc(q[1] ^ a.y) + __popc(q[2] ^ a.z) + __popc(q[3] ^ a.w) +
+                          __popc(q[4] ^ c.x) + __popc(q[5] ^ c.y) + __popc(q[6] ^ c.z) + __popc(q[7] ^ c.w);
+            if (d < b1) { b2 = b1; b1 = d; bi = t0 + j; }
+            else if (d < b2) b2 = d;
+        }
+    }
+    if (qi < nq) {
+        const size_t o = (size_t)b * cap + qi;
+        bestIdx[o] = bi; bestDist[o] = b1; secondDist[o] = b2;
+    }
+}
+
+}  // namespace rumi
+
+using namespace rumi;
+
+// ================================================ host side =======================================================
+struct RumiMatcher {
+    int device = 0, maxFeat = 0, maxQ = 0;
+    size_t listCap = 0;
+    // frame (train) side
+    RumiKeyPoint *dKeys = nullptr; uint8_t *dDesc = nullptr; float *dScale = nullptr;
+    uint16_t *dSorted = nullptr; int32_t *dCellStart = nullptr; int32_t *dFeatMp = nullptr;
+    uint32_t *dFvIdx = nullptr;      // frame FeatureVector indices (BoW)
+    // query side
+    Query *dQ = nullptr; uint8_t *dQDesc = nullptr; int32_t *dCounts = nullptr, *dOffsets = nullptr, *dAssign = nullptr;
+    uint32_t *dLists = nullptr;
+    int32_t *dNmatches = nullptr;
+    // raw inputs of the query builders
+    uint8_t *dU8a = nullptr, *dU8b = nullptr; float *dF[6] = {nullptr}; int32_t *dI[4] = {nullptr};
+    RumiKeyPoint *dQKeys = nullptr; uint32_t *dNodesA = nullptr, *dNodesB = nullptr, *dIdxA = nullptr;
+    int32_t *dOffA = nullptr, *dOffB = nullptr;
+    float *dPose = nullptr;
+};
+
+extern "C" int rumi_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+    uint64_t x[4], y[4];
+    std::memcpy(x, a, 32); std::memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) +
+           __builtin_popcountll(x[3] ^ y[3]);
+}
+
+extern "C" void rumi_match_destroy(RumiMatcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    void *p[] = {m->dKeys, m->dDesc, m->dScale, m->dSorted, m->dCellStart, m->dFeatMp, m->dFvIdx, m->dQ, m->dQDesc, m->dCounts,
+                 m->dOffsets, m->dAssign, m->dLists, m->dNmatches, m->dU8a, m->dU8b, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
+                 m->dF[4], m->dF[5], m->dI[0], m->dI[1], m->dI[2], m->dI[3], m->dQKeys, m->dNodesA, m->dNodesB, m->dIdxA,
+                 m->dOffA, m->dOffB, m->dPose};
+    for (void *q : p) if (q) (void)hipFree(q);
+    delete m;
+}
+
+template <class T> static int dalloc(T **p, size_t n) {
+    *p = nullptr;
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return RUMI_OK;
+}
+
+extern "C" int rumi_match_create(int32_t max_features, int32_t max_queries, int32_t device, RumiMatcher **out) {
+    if (!out) return RUMI_E_INVALID;
+    *out = nullptr;
+    if (max_features < 1 || max_features > kMaxSortN || max_queries < 1) {
+        g_lastError = "rumi_match_create: max_features must be in 1..8192, max_queries >= 1";
+        return RUMI_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_lastError = "no HIP device visible: librumi_hip has no CPU fallback";
+        return RUMI_E_NO_DEVICE;
+    }
+    RumiMatcher *m = new RumiMatcher();
+    if (device >= 0) m->device = device; else if (hipGetDevice(&m->device) != hipSuccess) m->device = 0;
+    if (hipSetDevice(m->device) != hipSuccess) { delete m; return RUMI_E_NO_DEVICE; }
+    m->maxFeat = max_features; m->maxQ = max_queries;
+    m->listCap = (size_t)max_queries * 256 + 65536;     // grown on demand
+    const size_t F = max_features, Q = max_queries;
+    int rc;
+#define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_match_destroy(m); return rc; }
+    TRYA(dalloc(&m->dKeys, F)); TRYA(dalloc(&m->dDesc, F * 32)); TRYA(dalloc(&m->dScale, 64));
+    TRYA(dalloc(&m->dSorted, F)); TRYA(dalloc(&m->dCellStart, kGridCells + 2)); TRYA(dalloc(&m->dFeatMp, F));
+    TRYA(dalloc(&m->dFvIdx, F));
+    TRYA(dalloc(&m->dQ, Q)); TRYA(dalloc(&m->dQDesc, Q * 32)); TRYA(dalloc(&m->dCounts, Q + 1)); TRYA(dalloc(&m->dOffsets, Q + 1));
+    TRYA(dalloc(&m->dAssign, Q)); TRYA(dalloc(&m->dLists, m->listCap)); TRYA(dalloc(&m->dNmatches, 1));
+    TRYA(dalloc(&m->dU8a, Q)); TRYA(dalloc(&m->dU8b, Q));
+    for (auto &f : m->dF) TRYA(dalloc(&f, Q * 3));
+    for (auto &i : m->dI) TRYA(dalloc(&i, Q + 1));
+    TRYA(dalloc(&m->dQKeys, Q)); TRYA(dalloc(&m->dNodesA, Q)); TRYA(dalloc(&m->dNodesB, F)); TRYA(dalloc(&m->dIdxA, Q));
+    TRYA(dalloc(&m->dOffA, Q + 1)); TRYA(dalloc(&m->dOffB, F + 1)); TRYA(dalloc(&m->dPose, 16));
+#undef TRYA
+    *out = m;
+    return RUMI_OK;
+}
+
+#define H2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(n) * sizeof(*(dst)), hipMemcpyHostToDevice, nullptr))
+
+static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd) {
+    if (!F || F->n < 0 || F->n > m->maxFeat || F->nlevels < 1 || F->nlevels > 64 || !(F->max_x > F->min_x) || !(F->max_y > F->min_y)) {
+        g_lastError = "bad RumiFrameFeatures (n, nlevels or bounds)";
+        return RUMI_E_INVALID;
+    }
+    if (F->n > 0) { H2D(m->dKeys, F->keys_un, F->n); H2D(m->dDesc, F->desc, (size_t)F->n * 32); }
+    H2D(m->dScale, F->scale_factors, F->nlevels);
+    fd->n = F->n; fd->keys = m->dKeys; fd->desc = m->dDesc;
+    fd->minX = F->min_x; fd->minY = F->min_y; fd->maxX = F->max_x; fd->maxY = F->max_y;
+    fd->wInv = (float)kGridCols / (float)(F->max_x - F->min_x);     // Frame.cc:322-323
+    fd->hInv = (float)kGridRows / (float)(F->max_y - F->min_y);
+    fd->sortedIdx = m->dSorted; fd->cellStart = m->dCellStart;
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(256), 0, nullptr, F->n, m->dKeys, fd->minX, fd->minY, fd->wInv, fd->hInv, m->dSorted,
+                       m->dCellStart);
+    return RUMI_OK;
+}
+
+// count pass, scan, (grow the list arena if needed), fill pass, resolve
+static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
+                      float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut) {
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
+                           m->dCounts, m->dOffsets, m->dLists);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, nullptr, nq, m->dCounts, m->dOffsets);
+        int32_t total = 0;
+        HIP_TRY(hipMemcpy(&total, m->dOffsets + nq, sizeof total, hipMemcpyDeviceToHost));
+        if ((size_t)total > m->listCap) {
+            (void)hipFree(m->dLists);
+            m->dLists = nullptr;
+            m->listCap = (size_t)total * 2;
+            int rc = dalloc(&m->dLists, m->listCap);
+            if (rc != RUMI_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_candidates<true>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
+                           m->dCounts, m->dOffsets, m->dLists);
+    }
+    ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
+                  nnratio, checkOri};
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(nmatchesOut, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (fd.n > 0) HIP_TRY(hipMemcpy(hostFeatMp, m->dFeatMp, (size_t)fd.n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RUMI_OK;
+}
+
+extern "C" int rumi_search_by_projection_mappoints(RumiMatcher *m, const RumiFrameFeatures *F, int32_t nmp,
+                                                   const uint8_t *track_in_view, const float *proj_x, const float *proj_y,
+                                                   const int32_t *scale_level, const float *view_cos, const float *track_depth,
+                                                   const uint8_t *is_bad, const uint8_t *mp_desc, const int32_t *mp_obs, float th,
+                                                   int32_t far_points, float th_far_points, float nnratio, int32_t *frame_mp,
+                                                   int32_t *nmatches_out) {
+    if (!m || !nmatches_out || !frame_mp || nmp < 0) return RUMI_E_INVALID;
+    if (nmp > m->maxQ) { g_lastError = "more map points than max_queries"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, F, &fd);
+    if (rc != RUMI_OK) return rc;
+    if (F->n > 0) H2D(m->dFeatMp, frame_mp, F->n);
+    if (nmp > 0) {
+        H2D(m->dU8a, track_in_view, nmp); H2D(m->dU8b, is_bad, nmp);
+        H2D(m->dF[0], proj_x, nmp); H2D(m->dF[1], proj_y, nmp); H2D(m->dF[2], view_cos, nmp); H2D(m->dF[3], track_depth, nmp);
+        H2D(m->dI[0], scale_level, nmp); H2D(m->dI[1], mp_obs, nmp);
+        H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1],
+                           m->dI[0], m->dF[2], m->dF[3], m->dU8b, m->dI[1], m->dScale, th, far_points, th_far_points, m->dQ);
+    }
+    return run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], nnratio, 0, frame_mp, nmatches_out);
+}
+
+extern "C" int rumi_search_by_projection_frame(RumiMatcher *m, const RumiFrameFeatures *Cur, const float *Tcw7, const float *K4,
+                                               const RumiKeyPoint *last_keys, int32_t nlast, const int32_t *last_mp,
+                                               const uint8_t *last_outlier, int32_t nmp, const float *mp_pos, const uint8_t *mp_desc,
+                                               const int32_t *mp_obs, float th, int32_t check_orientation, int32_t *cur_mp,
+                                               int32_t *nmatches_out) {
+    if (!m || !nmatches_out || !cur_mp || nlast < 0 || nmp < 0 || !Tcw7 || !K4) return RUMI_E_INVALID;
+    if (nlast > m->maxQ || nmp > m->maxQ) { g_lastError = "more last-frame features / map points than max_queries"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, Cur, &fd);
+    if (rc != RUMI_OK) return rc;
+    if (Cur->n > 0) H2D(m->dFeatMp, cur_mp, Cur->n);
+    float pose[11];
+    std::memcpy(pose, Tcw7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
+    H2D(m->dPose, pose, 11);
+    if (nmp > 0) { H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dI[1], mp_obs, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32); }
+    if (nlast > 0) {
+        H2D(m->dQKeys, last_keys, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast);
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a,
+                           m->dF[0], m->dI[1], m->dPose, m->dPose + 7, m->dScale, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    }
+    return run_search(m, MODE_FRAME, nlast, fd, m->dQDesc, m->dI[1], 0.f, check_orientation, cur_mp, nmatches_out);
+}
+
+extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, const RumiFeatureVector *kf_fv, const int32_t *kf_mp,
+                                  int32_t nmp, const uint8_t *mp_bad, const RumiFrameFeatures *F, const RumiFeatureVector *f_fv,
+                                  float nnratio, int32_t check_orientation, int32_t *matches, int32_t *nmatches_out) {
+    if (!m || !KF || !kf_fv || !f_fv || !matches || !nmatches_out || nmp < 0 || !kf_mp) return RUMI_E_INVALID;
+    const int nqe = kf_fv->n_nodes > 0 ? kf_fv->offsets[kf_fv->n_nodes] : 0;     // one query per FeatureVector entry
+    const int nfe = f_fv->n_nodes > 0 ? f_fv->offsets[f_fv->n_nodes] : 0;
+    if (KF->n > m->maxQ || nqe > m->maxQ || nmp > m->maxQ || kf_fv->n_nodes > m->maxQ || nfe > m->maxFeat || f_fv->n_nodes > m->maxFeat) {
+        g_lastError = "SearchByBoW: sizes exceed the matcher's capacities";
+        return RUMI_E_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, F, &fd);
+    if (rc != RUMI_OK) return rc;
+    if (KF->n > 0) { H2D(m->dQKeys, KF->keys_un, KF->n); H2D(m->dQDesc, KF->desc, (size_t)KF->n * 32); H2D(m->dI[0], kf_mp, KF->n); }
+    if (nmp > 0) H2D(m->dU8a, mp_bad, nmp);
+    if (kf_fv->n_nodes > 0) { H2D(m->dNodesA, kf_fv->node_ids, kf_fv->n_nodes); H2D(m->dOffA, kf_fv->offsets, kf_fv->n_nodes + 1); }
+    if (nqe > 0) H2D(m->dIdxA, kf_fv->indices, nqe);
+    if (f_fv->n_nodes > 0) { H2D(m->dNodesB, f_fv->node_ids, f_fv->n_nodes); H2D(m->dOffB, f_fv->offsets, f_fv->n_nodes + 1); }
+    if (nfe > 0) H2D(m->dFvIdx, f_fv->indices, nfe);
+    if (kf_fv->n_nodes > 0)
+        hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
+                           m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
+    return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
+}
+
+extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
+                                                  int32_t count_stride, int32_t cap, int32_t nbatch, void *d_best_idx,
+                                                  void *d_best_dist, void *d_second_dist, void *hip_stream) {
+    if (!d_query || !d_nq || !d_train || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || nbatch < 1 || count_stride < 1)
+        return RUMI_E_INVALID;
+    hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nbatch), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_query,
+                       (const int32_t *)d_nq, (const uint8_t *)d_train, (const int32_t *)d_nt, count_stride, cap, (int32_t *)d_best_idx,
+                       (int32_t *)d_best_dist, (int32_t *)d_second_dist);
+    HIP_TRY(hipGetLastError());
+    return RUMI_OK;
+}

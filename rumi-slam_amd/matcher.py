@@ -1,0 +1,143 @@
+"""Host-side mirror of ``ORB_SLAM3::ORBmatcher`` (R/include/cloud_edge_slam_lib/ORBmatcher.h:36-103) over the C ABI in
+include/rumi_match.h.  Frames / key-frames are passed as ``FrameView`` (the flat arrays the matchers read), map
+points as integer ids into caller-side arrays (-1 = NULL)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import KP_DTYPE
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+
+class RumiFrameFeatures(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("desc", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("max_x", C.c_float), ("max_y", C.c_float), ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
+
+
+class RumiFeatureVector(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+
+
+MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
+                 "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_match_bruteforce_batch_device"]
+
+
+def _lib():
+    L = capi.lib()
+    if getattr(L, "_match_ready", False):
+        return L
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.rumi_descriptor_distance.argtypes = [vp, vp]
+    L.rumi_match_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.rumi_match_destroy.argtypes = [vp]
+    L.rumi_match_destroy.restype = None
+    L.rumi_search_by_projection_mappoints.argtypes = [vp, C.POINTER(RumiFrameFeatures), i32] + [vp] * 9 + [f32, i32, f32, f32, vp, C.POINTER(i32)]
+    L.rumi_search_by_projection_frame.argtypes = [vp, C.POINTER(RumiFrameFeatures), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, f32, i32, vp, C.POINTER(i32)]
+    L.rumi_search_by_bow.argtypes = [vp, C.POINTER(RumiFrameFeatures), C.POINTER(RumiFeatureVector), vp, i32, vp,
+                                     C.POINTER(RumiFrameFeatures), C.POINTER(RumiFeatureVector), f32, i32, vp, C.POINTER(i32)]
+    L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L._match_ready = True
+    return L
+
+
+class FrameView:
+    """The part of a Frame / KeyFrame the matchers read (keeps the arrays alive)."""
+
+    def __init__(self, keys_un, desc, width, height, scale_factors, min_x=0.0, min_y=0.0):
+        self.keys = np.ascontiguousarray(keys_un, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        assert len(self.keys) == len(self.desc)
+        self.bounds = (float(min_x), float(min_y), float(width), float(height))
+        self.c = RumiFrameFeatures(len(self.keys), capi.ptr(self.keys), capi.ptr(self.desc), self.bounds[0], self.bounds[1],
+                                   self.bounds[2], self.bounds[3], capi.ptr(self.sf), len(self.sf))
+
+    @property
+    def n(self):
+        return len(self.keys)
+
+
+class FeatureVector:
+    """DBoW2::FeatureVector as CSR (node ids ascending = std::map order)."""
+
+    def __init__(self, mapping):
+        nodes = sorted(mapping)
+        self.node_ids = np.array(nodes, np.uint32)
+        self.offsets = np.zeros(len(nodes) + 1, np.int32)
+        idx = []
+        for k, nid in enumerate(nodes):
+            idx.extend(mapping[nid])
+            self.offsets[k + 1] = len(idx)
+        self.indices = np.array(idx, np.uint32)
+        self.c = RumiFeatureVector(len(nodes), capi.ptr(self.node_ids), capi.ptr(self.offsets), capi.ptr(self.indices))
+
+
+def DescriptorDistance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return _lib().rumi_descriptor_distance(capi.ptr(a), capi.ptr(b))
+
+
+class ORBmatcher:
+    def __init__(self, nnratio=0.6, checkOri=True, max_features=8192, max_queries=16384, device=-1):
+        self._lib = _lib()
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self._h = C.c_void_p()
+        capi.check(self._lib.rumi_match_create(max_features, max_queries, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rumi_match_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def SearchByProjection_MapPoints(self, F, mp, frame_mp, th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """mp: dict of arrays track_in_view,u8 proj_x,proj_y,view_cos,track_depth f32 scale_level,obs i32 is_bad u8 desc[n,32]."""
+        n = len(mp["proj_x"])
+        a = {k: np.ascontiguousarray(mp[k], t) for k, t in [("track_in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32),
+                                                             ("scale_level", np.int32), ("view_cos", np.float32), ("track_depth", np.float32),
+                                                             ("is_bad", np.uint8), ("desc", np.uint8), ("obs", np.int32)]}
+        frame_mp = np.ascontiguousarray(frame_mp, np.int32).copy()
+        nm = C.c_int32()
+        capi.check(self._lib.rumi_search_by_projection_mappoints(
+            self._h, C.byref(F.c), n, capi.ptr(a["track_in_view"]), capi.ptr(a["proj_x"]), capi.ptr(a["proj_y"]), capi.ptr(a["scale_level"]),
+            capi.ptr(a["view_cos"]), capi.ptr(a["track_depth"]), capi.ptr(a["is_bad"]), capi.ptr(a["desc"]), capi.ptr(a["obs"]),
+            float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, capi.ptr(frame_mp), C.byref(nm)))
+        return nm.value, frame_mp
+
+    def SearchByProjection_Frame(self, Cur, Tcw7, K4, last_keys, last_mp, last_outlier, mp_pos, mp_desc, mp_obs, cur_mp, th):
+        Tcw7 = np.ascontiguousarray(Tcw7, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+        last_keys = np.ascontiguousarray(last_keys, KP_DTYPE); last_mp = np.ascontiguousarray(last_mp, np.int32)
+        last_outlier = np.ascontiguousarray(last_outlier, np.uint8); mp_pos = np.ascontiguousarray(mp_pos, np.float32)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.int32)
+        cur_mp = np.ascontiguousarray(cur_mp, np.int32).copy()
+        nm = C.c_int32()
+        capi.check(self._lib.rumi_search_by_projection_frame(
+            self._h, C.byref(Cur.c), capi.ptr(Tcw7), capi.ptr(K4), capi.ptr(last_keys), len(last_keys), capi.ptr(last_mp),
+            capi.ptr(last_outlier), len(mp_obs), capi.ptr(mp_pos), capi.ptr(mp_desc), capi.ptr(mp_obs), float(th),
+            int(self.mbCheckOrientation), capi.ptr(cur_mp), C.byref(nm)))
+        return nm.value, cur_mp
+
+    def SearchByBoW(self, KF, kf_fv, kf_mp, mp_bad, F, f_fv):
+        kf_mp = np.ascontiguousarray(kf_mp, np.int32); mp_bad = np.ascontiguousarray(mp_bad, np.uint8)
+        matches = np.full(F.n, -1, np.int32)
+        nm = C.c_int32()
+        capi.check(self._lib.rumi_search_by_bow(self._h, C.byref(KF.c), C.byref(kf_fv.c), capi.ptr(kf_mp), len(mp_bad), capi.ptr(mp_bad),
+                                                C.byref(F.c), C.byref(f_fv.c), self.mfNNratio, int(self.mbCheckOrientation),
+                                                capi.ptr(matches), C.byref(nm)))
+        return nm.value, matches
+
+
+def bruteforce_batch(desc_q, counts_q, desc_t, counts_t, stream=None):
+    """desc_*: torch u8 CUDA [B,cap,32]; counts_*: torch i32 CUDA [B,2] (extractor counts).  Returns best_idx, best, second [B,cap]."""
+    import torch
+    B, cap, _ = desc_q.shape
+    out = [torch.empty((B, cap), dtype=torch.int32, device=desc_q.device) for _ in range(3)]
+    st = stream if stream is not None else torch.cuda.current_stream(desc_q.device)
+    capi.check(_lib().rumi_match_bruteforce_batch_device(desc_q.data_ptr(), counts_q.data_ptr(), desc_t.data_ptr(), counts_t.data_ptr(),
+                                                         counts_q.stride(0), cap, B, out[0].data_ptr(), out[1].data_ptr(),
+                                                         out[2].data_ptr(), st.cuda_stream))
+    return out

@@ -123,3 +123,76 @@ def octree(cand, min_x, max_x, min_y, max_y, n_want):
     out = np.zeros(len(cand) + 1, KP_DTYPE)
     m = lib().orc_octree(_p(cand), len(cand), min_x, max_x, min_y, max_y, n_want, _p(out), len(out))
     return out[:m].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# matchers (oracle/match_oracle.cc)
+# ---------------------------------------------------------------------------------------------------------
+def _mlib():
+    L = lib()
+    if getattr(L, "_m_ready", False):
+        return L
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.orc_descriptor_distance.argtypes = [vp, vp]
+    L.orc_features_in_area.argtypes = [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, i32]
+    L.orc_search_by_projection_mappoints.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32] + [vp] * 9 + [f32, i32, f32, f32, vp]
+    L.orc_search_by_projection_frame.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp]
+    L.orc_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
+    L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    L._m_ready = True
+    return L
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return _mlib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def features_in_area(keys, w, h, x, y, r, min_level, max_level):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    out = np.zeros(len(keys) + 1, np.int32)
+    n = _mlib().orc_features_in_area(_p(keys), len(keys), 0.0, 0.0, float(w), float(h), x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n]
+
+
+def search_by_projection_mappoints(keys, desc, w, h, sf, mp, frame_mp, th, far, th_far, nnratio):
+    keys = np.ascontiguousarray(keys, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); sf = np.ascontiguousarray(sf, np.float32)
+    a = {k: np.ascontiguousarray(mp[k], t) for k, t in [("track_in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32),
+                                                         ("scale_level", np.int32), ("view_cos", np.float32), ("track_depth", np.float32),
+                                                         ("is_bad", np.uint8), ("desc", np.uint8), ("obs", np.int32)]}
+    fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+    n = _mlib().orc_search_by_projection_mappoints(_p(keys), _p(desc), len(keys), 0.0, 0.0, float(w), float(h), _p(sf), len(a["proj_x"]),
+                                                  _p(a["track_in_view"]), _p(a["proj_x"]), _p(a["proj_y"]), _p(a["scale_level"]),
+                                                  _p(a["view_cos"]), _p(a["track_depth"]), _p(a["is_bad"]), _p(a["desc"]), _p(a["obs"]),
+                                                  th, int(far), th_far, nnratio, _p(fm))
+    return n, fm
+
+
+def search_by_projection_frame(cur_keys, cur_desc, w, h, sf, Tcw7, K4, last_keys, last_mp, last_outlier, mp_pos, mp_desc, mp_obs, cur_mp,
+                               th, check_ori):
+    arrs = [np.ascontiguousarray(cur_keys, KP_DTYPE), np.ascontiguousarray(cur_desc, np.uint8), np.ascontiguousarray(sf, np.float32),
+            np.ascontiguousarray(Tcw7, np.float32), np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(last_keys, KP_DTYPE),
+            np.ascontiguousarray(last_mp, np.int32), np.ascontiguousarray(last_outlier, np.uint8), np.ascontiguousarray(mp_pos, np.float32),
+            np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(mp_obs, np.int32)]
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    n = _mlib().orc_search_by_projection_frame(_p(arrs[0]), _p(arrs[1]), len(arrs[0]), 0.0, 0.0, float(w), float(h), _p(arrs[2]), _p(arrs[3]),
+                                              _p(arrs[4]), _p(arrs[5]), len(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]),
+                                              _p(arrs[10]), th, int(check_ori), _p(cm))
+    return n, cm
+
+
+def search_by_bow(kf_keys, kf_desc, kf_mp, mp_bad, kf_fv, f_keys, f_desc, f_fv, nnratio, check_ori):
+    """kf_fv / f_fv: (node_ids u32, offsets i32, indices u32)."""
+    kk = np.ascontiguousarray(kf_keys, KP_DTYPE); kd = np.ascontiguousarray(kf_desc, np.uint8); km = np.ascontiguousarray(kf_mp, np.int32)
+    mb = np.ascontiguousarray(mp_bad, np.uint8); fk = np.ascontiguousarray(f_keys, KP_DTYPE); fd = np.ascontiguousarray(f_desc, np.uint8)
+    out = np.full(len(fk), -1, np.int32)
+    n = _mlib().orc_search_by_bow(_p(kk), _p(kd), len(kk), _p(km), _p(mb), _p(kf_fv[0]), _p(kf_fv[1]), _p(kf_fv[2]), len(kf_fv[0]),
+                                  _p(fk), _p(fd), len(fk), _p(f_fv[0]), _p(f_fv[1]), _p(f_fv[2]), len(f_fv[0]), nnratio, int(check_ori), _p(out))
+    return n, out
+
+
+def bruteforce_match(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    bi, bd, sd = (np.zeros(len(q), np.int32) for _ in range(3))
+    _mlib().orc_bruteforce_match(_p(q), len(q), _p(t), len(t), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd

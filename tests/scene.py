@@ -1,0 +1,94 @@
+"""Synthetic tracking scenes for the matcher / optimiser tests: frame t, frame t+1 = frame t
+under a small similarity warp, pseudo map points = back-projection of frame-t key-points at seeded depths with the
+TUM3 pinhole intrinsics, placed so that they project (under the current pose) onto the warped key-point positions.
+TEST INFRASTRUCTURE: features come from the CPU oracle extractor."""
+import numpy as np
+
+import oracle_lib as O
+from rumi_slam_amd.synth import synth_frame, warp_frame
+
+K_TUM3 = np.array([535.4, 539.2, 320.1, 247.6], np.float32)     # R/config/TUM3.yaml:11-14
+
+
+def quat_from_rotvec(rv):
+    th = np.linalg.norm(rv)
+    if th < 1e-12:
+        return np.array([0, 0, 0, 1.0])
+    ax = rv / th
+    return np.concatenate([ax * np.sin(th / 2), [np.cos(th / 2)]])
+
+
+def quat_rotate(q, p):
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return p @ R.T, R
+
+
+class TrackingScene:
+    def __init__(self, seed=0, nfeatures=1000, w=640, h=480, th_noise=1.5):
+        rng = np.random.default_rng(seed)
+        self.w, self.h = w, h
+        ext = O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+        self.sf = ext.tables()["scale"]
+        img0 = synth_frame(9000 + seed, w=w, h=h)
+        img1, A = warp_frame(img0, 777 + seed)
+        _, self.last_keys, self.last_desc = ext.extract(img0, (0, 1000))
+        _, self.cur_keys, self.cur_desc = ext.extract(img1, (0, 1000))
+        nl = len(self.last_keys)
+        # current pose: small rotation + translation
+        q = quat_from_rotvec(rng.normal(size=3) * 0.02)
+        t = rng.normal(size=3) * 0.05
+        self.Tcw7 = np.concatenate([q, t]).astype(np.float32)
+        # map points: one per last-frame key-point (a few without), depth U[1,8]
+        px = self.last_keys["x"].astype(np.float64), self.last_keys["y"].astype(np.float64)
+        wx = A[0, 0] * px[0] + A[0, 1] * px[1] + A[0, 2] + rng.normal(size=nl) * th_noise
+        wy = A[1, 0] * px[0] + A[1, 1] * px[1] + A[1, 2] + rng.normal(size=nl) * th_noise
+        z = rng.uniform(1, 8, nl)
+        fx, fy, cx, cy = K_TUM3.astype(np.float64)
+        Xc = np.stack([(wx - cx) / fx * z, (wy - cy) / fy * z, z], 1)
+        _, R = quat_rotate(self.Tcw7[:4].astype(np.float64), np.zeros((1, 3)))
+        Xw = (Xc - self.Tcw7[4:].astype(np.float64)) @ R          # R^T (Xc - t)
+        self.mp_pos = Xw.astype(np.float32)
+        self.mp_desc = self.last_desc.copy()
+        self.mp_obs = np.where(rng.random(nl) < 0.97, rng.integers(1, 9, nl), 0).astype(np.int32)
+        self.last_mp = np.where(rng.random(nl) < 0.9, np.arange(nl), -1).astype(np.int32)
+        self.last_outlier = (rng.random(nl) < 0.05).astype(np.uint8)
+        self.proj = (wx, wy, z)
+        self.rng = rng
+
+    def mappoint_view(self, extra=300):
+        """Inputs of SearchByProjection(F, map points): the isInFrustum fields for the scene's points + random extras."""
+        rng = self.rng
+        nl = len(self.last_keys)
+        n = nl + extra
+        wx, wy, z = self.proj
+        px = np.concatenate([wx, rng.uniform(0, self.w, extra)]).astype(np.float32)
+        py = np.concatenate([wy, rng.uniform(0, self.h, extra)]).astype(np.float32)
+        lvl = np.concatenate([np.clip(self.last_keys["octave"] + rng.integers(-1, 2, nl), 0, 7), rng.integers(0, 8, extra)]).astype(np.int32)
+        desc = np.concatenate([self.mp_desc, rng.integers(0, 256, (extra, 32), dtype=np.uint8)])
+        return dict(track_in_view=(rng.random(n) < 0.9).astype(np.uint8), proj_x=px, proj_y=py, scale_level=lvl,
+                    view_cos=rng.uniform(0.99, 1.0, n).astype(np.float32),
+                    track_depth=np.concatenate([z, rng.uniform(1, 60, extra)]).astype(np.float32),
+                    is_bad=(rng.random(n) < 0.03).astype(np.uint8), desc=desc,
+                    obs=np.where(rng.random(n) < 0.95, rng.integers(1, 9, n), 0).astype(np.int32))
+
+    def feature_vectors(self, n_nodes=600):
+        """Synthetic DBoW2 FeatureVectors (ORBvoc.txt is a missing blob): true correspondences share a node."""
+        rng = self.rng
+        wx, wy, _ = self.proj
+        node_last = rng.integers(0, n_nodes, len(self.last_keys))
+        node_cur = rng.integers(0, n_nodes, len(self.cur_keys))
+        cx, cy, co = self.cur_keys["x"], self.cur_keys["y"], self.cur_keys["octave"]
+        for i in range(len(self.last_keys)):
+            d = np.abs(cx - wx[i] * 1.0) + np.abs(cy - wy[i] * 1.0)
+            j = int(np.argmin(np.where(co == self.last_keys["octave"][i], d, 1e9)))
+            if d[j] < 6:
+                node_cur[j] = node_last[i]
+        def group(nodes):
+            m = {}
+            for idx, nd in enumerate(nodes):
+                m.setdefault(int(nd) * 7 + 3, []).append(idx)      # non-contiguous ids
+            return m
+        return group(node_last), group(node_cur)

@@ -1,0 +1,127 @@
+"""GPU parity of the Hamming matchers against the CPU oracle (match indices bit-exact), through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from scene import K_TUM3, TrackingScene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from rumi_slam_amd.matcher import ORBmatcher
+    return lambda nn=0.6, ori=True: ORBmatcher(nn, ori)
+
+
+def _fv(mapping):
+    from rumi_slam_amd.matcher import FeatureVector
+    return FeatureVector(mapping)
+
+
+@pytest.mark.parametrize("seed,th", [(0, 15.0), (1, 30.0), (2, 7.0), (3, 15.0)])
+def test_search_by_projection_frame(matcher, seed, th):
+    from rumi_slam_amd.matcher import FrameView
+    s = TrackingScene(seed)
+    cur = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    cur_mp0 = np.full(cur.n, -1, np.int32)
+    for ori in (True, False):
+        n_ref, ref = O.search_by_projection_frame(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, s.Tcw7, K_TUM3, s.last_keys, s.last_mp,
+                                                  s.last_outlier, s.mp_pos, s.mp_desc, s.mp_obs, cur_mp0, th, ori)
+        n_gpu, got = matcher(0.9, ori).SearchByProjection_Frame(cur, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos,
+                                                               s.mp_desc, s.mp_obs, cur_mp0, th)
+        assert n_ref > 100, "scene should produce matches"
+        assert n_gpu == n_ref
+        assert np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} features differ"
+
+
+@pytest.mark.parametrize("seed,th", [(0, 1.0), (1, 3.0), (2, 5.0), (4, 15.0)])
+def test_search_by_projection_mappoints(matcher, seed, th):
+    from rumi_slam_amd.matcher import FrameView
+    s = TrackingScene(seed)
+    F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    mp = s.mappoint_view()
+    # some features already hold a map point (as after TrackWithMotionModel): exercises the occupancy rule
+    rng = np.random.default_rng(seed)
+    frame_mp = np.where(rng.random(F.n) < 0.15, rng.integers(0, len(mp["obs"]), F.n), -1).astype(np.int32)
+    n_ref, ref = O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, mp, frame_mp, th, True, 40.0, 0.8)
+    n_gpu, got = matcher(0.8).SearchByProjection_MapPoints(F, mp, frame_mp, th, True, 40.0)
+    assert n_ref > 50
+    assert n_gpu == n_ref
+    assert np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} features differ"
+
+
+@pytest.mark.parametrize("seed,nn", [(0, 0.7), (1, 0.75), (5, 0.9)])
+def test_search_by_bow(matcher, seed, nn):
+    from rumi_slam_amd.matcher import FrameView
+    s = TrackingScene(seed)
+    KF = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    fv_kf, fv_f = s.feature_vectors()
+    a, b = _fv(fv_kf), _fv(fv_f)
+    mp_bad = (np.random.default_rng(seed).random(len(s.mp_obs)) < 0.05).astype(np.uint8)
+    for ori in (True, False):
+        n_ref, ref = O.search_by_bow(s.last_keys, s.last_desc, s.last_mp, mp_bad, (a.node_ids, a.offsets, a.indices), s.cur_keys, s.cur_desc,
+                                     (b.node_ids, b.offsets, b.indices), nn, ori)
+        n_gpu, got = matcher(nn, ori).SearchByBoW(KF, a, s.last_mp, mp_bad, F, b)
+        assert n_ref > 50
+        assert n_gpu == n_ref
+        assert np.array_equal(got, ref)
+
+
+def test_dense_conflicts_force_many_fixpoint_rounds(matcher):
+    """Many identical descriptors in one window: every query wants the same feature, so the sequential 'already taken'
+    rule cascades — the worst case for the parallel fix-point resolver."""
+    from rumi_slam_amd.matcher import FrameView
+    rng = np.random.default_rng(3)
+    n = 400
+    keys = np.zeros(n, O.KP_DTYPE)
+    keys["x"] = 300 + rng.uniform(-6, 6, n); keys["y"] = 200 + rng.uniform(-6, 6, n); keys["octave"] = 0
+    keys["angle"] = rng.uniform(0, 360, n)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.tile(base, (n, 1)); desc[:, 0] = rng.integers(0, 4, n)            # near-duplicates
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    F = FrameView(keys, desc, 640, 480, sf)
+    nmp = 300
+    mp = dict(track_in_view=np.ones(nmp, np.uint8), proj_x=np.full(nmp, 300, np.float32), proj_y=np.full(nmp, 200, np.float32),
+              scale_level=np.zeros(nmp, np.int32), view_cos=np.full(nmp, 0.9, np.float32), track_depth=np.ones(nmp, np.float32),
+              is_bad=np.zeros(nmp, np.uint8), desc=np.tile(base, (nmp, 1)), obs=np.ones(nmp, np.int32))
+    frame_mp = np.full(n, -1, np.int32)
+    n_ref, ref = O.search_by_projection_mappoints(keys, desc, 640, 480, sf, mp, frame_mp, 3.0, False, 0.0, 1.1)
+    n_gpu, got = matcher(1.1).SearchByProjection_MapPoints(F, mp, frame_mp, 3.0)
+    assert n_ref >= 200
+    assert n_gpu == n_ref and np.array_equal(got, ref)
+
+
+def test_empty_inputs(matcher):
+    from rumi_slam_amd.matcher import FrameView
+    s = TrackingScene(0)
+    cur = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    n, got = matcher().SearchByProjection_Frame(cur, s.Tcw7, K_TUM3, s.last_keys[:0], s.last_mp[:0], s.last_outlier[:0], s.mp_pos, s.mp_desc,
+                                                s.mp_obs, np.full(cur.n, -1, np.int32), 15.0)
+    assert n == 0 and (got == -1).all()
+    empty = FrameView(s.cur_keys[:0], s.cur_desc[:0], s.w, s.h, s.sf)
+    n, got = matcher().SearchByProjection_Frame(empty, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos, s.mp_desc, s.mp_obs,
+                                                np.zeros(0, np.int32), 15.0)
+    assert n == 0
+
+
+def test_bruteforce_batch():
+    import torch
+    from rumi_slam_amd.matcher import bruteforce_batch
+    rng = np.random.default_rng(0)
+    B, cap = 3, 1100
+    q = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+    t[1, 5] = t[1, 900]                                    # exact duplicate: first index must win
+    q[1, 0] = t[1, 900]
+    cq = np.array([[1000, 0], [1100, 0], [37, 0]], np.int32)
+    ct = np.array([[1005, 0], [1100, 0], [300, 0]], np.int32)
+    bi, bd, sd = bruteforce_batch(torch.from_numpy(q).cuda(), torch.from_numpy(cq).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(ct).cuda())
+    torch.cuda.synchronize()
+    for b in range(B):
+        rbi, rbd, rsd = O.bruteforce_match(q[b, :cq[b, 0]], t[b, :ct[b, 0]])
+        n = cq[b, 0]
+        assert np.array_equal(bi[b, :n].cpu().numpy(), rbi) and np.array_equal(bd[b, :n].cpu().numpy(), rbd)
+        assert np.array_equal(sd[b, :n].cpu().numpy(), rsd)
+    assert bi[1, 0].item() == 5 and bd[1, 0].item() == 0 and sd[1, 0].item() == 0
