@@ -1,0 +1,70 @@
+/*
+ * rumi_opt.h — C ABI of the MI355X-native pose optimisation and local bundle adjustment (librumi_hip.so).
+ *
+ * Drop-in boundary for the two hot members of the all-static class ORB_SLAM3::Optimizer
+ * (R/ = /root/reference/src/rumi-slam/, G/ = R/Thirdparty/g2o/g2o/):
+ *   static int  PoseOptimization(Frame *pFrame)                                  R/include/cloud_edge_slam_lib/Optimizer.h:55, R/lib_src/Optimizer.cc:723-1001
+ *   static void LocalBundleAdjustment(KeyFrame*, bool *pbStopFlag, Map*, int&x4) R/include/cloud_edge_slam_lib/Optimizer.h:53, R/lib_src/Optimizer.cc:1003-1355
+ * and the g2o Levenberg-Marquardt / Huber / Schur machinery they run on (G/core/optimization_algorithm_levenberg.cpp:61-194,
+ * G/core/block_solver.hpp:353-604, G/core/base_{unary,binary}_edge.hpp, G/core/robust_kernel_impl.cpp:78-91, G/types/se3quat.h).
+ * The facade gathers the graph exactly as Optimizer.cc:763-897 / :1011-1271 do (under the same mutexes) and hands it over flat;
+ * erasing observations and writing poses / points back (Optimizer.cc:1325-1354) stays in the facade under Map::mMutexMapUpdate.
+ * Arithmetic is double precision on the device, float at both ends, as in the reference.  Results agree with the reference
+ * algorithm to 1e-4 relative (the reference's own edge order is pointer-order dependent).
+ *
+ * Status codes, error string and threading rules: rumi_orb.h.
+ */
+#ifndef RUMI_OPT_H
+#define RUMI_OPT_H
+
+#include <stdint.h>
+
+#include "rumi_orb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RumiOptimizer RumiOptimizer;
+
+/* Scratch arenas: pose problems of up to max_pose_edges correspondences in total per call (all problems of a batch),
+ * BA problems of up to max_kf key-frame vertices, max_mp points, max_edges observations. */
+int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, int32_t max_kf, int32_t max_mp, int32_t max_edges,
+                    int32_t device, RumiOptimizer **out);
+void rumi_opt_destroy(RumiOptimizer *o);
+
+/* Optimizer::PoseOptimization.  One entry per feature of the frame that holds a map point, in feature order:
+ * Xw n x 3 (MapPoint::GetWorldPos), obs n x 2 (mvKeysUn[i].pt), inv_sigma2 n (mvInvLevelSigma2[octave]); K4 = fx,fy,cx,cy;
+ * Tcw7 in/out = pFrame->GetPose() / SetPose() as (qx,qy,qz,qw,tx,ty,tz); outlier_out n (mvbOutlier).
+ * *n_good_out = the reference's return value nInitialCorrespondences - nBad (0, pose untouched, when n < 3). */
+int rumi_pose_optimization(RumiOptimizer *o, const float *Xw, const float *obs, const float *inv_sigma2, int32_t n,
+                           const float *K4, float *Tcw7, uint8_t *outlier_out, int32_t *n_good_out);
+
+/* The same for B independent frames in one launch (one workgroup per frame).  Problem b owns entries
+ * [start[b], start[b+1]) of Xw / obs / inv_sigma2 / outlier_out; Tcw7 is B x 7, n_good_out is B. */
+int rumi_pose_optimization_batch(RumiOptimizer *o, int32_t nbatch, const int32_t *start, const float *Xw, const float *obs,
+                                 const float *inv_sigma2, const float *K4, float *Tcw7, uint8_t *outlier_out,
+                                 int32_t *n_good_out);
+
+/* Optimizer::LocalBundleAdjustment on the flattened graph:
+ *   kf_pose7  nKF x 7 in/out  key-frame poses Tcw (local key-frames first or in any order); fixed ones are not written
+ *   kf_fixed  nKF             1 = fixed vertex (lFixedCameras, or the map's initial key-frame)
+ *   mp_pos3   nMP x 3 in/out  map point positions
+ *   edges     nE: e_mp / e_kf indices, e_obs nE x 2 (mvKeysUn pt), e_inv_sigma2 nE     (grouped by map point, as the
+ *             reference builds them; any order is accepted)
+ *   stop_flag the reference's pbStopFlag (host memory written by another thread; polled between LM trials; may be NULL)
+ *   erase_out nE: 1 where the reference would erase the observation (chi2 > 5.991 or depth <= 0, Optimizer.cc:1285-1297)
+ *   stats[4]: LM iterations run, LM trials run, number of optimised key-frames, 1 if aborted by the stop flag before start.
+ * Returns RUMI_E_INVALID when there is no fixed key-frame (the reference returns silently, Optimizer.cc:1057-1060). */
+int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                  int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                  const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats);
+
+/* Device time of the last rumi_local_ba call by stage, in ms (HIP events):
+ * [0] linearise+Hll/Hpl, [1] pose block J^T W J on f64 MFMA, [2] Schur complement, [3] reduced solve, [4] update+chi2, [5] total */
+int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUMI_OPT_H */

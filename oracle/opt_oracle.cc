@@ -1,0 +1,484 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement (double precision, scalar) of the reference's motion-only BA
+// and local BA, including the g2o machinery they run on.  R/ = /root/reference/src/rumi-slam/, G/ = R/Thirdparty/g2o/g2o/.
+//   Optimizer::PoseOptimization                      R/lib_src/Optimizer.cc:723-1001
+//   Optimizer::LocalBundleAdjustment                 R/lib_src/Optimizer.cc:1003-1355   (graph already flattened)
+//   EdgeSE3ProjectXYZOnlyPose / EdgeSE3ProjectXYZ    R/include/cloud_edge_slam_lib/OptimizableTypes.h:41-50,98-109, R/lib_src/OptimizableTypes.cpp:47-61,135-156
+//   Pinhole::project / projectJac                    R/lib_src/CameraModels/Pinhole.cpp:35-49,71-81
+//   OptimizationAlgorithmLevenberg::solve            G/core/optimization_algorithm_levenberg.cpp:61-194
+//   SparseOptimizer::optimize / activeRobustChi2     G/core/sparse_optimizer.cpp:100-114,354-419
+//   BlockSolver buildSystem/setLambda/solve (Schur)  G/core/block_solver.hpp:353-486,501-604
+//   constructQuadraticForm (unary / binary)          G/core/base_unary_edge.hpp:42-72, G/core/base_binary_edge.hpp:54-120
+//   RobustKernelHuber::robustify, robustInformation  G/core/robust_kernel_impl.cpp:78-91, G/core/base_edge.h:96-102
+//   SE3Quat exp / map / operator* / normalize         G/types/se3quat.h:104-121,217-285; VertexSE3Expmap::oplusImpl types_six_dof_expmap.h:73-76
+// The linear solvers (Eigen LDLT 6x6; SimplicialLDLT on the reduced pose system) are replaced by a dense Cholesky:
+// Eigen is not in the tree and the target is 1e-4 relative on poses / landmarks, not bit-exactness.
+// PARITY STATUS: "parity unpinned" against the reference binary (no tests / golden vectors exist; g2o cannot be
+// built here without Eigen); pinned by source and by the properties in tests/test_optimizer_cpu.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace orcopt {
+
+struct V3 { double x, y, z; };
+struct Quat { double x, y, z, w; };
+struct SE3 { Quat r; V3 t; };
+
+static inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// Eigen QuaternionBase::_transformVector: v + w*uv + q.vec x uv, uv = 2 q.vec x v
+static inline V3 rotate(const Quat &q, V3 v) {
+    V3 qv{q.x, q.y, q.z};
+    V3 uv = cross(qv, v);
+    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    V3 c = cross(qv, uv);
+    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+static inline V3 se3_map(const SE3 &T, V3 p) { return add(rotate(T.r, p), T.t); }      // SE3Quat::map
+
+static inline void normalize_rotation(Quat &q) {                                        // se3quat.h:280-285
+    if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+static inline Quat qmul(const Quat &a, const Quat &b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+// Eigen Quaternion(Matrix3) constructor
+static Quat quat_from_R(const double R[3][3]) {
+    Quat q;
+    double t = R[0][0] + R[1][1] + R[2][2];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (R[2][1] - R[1][2]) * t; q.y = (R[0][2] - R[2][0]) * t; q.z = (R[1][0] - R[0][1]) * t;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[0][0]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (R[k][j] - R[j][k]) * t;
+        v[j] = (R[j][i] + R[i][j]) * t;
+        v[k] = (R[k][i] + R[i][k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+static void quat_to_R(const Quat &q, double R[3][3]) {                                   // Eigen toRotationMatrix
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+    R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+}
+// SE3Quat::exp(update): first three = rotation, last three = translation   se3quat.h:217-257
+static SE3 se3_exp(const double u[6]) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = std::sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double O2[3][3], R[3][3], V[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { O2[i][j] = 0; for (int k = 0; k < 3; k++) O2[i][j] += O[i][k] * O[k][j]; }
+    if (theta < 0.00001) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = (i == j) + O[i][j] + O2[i][j]; V[i][j] = R[i][j]; }
+    } else {
+        const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta), c = (theta - std::sin(theta)) / std::pow(theta, 3);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = (i == j) + a * O[i][j] + b * O2[i][j]; V[i][j] = (i == j) + b * O[i][j] + c * O2[i][j]; }
+    }
+    SE3 T;
+    T.r = quat_from_R(R);
+    T.t = {V[0][0] * u[3] + V[0][1] * u[4] + V[0][2] * u[5], V[1][0] * u[3] + V[1][1] * u[4] + V[1][2] * u[5],
+           V[2][0] * u[3] + V[2][1] * u[4] + V[2][2] * u[5]};
+    normalize_rotation(T.r);                      // SE3Quat(q, t) constructor
+    return T;
+}
+static SE3 se3_mul(const SE3 &a, const SE3 &b) {  // SE3Quat::operator*
+    SE3 r = a;
+    r.t = add(r.t, rotate(a.r, b.t));
+    r.r = qmul(a.r, b.r);
+    normalize_rotation(r.r);
+    return r;
+}
+static SE3 se3_from_float7(const float *T7) {     // g2o::SE3Quat(Tcw.unit_quaternion().cast<double>(), Tcw.translation().cast<double>())
+    SE3 T{{T7[0], T7[1], T7[2], T7[3]}, {T7[4], T7[5], T7[6]}};
+    normalize_rotation(T.r);
+    return T;
+}
+static void se3_to_float7(const SE3 &T, float *o) {   // Sophus::SE3f(rotation().cast<float>(), translation().cast<float>()) normalises the float quaternion
+    float q[4] = {(float)T.r.x, (float)T.r.y, (float)T.r.z, (float)T.r.w};
+    const float n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) o[i] = q[i] / n;
+    o[4] = (float)T.t.x; o[5] = (float)T.t.y; o[6] = (float)T.t.z;
+}
+
+struct Cam { double fx, fy, cx, cy; };
+static inline void project(const Cam &c, V3 p, double &u, double &v) { u = c.fx * p.x / p.z + c.cx; v = c.fy * p.y / p.z + c.cy; }
+static inline void huber(double e, double delta, double dsqr, double rho[3]) {
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { const double s = std::sqrt(e); rho[0] = 2 * s * delta - dsqr; rho[1] = delta / s; rho[2] = -0.5 * rho[1] / e; }
+}
+
+// dense Cholesky solve of a symmetric system; false when a pivot is not positive (g2o: !isPositive / info != Success)
+static bool chol_solve(std::vector<double> A, int n, const double *b, double *x) {
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0) || !std::isfinite(d)) return false;
+        d = std::sqrt(d);
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    std::vector<double> y(n);
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * y[k]; y[i] = s / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    return true;
+}
+
+// Jacobian of the reprojection error w.r.t. the pose increment: -projectJac(Xc) * [ -[Xc]x | I ]   (2 x 6)
+static inline void jac_pose(const Cam &c, V3 p, double J[2][6]) {
+    const double x = p.x, y = p.y, z = p.z;
+    const double j00 = c.fx / z, j02 = -c.fx * x / (z * z), j11 = c.fy / z, j12 = -c.fy * y / (z * z);
+    const double D[3][6] = {{0, z, -y, 1, 0, 0}, {-z, 0, x, 0, 1, 0}, {y, -x, 0, 0, 0, 1}};
+    for (int k = 0; k < 6; k++) { J[0][k] = -(j00 * D[0][k] + j02 * D[2][k]); J[1][k] = -(j11 * D[1][k] + j12 * D[2][k]); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One g2o optimize(iterations) run of Levenberg-Marquardt over a generic problem described by callbacks.
+// ---------------------------------------------------------------------------------------------------------------
+struct LMProblem {
+    virtual ~LMProblem() {}
+    virtual double robust_chi2() = 0;                 // computeActiveErrors + activeRobustChi2
+    virtual void build() = 0;                         // buildSystem at the current estimate
+    virtual double max_diag() = 0;                    // computeLambdaInit's max |H_jj|
+    virtual bool solve(double lambda) = 0;            // setLambda + solve + restoreDiagonal -> x
+    virtual double scale(double lambda) = 0;          // sum_j x_j (lambda x_j + b_j)
+    virtual void push() = 0; virtual void pop() = 0;  // save / restore estimates
+    virtual void update() = 0;                        // oplus(x)
+    virtual bool terminate() { return false; }
+};
+
+static int lm_optimize(LMProblem &P, int iterations) {
+    double lambda = -1, ni = 2;
+    int nBad = 0, done = 0;
+    const double goodUpper = 2. / 3., goodLower = 1. / 3., tau = 1e-5;
+    for (int it = 0; it < iterations && !P.terminate(); it++) {
+        double currentChi = P.robust_chi2(), tempChi = currentChi;
+        const double iniChi = currentChi;
+        P.build();
+        if (it == 0) { lambda = tau * P.max_diag(); ni = 2; nBad = 0; }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            P.push();
+            const bool ok2 = P.solve(lambda);
+            P.update();
+            tempChi = P.robust_chi2();
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            double sc = P.scale(lambda);
+            sc += 1e-3;
+            rho /= sc;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, goodUpper);
+                const double scaleFactor = std::max(goodLower, alpha);
+                lambda *= scaleFactor;
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                P.pop();
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10 && !P.terminate());
+        done++;
+        if (qmax == 10 || rho == 0) break;                 // Terminate
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+    }
+    return done;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct PoseProblem : LMProblem {
+    int n; const V3 *Xw; const double *obs, *info; const uint8_t *active; Cam cam; bool robust; double delta, dsqr;
+    SE3 T, saved;
+    double H[36], b[6], x[6];
+    std::vector<double> lastChi2;      // chi2 of each edge as of the last computeActiveErrors() (g2o keeps _error on the edge)
+    double edge_chi2(int i, double e[2]) const {
+        double u, v;
+        project(cam, se3_map(T, Xw[i]), u, v);
+        e[0] = obs[2 * i] - u; e[1] = obs[2 * i + 1] - v;
+        return e[0] * info[i] * e[0] + e[1] * info[i] * e[1];
+    }
+    double robust_chi2() override {
+        double chi = 0;
+        for (int i = 0; i < n; i++) {
+            if (!active[i]) continue;
+            double e[2], c = edge_chi2(i, e);
+            lastChi2[i] = c;
+            if (robust) { double r[3]; huber(c, delta, dsqr, r); chi += r[0]; } else chi += c;
+        }
+        return chi;
+    }
+    void build() override {
+        std::memset(H, 0, sizeof H); std::memset(b, 0, sizeof b);
+        for (int i = 0; i < n; i++) {
+            if (!active[i]) continue;
+            double e[2], c = edge_chi2(i, e), r[3] = {c, 1, 0};
+            if (robust) huber(c, delta, dsqr, r);
+            double J[2][6];
+            jac_pose(cam, se3_map(T, Xw[i]), J);
+            const double w = info[i];
+            for (int a = 0; a < 6; a++) {
+                b[a] -= r[1] * (J[0][a] * w * e[0] + J[1][a] * w * e[1]);
+                for (int c2 = 0; c2 < 6; c2++) H[a * 6 + c2] += (r[1] * w) * (J[0][a] * J[0][c2] + J[1][a] * J[1][c2]);
+            }
+        }
+    }
+    double max_diag() override { double m = 0; for (int j = 0; j < 6; j++) m = std::max(std::fabs(H[j * 7]), m); return m; }
+    bool solve(double lambda) override {
+        std::vector<double> A(H, H + 36);
+        for (int j = 0; j < 6; j++) A[j * 7] += lambda;
+        return chol_solve(A, 6, b, x);
+    }
+    double scale(double lambda) override { double s = 0; for (int j = 0; j < 6; j++) s += x[j] * (lambda * x[j] + b[j]); return s; }
+    void push() override { saved = T; }
+    void pop() override { T = saved; }
+    void update() override { T = se3_mul(se3_exp(x), T); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+struct BAProblem : LMProblem {
+    int nKF, nMP, nE;
+    std::vector<SE3> T, Tsaved; std::vector<V3> X, Xsaved;
+    const uint8_t *fixedKF; const int32_t *eMP, *eKF; const double *obs, *info; Cam cam; double delta, dsqr;
+    const volatile uint8_t *stop;
+    std::vector<int> poseCol;                     // column block of each non-fixed KF, -1 if fixed
+    int nOpt = 0;
+    std::vector<double> Hpp, bp, Hll, bl, Hpl, x, Dinv;  // Hpp: nOpt x 36, Hll: nMP x 9, Hpl: nE x 18 (6x3), x: 6nOpt + 3nMP
+    std::vector<std::vector<int>> edgesOfPoint;
+    std::vector<double> lastChi2;                 // per edge, as of the last computeActiveErrors()
+
+    void init() {
+        poseCol.assign(nKF, -1);
+        for (int k = 0; k < nKF; k++) if (!fixedKF[k]) poseCol[k] = nOpt++;
+        edgesOfPoint.assign(nMP, {});
+        for (int e = 0; e < nE; e++) edgesOfPoint[eMP[e]].push_back(e);
+        Hpp.assign((size_t)nOpt * 36, 0); bp.assign((size_t)nOpt * 6, 0); Hll.assign((size_t)nMP * 9, 0); bl.assign((size_t)nMP * 3, 0);
+        Hpl.assign((size_t)nE * 18, 0); x.assign((size_t)nOpt * 6 + (size_t)nMP * 3, 0); Dinv.assign((size_t)nMP * 9, 0);
+    }
+    double edge_err(int e, double r[2], V3 *pc = nullptr) const {
+        const V3 p = se3_map(T[eKF[e]], X[eMP[e]]);
+        if (pc) *pc = p;
+        double u, v;
+        project(cam, p, u, v);
+        r[0] = obs[2 * e] - u; r[1] = obs[2 * e + 1] - v;
+        return r[0] * info[e] * r[0] + r[1] * info[e] * r[1];
+    }
+    double robust_chi2() override {
+        double chi = 0;
+        lastChi2.resize(nE);
+        for (int e = 0; e < nE; e++) { double r[2], rho[3]; lastChi2[e] = edge_err(e, r); huber(lastChi2[e], delta, dsqr, rho); chi += rho[0]; }
+        return chi;
+    }
+    void build() override {
+        std::fill(Hpp.begin(), Hpp.end(), 0.); std::fill(bp.begin(), bp.end(), 0.); std::fill(Hll.begin(), Hll.end(), 0.);
+        std::fill(bl.begin(), bl.end(), 0.); std::fill(Hpl.begin(), Hpl.end(), 0.);
+        for (int e = 0; e < nE; e++) {
+            double r[2], rho[3];
+            V3 pc;
+            const double c = edge_err(e, r, &pc);
+            huber(c, delta, dsqr, rho);
+            const double w = rho[1] * info[e];
+            double B[2][6], A[2][3], R[3][3];
+            jac_pose(cam, pc, B);                                        // d e / d pose
+            quat_to_R(T[eKF[e]].r, R);
+            const double j00 = cam.fx / pc.z, j02 = -cam.fx * pc.x / (pc.z * pc.z), j11 = cam.fy / pc.z, j12 = -cam.fy * pc.y / (pc.z * pc.z);
+            for (int k = 0; k < 3; k++) { A[0][k] = -(j00 * R[0][k] + j02 * R[2][k]); A[1][k] = -(j11 * R[1][k] + j12 * R[2][k]); }   // -projectJac * R
+            const int p = eMP[e], col = poseCol[eKF[e]];
+            for (int a = 0; a < 3; a++) {
+                bl[p * 3 + a] -= rho[1] * info[e] * (A[0][a] * r[0] + A[1][a] * r[1]);
+                for (int c2 = 0; c2 < 3; c2++) Hll[p * 9 + a * 3 + c2] += w * (A[0][a] * A[0][c2] + A[1][a] * A[1][c2]);
+            }
+            if (col >= 0) {
+                for (int a = 0; a < 6; a++) {
+                    bp[col * 6 + a] -= rho[1] * info[e] * (B[0][a] * r[0] + B[1][a] * r[1]);
+                    for (int c2 = 0; c2 < 6; c2++) Hpp[col * 36 + a * 6 + c2] += w * (B[0][a] * B[0][c2] + B[1][a] * B[1][c2]);
+                    for (int c2 = 0; c2 < 3; c2++) Hpl[(size_t)e * 18 + a * 3 + c2] = w * (B[0][a] * A[0][c2] + B[1][a] * A[1][c2]);
+                }
+            }
+        }
+    }
+    double max_diag() override {
+        double m = 0;
+        for (int k = 0; k < nOpt; k++) for (int j = 0; j < 6; j++) m = std::max(std::fabs(Hpp[k * 36 + j * 7]), m);
+        for (int p = 0; p < nMP; p++) for (int j = 0; j < 3; j++) m = std::max(std::fabs(Hll[p * 9 + j * 4]), m);
+        return m;
+    }
+    bool solve(double lambda) override {
+        const int n = 6 * nOpt;
+        std::vector<double> S((size_t)n * n, 0.), bs(bp);
+        for (int k = 0; k < nOpt; k++)
+            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) S[(size_t)(k * 6 + a) * n + k * 6 + c] = Hpp[k * 36 + a * 6 + c] + (a == c ? lambda : 0.);
+        for (int p = 0; p < nMP; p++) {
+            double D[9];
+            for (int i = 0; i < 9; i++) D[i] = Hll[p * 9 + i];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            // 3x3 inverse by cofactors (Eigen Matrix3d::inverse)
+            const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+            const double det = D[0] * c00 + D[1] * c01 + D[2] * c02, id = 1.0 / det;
+            double *I = &Dinv[p * 9];
+            I[0] = c00 * id; I[1] = (D[2] * D[7] - D[1] * D[8]) * id; I[2] = (D[1] * D[5] - D[2] * D[4]) * id;
+            I[3] = c01 * id; I[4] = (D[0] * D[8] - D[2] * D[6]) * id; I[5] = (D[2] * D[3] - D[0] * D[5]) * id;
+            I[6] = c02 * id; I[7] = (D[1] * D[6] - D[0] * D[7]) * id; I[8] = (D[0] * D[4] - D[1] * D[3]) * id;
+            double db[3];
+            for (int a = 0; a < 3; a++) db[a] = I[a * 3] * bl[p * 3] + I[a * 3 + 1] * bl[p * 3 + 1] + I[a * 3 + 2] * bl[p * 3 + 2];
+            for (int e1 : edgesOfPoint[p]) {
+                const int c1 = poseCol[eKF[e1]];
+                if (c1 < 0) continue;
+                const double *B1 = &Hpl[(size_t)e1 * 18];
+                double BD[18];
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a * 3 + c] = B1[a * 3] * I[c] + B1[a * 3 + 1] * I[3 + c] + B1[a * 3 + 2] * I[6 + c];
+                for (int a = 0; a < 6; a++) bs[c1 * 6 + a] -= B1[a * 3] * db[0] + B1[a * 3 + 1] * db[1] + B1[a * 3 + 2] * db[2];
+                for (int e2 : edgesOfPoint[p]) {
+                    const int c2 = poseCol[eKF[e2]];
+                    if (c2 < 0) continue;
+                    const double *B2 = &Hpl[(size_t)e2 * 18];
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                        S[(size_t)(c1 * 6 + a) * n + c2 * 6 + c] -= BD[a * 3] * B2[c * 3] + BD[a * 3 + 1] * B2[c * 3 + 1] + BD[a * 3 + 2] * B2[c * 3 + 2];
+                }
+            }
+        }
+        std::fill(x.begin(), x.end(), 0.);
+        if (n > 0 && !chol_solve(S, n, bs.data(), x.data())) return false;
+        for (int p = 0; p < nMP; p++) {                                   // xl = Dinv (bl - Hpl^T xp)
+            double cl[3] = {bl[p * 3], bl[p * 3 + 1], bl[p * 3 + 2]};
+            for (int e : edgesOfPoint[p]) {
+                const int c1 = poseCol[eKF[e]];
+                if (c1 < 0) continue;
+                const double *B1 = &Hpl[(size_t)e * 18];
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 6; a++) cl[c] -= B1[a * 3 + c] * x[c1 * 6 + a];
+            }
+            const double *I = &Dinv[p * 9];
+            for (int a = 0; a < 3; a++) x[n + p * 3 + a] = I[a * 3] * cl[0] + I[a * 3 + 1] * cl[1] + I[a * 3 + 2] * cl[2];
+        }
+        return true;
+    }
+    double scale(double lambda) override {
+        double s = 0;
+        const int n = 6 * nOpt;
+        for (int j = 0; j < n; j++) s += x[j] * (lambda * x[j] + bp[j]);
+        for (int j = 0; j < 3 * nMP; j++) s += x[n + j] * (lambda * x[n + j] + bl[j]);
+        return s;
+    }
+    void push() override { Tsaved = T; Xsaved = X; }
+    void pop() override { T = Tsaved; X = Xsaved; }
+    void update() override {
+        const int n = 6 * nOpt;
+        for (int k = 0; k < nKF; k++) if (poseCol[k] >= 0) T[k] = se3_mul(se3_exp(&x[poseCol[k] * 6]), T[k]);
+        for (int p = 0; p < nMP; p++) { X[p].x += x[n + p * 3]; X[p].y += x[n + p * 3 + 1]; X[p].z += x[n + p * 3 + 2]; }
+    }
+    bool terminate() override { return stop && *stop; }
+};
+
+}  // namespace orcopt
+
+using namespace orcopt;
+
+extern "C" {
+
+// Optimizer::PoseOptimization on flat arrays (one entry per feature that holds a map point, in feature order).
+// Xw: n x 3 float (GetWorldPos), obs: n x 2 float (mvKeysUn pt), invSigma2: n float, K4: fx fy cx cy, Tcw7 in/out
+// (qx qy qz qw tx ty tz), outlier: n u8 out.  Returns nInitialCorrespondences - nBad (0 and no change if n < 3).
+int orc_pose_optimization(const float *Xw, const float *obs, const float *invSigma2, int n, const float *K4, float *Tcw7,
+                          uint8_t *outlier) {
+    for (int i = 0; i < n; i++) outlier[i] = 0;
+    if (n < 3) return 0;
+    std::vector<V3> X(n);
+    std::vector<double> o(2 * (size_t)n), w(n);
+    for (int i = 0; i < n; i++) {
+        X[i] = {Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2]};
+        o[2 * i] = obs[2 * i]; o[2 * i + 1] = obs[2 * i + 1]; w[i] = invSigma2[i];
+    }
+    std::vector<uint8_t> active(n, 1);
+    PoseProblem P;
+    P.lastChi2.assign(n, 0.);
+    P.n = n; P.Xw = X.data(); P.obs = o.data(); P.info = w.data(); P.active = active.data();
+    P.cam = {K4[0], K4[1], K4[2], K4[3]};
+    const float deltaMono = (float)std::sqrt(5.991);
+    P.delta = deltaMono; P.dsqr = P.delta * P.delta; P.robust = true;
+    const SE3 T0 = se3_from_float7(Tcw7);
+    const float chi2Mono[4] = {5.991f, 5.991f, 5.991f, 5.991f};
+    int nBad = 0;
+    for (int it = 0; it < 4; it++) {
+        P.T = T0;                                                   // the estimate is reset to pFrame->GetPose() every round
+        int nActive = 0;
+        for (int i = 0; i < n; i++) nActive += active[i];
+        if (nActive > 0) lm_optimize(P, 10);                        // initializeOptimization(0) + optimize(10)
+        nBad = 0;
+        for (int i = 0; i < n; i++) {
+            // Optimizer.cc:917-926: edges that were outliers (inactive) get computeError() at the final pose; active edges
+            // keep the error of the LAST computeActiveErrors(), which after 10 rejected trials is the rejected state.
+            double e[2];
+            const float chi2 = (float)(outlier[i] ? P.edge_chi2(i, e) : P.lastChi2[i]);
+            if (chi2 > chi2Mono[it]) { outlier[i] = 1; active[i] = 0; nBad++; }
+            else { outlier[i] = 0; active[i] = 1; }
+        }
+        if (it == 2) P.robust = false;
+        if (n < 10) break;
+    }
+    se3_to_float7(P.T, Tcw7);
+    return n - nBad;
+}
+
+// Optimizer::LocalBundleAdjustment on a flattened graph.  kfPose: nKF x 7 float in/out (only non-fixed are written),
+// kfFixed: nKF u8, mpPos: nMP x 3 float in/out, edges: (mp, kf, obs x/y float, invSigma2 float), K4, stop flag (may be null).
+// eraseOut: nE u8 (chi2 > 5.991 || depth <= 0 after optimisation).  Returns the number of LM iterations run, -1 if aborted
+// before optimising (stop flag set, Optimizer.cc:1274-1276).
+int orc_local_ba(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float *mpPos, int nE, const int32_t *eMP,
+                 const int32_t *eKF, const float *eObs, const float *eInvSigma2, const float *K4, const volatile uint8_t *stop,
+                 uint8_t *eraseOut) {
+    if (stop && *stop) return -1;
+    BAProblem P;
+    P.nKF = nKF; P.nMP = nMP; P.nE = nE; P.fixedKF = kfFixed; P.eMP = eMP; P.eKF = eKF; P.stop = stop;
+    P.T.resize(nKF); P.X.resize(nMP);
+    for (int k = 0; k < nKF; k++) P.T[k] = se3_from_float7(kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) P.X[p] = {mpPos[3 * p], mpPos[3 * p + 1], mpPos[3 * p + 2]};
+    std::vector<double> o(2 * (size_t)nE), w(nE);
+    for (int e = 0; e < nE; e++) { o[2 * e] = eObs[2 * e]; o[2 * e + 1] = eObs[2 * e + 1]; w[e] = eInvSigma2[e]; }
+    P.obs = o.data(); P.info = w.data();
+    P.cam = {K4[0], K4[1], K4[2], K4[3]};
+    const float thHuberMono = (float)std::sqrt(5.991);
+    P.delta = thHuberMono; P.dsqr = P.delta * P.delta;
+    P.init();
+    const int its = lm_optimize(P, 10);
+    for (int e = 0; e < nE; e++) {
+        double r[2];
+        V3 pc;
+        P.edge_err(e, r, &pc);                                            // isDepthPositive() uses the current estimates
+        const double chi2 = its > 0 ? P.lastChi2[e] : P.edge_err(e, r);   // e->chi2() = error of the last computeActiveErrors()
+        eraseOut[e] = (chi2 > 5.991 || !(pc.z > 0.0)) ? 1 : 0;
+    }
+    for (int k = 0; k < nKF; k++) if (!kfFixed[k]) se3_to_float7(P.T[k], kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) { mpPos[3 * p] = (float)P.X[p].x; mpPos[3 * p + 1] = (float)P.X[p].y; mpPos[3 * p + 2] = (float)P.X[p].z; }
+    return its;
+}
+
+}  // extern "C"

@@ -84,6 +84,9 @@ def ptr(a):
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_match_bruteforce_batch_device"]
 
+OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba",
+               "rumi_opt_stage_ms"]
+
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
                 "rumi_hook_fast_atan2", "rumi_hook_cv_round"]
 

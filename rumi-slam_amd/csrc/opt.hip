@@ -1,0 +1,787 @@
+// MI355X-native pose optimisation and local bundle adjustment behind include/rumi_opt.h (kernels + host side).
+//
+// PoseOptimization  one 256-thread workgroup per frame runs the whole 4-round / 10-iteration Levenberg-Marquardt loop
+//                   in-kernel: residuals + 2x6 Jacobians per lane, 6x6 normal equations by wave shuffles + LDS, 6x6
+//                   Cholesky, SE3 exp update, Huber, outlier re-classification (Optimizer.cc:909-991).  Frames batch.
+// LocalBundleAdjustment  host-driven LM trials over device-resident double-precision state (stop flag polled per trial):
+//   k_ba_build      one lane per observation: residual, Huber weight, 2x3 / 2x6 Jacobians; H_ll, b_l (f64 atomics),
+//                   H_pl per edge, and the sqrt(w)-scaled rows [J_pose | r] of the pose panel, stored per key-frame
+//   k_ba_hpp_mfma   the pose block H_pp = J_p^T W J_p and b_p as a dense Gram contraction on the f64 matrix cores
+//                   (v_mfma_f64_16x16x4_f64, one workgroup per key-frame) — the only GEMM-shaped piece of local BA
+//   k_ba_schur      one wave per landmark: D^-1 = (H_ll + lambda I)^-1, S -= H_pl D^-1 H_pl^T accumulated per workgroup
+//                   in LDS (f64 LDS atomics), flushed once with global f64 atomics
+//   k_ba_solve      reduced pose system (<= 138 unknowns in LDS, larger in L2) by Cholesky in one workgroup
+//   k_ba_update     landmark back-substitution, oplus on poses / points into the TRIAL state, x^T(lambda x + b)
+//   k_ba_chi2       robustified chi2 of a state
+// Accept / reject just swaps the current and trial state pointers (g2o's push / pop / discardTop).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "opt_math.h"
+#include "rumi_common.h"
+#include "rumi_opt.h"
+
+namespace rumi {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ---- block reduction of NV doubles per thread (256 threads); every thread gets the total ----
+template <int NV> __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [4][NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double s = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        v[k] = s;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = (red[k] + red[NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
+}
+
+__device__ __forceinline__ bool chol6_solve(const double *H /*upper 21, row-major packed*/, double lambda, const double *b, double *x) {
+    double A[6][6];
+    int p = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { A[i][j] = H[p]; A[j][i] = H[p]; p++; }
+    for (int i = 0; i < 6; i++) A[i][i] += lambda;
+    for (int j = 0; j < 6; j++) {
+        double d = A[j][j];
+        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+        if (!(d > 0) || !isfinite(d)) return false;
+        d = sqrt(d);
+        A[j][j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i][j];
+            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s / A[i][i]; }
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= A[k][i] * x[k]; x[i] = s / A[i][i]; }
+    return true;
+}
+
+// ==================================================================================================================
+// PoseOptimization
+// ==================================================================================================================
+struct PoseArgs {
+    const int32_t *start;
+    const float *Xw, *obs, *w, *K4;
+    float *Tcw7;
+    uint8_t *outlier;
+    int32_t *nGood;
+    uint8_t *active;      // scratch, one per correspondence
+    double *lastChi2;     // scratch, one per correspondence
+};
+
+__global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
+    __shared__ double red[4 * 28];
+    __shared__ double bc[16];          // broadcast: trial pose (7), ok flag
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int s0 = A.start[b], n = A.start[b + 1] - s0;
+    const float *Xw = A.Xw + (size_t)s0 * 3, *obs = A.obs + (size_t)s0 * 2, *wgt = A.w + s0;
+    uint8_t *outlier = A.outlier + s0, *active = A.active + s0;
+    double *lastChi2 = A.lastChi2 + s0;
+    for (int i = tid; i < n; i += 256) { outlier[i] = 0; active[i] = 1; }
+    if (n < 3) {                                                            // Optimizer.cc:899-900
+        if (tid == 0) A.nGood[b] = 0;
+        return;
+    }
+    const DCam cam{A.K4[0], A.K4[1], A.K4[2], A.K4[3]};
+    const double delta = (double)(float)sqrt(5.991), dsqr = delta * delta;  // const float deltaMono = sqrt(5.991)
+    const DSE3 T0 = se3_from_float7(A.Tcw7 + (size_t)b * 7);
+    DSE3 T = T0;
+    bool robust = true;
+    int nBadRound = 0;
+
+    auto edge_chi2 = [&](int i, const DSE3 &P, double &e0, double &e1, D3 &pc) -> double {
+        pc = se3_map(P, D3{(double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2]});
+        double u, v;
+        cam_project(cam, pc, u, v);
+        e0 = (double)obs[2 * i] - u; e1 = (double)obs[2 * i + 1] - v;
+        const double w = (double)wgt[i];
+        return e0 * w * e0 + e1 * w * e1;
+    };
+    auto robust_chi2 = [&](const DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
+        double acc[1] = {0};
+        for (int i = tid; i < n; i += 256) {
+            if (!active[i]) continue;
+            double e0, e1; D3 pc;
+            const double c = edge_chi2(i, P, e0, e1, pc);
+            lastChi2[i] = c;
+            double r0 = c, r1 = 1;
+            if (robust) huber(c, delta, dsqr, r0, r1);
+            acc[0] += r0;
+        }
+        block_sum<1>(acc, red);
+        return acc[0];
+    };
+
+    for (int it = 0; it < 4; it++) {
+        T = T0;                                                            // estimate reset every round (:910-911)
+        double cnt[1] = {0};
+        for (int i = tid; i < n; i += 256) cnt[0] += active[i];
+        block_sum<1>(cnt, red);
+        if (cnt[0] > 0) {
+            // ---- g2o optimize(10): optimization_algorithm_levenberg.cpp:61-169 ----
+            double lambda = -1, ni = 2;
+            int nBad = 0;
+            for (int itl = 0; itl < 10; itl++) {
+                double currentChi = robust_chi2(T);
+                const double iniChi = currentChi;
+                double hb[27];                                             // buildSystem: 21 upper entries of H, 6 of b
+#pragma unroll
+                for (int k = 0; k < 27; k++) hb[k] = 0;
+                for (int i = tid; i < n; i += 256) {
+                    if (!active[i]) continue;
+                    double e0, e1; D3 pc;
+                    const double c = edge_chi2(i, T, e0, e1, pc);
+                    double r0 = c, r1 = 1;
+                    if (robust) huber(c, delta, dsqr, r0, r1);
+                    double J0[6], J1[6];
+                    jac_pose(cam, pc, J0, J1);
+                    const double w = (double)wgt[i], rw = r1 * w;
+                    int p = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int c2 = a; c2 < 6; c2++) hb[p++] += rw * (J0[a] * J0[c2] + J1[a] * J1[c2]);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
+                }
+                block_sum<27>(hb, red);
+                if (itl == 0) {                                            // computeLambdaInit: tau * max |H_jj|
+                    double m = 0;
+                    int p = 0;
+                    for (int a = 0; a < 6; a++) { m = fmax(fabs(hb[p]), m); p += 6 - a; }
+                    lambda = 1e-5 * m; ni = 2; nBad = 0;
+                }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    const DSE3 saved = T;                                  // push()
+                    double x[6];
+                    const bool ok2 = chol6_solve(hb, lambda, hb + 21, x);   // setLambda + solve + restoreDiagonal
+                    if (ok2) T = se3_mul(se3_exp(x), T);                    // oplusImpl: exp(update) * estimate
+                    double tempChi = robust_chi2(T);
+                    if (!ok2) tempChi = DBL_MAX;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+                    if (ok2) for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + hb[21 + j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha);
+                        ni = 2;
+                        currentChi = tempChi;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                        T = saved;                                         // pop()
+                    }
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                if (qmax == 10 || rho == 0) break;                         // Terminate
+                if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+                if (nBad >= 3) break;
+            }
+        }
+        // re-classification (:916-939): former outliers get a fresh error, active edges keep the last computed one
+        double bad[1] = {0};
+        for (int i = tid; i < n; i += 256) {
+            double e0, e1; D3 pc;
+            const float chi2 = (float)(outlier[i] ? edge_chi2(i, T, e0, e1, pc) : lastChi2[i]);
+            if (chi2 > 5.991f) { outlier[i] = 1; active[i] = 0; bad[0] += 1; }
+            else { outlier[i] = 0; active[i] = 1; }
+        }
+        block_sum<1>(bad, red);
+        nBadRound = (int)bad[0];
+        if (it == 2) robust = false;                                       // setRobustKernel(0)
+        if (n < 10) break;                                                 // optimizer.edges().size() < 10
+    }
+    if (tid == 0) {
+        se3_to_float7(T, A.Tcw7 + (size_t)b * 7);
+        A.nGood[b] = n - nBadRound;
+    }
+    (void)bc;
+}
+
+// ==================================================================================================================
+// LocalBundleAdjustment
+// ==================================================================================================================
+struct BADev {
+    int nKF, nMP, nE, nOpt, n;                 // n = 6 nOpt
+    const int32_t *eMP, *eKF, *poseCol;        // poseCol[kf] = column block or -1 (fixed)
+    const int32_t *ptStart, *ptEdge;           // edges grouped by landmark (CSR)
+    const int32_t *rowSlot;                    // edge -> first of its two rows in the key-frame-ordered pose panel (-1 fixed)
+    const int32_t *kfRowStart;                 // [nOpt + 1] row ranges of the panel
+    const double *obs, *info;
+    DCam cam;
+    double delta, dsqr;
+    double *Hll, *bl, *Hpl, *panel, *Hpp, *bp, *Dinv, *S, *bs, *x, *lastChi2;
+    double *scal;                              // [0] chi2, [1] scale, [2] max diag (as bits), [3] ok flag
+};
+
+__device__ __forceinline__ DSE3 load_pose(const double *T, int k) {
+    const double *p = T + (size_t)k * 8;
+    return DSE3{{p[0], p[1], p[2], p[3]}, {p[4], p[5], p[6]}};
+}
+__device__ __forceinline__ void store_pose(double *T, int k, const DSE3 &P) {
+    double *p = T + (size_t)k * 8;
+    p[0] = P.r.x; p[1] = P.r.y; p[2] = P.r.z; p[3] = P.r.w; p[4] = P.t.x; p[5] = P.t.y; p[6] = P.t.z; p[7] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ba_chi2(BADev B, const double *T, const double *X) {
+    __shared__ double red[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double acc[1] = {0};
+    if (e < B.nE) {
+        const int p = B.eMP[e];
+        const D3 pc = se3_map(load_pose(T, B.eKF[e]), D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
+        double u, v;
+        cam_project(B.cam, pc, u, v);
+        const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, w = B.info[e];
+        const double c = e0 * w * e0 + e1 * w * e1;
+        B.lastChi2[e] = c;
+        double r0, r1;
+        huber(c, B.delta, B.dsqr, r0, r1);
+        acc[0] = r0;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&B.scal[0], acc[0]);
+}
+
+__global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, const double *X) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B.nE) return;
+    const int p = B.eMP[e], kf = B.eKF[e];
+    const DSE3 P = load_pose(T, kf);
+    const D3 pc = se3_map(P, D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
+    double u, v;
+    cam_project(B.cam, pc, u, v);
+    const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, info = B.info[e];
+    const double c = e0 * info * e0 + e1 * info * e1;
+    double r0, r1;
+    huber(c, B.delta, B.dsqr, r0, r1);
+    const double w = r1 * info;
+    double J0[6], J1[6], R[3][3], A0[3], A1[3];
+    jac_pose(B.cam, pc, J0, J1);
+    quat_to_matrix(P.r, R);
+    const double iz = 1.0 / pc.z, iz2 = iz * iz;
+    const double j00 = B.cam.fx * iz, j02 = -B.cam.fx * pc.x * iz2, j11 = B.cam.fy * iz, j12 = -B.cam.fy * pc.y * iz2;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A0[k] = -(j00 * R[0][k] + j02 * R[2][k]); A1[k] = -(j11 * R[1][k] + j12 * R[2][k]); }   // -projectJac * R
+    // landmark block and right-hand side
+    double *Hl = B.Hll + (size_t)p * 9, *bL = B.bl + (size_t)p * 3;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        atomicAdd(&bL[a], -w * (A0[a] * e0 + A1[a] * e1));
+#pragma unroll
+        for (int c2 = a; c2 < 3; c2++) {
+            const double hv = w * (A0[a] * A0[c2] + A1[a] * A1[c2]);
+            atomicAdd(&Hl[a * 3 + c2], hv);
+            if (c2 != a) atomicAdd(&Hl[c2 * 3 + a], hv);
+        }
+    }
+    const int slot = B.rowSlot[e];
+    if (slot >= 0) {
+        double *hp = B.Hpl + (size_t)e * 18;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) hp[a * 3 + c2] = w * (J0[a] * A0[c2] + J1[a] * A1[c2]);
+        const double sw = sqrt(w);
+        double *r0p = B.panel + (size_t)slot * 8, *r1p = r0p + 8;
+#pragma unroll
+        for (int a = 0; a < 6; a++) { r0p[a] = sw * J0[a]; r1p[a] = sw * J1[a]; }
+        r0p[6] = sw * e0; r0p[7] = 0; r1p[6] = sw * e1; r1p[7] = 0;
+    }
+}
+
+// H_pp(kf) = sum over the key-frame's rows of row^T row on the f64 matrix cores; [0:6,0:6] is the 6x6 block, -[0:6,6] is b_p.
+// Lane l feeds element (row l>>4, column l&15) of a 4-row chunk as BOTH operands (A = chunk^T, B = chunk).
+__global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
+    __shared__ double part[4][8][8];
+    const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = B.kfRowStart[kf], r1 = B.kfRowStart[kf + 1];
+    const int col = lane & 15, sub = lane >> 4;
+    v4f64 acc = {0, 0, 0, 0};
+    for (int r = r0 + wave * 4; r < r1; r += 16) {
+        const int row = r + sub;
+        const double v = (row < r1 && col < 8) ? B.panel[(size_t)row * 8 + col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+    // D[row = sub + 4*reg][col]: rows 0..7 live in reg 0 (sub 0..3) and reg 1 (sub 0..3)
+    if (col < 8) { part[wave][sub][col] = acc[0]; part[wave][sub + 4][col] = acc[1]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int a = threadIdx.x >> 3, c = threadIdx.x & 7;
+        const double g = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
+        if (a < 6 && c < 6) B.Hpp[(size_t)kf * 36 + a * 6 + c] = g;
+        if (a < 6 && c == 6) B.bp[(size_t)kf * 6 + a] = -g;
+    }
+}
+
+__global__ void k_ba_maxdiag(BADev B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double m = 0;
+    if (i < B.nOpt * 6) m = fabs(B.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]);
+    else if (i < B.nOpt * 6 + B.nMP * 3) { const int j = i - B.nOpt * 6; m = fabs(B.Hll[(size_t)(j / 3) * 9 + (j % 3) * 4]); }
+    else return;
+    atomicMax(reinterpret_cast<unsigned long long *>(&B.scal[2]), (unsigned long long)__double_as_longlong(m));   // m >= 0: bit order = value order
+}
+
+// Schur complement, one wave per landmark; S and b_schur contributions are accumulated in LDS per workgroup.
+__global__ __launch_bounds__(256) void k_ba_schur(BADev B, double lambda) {
+    extern __shared__ double sl[];               // [n*n] local -(H_pl D^-1 H_pl^T), then [n] local b contribution
+    const int n = B.n, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *Sloc = sl, *bloc = sl + (size_t)n * n;
+    for (int i = threadIdx.x; i < n * n + n; i += 256) sl[i] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * 4 + wave; p < B.nMP; p += gridDim.x * 4) {
+        double D[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) D[i] = B.Hll[(size_t)p * 9 + i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+        const double id = 1.0 / (D[0] * c00 + D[1] * c01 + D[2] * c02);
+        double I[9];
+        I[0] = c00 * id; I[1] = (D[2] * D[7] - D[1] * D[8]) * id; I[2] = (D[1] * D[5] - D[2] * D[4]) * id;
+        I[3] = c01 * id; I[4] = (D[0] * D[8] - D[2] * D[6]) * id; I[5] = (D[2] * D[3] - D[0] * D[5]) * id;
+        I[6] = c02 * id; I[7] = (D[1] * D[6] - D[0] * D[7]) * id; I[8] = (D[0] * D[4] - D[1] * D[3]) * id;
+        if (lane < 9) B.Dinv[(size_t)p * 9 + lane] = I[lane];
+        const double bl0 = B.bl[(size_t)p * 3], bl1 = B.bl[(size_t)p * 3 + 1], bl2 = B.bl[(size_t)p * 3 + 2];
+        const double db0 = I[0] * bl0 + I[1] * bl1 + I[2] * bl2, db1 = I[3] * bl0 + I[4] * bl1 + I[5] * bl2,
+                     db2 = I[6] * bl0 + I[7] * bl1 + I[8] * bl2;
+        const int s0 = B.ptStart[p], m = B.ptStart[p + 1] - s0;
+        // work items: (i, j, a, c) with i, j edges of the landmark, (a, c) an entry of the 6x6 block; upper block-triangle only
+        for (int i = 0; i < m; i++) {
+            const int ei = B.ptEdge[s0 + i], ci = B.poseCol[B.eKF[ei]];
+            if (ci < 0) continue;
+            const double *Hi = B.Hpl + (size_t)ei * 18;
+            if (lane < 6) {
+                const double *h = Hi + lane * 3;
+                atomicAdd(&bloc[ci * 6 + lane], -(h[0] * db0 + h[1] * db1 + h[2] * db2));
+            }
+            for (int j = 0; j < m; j++) {
+                const int ej = B.ptEdge[s0 + j], cj = B.poseCol[B.eKF[ej]];
+                if (cj < ci) continue;                               // cj < 0 (fixed) or lower triangle
+                if (lane < 36) {
+                    const int a = lane / 6, c = lane - a * 6;
+                    const double *hi = Hi + a * 3, *hj = B.Hpl + (size_t)ej * 18 + c * 3;
+                    const double bd0 = hi[0] * I[0] + hi[1] * I[3] + hi[2] * I[6], bd1 = hi[0] * I[1] + hi[1] * I[4] + hi[2] * I[7],
+                                 bd2 = hi[0] * I[2] + hi[1] * I[5] + hi[2] * I[8];
+                    atomicAdd(&Sloc[(size_t)(ci * 6 + a) * n + cj * 6 + c], -(bd0 * hj[0] + bd1 * hj[1] + bd2 * hj[2]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * n; i += 256) { const double v = Sloc[i]; if (v != 0.0) atomicAdd(&B.S[i], v); }
+    for (int i = threadIdx.x; i < n; i += 256) { const double v = bloc[i]; if (v != 0.0) atomicAdd(&B.bs[i], v); }
+}
+
+// Reduced system (H_pp + lambda I + S) x_p = b_p + b_s by Cholesky in one workgroup.  A lives in LDS when it fits, else in `Aglob`.
+__global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, double *Aglob, int useLds) {
+    extern __shared__ double sa[];
+    __shared__ int sFail;
+    const int n = B.n, tid = threadIdx.x, nt = blockDim.x;
+    double *A = useLds ? sa : Aglob;
+    double *rhs = useLds ? sa + (size_t)n * n : Aglob + (size_t)n * n;
+    if (tid == 0) sFail = 0;
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int i = idx / n, j = idx - i * n;
+        const int bi = i / 6, bj = j / 6;
+        // S holds the upper block triangle of the Schur update; H_pp is block diagonal
+        double v = bi <= bj ? B.S[(size_t)i * n + j] : B.S[(size_t)j * n + i];
+        if (bi == bj) {
+            v = B.S[(size_t)(i <= j ? i : j) * n + (i <= j ? j : i)];     // diagonal blocks: keep them symmetric from their upper part
+            v += B.Hpp[(size_t)bi * 36 + (i - bi * 6) * 6 + (j - bj * 6)];
+            if (i == j) v += lambda;
+        }
+        A[idx] = v;
+    }
+    for (int i = tid; i < n; i += nt) rhs[i] = B.bp[i] + B.bs[i];
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double d = A[(size_t)j * n + j];
+            if (!(d > 0) || !isfinite(d)) sFail = 1; else A[(size_t)j * n + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (sFail) break;
+        const double dj = A[(size_t)j * n + j];
+        for (int i = j + 1 + tid; i < n; i += nt) A[(size_t)i * n + j] /= dj;
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int idx = tid; idx < m * m; idx += nt) {
+            const int ii = idx / m, kk = idx - ii * m;
+            if (kk <= ii) A[(size_t)(j + 1 + ii) * n + j + 1 + kk] -= A[(size_t)(j + 1 + ii) * n + j] * A[(size_t)(j + 1 + kk) * n + j];
+        }
+        __syncthreads();
+    }
+    if (sFail) {
+        if (tid == 0) B.scal[3] = 0.0;
+        for (int i = tid; i < n; i += nt) B.x[i] = 0;
+        return;
+    }
+    // forward then backward substitution (column oriented)
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) rhs[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double yj = rhs[j];
+        for (int i = j + 1 + tid; i < n; i += nt) rhs[i] -= A[(size_t)i * n + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (tid == 0) rhs[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double xj = rhs[j];
+        for (int i = tid; i < j; i += nt) rhs[i] -= A[(size_t)j * n + i] * xj;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nt) B.x[i] = rhs[i];
+    if (tid == 0) B.scal[3] = 1.0;
+}
+
+// x_l = D^-1 (b_l - H_pl^T x_p); trial state = oplus(current, x); scale += x^T (lambda x + b)
+__global__ __launch_bounds__(256) void k_ba_update(BADev B, double lambda, const double *T, const double *X, double *Tt, double *Xt) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[1] = {0};
+    if (i < B.nMP) {
+        const int p = i;
+        double c0 = B.bl[3 * p], c1 = B.bl[3 * p + 1], c2 = B.bl[3 * p + 2];
+        for (int s = B.ptStart[p]; s < B.ptStart[p + 1]; s++) {
+            const int e = B.ptEdge[s], col = B.poseCol[B.eKF[e]];
+            if (col < 0) continue;
+            const double *h = B.Hpl + (size_t)e * 18, *xp = B.x + col * 6;
+#pragma unroll
+            for (int a = 0; a < 6; a++) { c0 -= h[a * 3] * xp[a]; c1 -= h[a * 3 + 1] * xp[a]; c2 -= h[a * 3 + 2] * xp[a]; }
+        }
+        const double *I = B.Dinv + (size_t)p * 9;
+        const double x0 = I[0] * c0 + I[1] * c1 + I[2] * c2, x1 = I[3] * c0 + I[4] * c1 + I[5] * c2, x2 = I[6] * c0 + I[7] * c1 + I[8] * c2;
+        B.x[B.n + 3 * p] = x0; B.x[B.n + 3 * p + 1] = x1; B.x[B.n + 3 * p + 2] = x2;
+        Xt[3 * p] = X[3 * p] + x0; Xt[3 * p + 1] = X[3 * p + 1] + x1; Xt[3 * p + 2] = X[3 * p + 2] + x2;
+        acc[0] = x0 * (lambda * x0 + B.bl[3 * p]) + x1 * (lambda * x1 + B.bl[3 * p + 1]) + x2 * (lambda * x2 + B.bl[3 * p + 2]);
+    } else if (i < B.nMP + B.nKF) {
+        const int k = i - B.nMP, col = B.poseCol[k];
+        DSE3 P = load_pose(T, k);
+        if (col >= 0) {
+            const double *xp = B.x + col * 6;
+            double u[6];
+            for (int a = 0; a < 6; a++) { u[a] = xp[a]; acc[0] += xp[a] * (lambda * xp[a] + B.bp[col * 6 + a]); }
+            P = se3_mul(se3_exp(u), P);
+        }
+        store_pose(Tt, k, P);
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0 && acc[0] != 0.0) atomicAdd(&B.scal[1], acc[0]);
+}
+
+__global__ void k_ba_finalize(BADev B, const double *T, const double *X, int useLast, uint8_t *erase) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B.nE) return;
+    const int p = B.eMP[e];
+    const D3 pc = se3_map(load_pose(T, B.eKF[e]), D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
+    double chi2 = B.lastChi2[e];
+    if (!useLast) {
+        double u, v;
+        cam_project(B.cam, pc, u, v);
+        const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v;
+        chi2 = e0 * B.info[e] * e0 + e1 * B.info[e] * e1;
+    }
+    erase[e] = (chi2 > 5.991 || !(pc.z > 0.0)) ? 1 : 0;       // Optimizer.cc:1292
+}
+
+}  // namespace rumi
+
+using namespace rumi;
+
+// ================================================ host side =======================================================
+struct RumiOptimizer {
+    int device = 0;
+    int maxPoseEdges = 0, maxPoseBatch = 0, maxKF = 0, maxMP = 0, maxE = 0;
+    // pose optimisation
+    int32_t *dStart = nullptr, *dNGood = nullptr;
+    float *dXw = nullptr, *dObs = nullptr, *dW = nullptr, *dK = nullptr, *dT7 = nullptr;
+    uint8_t *dOutlier = nullptr, *dActive = nullptr;
+    double *dLastChi2 = nullptr;
+    // BA
+    int32_t *dEMP = nullptr, *dEKF = nullptr, *dPoseCol = nullptr, *dPtStart = nullptr, *dPtEdge = nullptr, *dRowSlot = nullptr,
+            *dKfRowStart = nullptr;
+    double *dObsD = nullptr, *dInfo = nullptr, *dT[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr};
+    double *dHll = nullptr, *dBl = nullptr, *dHpl = nullptr, *dPanel = nullptr, *dHpp = nullptr, *dBp = nullptr, *dDinv = nullptr,
+           *dS = nullptr, *dBs = nullptr, *dXv = nullptr, *dChi = nullptr, *dScal = nullptr, *dAglob = nullptr;
+    uint8_t *dErase = nullptr;
+    double *hScal = nullptr;
+    float stageMs[8] = {0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+template <class T> static int oalloc(T **p, size_t n) {
+    *p = nullptr;
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return RUMI_OK;
+}
+
+extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    void *p[] = {o->dStart, o->dNGood, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dActive, o->dLastChi2, o->dEMP, o->dEKF,
+                 o->dPoseCol, o->dPtStart, o->dPtEdge, o->dRowSlot, o->dKfRowStart, o->dObsD, o->dInfo, o->dT[0], o->dT[1], o->dX[0],
+                 o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
+                 o->dAglob, o->dErase};
+    for (void *q : p) if (q) (void)hipFree(q);
+    if (o->hScal) (void)hipHostFree(o->hScal);
+    for (auto &e : o->ev) if (e) (void)hipEventDestroy(e);
+    delete o;
+}
+
+extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, int32_t max_kf, int32_t max_mp, int32_t max_edges,
+                               int32_t device, RumiOptimizer **out) {
+    if (!out) return RUMI_E_INVALID;
+    *out = nullptr;
+    if (max_pose_edges < 1 || max_pose_batch < 1 || max_kf < 1 || max_mp < 1 || max_edges < 1) { g_lastError = "rumi_opt_create: sizes must be >= 1"; return RUMI_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_lastError = "no HIP device visible: librumi_hip has no CPU fallback"; return RUMI_E_NO_DEVICE; }
+    RumiOptimizer *o = new RumiOptimizer();
+    if (device >= 0) o->device = device; else if (hipGetDevice(&o->device) != hipSuccess) o->device = 0;
+    if (hipSetDevice(o->device) != hipSuccess) { delete o; return RUMI_E_NO_DEVICE; }
+    o->maxPoseEdges = max_pose_edges; o->maxPoseBatch = max_pose_batch; o->maxKF = max_kf; o->maxMP = max_mp; o->maxE = max_edges;
+    const size_t PE = max_pose_edges, PB = max_pose_batch, K = max_kf, M = max_mp, E = max_edges, N = 6 * K;
+    int rc;
+#define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_opt_destroy(o); return rc; }
+    TRYA(oalloc(&o->dStart, PB + 1)); TRYA(oalloc(&o->dNGood, PB)); TRYA(oalloc(&o->dXw, PE * 3)); TRYA(oalloc(&o->dObs, PE * 2));
+    TRYA(oalloc(&o->dW, PE)); TRYA(oalloc(&o->dK, 4)); TRYA(oalloc(&o->dT7, PB * 7)); TRYA(oalloc(&o->dOutlier, PE));
+    TRYA(oalloc(&o->dActive, PE)); TRYA(oalloc(&o->dLastChi2, PE));
+    TRYA(oalloc(&o->dEMP, E)); TRYA(oalloc(&o->dEKF, E)); TRYA(oalloc(&o->dPoseCol, K)); TRYA(oalloc(&o->dPtStart, M + 1));
+    TRYA(oalloc(&o->dPtEdge, E)); TRYA(oalloc(&o->dRowSlot, E)); TRYA(oalloc(&o->dKfRowStart, K + 1));
+    TRYA(oalloc(&o->dObsD, E * 2)); TRYA(oalloc(&o->dInfo, E));
+    for (int i = 0; i < 2; i++) { TRYA(oalloc(&o->dT[i], K * 8)); TRYA(oalloc(&o->dX[i], M * 3)); }
+    TRYA(oalloc(&o->dHll, M * 9)); TRYA(oalloc(&o->dBl, M * 3)); TRYA(oalloc(&o->dHpl, E * 18)); TRYA(oalloc(&o->dPanel, E * 16 + 64));
+    TRYA(oalloc(&o->dHpp, K * 36)); TRYA(oalloc(&o->dBp, N)); TRYA(oalloc(&o->dDinv, M * 9)); TRYA(oalloc(&o->dS, N * N));
+    TRYA(oalloc(&o->dBs, N)); TRYA(oalloc(&o->dXv, N + M * 3)); TRYA(oalloc(&o->dChi, E)); TRYA(oalloc(&o->dScal, 8));
+    TRYA(oalloc(&o->dAglob, N * N + N)); TRYA(oalloc(&o->dErase, E));
+#undef TRYA
+    if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    for (auto &e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    *out = o;
+    return RUMI_OK;
+}
+
+extern "C" int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]) {
+    if (!o || !ms) return RUMI_E_INVALID;
+    for (int i = 0; i < 8; i++) ms[i] = o->stageMs[i];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_pose_optimization_batch(RumiOptimizer *o, int32_t nbatch, const int32_t *start, const float *Xw, const float *obs,
+                                            const float *inv_sigma2, const float *K4, float *Tcw7, uint8_t *outlier_out,
+                                            int32_t *n_good_out) {
+    if (!o || nbatch < 1 || !start || !K4 || !Tcw7 || !n_good_out) return RUMI_E_INVALID;
+    const int total = start[nbatch];
+    if (nbatch > o->maxPoseBatch || total > o->maxPoseEdges) { g_lastError = "pose optimisation: batch larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    if (total > 0 && (!Xw || !obs || !inv_sigma2 || !outlier_out)) return RUMI_E_INVALID;
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipMemcpy(o->dStart, start, (size_t)(nbatch + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (total > 0) {
+        HIP_TRY(hipMemcpy(o->dXw, Xw, (size_t)total * 3 * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(o->dObs, obs, (size_t)total * 2 * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(o->dW, inv_sigma2, (size_t)total * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(o->dK, K4, 4 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(o->dT7, Tcw7, (size_t)nbatch * 7 * sizeof(float), hipMemcpyHostToDevice));
+    PoseArgs A{o->dStart, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dNGood, o->dActive, o->dLastChi2};
+    hipLaunchKernelGGL(k_pose_opt, dim3(nbatch), dim3(256), 0, nullptr, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(n_good_out, o->dNGood, (size_t)nbatch * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // the reference leaves the pose untouched when it returns early with < 3 correspondences
+    std::vector<float> T((size_t)nbatch * 7);
+    HIP_TRY(hipMemcpy(T.data(), o->dT7, T.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nbatch; b++)
+        if (start[b + 1] - start[b] >= 3) std::memcpy(Tcw7 + (size_t)b * 7, T.data() + (size_t)b * 7, 7 * sizeof(float));
+    if (total > 0) HIP_TRY(hipMemcpy(outlier_out, o->dOutlier, (size_t)total, hipMemcpyDeviceToHost));
+    return RUMI_OK;
+}
+
+extern "C" int rumi_pose_optimization(RumiOptimizer *o, const float *Xw, const float *obs, const float *inv_sigma2, int32_t n,
+                                      const float *K4, float *Tcw7, uint8_t *outlier_out, int32_t *n_good_out) {
+    if (n < 0) return RUMI_E_INVALID;
+    const int32_t start[2] = {0, n};
+    return rumi_pose_optimization_batch(o, 1, start, Xw, obs, inv_sigma2, K4, Tcw7, outlier_out, n_good_out);
+}
+
+extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                             int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                             const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
+    if (!o || nKF < 1 || nMP < 0 || nE < 0 || !kf_pose7 || !kf_fixed || !K4 || (nMP > 0 && !mp_pos3) ||
+        (nE > 0 && (!e_mp || !e_kf || !e_obs || !e_inv_sigma2 || !erase_out)))
+        return RUMI_E_INVALID;
+    if (nKF > o->maxKF || nMP > o->maxMP || nE > o->maxE) { g_lastError = "local BA: problem larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    int nFixed = 0;
+    for (int k = 0; k < nKF; k++) nFixed += kf_fixed[k] ? 1 : 0;
+    if (nFixed == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
+    if (stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                                     // :1274-1276
+    for (int e = 0; e < nE; e++)
+        if (e_mp[e] < 0 || e_mp[e] >= nMP || e_kf[e] < 0 || e_kf[e] >= nKF) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(o->device));
+
+    // ---- host-side structure (g2o buildStructure): column blocks, edges by landmark, rows by key-frame ----
+    std::vector<int32_t> poseCol(nKF, -1), ptStart(nMP + 1, 0), ptEdge(nE), rowSlot(nE, -1);
+    int nOpt = 0;
+    for (int k = 0; k < nKF; k++) if (!kf_fixed[k]) poseCol[k] = nOpt++;
+    const int n = 6 * nOpt;
+    for (int e = 0; e < nE; e++) ptStart[e_mp[e] + 1]++;
+    for (int p = 0; p < nMP; p++) ptStart[p + 1] += ptStart[p];
+    { std::vector<int32_t> fill(ptStart.begin(), ptStart.end() - 1); for (int e = 0; e < nE; e++) ptEdge[fill[e_mp[e]]++] = e; }
+    std::vector<int32_t> kfRowStart(nOpt + 1, 0);
+    for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) kfRowStart[c + 1] += 2; }
+    for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
+    { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; fill[c] += 2; } } }
+    std::vector<double> T0((size_t)nKF * 8), X0((size_t)nMP * 3), obsD((size_t)nE * 2), info(nE);
+    for (int k = 0; k < nKF; k++) {
+        const DSE3 P = se3_from_float7(kf_pose7 + (size_t)k * 7);
+        double *t = &T0[(size_t)k * 8];
+        t[0] = P.r.x; t[1] = P.r.y; t[2] = P.r.z; t[3] = P.r.w; t[4] = P.t.x; t[5] = P.t.y; t[6] = P.t.z; t[7] = 0;
+    }
+    for (size_t i = 0; i < X0.size(); i++) X0[i] = mp_pos3[i];
+    for (int e = 0; e < nE; e++) { obsD[2 * e] = e_obs[2 * e]; obsD[2 * e + 1] = e_obs[2 * e + 1]; info[e] = e_inv_sigma2[e]; }
+#define UP(dst, v) HIP_TRY(hipMemcpy((dst), (v).data(), (v).size() * sizeof((v)[0]), hipMemcpyHostToDevice))
+    UP(o->dPoseCol, poseCol); UP(o->dPtStart, ptStart); UP(o->dKfRowStart, kfRowStart);
+    if (nE > 0) {
+        UP(o->dPtEdge, ptEdge); UP(o->dRowSlot, rowSlot); UP(o->dObsD, obsD); UP(o->dInfo, info);
+        HIP_TRY(hipMemcpy(o->dEMP, e_mp, (size_t)nE * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(o->dEKF, e_kf, (size_t)nE * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    UP(o->dT[0], T0);
+    if (nMP > 0) UP(o->dX[0], X0);
+#undef UP
+    BADev B{};
+    B.nKF = nKF; B.nMP = nMP; B.nE = nE; B.nOpt = nOpt; B.n = n;
+    B.eMP = o->dEMP; B.eKF = o->dEKF; B.poseCol = o->dPoseCol; B.ptStart = o->dPtStart; B.ptEdge = o->dPtEdge; B.rowSlot = o->dRowSlot;
+    B.kfRowStart = o->dKfRowStart; B.obs = o->dObsD; B.info = o->dInfo;
+    B.cam = DCam{K4[0], K4[1], K4[2], K4[3]};
+    B.delta = (double)(float)std::sqrt(5.991); B.dsqr = B.delta * B.delta;          // const float thHuberMono = sqrt(5.991)
+    B.Hll = o->dHll; B.bl = o->dBl; B.Hpl = o->dHpl; B.panel = o->dPanel; B.Hpp = o->dHpp; B.bp = o->dBp; B.Dinv = o->dDinv; B.S = o->dS;
+    B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
+
+    const int gE = std::max(1, (nE + 255) / 256);
+    const size_t ldsSolve = ((size_t)n * n + n) * sizeof(double);
+    const int useLds = ldsSolve <= 150 * 1024;
+    const size_t ldsSchur = ((size_t)n * n + n) * sizeof(double);
+    const bool schurLds = ldsSchur <= 150 * 1024;
+    if (!schurLds) { g_lastError = "local BA: more than 23 optimised key-frames is not supported yet (Schur accumulator must fit LDS)"; return RUMI_E_CAPACITY; }
+    // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses (static LDS counts against 160 KiB too)
+    if (ldsSchur > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSchur));
+    if (useLds && ldsSolve > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    hipStream_t st = nullptr;
+    auto chi2_of = [&](int which, double *out) -> int {
+        HIP_TRY(hipMemsetAsync(o->dScal, 0, sizeof(double), st));
+        hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[which], o->dX[which]);
+        HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *out = o->hScal[0];
+        return RUMI_OK;
+    };
+    HIP_TRY(hipEventRecord(o->ev[0], st));
+    int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
+    double lambda = -1, ni = 2;
+    int nBad = 0;
+    bool ranChi2 = false;
+    double currentChi = 0;
+    for (int it = 0; it < 10 && !(stop_flag && *stop_flag); it++) {
+        // g2o recomputes the active errors here; the value is already known after the first iteration (an accepted trial
+        // left it in tempChi, a rejected one did not change the state), so only the first iteration launches the kernel.
+        if (it == 0 && (rc = chi2_of(cur, &currentChi)) != RUMI_OK) return rc;
+        ranChi2 = true;
+        const double iniChi = currentChi;
+        // buildSystem
+        HIP_TRY(hipMemsetAsync(o->dHll, 0, (size_t)nMP * 9 * sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(o->dBl, 0, (size_t)nMP * 3 * sizeof(double), st));
+        if (nE > 0) hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur]);
+        if (nOpt > 0) hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt), dim3(256), 0, st, B);
+        if (it == 0) {
+            HIP_TRY(hipMemsetAsync(o->dScal + 2, 0, sizeof(double), st));
+            const int nd = nOpt * 6 + nMP * 3;
+            hipLaunchKernelGGL(k_ba_maxdiag, dim3((nd + 255) / 256), dim3(256), 0, st, B);
+            HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            lambda = 1e-5 * o->hScal[2]; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const int trial = cur ^ 1;
+            HIP_TRY(hipMemsetAsync(o->dS, 0, (size_t)n * n * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(o->dBs, 0, (size_t)n * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(o->dScal, 0, 2 * sizeof(double), st));
+            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_schur, dim3(std::min(64, (nMP + 3) / 4)), dim3(256), ldsSchur, st, B, lambda);
+            if (n > 0) hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(1024), useLds ? ldsSolve : 0, st, B, lambda, o->dAglob, useLds);
+            else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
+            hipLaunchKernelGGL(k_ba_update, dim3((nMP + nKF + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
+            hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const bool ok2 = n == 0 || o->hScal[3] != 0.0;
+            double tempChi = o->hScal[0];
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            const double scale = o->hScal[1] + 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                cur = trial;                       // discardTop(): the trial state becomes the estimate
+            } else {
+                lambda *= ni;
+                ni *= 2;                           // pop(): keep the current state
+            }
+            qmax++;
+            trials++;
+        } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+        iters++;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+    }
+    if (nE > 0) hipLaunchKernelGGL(k_ba_finalize, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dErase);
+    HIP_TRY(hipEventRecord(o->ev[1], st));
+    HIP_TRY(hipGetLastError());
+    std::vector<double> T1((size_t)nKF * 8), X1((size_t)nMP * 3);
+    HIP_TRY(hipMemcpy(T1.data(), o->dT[cur], T1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (nMP > 0) HIP_TRY(hipMemcpy(X1.data(), o->dX[cur], X1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (nE > 0) HIP_TRY(hipMemcpy(erase_out, o->dErase, (size_t)nE, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventElapsedTime(&o->stageMs[5], o->ev[0], o->ev[1]));
+    for (int k = 0; k < nKF; k++) {
+        if (kf_fixed[k]) continue;
+        const double *t = &T1[(size_t)k * 8];
+        se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
+    }
+    for (size_t i = 0; i < X1.size(); i++) mp_pos3[i] = (float)X1[i];
+    if (stats) { stats[0] = iters; stats[1] = trials; stats[2] = nOpt; stats[3] = 0; }
+    return RUMI_OK;
+}

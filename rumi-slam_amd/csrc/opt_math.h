@@ -1,0 +1,141 @@
+// SE(3) / camera / robust-kernel scalar math shared by the optimiser kernels (double precision), restating
+// G/types/se3quat.h (exp :217-257, map :213, operator* :104-110, normalizeRotation :280-285), Eigen's
+// Quaternion <-> Matrix3 conversions, Pinhole::project / projectJac (R/lib_src/CameraModels/Pinhole.cpp:35-49,71-81)
+// and RobustKernelHuber::robustify (G/core/robust_kernel_impl.cpp:78-91).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define RUMI_HD __host__ __device__ inline
+#else
+#define RUMI_HD inline
+#endif
+
+namespace rumi {
+
+struct D3 { double x, y, z; };
+struct DQuat { double x, y, z, w; };
+struct DSE3 { DQuat r; D3 t; };
+struct DCam { double fx, fy, cx, cy; };
+
+RUMI_HD D3 d3_cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+RUMI_HD D3 quat_rotate(const DQuat &q, D3 v) {          // Eigen _transformVector
+    const D3 qv{q.x, q.y, q.z};
+    D3 uv = d3_cross(qv, v);
+    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    const D3 c = d3_cross(qv, uv);
+    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+RUMI_HD D3 se3_map(const DSE3 &T, D3 p) {
+    const D3 r = quat_rotate(T.r, p);
+    return {r.x + T.t.x, r.y + T.t.y, r.z + T.t.z};
+}
+RUMI_HD void quat_normalize_pos(DQuat &q) {
+    if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+RUMI_HD DQuat quat_mul(const DQuat &a, const DQuat &b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+RUMI_HD DQuat quat_from_matrix(const double R[3][3]) {
+    DQuat q;
+    double t = R[0][0] + R[1][1] + R[2][2];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (R[2][1] - R[1][2]) * t; q.y = (R[0][2] - R[2][0]) * t; q.z = (R[1][0] - R[0][1]) * t;
+    } else {
+        // largest diagonal element decides the branch (written out: no runtime-indexed arrays on the device)
+        if (R[0][0] >= R[1][1] && R[0][0] >= R[2][2]) {
+            t = sqrt(R[0][0] - R[1][1] - R[2][2] + 1.0);
+            q.x = 0.5 * t; t = 0.5 / t;
+            q.w = (R[2][1] - R[1][2]) * t; q.y = (R[1][0] + R[0][1]) * t; q.z = (R[2][0] + R[0][2]) * t;
+        } else if (R[1][1] >= R[2][2]) {
+            t = sqrt(R[1][1] - R[2][2] - R[0][0] + 1.0);
+            q.y = 0.5 * t; t = 0.5 / t;
+            q.w = (R[0][2] - R[2][0]) * t; q.z = (R[2][1] + R[1][2]) * t; q.x = (R[0][1] + R[1][0]) * t;
+        } else {
+            t = sqrt(R[2][2] - R[0][0] - R[1][1] + 1.0);
+            q.z = 0.5 * t; t = 0.5 / t;
+            q.w = (R[1][0] - R[0][1]) * t; q.x = (R[0][2] + R[2][0]) * t; q.y = (R[1][2] + R[2][1]) * t;
+        }
+    }
+    return q;
+}
+RUMI_HD void quat_to_matrix(const DQuat &q, double R[3][3]) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+    R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+}
+// SE3Quat::exp: u = (omega, upsilon)
+RUMI_HD DSE3 se3_exp(const double u[6]) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double O2[3][3], R[3][3], V[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+    double a = 1, b = 1, c = 1;
+    const bool small = theta < 0.00001;
+    if (!small) { a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c = (theta - sin(theta)) / (theta * theta * theta); }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const double I = i == j ? 1.0 : 0.0;
+            R[i][j] = small ? I + O[i][j] + O2[i][j] : I + a * O[i][j] + b * O2[i][j];
+            V[i][j] = small ? R[i][j] : I + b * O[i][j] + c * O2[i][j];
+        }
+    DSE3 T;
+    T.r = quat_from_matrix(R);
+    T.t = {V[0][0] * u[3] + V[0][1] * u[4] + V[0][2] * u[5], V[1][0] * u[3] + V[1][1] * u[4] + V[1][2] * u[5],
+           V[2][0] * u[3] + V[2][1] * u[4] + V[2][2] * u[5]};
+    quat_normalize_pos(T.r);
+    return T;
+}
+RUMI_HD DSE3 se3_mul(const DSE3 &a, const DSE3 &b) {
+    DSE3 r;
+    const D3 rt = quat_rotate(a.r, b.t);
+    r.t = {a.t.x + rt.x, a.t.y + rt.y, a.t.z + rt.z};
+    r.r = quat_mul(a.r, b.r);
+    quat_normalize_pos(r.r);
+    return r;
+}
+RUMI_HD DSE3 se3_from_float7(const float *T7) {
+    DSE3 T{{T7[0], T7[1], T7[2], T7[3]}, {T7[4], T7[5], T7[6]}};
+    quat_normalize_pos(T.r);
+    return T;
+}
+RUMI_HD void se3_to_float7(const DSE3 &T, float *o) {     // Sophus::SE3f(q.cast<float>(), t.cast<float>()) normalises the float quaternion
+    const float q0 = (float)T.r.x, q1 = (float)T.r.y, q2 = (float)T.r.z, q3 = (float)T.r.w;
+    const float n = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    o[0] = q0 / n; o[1] = q1 / n; o[2] = q2 / n; o[3] = q3 / n;
+    o[4] = (float)T.t.x; o[5] = (float)T.t.y; o[6] = (float)T.t.z;
+}
+
+RUMI_HD void cam_project(const DCam &c, D3 p, double &u, double &v) { u = c.fx * p.x / p.z + c.cx; v = c.fy * p.y / p.z + c.cy; }
+
+// rho[0] = rho(e), rho[1] = rho'(e)
+RUMI_HD void huber(double e, double delta, double dsqr, double &rho0, double &rho1) {
+    if (e <= dsqr) { rho0 = e; rho1 = 1.; }
+    else { const double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// d e / d (pose increment) = -projectJac(Xc) * [ -[Xc]x | I ]      (OptimizableTypes.cpp:47-61)
+RUMI_HD void jac_pose(const DCam &c, D3 p, double J0[6], double J1[6]) {
+    const double iz = 1.0 / p.z, iz2 = 1.0 / (p.z * p.z);
+    const double j00 = c.fx * iz, j02 = -c.fx * p.x * iz2, j11 = c.fy * iz, j12 = -c.fy * p.y * iz2;
+    // rows of SE3deriv: [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
+    J0[0] = -(j02 * p.y);            J0[1] = -(j00 * p.z - j02 * p.x); J0[2] = -(-j00 * p.y);
+    J0[3] = -j00;                    J0[4] = 0;                         J0[5] = -j02;
+    J1[0] = -(-j11 * p.z + j12 * p.y); J1[1] = -(-j12 * p.x);            J1[2] = -(j11 * p.x);
+    J1[3] = 0;                       J1[4] = -j11;                      J1[5] = -j12;
+}
+
+}  // namespace rumi

@@ -1,0 +1,81 @@
+"""Host-side mirror of the two hot members of the all-static ``ORB_SLAM3::Optimizer``
+(R/include/cloud_edge_slam_lib/Optimizer.h:53,55) over the C ABI in include/rumi_opt.h."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba",
+               "rumi_opt_stage_ms"]
+
+
+def _lib():
+    L = capi.lib()
+    if getattr(L, "_opt_ready", False):
+        return L
+    vp, i32 = C.c_void_p, C.c_int32
+    L.rumi_opt_create.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.rumi_opt_destroy.argtypes = [vp]
+    L.rumi_opt_destroy.restype = None
+    L.rumi_pose_optimization.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
+    L.rumi_pose_optimization_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_local_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_opt_stage_ms.argtypes = [vp, vp]
+    L._opt_ready = True
+    return L
+
+
+class Optimizer:
+    def __init__(self, max_pose_edges=1 << 18, max_pose_batch=1024, max_kf=64, max_mp=16384, max_edges=1 << 18, device=-1):
+        self._lib = _lib()
+        self._h = C.c_void_p()
+        capi.check(self._lib.rumi_opt_create(max_pose_edges, max_pose_batch, max_kf, max_mp, max_edges, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rumi_opt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def PoseOptimization(self, Xw, obs, inv_sigma2, K4, Tcw7):
+        """Returns (nInitialCorrespondences - nBad, Tcw7, outlier[n])."""
+        Xw = np.ascontiguousarray(Xw, np.float32); obs = np.ascontiguousarray(obs, np.float32)
+        w = np.ascontiguousarray(inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+        T = np.ascontiguousarray(Tcw7, np.float32).copy()
+        out = np.zeros(max(len(w), 1), np.uint8)
+        ng = C.c_int32()
+        capi.check(self._lib.rumi_pose_optimization(self._h, capi.ptr(Xw), capi.ptr(obs), capi.ptr(w), len(w), capi.ptr(K4), capi.ptr(T),
+                                                    capi.ptr(out), C.byref(ng)))
+        return ng.value, T, out[:len(w)]
+
+    def PoseOptimizationBatch(self, start, Xw, obs, inv_sigma2, K4, Tcw7):
+        start = np.ascontiguousarray(start, np.int32)
+        Xw = np.ascontiguousarray(Xw, np.float32); obs = np.ascontiguousarray(obs, np.float32)
+        w = np.ascontiguousarray(inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+        T = np.ascontiguousarray(Tcw7, np.float32).copy()
+        B = len(start) - 1
+        out = np.zeros(max(len(w), 1), np.uint8)
+        ng = np.zeros(B, np.int32)
+        capi.check(self._lib.rumi_pose_optimization_batch(self._h, B, capi.ptr(start), capi.ptr(Xw), capi.ptr(obs), capi.ptr(w), capi.ptr(K4),
+                                                          capi.ptr(T), capi.ptr(out), capi.ptr(ng)))
+        return ng, T, out[:len(w)]
+
+    def LocalBundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag=None):
+        """Returns (stats[4], kf_pose, mp_pos, erase[nE])."""
+        kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
+        mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32)
+        ek = np.ascontiguousarray(e_kf, np.int32); eo = np.ascontiguousarray(e_obs, np.float32)
+        ew = np.ascontiguousarray(e_inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+        erase = np.zeros(max(len(em), 1), np.uint8)
+        stats = np.zeros(4, np.int32)
+        sp = capi.ptr(stop_flag) if stop_flag is not None else None
+        capi.check(self._lib.rumi_local_ba(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
+                                           capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
+        return stats, kp, mp, erase[:len(em)]
+
+    def stage_ms(self):
+        ms = np.zeros(8, np.float32)
+        capi.check(self._lib.rumi_opt_stage_ms(self._h, capi.ptr(ms)))
+        return ms

@@ -196,3 +196,36 @@ def bruteforce_match(q, t):
     bi, bd, sd = (np.zeros(len(q), np.int32) for _ in range(3))
     _mlib().orc_bruteforce_match(_p(q), len(q), _p(t), len(t), _p(bi), _p(bd), _p(sd))
     return bi, bd, sd
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimiser (oracle/opt_oracle.cc)
+# ---------------------------------------------------------------------------------------------------------
+def _olib():
+    L = lib()
+    if getattr(L, "_o_ready", False):
+        return L
+    vp, i32 = C.c_void_p, C.c_int
+    L.orc_pose_optimization.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.orc_local_ba.argtypes = [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L._o_ready = True
+    return L
+
+
+def pose_optimization(Xw, obs, inv_sigma2, K4, Tcw7):
+    Xw = np.ascontiguousarray(Xw, np.float32); obs = np.ascontiguousarray(obs, np.float32)
+    w = np.ascontiguousarray(inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+    T = np.ascontiguousarray(Tcw7, np.float32).copy()
+    out = np.zeros(len(w), np.uint8)
+    ngood = _olib().orc_pose_optimization(_p(Xw), _p(obs), _p(w), len(w), _p(K4), _p(T), _p(out))
+    return ngood, T, out
+
+
+def local_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop=None):
+    kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
+    mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32); ek = np.ascontiguousarray(e_kf, np.int32)
+    eo = np.ascontiguousarray(e_obs, np.float32); ew = np.ascontiguousarray(e_inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+    erase = np.zeros(len(em), np.uint8)
+    sp = _p(stop) if stop is not None else None
+    its = _olib().orc_local_ba(len(kfix), _p(kp), _p(kfix), len(mp), _p(mp), len(em), _p(em), _p(ek), _p(eo), _p(ew), _p(K4), sp, _p(erase))
+    return its, kp, mp, erase

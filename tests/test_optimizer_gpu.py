@@ -1,0 +1,83 @@
+"""GPU parity of PoseOptimization / LocalBundleAdjustment against the CPU oracle: poses and landmarks within 1e-4
+relative (north_star), inlier counts and erase flags identical."""
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ba_scene import ba_problem, pose_problem
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def opt():
+    from rumi_slam_amd.optimizer import Optimizer
+    return Optimizer()
+
+
+def _pose_close(a, b, tag=""):
+    # quaternion (unit, w >= 0 by construction) and translation: 1e-4 relative to the vector norms
+    assert np.linalg.norm(a[:4] - b[:4]) <= RTOL * max(1.0, np.linalg.norm(b[:4])), f"{tag} rotation {a[:4]} vs {b[:4]}"
+    assert np.linalg.norm(a[4:] - b[4:]) <= RTOL * max(1e-2, np.linalg.norm(b[4:])), f"{tag} translation {a[4:]} vs {b[4:]}"
+
+
+@pytest.mark.parametrize("seed,n,frac", [(0, 300, 0.1), (1, 600, 0.2), (2, 100, 0.0), (3, 1500, 0.3), (4, 12, 0.1), (5, 9, 0.0)])
+def test_pose_optimization(opt, seed, n, frac):
+    p = pose_problem(seed, n, frac)
+    ng_ref, T_ref, out_ref = O.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["K"], p["T0"])
+    ng, T, out = opt.PoseOptimization(p["Xw"], p["obs"], p["inv_sigma2"], p["K"], p["T0"])
+    assert ng == ng_ref
+    assert np.array_equal(out, out_ref), f"{np.count_nonzero(out != out_ref)} outlier flags differ"
+    _pose_close(T, T_ref, f"seed {seed}")
+
+
+def test_pose_optimization_degenerate(opt):
+    p = pose_problem(7, 300)
+    ng, T, out = opt.PoseOptimization(p["Xw"][:2], p["obs"][:2], p["inv_sigma2"][:2], p["K"], p["T0"])
+    assert ng == 0 and np.array_equal(T, p["T0"]) and not out.any()          # < 3 correspondences: returns 0, pose untouched
+    ng, T, out = opt.PoseOptimization(p["Xw"][:0], p["obs"][:0], p["inv_sigma2"][:0], p["K"], p["T0"])
+    assert ng == 0
+
+
+def test_pose_optimization_batch(opt):
+    probs = [pose_problem(20 + i, 150 + 37 * i, 0.15) for i in range(7)]
+    start = np.cumsum([0] + [len(p["inv_sigma2"]) for p in probs]).astype(np.int32)
+    ng, T, out = opt.PoseOptimizationBatch(start, np.concatenate([p["Xw"] for p in probs]), np.concatenate([p["obs"] for p in probs]),
+                                           np.concatenate([p["inv_sigma2"] for p in probs]), probs[0]["K"], np.stack([p["T0"] for p in probs]))
+    for i, p in enumerate(probs):
+        ng_ref, T_ref, out_ref = O.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["K"], p["T0"])
+        assert ng[i] == ng_ref and np.array_equal(out[start[i]:start[i + 1]], out_ref)
+        _pose_close(T[i], T_ref, f"batch {i}")
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=0, n_opt=20, n_fixed=5, n_points=3000), dict(seed=1, n_opt=6, n_fixed=2, n_points=500),
+                                 dict(seed=2, n_opt=1, n_fixed=3, n_points=200), dict(seed=3, n_opt=12, n_fixed=1, n_points=1500, outlier_frac=0.15)])
+def test_local_bundle_adjustment(opt, cfg):
+    b = ba_problem(**cfg)
+    t0 = time.time()
+    its_ref, kp_ref, mp_ref, er_ref = O.local_ba(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    t_cpu = time.time() - t0
+    t0 = time.time()
+    stats, kp, mp, er = opt.LocalBundleAdjustment(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    t_gpu = time.time() - t0
+    print(f"LBA {cfg}: edges {len(b['e_mp'])} iters ref/gpu {its_ref}/{stats[0]} cpu {t_cpu*1e3:.1f} ms gpu wall {t_gpu*1e3:.1f} ms dev {opt.stage_ms()[5]:.2f} ms")
+    assert stats[0] == its_ref, "number of LM iterations"
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    assert np.array_equal(kp[b["kf_fixed"] == 1], b["kf_pose"][b["kf_fixed"] == 1]), "fixed key-frames must not move"
+    scale = np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-2)
+    assert (np.linalg.norm(mp - mp_ref, axis=1) <= RTOL * scale).all(), "landmarks"
+    assert np.count_nonzero(er != er_ref) == 0, "erase flags"
+
+
+def test_local_ba_stop_flag_and_no_fixed(opt):
+    from rumi_slam_amd import capi
+    b = ba_problem(seed=5, n_opt=4, n_fixed=2, n_points=200)
+    stop = np.ones(1, np.uint8)
+    stats, kp, mp, er = opt.LocalBundleAdjustment(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"], stop)
+    assert stats[3] == 1 and np.array_equal(kp, b["kf_pose"]) and np.array_equal(mp, b["mp_pos"])   # aborted before optimising
+    with pytest.raises(capi.RumiError):
+        opt.LocalBundleAdjustment(b["kf_pose"], np.zeros_like(b["kf_fixed"]), b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
