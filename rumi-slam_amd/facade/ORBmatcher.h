@@ -1,0 +1,167 @@
+// Drop-in ORB_SLAM3::ORBmatcher over the MI355X C ABI (include/rumi_match.h).
+// Class surface: R/include/cloud_edge_slam_lib/ORBmatcher.h:36-103.  The three hot searches are member templates over the
+// data-model types so that this header compiles both against the reference's Frame / KeyFrame / MapPoint (same member
+// names are used: mvKeysUn, mDescriptors, mvpMapPoints, mbTrackInView, ...) and against the small mock types of
+// tests/cpp.  Everything here is marshalling: pointers become indices, results are written back into the caller's vectors.
+#pragma once
+#include <map>
+#include <unordered_map>
+#include <vector>
+
+#include "cv_shim.h"
+#include "rumi_match.h"
+
+namespace ORB_SLAM3 {
+
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    static const int TH_LOW = RUMI_TH_LOW;
+    static const int TH_HIGH = RUMI_TH_HIGH;
+    static const int HISTO_LENGTH = RUMI_HISTO_LENGTH;
+
+    // Computes the Hamming distance between two ORB descriptors
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return rumi_descriptor_distance(a.ptr(0), b.ptr(0)); }
+
+    // One matcher arena per calling thread (handles are not re-entrant).
+    static RumiMatcher *arena() {
+        thread_local RumiMatcher *m = nullptr;
+        if (!m && rumi_match_create(8192, 32768, -1, &m) != RUMI_OK) return nullptr;
+        return m;
+    }
+
+    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches (TrackLocalMap)
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                           const float thFarPoints = 50.0f) {
+        const int nmp = (int)vpMapPoints.size();
+        std::vector<uint8_t> inView(nmp), bad(nmp), desc((size_t)nmp * 32);
+        std::vector<float> px(nmp), py(nmp), vc(nmp), depth(nmp);
+        std::vector<int32_t> lvl(nmp), obs(nmp);
+        std::unordered_map<const MapPointT *, int> idOf;
+        std::vector<MapPointT *> byId(vpMapPoints);
+        for (int i = 0; i < nmp; i++) {
+            MapPointT *p = vpMapPoints[i];
+            idOf.emplace(p, i);
+            inView[i] = p->mbTrackInView; bad[i] = p->isBad();
+            px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; vc[i] = p->mTrackViewCos; depth[i] = p->mTrackDepth;
+            lvl[i] = p->mnTrackScaleLevel; obs[i] = p->Observations();
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+        }
+        // features that already hold a map point: ids beyond nmp for points that are not in vpMapPoints
+        std::vector<int32_t> frameMp(F.N, -1);
+        for (int f = 0; f < F.N; f++) {
+            MapPointT *p = F.mvpMapPoints[f];
+            if (!p) continue;
+            auto it = idOf.find(p);
+            if (it != idOf.end()) frameMp[f] = it->second;
+            else { frameMp[f] = (int)byId.size(); idOf.emplace(p, (int)byId.size()); byId.push_back(p); obs.push_back(p->Observations()); }
+        }
+        // the extra ids only need Observations(): pad the per-point arrays the device indexes by id
+        const int nid = (int)byId.size();
+        std::vector<int32_t> obsAll(obs);
+        RumiFrameFeatures fv = view(F);
+        int32_t nmatches = 0;
+        // the kernel reads mp_obs[id] for every id a feature may hold, so pass the extended array; queries are the first nmp ids
+        inView.resize(nid, 0); bad.resize(nid, 1); px.resize(nid, 0); py.resize(nid, 0); vc.resize(nid, 0); depth.resize(nid, 0);
+        lvl.resize(nid, 0); desc.resize((size_t)nid * 32, 0);
+        if (rumi_search_by_projection_mappoints(arena(), &fv, nid, inView.data(), px.data(), py.data(), lvl.data(), vc.data(), depth.data(),
+                                                bad.data(), desc.data(), obsAll.data(), th, bFarPoints, thFarPoints, mfNNratio,
+                                                frameMp.data(), &nmatches) != RUMI_OK)
+            return -1;
+        for (int f = 0; f < F.N; f++) F.mvpMapPoints[f] = frameMp[f] >= 0 ? byId[frameMp[f]] : nullptr;
+        return nmatches;
+    }
+
+    // Project MapPoints tracked in last frame into the current frame and search matches (TrackWithMotionModel)
+    template <class FrameT>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool /*bMono*/) {
+        using MapPointT = typename std::remove_pointer<typename std::decay<decltype(CurrentFrame.mvpMapPoints[0])>::type>::type;
+        std::unordered_map<const MapPointT *, int> idOf;
+        std::vector<MapPointT *> byId;
+        auto id_of = [&](MapPointT *p) { auto it = idOf.find(p); if (it != idOf.end()) return it->second; idOf.emplace(p, (int)byId.size()); byId.push_back(p); return (int)byId.size() - 1; };
+        std::vector<int32_t> lastMp(LastFrame.N, -1), curMp(CurrentFrame.N, -1);
+        std::vector<uint8_t> lastOut(LastFrame.N, 0);
+        for (int i = 0; i < LastFrame.N; i++) { if (LastFrame.mvpMapPoints[i]) lastMp[i] = id_of(LastFrame.mvpMapPoints[i]); lastOut[i] = LastFrame.mvbOutlier[i]; }
+        for (int i = 0; i < CurrentFrame.N; i++) if (CurrentFrame.mvpMapPoints[i]) curMp[i] = id_of(CurrentFrame.mvpMapPoints[i]);
+        const int nmp = (int)byId.size();
+        std::vector<float> pos((size_t)nmp * 3);
+        std::vector<uint8_t> desc((size_t)nmp * 32);
+        std::vector<int32_t> obs(nmp);
+        for (int i = 0; i < nmp; i++) {
+            const auto P = byId[i]->GetWorldPos();
+            pos[3 * i] = P(0); pos[3 * i + 1] = P(1); pos[3 * i + 2] = P(2);
+            const cv::Mat d = byId[i]->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+            obs[i] = byId[i]->Observations();
+        }
+        const auto Tcw = CurrentFrame.GetPose();
+        const auto q = Tcw.unit_quaternion();
+        const auto t = Tcw.translation();
+        const float T7[7] = {q.x(), q.y(), q.z(), q.w(), t(0), t(1), t(2)};
+        const float K4[4] = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy};
+        RumiFrameFeatures cv_ = view(CurrentFrame);
+        int32_t nmatches = 0;
+        if (rumi_search_by_projection_frame(arena(), &cv_, T7, K4, reinterpret_cast<const RumiKeyPoint *>(LastFrame.mvKeysUn.data()), LastFrame.N,
+                                            lastMp.data(), lastOut.data(), nmp, pos.data(), desc.data(), obs.data(), th, mbCheckOrientation,
+                                            curMp.data(), &nmatches) != RUMI_OK)
+            return -1;
+        for (int f = 0; f < CurrentFrame.N; f++) CurrentFrame.mvpMapPoints[f] = curMp[f] >= 0 ? byId[curMp[f]] : nullptr;
+        return nmatches;
+    }
+
+    // Search matches between MapPoints in a KeyFrame and ORB in a Frame, by vocabulary node (TrackReferenceKeyFrame, Relocalization)
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> &vpMapPointMatches) {
+        const std::vector<MapPointT *> vpMapPointsKF = pKF->GetMapPointMatches();
+        std::vector<int32_t> kfMp(vpMapPointsKF.size(), -1);
+        std::vector<uint8_t> bad(vpMapPointsKF.size(), 0);
+        for (size_t i = 0; i < vpMapPointsKF.size(); i++)
+            if (vpMapPointsKF[i]) { kfMp[i] = (int)i; bad[i] = vpMapPointsKF[i]->isBad(); }     // id = key-frame feature index
+        Csr a = csr(pKF->mFeatVec), b = csr(F.mFeatVec);
+        RumiFrameFeatures kv = view(*pKF), fv = view(F);
+        std::vector<int32_t> matches(F.N, -1);
+        int32_t nmatches = 0;
+        if (rumi_search_by_bow(arena(), &kv, &a.v, kfMp.data(), (int)bad.size(), bad.data(), &fv, &b.v, mfNNratio, mbCheckOrientation,
+                               matches.data(), &nmatches) != RUMI_OK)
+            return -1;
+        vpMapPointMatches.assign(F.N, static_cast<MapPointT *>(nullptr));
+        for (int f = 0; f < F.N; f++) if (matches[f] >= 0) vpMapPointMatches[f] = vpMapPointsKF[matches[f]];
+        return nmatches;
+    }
+
+protected:
+    struct Csr {
+        std::vector<uint32_t> nodes, idx;
+        std::vector<int32_t> off;
+        RumiFeatureVector v;
+    };
+    template <class FeatVecT> static Csr csr(const FeatVecT &fv) {      // DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned>>
+        Csr c;
+        c.off.push_back(0);
+        for (const auto &kv : fv) {
+            c.nodes.push_back((uint32_t)kv.first);
+            for (unsigned i : kv.second) c.idx.push_back(i);
+            c.off.push_back((int32_t)c.idx.size());
+        }
+        c.v = RumiFeatureVector{(int32_t)c.nodes.size(), c.nodes.data(), c.off.data(), c.idx.data()};
+        return c;
+    }
+    template <class FrameT> static RumiFrameFeatures view(const FrameT &F) {
+        RumiFrameFeatures v;
+        v.n = F.N;
+        v.keys_un = reinterpret_cast<const RumiKeyPoint *>(F.mvKeysUn.data());
+        v.desc = F.mDescriptors.ptr(0);
+        v.min_x = F.mnMinX; v.min_y = F.mnMinY; v.max_x = F.mnMaxX; v.max_y = F.mnMaxY;
+        v.scale_factors = F.mvScaleFactors.data();
+        v.nlevels = (int32_t)F.mvScaleFactors.size();
+        return v;
+    }
+
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}  // namespace ORB_SLAM3

@@ -1,0 +1,224 @@
+// GPU test of the C++ facade classes (reference signatures) against the CPU oracle, with a mock data model that has the
+// reference's member names.  Built and run by tests/test_facade_gpu.py:  g++ ... librumi_hip.so liboracle.so
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
+#include <tuple>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "Optimizer.h"
+#include "orb_oracle.h"
+
+extern "C" {
+int orc_search_by_projection_frame(const orc::KeyPoint *, const uint8_t *, int, float, float, float, float, const float *, const float *,
+                                   const float *, const orc::KeyPoint *, int, const int32_t *, const uint8_t *, const float *, const uint8_t *,
+                                   const int32_t *, float, int, int32_t *);
+int orc_pose_optimization(const float *, const float *, const float *, int, const float *, float *, uint8_t *);
+int orc_local_ba(int, float *, const uint8_t *, int, float *, int, const int32_t *, const int32_t *, const float *, const float *, const float *,
+                 const volatile uint8_t *, uint8_t *);
+}
+
+// ---- mock data model: only the members the facades touch, named as in the reference ----
+struct V3f { float v[3]; float operator()(int i) const { return v[i]; } };
+struct Q4f { float q[4]; float x() const { return q[0]; } float y() const { return q[1]; } float z() const { return q[2]; } float w() const { return q[3]; } };
+struct SE3f { float T[7]; Q4f unit_quaternion() const { return Q4f{{T[0], T[1], T[2], T[3]}}; } V3f translation() const { return V3f{{T[4], T[5], T[6]}}; } };
+struct Map { std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int changes = 0; void IncreaseChangeIndex() { changes++; } };
+struct KeyFrame;
+struct MapPoint {
+    static std::mutex mGlobalMutex;
+    V3f pos; cv::Mat desc; int nObs = 1; bool bad = false; Map *map = nullptr; long mnBALocalForKF = -1;
+    std::map<KeyFrame *, std::tuple<int, int>> obs;
+    V3f GetWorldPos() { return pos; }
+    cv::Mat GetDescriptor() { return desc; }
+    int Observations() { return nObs; }
+    bool isBad() { return bad; }
+    Map *GetMap() { return map; }
+    std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return obs; }
+    void EraseObservation(KeyFrame *k) { obs.erase(k); }
+    void SetWorldPosXYZ(float x, float y, float z) { pos = V3f{{x, y, z}}; }
+    void UpdateNormalAndDepth() {}
+    bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
+};
+std::mutex MapPoint::mGlobalMutex;
+struct Frame {
+    int N = 0;
+    std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<MapPoint *> mvpMapPoints; std::vector<bool> mvbOutlier;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2; std::vector<float> mvuRight;
+    float mnMinX = 0, mnMinY = 0, mnMaxX = 640, mnMaxY = 480, fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
+    SE3f pose;
+    SE3f GetPose() const { return pose; }
+    void SetPoseFromQuatTrans(const float *T7) { std::memcpy(pose.T, T7, 28); }
+};
+struct KeyFrame : Frame {
+    long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1; Map *map = nullptr; bool bad = false;
+    std::vector<KeyFrame *> covis;
+    std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return covis; }
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    bool isBad() { return bad; }
+    Map *GetMap() { return map; }
+    void EraseMapPointMatch(MapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
+};
+
+static int fails = 0;
+#define CHECK(c, msg) do { if (!(c)) { std::printf("FAIL: %s (%s:%d)\n", msg, __FILE__, __LINE__); fails++; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 3) { std::printf("usage: test_facade frame0.bin frame1.bin (640x480 u8)\n"); return 2; }
+    std::vector<uint8_t> im[2];
+    for (int k = 0; k < 2; k++) {
+        im[k].resize(640 * 480);
+        FILE *f = std::fopen(argv[1 + k], "rb");
+        if (!f || std::fread(im[k].data(), 1, im[k].size(), f) != im[k].size()) { std::printf("cannot read %s\n", argv[1 + k]); return 2; }
+        std::fclose(f);
+    }
+    // ---- ORBextractor facade == oracle, bit for bit ----
+    ORB_SLAM3::ORBextractor ext(1000, 1.2f, 8, 20, 7);
+    ext.keepPyramid = true;
+    orc::OrbExtractor ref(1000, 1.2f, 8, 20, 7);
+    std::vector<int> lap = {0, 1000};
+    Frame fr[2];
+    for (int k = 0; k < 2; k++) {
+        cv::Mat image(480, 640, CV_8U, im[k].data(), 640), mask;
+        const int mono = ext(image, mask, fr[k].mvKeysUn, fr[k].mDescriptors, lap);
+        std::vector<orc::KeyPoint> rk; std::vector<uint8_t> rd;
+        const int rmono = ref.extract(im[k].data(), 640, 480, 640, 0, 1000, rk, rd);
+        CHECK(mono == rmono && fr[k].mvKeysUn.size() == rk.size(), "extractor count / monoIndex");
+        CHECK(std::memcmp(fr[k].mvKeysUn.data(), rk.data(), rk.size() * 28) == 0, "extractor key-points");
+        bool dsame = true;
+        for (size_t i = 0; i < rk.size(); i++) dsame &= std::memcmp(fr[k].mDescriptors.ptr((int)i), &rd[i * 32], 32) == 0;
+        CHECK(dsame, "extractor descriptors");
+        fr[k].N = (int)rk.size();
+        fr[k].mvScaleFactors = ext.GetScaleFactors(); fr[k].mvInvLevelSigma2 = ext.GetInverseScaleSigmaSquares();
+        fr[k].mvpMapPoints.assign(fr[k].N, nullptr); fr[k].mvbOutlier.assign(fr[k].N, false); fr[k].mvuRight.assign(fr[k].N, -1.f);
+    }
+    CHECK(ext.GetLevels() == 8 && std::fabs(ext.GetScaleFactor() - 1.2f) < 1e-6, "getters");
+    CHECK(ext.mvImagePyramid[1].cols == 533 && ext.mvImagePyramid[1].rows == 400, "mvImagePyramid level size");
+    CHECK(ext.mvImagePyramid[0].ptr(0)[-19 * (int)ext.mvImagePyramid[0].step - 19] == im[1][19 * 640 + 19], "REFLECT_101 border of level 0");
+    cv::Mat empty, mask;
+    std::vector<cv::KeyPoint> k0; cv::Mat d0;
+    CHECK(ext(empty, mask, k0, d0, lap) == -1, "empty image returns -1");
+
+    // ---- SearchByProjection(Cur, Last) facade == oracle ----
+    std::mt19937 rng(5);
+    std::vector<MapPoint> mps(fr[0].N);
+    std::vector<float> pos((size_t)fr[0].N * 3);
+    std::vector<int32_t> lastMp(fr[0].N), obs(fr[0].N);
+    std::vector<uint8_t> outl(fr[0].N, 0), mpDesc((size_t)fr[0].N * 32);
+    const float T7[7] = {0.004f, -0.003f, 0.002f, 0.99998f, 0.02f, -0.01f, 0.03f};
+    std::memcpy(fr[1].pose.T, T7, 28);
+    for (int i = 0; i < fr[0].N; i++) {
+        const float z = 2.f + (rng() % 600) / 100.f;
+        const float u = fr[0].mvKeysUn[i].pt.x + 3.f, v = fr[0].mvKeysUn[i].pt.y - 2.f;
+        mps[i].pos = V3f{{(u - 320.1f) / 535.4f * z, (v - 247.6f) / 539.2f * z, z}};
+        mps[i].desc = cv::Mat(1, 32, CV_8U, fr[0].mDescriptors.ptr(i), 32);
+        mps[i].nObs = (rng() % 20) ? 2 : 0;
+        std::memcpy(&pos[3 * i], mps[i].pos.v, 12); std::memcpy(&mpDesc[(size_t)i * 32], fr[0].mDescriptors.ptr(i), 32);
+        const bool has = rng() % 10 != 0;
+        fr[0].mvpMapPoints[i] = has ? &mps[i] : nullptr;
+        lastMp[i] = has ? i : -1; obs[i] = mps[i].nObs;
+        outl[i] = rng() % 25 == 0; fr[0].mvbOutlier[i] = outl[i];
+    }
+    std::vector<int32_t> curRef(fr[1].N, -1);
+    std::vector<uint8_t> curDesc((size_t)fr[1].N * 32);
+    for (int i = 0; i < fr[1].N; i++) std::memcpy(&curDesc[(size_t)i * 32], fr[1].mDescriptors.ptr(i), 32);
+    const float K4[4] = {535.4f, 539.2f, 320.1f, 247.6f};
+    const int nref = orc_search_by_projection_frame((const orc::KeyPoint *)fr[1].mvKeysUn.data(), curDesc.data(), fr[1].N, 0, 0, 640, 480,
+                                                    fr[1].mvScaleFactors.data(), T7, K4, (const orc::KeyPoint *)fr[0].mvKeysUn.data(), fr[0].N,
+                                                    lastMp.data(), outl.data(), pos.data(), mpDesc.data(), obs.data(), 15.f, 1, curRef.data());
+    ORB_SLAM3::ORBmatcher matcher(0.9f, true);
+    const int ngpu = matcher.SearchByProjection(fr[1], fr[0], 15.f, true);
+    CHECK(ngpu == nref && nref > 50, "SearchByProjection(Cur, Last) count");
+    bool msame = true;
+    for (int i = 0; i < fr[1].N; i++) msame &= (fr[1].mvpMapPoints[i] ? (int)(fr[1].mvpMapPoints[i] - mps.data()) : -1) == curRef[i];
+    CHECK(msame, "SearchByProjection(Cur, Last) assignments");
+
+    // ---- PoseOptimization facade ~ oracle ----
+    std::vector<float> Xw, ob, w;
+    for (int i = 0; i < fr[1].N; i++) if (fr[1].mvpMapPoints[i]) {
+        for (int c = 0; c < 3; c++) Xw.push_back(fr[1].mvpMapPoints[i]->pos.v[c]);
+        ob.push_back(fr[1].mvKeysUn[i].pt.x); ob.push_back(fr[1].mvKeysUn[i].pt.y);
+        w.push_back(fr[1].mvInvLevelSigma2[fr[1].mvKeysUn[i].octave]);
+    }
+    float Tref[7]; std::memcpy(Tref, T7, 28);
+    std::vector<uint8_t> oref(w.size());
+    const int goodRef = orc_pose_optimization(Xw.data(), ob.data(), w.data(), (int)w.size(), K4, Tref, oref.data());
+    const int good = ORB_SLAM3::Optimizer::PoseOptimization(&fr[1]);
+    CHECK(good == goodRef, "PoseOptimization inlier count");
+    double dT = 0; for (int c = 0; c < 7; c++) dT = std::fmax(dT, std::fabs(fr[1].pose.T[c] - Tref[c]));
+    CHECK(dT < 1e-4, "PoseOptimization pose");
+
+    // ---- LocalBundleAdjustment facade ~ oracle on a small synthetic map ----
+    Map map;
+    const int nKF = 6, nMP = 300;
+    std::vector<KeyFrame> kfs(nKF);
+    std::vector<MapPoint> pts(nMP);
+    std::normal_distribution<float> g(0.f, 1.f);
+    for (int p = 0; p < nMP; p++) { pts[p].map = &map; pts[p].pos = V3f{{(rng() % 600) / 100.f - 3.f, (rng() % 400) / 100.f - 2.f, 3.f + (rng() % 500) / 100.f}}; }
+    std::vector<float> kfPose, mpPos, eObs, eW; std::vector<uint8_t> kfFixed; std::vector<int32_t> eMp, eKf;
+    for (int k = 0; k < nKF; k++) {
+        KeyFrame &K = kfs[k];
+        K.mnId = k; K.map = &map; K.mvInvLevelSigma2 = fr[0].mvInvLevelSigma2;
+        const float a = 0.03f * (k - 3);
+        const float T[7] = {0, std::sin(a / 2), 0, std::cos(a / 2), -0.25f * k + 0.6f, 0.01f * k, 0.02f * k};
+        std::memcpy(K.pose.T, T, 28);
+    }
+    for (int k = 1; k < nKF - 1; k++) kfs[nKF - 1].covis.push_back(&kfs[k]);     // kf 5 is "current"; kf 0 sees points but is not covisible -> fixed
+    // observations (truth projection + noise), then perturb the local key-frames and the points
+    for (int p = 0; p < nMP; p++)
+        for (int k = 0; k < nKF; k++) {
+            KeyFrame &K = kfs[k];
+            const float *T = K.pose.T;
+            const float qy = T[1], qw = T[3];
+            const float X = pts[p].pos.v[0], Y = pts[p].pos.v[1], Z = pts[p].pos.v[2];
+            const float xc = (1 - 2 * qy * qy) * X + 2 * qy * qw * Z + T[4], yc = Y + T[5], zc = -2 * qy * qw * X + (1 - 2 * qy * qy) * Z + T[6];
+            const float u = 535.4f * xc / zc + 320.1f, v = 539.2f * yc / zc + 247.6f;
+            if (zc < 0.5f || u < 0 || u >= 640 || v < 0 || v >= 480) continue;
+            cv::KeyPoint kp; kp.pt.x = u + 0.7f * g(rng); kp.pt.y = v + 0.7f * g(rng); kp.octave = rng() % 3;
+            if (rng() % 30 == 0) kp.pt.x += 25.f;
+            const int idx = (int)K.mvKeysUn.size();
+            K.mvKeysUn.push_back(kp); K.mvuRight.push_back(-1.f); K.mvpMapPoints.push_back(&pts[p]); K.N++;
+            pts[p].obs[&K] = std::make_tuple(idx, -1);
+        }
+    for (int k = 1; k < nKF; k++) { kfs[k].pose.T[4] += 0.01f * g(rng); kfs[k].pose.T[6] += 0.01f * g(rng); }
+    for (int p = 0; p < nMP; p++) for (int c = 0; c < 3; c++) pts[p].pos.v[c] += 0.02f * g(rng);
+    // the oracle problem in the facade's construction order: local KFs (5,1,2,3,4), fixed (0); points in first-seen order
+    std::vector<int> order = {5, 1, 2, 3, 4, 0};
+    std::map<KeyFrame *, int> kid;
+    for (size_t i = 0; i < order.size(); i++) { kid[&kfs[order[i]]] = (int)i; kfPose.insert(kfPose.end(), kfs[order[i]].pose.T, kfs[order[i]].pose.T + 7); kfFixed.push_back(order[i] == 0); }
+    std::vector<MapPoint *> plist; std::map<MapPoint *, bool> seen;
+    for (int oi = 0; oi < 5; oi++) for (MapPoint *p : kfs[order[oi]].mvpMapPoints) if (p && !seen[p]) { seen[p] = true; plist.push_back(p); }
+    for (size_t p = 0; p < plist.size(); p++) {
+        mpPos.insert(mpPos.end(), plist[p]->pos.v, plist[p]->pos.v + 3);
+        for (auto &ob2 : plist[p]->obs) {
+            eMp.push_back((int)p); eKf.push_back(kid[ob2.first]);
+            const cv::KeyPoint &kp = ob2.first->mvKeysUn[std::get<0>(ob2.second)];
+            eObs.push_back(kp.pt.x); eObs.push_back(kp.pt.y); eW.push_back(ob2.first->mvInvLevelSigma2[kp.octave]);
+        }
+    }
+    std::vector<uint8_t> er(eMp.size());
+    std::vector<float> kpRef(kfPose), mpRef(mpPos);
+    orc_local_ba((int)order.size(), kpRef.data(), kfFixed.data(), (int)plist.size(), mpRef.data(), (int)eMp.size(), eMp.data(), eKf.data(), eObs.data(),
+                 eW.data(), K4, nullptr, er.data());
+    int nFixed, nOpt, nMPs, nEdges; bool stop = false;
+    ORB_SLAM3::Optimizer::LocalBundleAdjustment(&kfs[5], &stop, &map, nFixed, nOpt, nMPs, nEdges);
+    CHECK(nFixed == 1 && nOpt == 5 && nMPs == (int)plist.size() && nEdges == (int)eMp.size(), "LBA graph sizes");
+    double dK = 0, dP = 0;
+    for (size_t i = 0; i < order.size(); i++) for (int c = 0; c < 7; c++) dK = std::fmax(dK, std::fabs(kfs[order[i]].pose.T[c] - kpRef[i * 7 + c]));
+    for (size_t p = 0; p < plist.size(); p++) for (int c = 0; c < 3; c++) dP = std::fmax(dP, std::fabs(plist[p]->pos.v[c] - mpRef[p * 3 + c]));
+    CHECK(dK < 2e-4 && dP < 1e-3, "LBA poses / points vs oracle");
+    int erased = 0, erasedRef = 0;
+    for (size_t e = 0; e < er.size(); e++) erasedRef += er[e];
+    for (size_t p = 0; p < plist.size(); p++) erased += (int)(0);
+    size_t remaining = 0; for (auto *p : plist) remaining += p->obs.size();
+    CHECK(remaining + erasedRef == eMp.size(), "LBA erased observations");
+    CHECK(map.changes == 1, "IncreaseChangeIndex");
+    std::printf("facade test: %d failure(s); matches %d, pose inliers %d, LBA edges %d (erased %d) dK %.2e dP %.2e\n", fails, ngpu, good, nEdges, erasedRef, dK, dP);
+    (void)erased;
+    return fails ? 1 : 0;
+}
