@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Hot-path benchmark (driver contract: python bench.py --gpus N --steps K --warmup W).
 
-Workload (BASELINE.json configs[1], the configuration the fps target is quoted on): ORB extraction of
-synthetic 640x480 frames, 8-level pyramid, 1000 features/frame, on 1 x MI355X.  One *step* = one batch of
-`--batch` frames (already resident in HBM) through the whole extractor: pyramid -> per-cell FAST+NMS ->
-quadtree -> IC_Angle -> Gaussian blur -> rBRIEF, key-points and descriptors left in HBM.
-With N > 1 (one process per GPU, RCCL) every rank extracts its own `--batch` frames of the rumination queue
+Workload (BASELINE.json configs[1]+[2], the configuration the ">= 10 000 fps ORB extract+match at 1 GPU" target is quoted
+on): synthetic 640x480 frames, 8-level pyramid, 1000 features/frame, on 1 x MI355X.  One *step* = one batch of `--batch`
+frames (already resident in HBM) through the whole extractor (pyramid -> per-cell FAST+NMS -> quadtree -> IC_Angle ->
+Gaussian blur -> rBRIEF) followed by brute-force 256-bit Hamming matching of every frame against its successor in the
+batch; key-points, descriptors and match indices stay in HBM.
+With N > 1 (one process per GPU, RCCL) every rank extracts and matches its own `--batch` frames of the rumination queue
 (weak scaling, configs[4]) and the step ends with the all-gather of (counts, key-points, descriptors).
+The JSON line also carries an `lba` object: BASELINE.json configs[3] (20 key-frames x 3000 map points) on the GPU next to
+the CPU oracle, and `pose_opt` (PoseOptimization, 256 frames x 300 correspondences in one launch).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (per-stage device time from HIP events
 on the stream the kernels run on); `cpu_baseline` is the CPU oracle (kind "port": the reference itself cannot
@@ -41,6 +44,44 @@ def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
                 per_kp=1369 + 749 + 60, total=px[0] + (total - px[0]) + total + 2 * total + n_kp * (1369 + 749 + 60))
 
 
+def side_legs(args):
+    """BASELINE.json configs[3] (local BA) and PoseOptimization, GPU next to the CPU oracle (rank 0, N = 1)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from ba_scene import ba_problem, pose_problem
+    from rumi_slam_amd.optimizer import Optimizer
+    opt = Optimizer()
+    b = ba_problem(seed=0, n_opt=20, n_fixed=5, n_points=3000)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    opt.LocalBundleAdjustment(*a)                                   # warm-up
+    g = []
+    for _ in range(5):
+        t0 = time.perf_counter(); stats, kp, mp, er = opt.LocalBundleAdjustment(*a); g.append(time.perf_counter() - t0)
+    dev_ms = float(opt.stage_ms()[5])
+    c = []
+    for _ in range(3):
+        t0 = time.perf_counter(); its, kpr, mpr, err = oracle_lib.local_ba(*a); c.append(time.perf_counter() - t0)
+    rel = float(np.max(np.linalg.norm(mp - mpr, axis=1) / np.maximum(np.linalg.norm(mpr, axis=1), 1e-2)))
+    lba = {"workload": "LocalBundleAdjustment: 20 optimised + 5 fixed key-frames x 3000 map points (BASELINE.json configs[3])",
+           "edges": int(len(b["e_mp"])), "lm_iterations": int(stats[0]), "lm_trials": int(stats[1]),
+           "gpu_ms_wall": round(min(g) * 1e3, 3), "gpu_ms_device": round(dev_ms, 3), "cpu_ms": round(min(c) * 1e3, 2),
+           "speedup_wall": round(min(c) / min(g), 1), "max_rel_landmark_diff_vs_oracle": rel, "cpu_cores": 1}
+    probs = [pose_problem(100 + i, 300, 0.1) for i in range(256)]
+    start = np.cumsum([0] + [len(p["inv_sigma2"]) for p in probs]).astype(np.int32)
+    pa = (start, np.concatenate([p["Xw"] for p in probs]), np.concatenate([p["obs"] for p in probs]),
+          np.concatenate([p["inv_sigma2"] for p in probs]), probs[0]["K"], np.stack([p["T0"] for p in probs]))
+    opt.PoseOptimizationBatch(*pa)
+    t0 = time.perf_counter(); opt.PoseOptimizationBatch(*pa); gp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for p in probs[:64]:
+        oracle_lib.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["K"], p["T0"])
+    cp = (time.perf_counter() - t0) / 64
+    pose = {"workload": "PoseOptimization: 256 frames x 300 correspondences, one launch (host arrays in, PCIe included)",
+            "gpu_us_per_frame": round(gp / 256 * 1e6, 2), "cpu_us_per_frame": round(cp * 1e6, 2), "speedup": round(cp / (gp / 256), 1)}
+    return {"lba": lba, "pose_opt": pose}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +110,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.matcher import bruteforce_batch
+    from rumi_slam_amd import rumination
     from rumi_slam_amd.synth import synth_frame
 
     B, W, H = args.batch, 640, 480
@@ -82,16 +125,13 @@ def main():
 
     def step():
         kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap)
+        # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
+        match = bruteforce_batch(desc, counts, torch.roll(desc, -1, 0), torch.roll(counts, -1, 0))
         if world > 1:
             # the path's one exchange step: every GPU ends up with all key-points / descriptors
-            gk = torch.empty((world,) + kp.shape, dtype=kp.dtype, device=dev)
-            gd = torch.empty((world,) + desc.shape, dtype=desc.dtype, device=dev)
-            gc = torch.empty((world,) + counts.shape, dtype=counts.dtype, device=dev)
-            dist.all_gather_into_tensor(gk, kp)
-            dist.all_gather_into_tensor(gd, desc)
-            dist.all_gather_into_tensor(gc, counts)
-            return gk, gd, gc
-        return kp, desc, counts
+            gc, gk, gd = rumination.all_gather_records(counts, kp, desc, B * world)
+            return gk, gd, gc, match
+        return kp, desc, counts, match
 
     for _ in range(args.warmup):
         out = step()
@@ -130,10 +170,10 @@ def main():
         dom = max(kern_ms, key=kern_ms.get)
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         line = {
-            "metric": "frames/sec ORB extract", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec ORB extract+match", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ORB extraction only: 640x480, 8-level pyramid, %d features/frame (BASELINE.json configs[1])" % args.nfeatures,
+            "config": {"workload": "ORB extract (640x480, 8-level pyramid, %d features/frame) + brute-force 256-bit Hamming match of consecutive frames (BASELINE.json configs[1]+[2])" % args.nfeatures,
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": round(n_kp, 1),
                        "exchange": "all_gather(counts,keypoints,descriptors) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -146,13 +186,17 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib                      # the checker, timed as the CPU baseline (kind "port")
             orc = oracle_lib.OracleExtractor(args.nfeatures, 1.2, 8, 20, 7)
-            n, c0 = 0, time.perf_counter()
+            n, c0, prev = 0, time.perf_counter(), None
             while n < len(host) * 8 and time.perf_counter() - c0 < args.cpu_seconds:
-                orc.extract(host[n % len(host)], (0, 1000))
+                _, _, d = orc.extract(host[n % len(host)], (0, 1000))
+                if prev is not None:
+                    oracle_lib.bruteforce_match(prev, d)
+                prev = d
                 n += 1
             cdt = time.perf_counter() - c0
             line["cpu_baseline"] = {"value": round(n / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": "%d of the same synthetic frames, oracle/ (g++ -O2, scalar), %.1f s" % (n, cdt)}
+                                    "sample": "%d of the same synthetic frames (extract + brute-force match), oracle/ (g++ -O2, scalar, 1 thread), %.1f s" % (n, cdt)}
+            line.update(side_legs(args))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
