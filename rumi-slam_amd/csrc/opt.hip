@@ -8,9 +8,10 @@
 //                   H_pl per edge, and the sqrt(w)-scaled rows [J_pose | r] of the pose panel, stored per key-frame
 //   k_ba_hpp_mfma   the pose block H_pp = J_p^T W J_p and b_p as a dense Gram contraction on the f64 matrix cores
 //                   (v_mfma_f64_16x16x4_f64, one workgroup per key-frame) — the only GEMM-shaped piece of local BA
-//   k_ba_schur      one wave per landmark: D^-1 = (H_ll + lambda I)^-1, S -= H_pl D^-1 H_pl^T accumulated per workgroup
-//                   in LDS (f64 LDS atomics), flushed once with global f64 atomics
-//   k_ba_solve      reduced pose system (<= 138 unknowns in LDS, larger in L2) by Cholesky in one workgroup
+//   k_ba_dinv/yfill one lane per landmark: D^-1 = (H_ll + lambda I)^-1 = L L^T, z = L^T b_l; one lane per edge: H_pl L into the dense panel Y
+//   k_ba_syrk_mfma  Schur complement Y Y^T (and Y z) as a split-K SYRK on the f64 matrix cores (the window's Y is ~75 % dense)
+//   k_ba_solve      reduced pose system (<= 137 unknowns in LDS, up to 255 in L2): blocked Cholesky (panel 8) with the right-hand
+//                   side as an extra row, two barriers per panel, backward substitution on one wave
 //   k_ba_update     landmark back-substitution, oplus on poses / points into the TRIAL state, x^T(lambda x + b)
 //   k_ba_chi2       robustified chi2 of a state
 // Accept / reject just swaps the current and trial state pointers (g2o's push / pop / discardTop).
@@ -316,25 +317,34 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
 
 // H_pp(kf) = sum over the key-frame's rows of row^T row on the f64 matrix cores; [0:6,0:6] is the 6x6 block, -[0:6,6] is b_p.
 // Lane l feeds element (row l>>4, column l&15) of a 4-row chunk as BOTH operands (A = chunk^T, B = chunk).
+// grid (nOpt, kHppSlices): every wave owns an interleaved subset of the 4-row chunks (4 loads in flight per wave); the
+// slices of one key-frame are combined with f64 atomics into the zeroed H_pp / b_p.
+constexpr int kHppSlices = 8;
 __global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
-    __shared__ double part[4][8][8];
     const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = B.kfRowStart[kf], r1 = B.kfRowStart[kf + 1];
     const int col = lane & 15, sub = lane >> 4;
+    const int nw = kHppSlices * 4, w = blockIdx.y * 4 + wave;
     v4f64 acc = {0, 0, 0, 0};
-    for (int r = r0 + wave * 4; r < r1; r += 16) {
-        const int row = r + sub;
-        const double v = (row < r1 && col < 8) ? B.panel[(size_t)row * 8 + col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    for (int r = r0 + w * 4; r < r1; r += nw * 16) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = r + u * nw * 4 + sub;
+            v[u] = (row < r1 && col < 8) ? B.panel[(size_t)row * 8 + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
     }
-    // D[row = sub + 4*reg][col]: rows 0..7 live in reg 0 (sub 0..3) and reg 1 (sub 0..3)
-    if (col < 8) { part[wave][sub][col] = acc[0]; part[wave][sub + 4][col] = acc[1]; }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int a = threadIdx.x >> 3, c = threadIdx.x & 7;
-        const double g = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
-        if (a < 6 && c < 6) B.Hpp[(size_t)kf * 36 + a * 6 + c] = g;
-        if (a < 6 && c == 6) B.bp[(size_t)kf * 6 + a] = -g;
+    // D[row = sub + 4*reg][col]: rows 0..7 live in reg 0 and reg 1
+#pragma unroll
+    for (int reg = 0; reg < 2; reg++) {
+        const int a = sub + 4 * reg, c = col;
+        const double g = acc[reg];
+        if (g != 0.0) {
+            if (a < 6 && c < 6) atomicAdd(&B.Hpp[(size_t)kf * 36 + a * 6 + c], g);
+            if (a < 6 && c == 6) atomicAdd(&B.bp[(size_t)kf * 6 + a], -g);
+        }
     }
 }
 
@@ -347,92 +357,194 @@ __global__ void k_ba_maxdiag(BADev B) {
     atomicMax(reinterpret_cast<unsigned long long *>(&B.scal[2]), (unsigned long long)__double_as_longlong(m));   // m >= 0: bit order = value order
 }
 
-// Schur complement, one wave per landmark; S and b_schur contributions are accumulated in LDS per workgroup.
-__global__ __launch_bounds__(256) void k_ba_schur(BADev B, double lambda) {
-    extern __shared__ double sl[];               // [n*n] local -(H_pl D^-1 H_pl^T), then [n] local b contribution
-    const int n = B.n, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *Sloc = sl, *bloc = sl + (size_t)n * n;
-    for (int i = threadIdx.x; i < n * n + n; i += 256) sl[i] = 0;
-    __syncthreads();
-    for (int p = blockIdx.x * 4 + wave; p < B.nMP; p += gridDim.x * 4) {
-        double D[9];
+// Schur complement as a dense SYRK on the f64 matrix cores.  With D^-1 = L L^T (3x3 Cholesky per landmark) the update is
+//   S = H_pp + lambda I - Y Y^T,   b_s = b_p - Y z,     Y(:, 3p..3p+2) = stack of H_pl(e) L over the landmark's edges,  z = L^T b_l,
+// and Y is ~75 % dense for a covisibility window (every landmark is seen by most key-frames), so the block-sparse loops of
+// g2o (block_solver.hpp:379-438) become one Gram product.  Yt is stored K-major: row k = 3p+c holds the NP-padded column
+// of Y plus z in entry n, so the augmented Gram matrix G = Yt^T Yt carries Y Y^T in G[0:n,0:n] and Y z in G[0:n,n].
+__global__ void k_ba_dinv(BADev B, double lambda, double *Yt, int NP, double *Lp) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B.nMP) return;
+    double D[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) D[i] = B.Hll[(size_t)p * 9 + i];
-        D[0] += lambda; D[4] += lambda; D[8] += lambda;
-        const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
-        const double id = 1.0 / (D[0] * c00 + D[1] * c01 + D[2] * c02);
-        double I[9];
-        I[0] = c00 * id; I[1] = (D[2] * D[7] - D[1] * D[8]) * id; I[2] = (D[1] * D[5] - D[2] * D[4]) * id;
-        I[3] = c01 * id; I[4] = (D[0] * D[8] - D[2] * D[6]) * id; I[5] = (D[2] * D[3] - D[0] * D[5]) * id;
-        I[6] = c02 * id; I[7] = (D[1] * D[6] - D[0] * D[7]) * id; I[8] = (D[0] * D[4] - D[1] * D[3]) * id;
-        if (lane < 9) B.Dinv[(size_t)p * 9 + lane] = I[lane];
-        const double bl0 = B.bl[(size_t)p * 3], bl1 = B.bl[(size_t)p * 3 + 1], bl2 = B.bl[(size_t)p * 3 + 2];
-        const double db0 = I[0] * bl0 + I[1] * bl1 + I[2] * bl2, db1 = I[3] * bl0 + I[4] * bl1 + I[5] * bl2,
-                     db2 = I[6] * bl0 + I[7] * bl1 + I[8] * bl2;
-        const int s0 = B.ptStart[p], m = B.ptStart[p + 1] - s0;
-        // work items: (i, j, a, c) with i, j edges of the landmark, (a, c) an entry of the 6x6 block; upper block-triangle only
-        for (int i = 0; i < m; i++) {
-            const int ei = B.ptEdge[s0 + i], ci = B.poseCol[B.eKF[ei]];
-            if (ci < 0) continue;
-            const double *Hi = B.Hpl + (size_t)ei * 18;
-            if (lane < 6) {
-                const double *h = Hi + lane * 3;
-                atomicAdd(&bloc[ci * 6 + lane], -(h[0] * db0 + h[1] * db1 + h[2] * db2));
-            }
-            for (int j = 0; j < m; j++) {
-                const int ej = B.ptEdge[s0 + j], cj = B.poseCol[B.eKF[ej]];
-                if (cj < ci) continue;                               // cj < 0 (fixed) or lower triangle
-                if (lane < 36) {
-                    const int a = lane / 6, c = lane - a * 6;
-                    const double *hi = Hi + a * 3, *hj = B.Hpl + (size_t)ej * 18 + c * 3;
-                    const double bd0 = hi[0] * I[0] + hi[1] * I[3] + hi[2] * I[6], bd1 = hi[0] * I[1] + hi[1] * I[4] + hi[2] * I[7],
-                                 bd2 = hi[0] * I[2] + hi[1] * I[5] + hi[2] * I[8];
-                    atomicAdd(&Sloc[(size_t)(ci * 6 + a) * n + cj * 6 + c], -(bd0 * hj[0] + bd1 * hj[1] + bd2 * hj[2]));
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n * n; i += 256) { const double v = Sloc[i]; if (v != 0.0) atomicAdd(&B.S[i], v); }
-    for (int i = threadIdx.x; i < n; i += 256) { const double v = bloc[i]; if (v != 0.0) atomicAdd(&B.bs[i], v); }
+    for (int i = 0; i < 9; i++) D[i] = B.Hll[(size_t)p * 9 + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+    const double id = 1.0 / (D[0] * c00 + D[1] * c01 + D[2] * c02);        // Eigen Matrix3d::inverse (cofactors)
+    double I[9];
+    I[0] = c00 * id; I[1] = (D[2] * D[7] - D[1] * D[8]) * id; I[2] = (D[1] * D[5] - D[2] * D[4]) * id;
+    I[3] = c01 * id; I[4] = (D[0] * D[8] - D[2] * D[6]) * id; I[5] = (D[2] * D[3] - D[0] * D[5]) * id;
+    I[6] = c02 * id; I[7] = (D[1] * D[6] - D[0] * D[7]) * id; I[8] = (D[0] * D[4] - D[1] * D[3]) * id;
+#pragma unroll
+    for (int i = 0; i < 9; i++) B.Dinv[(size_t)p * 9 + i] = I[i];
+    const double l00 = sqrt(I[0]), l10 = I[3] / l00, l20 = I[6] / l00;
+    const double l11 = sqrt(I[4] - l10 * l10), l21 = (I[7] - l20 * l10) / l11, l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
+    double *L = Lp + (size_t)p * 6;
+    L[0] = l00; L[1] = l10; L[2] = l20; L[3] = l11; L[4] = l21; L[5] = l22;
+    const double b0 = B.bl[3 * p], b1 = B.bl[3 * p + 1], b2 = B.bl[3 * p + 2];
+    double *y0 = Yt + (size_t)(3 * p) * NP;
+    y0[B.n] = l00 * b0 + l10 * b1 + l20 * b2; y0[NP + B.n] = l11 * b1 + l21 * b2; y0[2 * NP + B.n] = l22 * b2;    // z = L^T b_l
 }
 
-// Reduced system (H_pp + lambda I + S) x_p = b_p + b_s by Cholesky in one workgroup.  A lives in LDS when it fits, else in `Aglob`.
-__global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, double *Aglob, int useLds) {
+__global__ void k_ba_yfill(BADev B, double *Yt, int NP, const double *Lp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B.nE) return;
+    const int col = B.poseCol[B.eKF[e]];
+    if (col < 0) return;
+    const int p = B.eMP[e];
+    const double *L = Lp + (size_t)p * 6, *h = B.Hpl + (size_t)e * 18;
+    const double l00 = L[0], l10 = L[1], l20 = L[2], l11 = L[3], l21 = L[4], l22 = L[5];
+    double *y0 = Yt + (size_t)(3 * p) * NP + col * 6, *y1 = y0 + NP, *y2 = y1 + NP;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double h0 = h[a * 3], h1 = h[a * 3 + 1], h2 = h[a * 3 + 2];
+        y0[a] = h0 * l00 + h1 * l10 + h2 * l20;
+        y1[a] = h1 * l11 + h2 * l21;
+        y2[a] = h2 * l22;
+    }
+}
+
+// G += Yt^T Yt over a K-slice; one wave per (upper 16x16 tile, slice); grid (tiles, slices/4), 256 threads.
+__global__ __launch_bounds__(256) void k_ba_syrk_mfma(const double *__restrict__ Yt, int K, int NP, int nSlices, double *G) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NT = NP / 16;
+    int t = blockIdx.x, tr = 0;                         // upper-triangle tile index -> (tr, tc)
+    while (t >= NT - tr) { t -= NT - tr; tr++; }
+    const int tc = tr + t;
+    const int slice = blockIdx.y * 4 + wave;
+    const int per = (((K + nSlices - 1) / nSlices) + 3) & ~3;
+    const int k0 = slice * per, k1 = min(K, k0 + per);
+    const int i = lane & 15, kk = lane >> 4;
+    v4f64 acc = {0, 0, 0, 0};
+    for (int k = k0; k < k1; k += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = k + u * 4 + kk;
+            const bool ok = row < k1;
+            a[u] = ok ? Yt[(size_t)row * NP + tr * 16 + i] : 0.0;
+            b[u] = ok ? Yt[(size_t)row * NP + tc * 16 + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const double g = acc[reg];
+        if (g != 0.0) atomicAdd(&G[(size_t)(tr * 16 + kk + 4 * reg) * NP + tc * 16 + i], g);
+    }
+}
+
+// 1/sqrt(d) from the hardware estimate plus two Newton steps (full double accuracy for the well-scaled pivots here); the
+// IEEE sqrt and divide sequences are ~10x longer and sit on the serial pivot chain of the factorisation.
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+
+// Reduced system (H_pp + lambda I - Y Y^T) x_p = b_p - Y z: blocked right-looking Cholesky (panel width 8) of the matrix
+// augmented with the right-hand side as an extra ROW (its factor row is the forward substitution).  Per panel: wave 0
+// factors the 8x8 diagonal block in registers and publishes it through LDS, one thread per row solves its 8 panel entries,
+// then the trailing matrix takes the rank-8 update: three barriers per 8 columns.  The backward substitution keeps y in the
+// registers of wave 0 and walks rows of L (contiguous), so its serial chain is a broadcast and one FMA per unknown.
+// A lives in LDS when it fits (n <= 136), else in `Aglob` (L2).
+constexpr int kPW = 8;
+// USE_LDS is a template parameter so that every access keeps a static address space (a runtime select would make A a
+// generic pointer and turn each LDS access into a flat_load / flat_store).
+template <bool USE_LDS>
+__global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const double *G, int NP, double *Aglob) {
     extern __shared__ double sa[];
+    __shared__ double ldb[kPW * kPW], rdb[kPW];
     __shared__ int sFail;
     const int n = B.n, tid = threadIdx.x, nt = blockDim.x;
-    double *A = useLds ? sa : Aglob;
-    double *rhs = useLds ? sa + (size_t)n * n : Aglob + (size_t)n * n;
+    const int ld = n + 1;
+    auto A = [&]() { if constexpr (USE_LDS) return sa; else return Aglob; }();
+    auto rdg = A + (size_t)(n + 1) * ld;                     // reciprocals of the factor's diagonal
+    auto g = [&](int r, int c) -> double { return (r / 16 <= c / 16) ? G[(size_t)r * NP + c] : G[(size_t)c * NP + r]; };
     if (tid == 0) sFail = 0;
-    for (int idx = tid; idx < n * n; idx += nt) {
+    for (int idx = tid; idx < (n + 1) * n; idx += nt) {
         const int i = idx / n, j = idx - i * n;
-        const int bi = i / 6, bj = j / 6;
-        // S holds the upper block triangle of the Schur update; H_pp is block diagonal
-        double v = bi <= bj ? B.S[(size_t)i * n + j] : B.S[(size_t)j * n + i];
-        if (bi == bj) {
-            v = B.S[(size_t)(i <= j ? i : j) * n + (i <= j ? j : i)];     // diagonal blocks: keep them symmetric from their upper part
-            v += B.Hpp[(size_t)bi * 36 + (i - bi * 6) * 6 + (j - bj * 6)];
+        if (j > i) continue;
+        double v;
+        if (i == n) v = B.bp[j] - g(j, n);
+        else {
+            v = -g(i, j);
+            if (i / 6 == j / 6) v += B.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 6 + (j % 6)];
             if (i == j) v += lambda;
         }
-        A[idx] = v;
+        A[(size_t)i * ld + j] = v;
     }
-    for (int i = tid; i < n; i += nt) rhs[i] = B.bp[i] + B.bs[i];
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double d = A[(size_t)j * n + j];
-            if (!(d > 0) || !isfinite(d)) sFail = 1; else A[(size_t)j * n + j] = sqrt(d);
+    for (int c0 = 0; c0 < n; c0 += kPW) {
+        const int w = min(kPW, n - c0);
+        if (tid < 64) {                                      // wave 0: 8x8 diagonal block in registers (all lanes alike)
+            double Ld[kPW][kPW], rd[kPW];
+#pragma unroll
+            for (int a = 0; a < kPW; a++)
+#pragma unroll
+                for (int b = 0; b < kPW; b++) Ld[a][b] = (a < w && b <= a) ? A[(size_t)(c0 + a) * ld + c0 + b] : (a == b ? 1.0 : 0.0);
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < kPW; j++) {
+                double d = Ld[j][j];
+#pragma unroll
+                for (int k = 0; k < kPW; k++) if (k < j) d -= Ld[j][k] * Ld[j][k];
+                if (!(d > 0) || !isfinite(d)) bad = true;
+                const double rs = fast_rsqrt(d);
+                rd[j] = rs;
+                Ld[j][j] = d * rs;
+#pragma unroll
+                for (int i = 0; i < kPW; i++) if (i > j) {
+                    double t = Ld[i][j];
+#pragma unroll
+                    for (int k = 0; k < kPW; k++) if (k < j) t -= Ld[i][k] * Ld[j][k];
+                    Ld[i][j] = t * rs;
+                }
+            }
+            // publish: lane (a*8+b) stores one entry of the block (static register selection)
+            double mine = 0, myrd = 0;
+#pragma unroll
+            for (int a = 0; a < kPW; a++)
+#pragma unroll
+                for (int b = 0; b < kPW; b++) if (tid == a * kPW + b) mine = Ld[a][b];
+#pragma unroll
+            for (int a = 0; a < kPW; a++) if (tid == a) myrd = rd[a];
+            ldb[tid] = mine;
+            if (tid < kPW) { rdb[tid] = myrd; if (tid < w) rdg[c0 + tid] = myrd; }
+            const int a = tid / kPW, b = tid - a * kPW;
+            if (a < w && b <= a) A[(size_t)(c0 + a) * ld + c0 + b] = mine;    // nobody else reads the diagonal block now
+            if (tid == 0 && bad) sFail = 1;
         }
         __syncthreads();
         if (sFail) break;
-        const double dj = A[(size_t)j * n + j];
-        for (int i = j + 1 + tid; i < n; i += nt) A[(size_t)i * n + j] /= dj;
+        // rows below the block: L[r][c0..] = A[r][c0..] * Ld^-T  (one thread per row)
+        for (int r = c0 + w + tid; r <= n; r += nt) {
+            double x[kPW];
+#pragma unroll
+            for (int b = 0; b < kPW; b++) x[b] = b < w ? A[(size_t)r * ld + c0 + b] : 0.0;
+#pragma unroll
+            for (int b = 0; b < kPW; b++) {
+                double t = x[b];
+#pragma unroll
+                for (int k = 0; k < kPW; k++) if (k < b) t -= x[k] * ldb[b * kPW + k];
+                x[b] = t * rdb[b];
+            }
+#pragma unroll
+            for (int b = 0; b < kPW; b++) if (b < w) A[(size_t)r * ld + c0 + b] = x[b];
+        }
         __syncthreads();
-        const int m = n - j - 1;
+        // trailing update: A[i][k] -= sum_q L[i][c0+q] L[k][c0+q] for c0+w <= k <= i <= n, k < n
+        const int t0 = c0 + w, m = n + 1 - t0;
         for (int idx = tid; idx < m * m; idx += nt) {
             const int ii = idx / m, kk = idx - ii * m;
-            if (kk <= ii) A[(size_t)(j + 1 + ii) * n + j + 1 + kk] -= A[(size_t)(j + 1 + ii) * n + j] * A[(size_t)(j + 1 + kk) * n + j];
+            const int i = t0 + ii, k = t0 + kk;
+            if (kk > ii || k >= n) continue;
+            double acc = 0;
+#pragma unroll
+            for (int q = 0; q < kPW; q++) if (q < w) acc += A[(size_t)i * ld + c0 + q] * A[(size_t)k * ld + c0 + q];
+            A[(size_t)i * ld + k] -= acc;
         }
         __syncthreads();
     }
@@ -441,23 +553,29 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, doubl
         for (int i = tid; i < n; i += nt) B.x[i] = 0;
         return;
     }
-    // forward then backward substitution (column oriented)
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) rhs[j] /= A[(size_t)j * n + j];
-        __syncthreads();
-        const double yj = rhs[j];
-        for (int i = j + 1 + tid; i < n; i += nt) rhs[i] -= A[(size_t)i * n + j] * yj;
-        __syncthreads();
+    // backward substitution L^T x = y on wave 0: lane owns unknowns lane, lane+64, lane+128, lane+192
+    if (tid < 64) {
+        double y[4], x[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = tid + 64 * q; y[q] = i < n ? A[(size_t)n * ld + i] : 0.0; }
+        for (int j = n - 1; j >= 0; j--) {
+            const int jq = j >> 6, jl = j & 63;
+            double row[4];                                   // row j of L: independent of the chain, issued first
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = tid + 64 * q; row[q] = i < j ? A[(size_t)j * ld + i] : 0.0; }
+            const double rdj = rdg[j];
+            const double ysel = jq == 0 ? y[0] : jq == 1 ? y[1] : jq == 2 ? y[2] : y[3];
+            const double xj = __shfl(ysel, jl) * rdj;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                y[q] -= row[q] * xj;
+                if (q == jq && tid == jl) x[q] = xj;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = tid + 64 * q; if (i < n) B.x[i] = x[q]; }
+        if (tid == 0) B.scal[3] = 1.0;
     }
-    for (int j = n - 1; j >= 0; j--) {
-        if (tid == 0) rhs[j] /= A[(size_t)j * n + j];
-        __syncthreads();
-        const double xj = rhs[j];
-        for (int i = tid; i < j; i += nt) rhs[i] -= A[(size_t)j * n + i] * xj;
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += nt) B.x[i] = rhs[i];
-    if (tid == 0) B.scal[3] = 1.0;
 }
 
 // x_l = D^-1 (b_l - H_pl^T x_p); trial state = oplus(current, x); scale += x^T (lambda x + b)
@@ -528,7 +646,8 @@ struct RumiOptimizer {
             *dKfRowStart = nullptr;
     double *dObsD = nullptr, *dInfo = nullptr, *dT[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr};
     double *dHll = nullptr, *dBl = nullptr, *dHpl = nullptr, *dPanel = nullptr, *dHpp = nullptr, *dBp = nullptr, *dDinv = nullptr,
-           *dS = nullptr, *dBs = nullptr, *dXv = nullptr, *dChi = nullptr, *dScal = nullptr, *dAglob = nullptr;
+           *dS = nullptr, *dBs = nullptr, *dXv = nullptr, *dChi = nullptr, *dScal = nullptr, *dAglob = nullptr, *dYt = nullptr, *dG = nullptr, *dLp = nullptr;
+    int npCap = 0;
     uint8_t *dErase = nullptr;
     double *hScal = nullptr;
     float stageMs[8] = {0};
@@ -547,7 +666,7 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     void *p[] = {o->dStart, o->dNGood, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dActive, o->dLastChi2, o->dEMP, o->dEKF,
                  o->dPoseCol, o->dPtStart, o->dPtEdge, o->dRowSlot, o->dKfRowStart, o->dObsD, o->dInfo, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
-                 o->dAglob, o->dErase};
+                 o->dAglob, o->dErase, o->dYt, o->dG, o->dLp};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->hScal) (void)hipHostFree(o->hScal);
     for (auto &e : o->ev) if (e) (void)hipEventDestroy(e);
@@ -578,7 +697,9 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     TRYA(oalloc(&o->dHll, M * 9)); TRYA(oalloc(&o->dBl, M * 3)); TRYA(oalloc(&o->dHpl, E * 18)); TRYA(oalloc(&o->dPanel, E * 16 + 64));
     TRYA(oalloc(&o->dHpp, K * 36)); TRYA(oalloc(&o->dBp, N)); TRYA(oalloc(&o->dDinv, M * 9)); TRYA(oalloc(&o->dS, N * N));
     TRYA(oalloc(&o->dBs, N)); TRYA(oalloc(&o->dXv, N + M * 3)); TRYA(oalloc(&o->dChi, E)); TRYA(oalloc(&o->dScal, 8));
-    TRYA(oalloc(&o->dAglob, N * N + N)); TRYA(oalloc(&o->dErase, E));
+    o->npCap = (int)std::min<size_t>((N + 1 + 15) / 16 * 16, 256);
+    TRYA(oalloc(&o->dAglob, (N + 2) * (N + 2) + 2 * N)); TRYA(oalloc(&o->dErase, E));
+    TRYA(oalloc(&o->dYt, 3 * M * (size_t)o->npCap)); TRYA(oalloc(&o->dG, (size_t)o->npCap * o->npCap)); TRYA(oalloc(&o->dLp, M * 6));
 #undef TRYA
     if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
     for (auto &e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
@@ -684,16 +805,15 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
     B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
 
     const int gE = std::max(1, (nE + 255) / 256);
-    const size_t ldsSolve = ((size_t)n * n + n) * sizeof(double);
-    const int useLds = ldsSolve <= 150 * 1024;
-    const size_t ldsSchur = ((size_t)n * n + n) * sizeof(double);
-    const bool schurLds = ldsSchur <= 150 * 1024;
-    if (!schurLds) { g_lastError = "local BA: more than 23 optimised key-frames is not supported yet (Schur accumulator must fit LDS)"; return RUMI_E_CAPACITY; }
-    // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses (static LDS counts against 160 KiB too)
-    if (ldsSchur > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSchur));
+    if (n > 255) { g_lastError = "local BA: more than 42 optimised key-frames is not supported (reduced system limited to 255 unknowns)"; return RUMI_E_CAPACITY; }
+    const int NP = (n + 1 + 15) / 16 * 16, NT = NP / 16, K3 = 3 * nMP;
+    if (NP > o->npCap) { g_lastError = "local BA: reduced system larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    const size_t ldsSolve = ((size_t)(n + 1) * (n + 1) + (size_t)n) * sizeof(double);
+    const int useLds = ldsSolve <= 158 * 1024;
+    // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses
     if (useLds && ldsSolve > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    const int nSlices = 64;
     hipStream_t st = nullptr;
     auto chi2_of = [&](int which, double *out) -> int {
         HIP_TRY(hipMemsetAsync(o->dScal, 0, sizeof(double), st));
@@ -703,6 +823,7 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
         *out = o->hScal[0];
         return RUMI_OK;
     };
+    if (nMP > 0) HIP_TRY(hipMemsetAsync(o->dYt, 0, (size_t)K3 * NP * sizeof(double), st));   // pattern of Y is fixed: zero once, live entries are rewritten per trial
     HIP_TRY(hipEventRecord(o->ev[0], st));
     int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
     double lambda = -1, ni = 2;
@@ -719,7 +840,11 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
         HIP_TRY(hipMemsetAsync(o->dHll, 0, (size_t)nMP * 9 * sizeof(double), st));
         HIP_TRY(hipMemsetAsync(o->dBl, 0, (size_t)nMP * 3 * sizeof(double), st));
         if (nE > 0) hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur]);
-        if (nOpt > 0) hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt), dim3(256), 0, st, B);
+        if (nOpt > 0) {
+            HIP_TRY(hipMemsetAsync(o->dHpp, 0, (size_t)nOpt * 36 * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(o->dBp, 0, (size_t)n * sizeof(double), st));
+            hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt, kHppSlices), dim3(256), 0, st, B);
+        }
         if (it == 0) {
             HIP_TRY(hipMemsetAsync(o->dScal + 2, 0, sizeof(double), st));
             const int nd = nOpt * 6 + nMP * 3;
@@ -732,11 +857,15 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
         int qmax = 0;
         do {
             const int trial = cur ^ 1;
-            HIP_TRY(hipMemsetAsync(o->dS, 0, (size_t)n * n * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(o->dBs, 0, (size_t)n * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(o->dG, 0, (size_t)NP * NP * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(o->dScal, 0, 2 * sizeof(double), st));
-            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_schur, dim3(std::min(64, (nMP + 3) / 4)), dim3(256), ldsSchur, st, B, lambda);
-            if (n > 0) hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(1024), useLds ? ldsSolve : 0, st, B, lambda, o->dAglob, useLds);
+            if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
+            if (nE > 0) hipLaunchKernelGGL(k_ba_yfill, dim3(gE), dim3(256), 0, st, B, o->dYt, NP, o->dLp);
+            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
+            if (n > 0) {
+                if (useLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(1024), ldsSolve, st, B, lambda, o->dG, NP, o->dAglob);
+                else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(1024), 0, st, B, lambda, o->dG, NP, o->dAglob);
+            }
             else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
             hipLaunchKernelGGL(k_ba_update, dim3((nMP + nKF + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
             hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
