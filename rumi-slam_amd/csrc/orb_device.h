@@ -30,16 +30,17 @@ struct DevParams {
     DevLevel lv[kMaxLevels];
 };
 
-// Where the kernels find pixels: level 0 is the caller's image batch, levels >= 1 live in `pyr`,
-// blurred levels (all, including 0) in `blur`.
+// Where the kernels find pixels: every level (0 included: k_pyr0 copies the caller's frame in) lives in `pyr` with a
+// REFLECT_101 frame of kPadX x kPadY around it, the blurred levels in `blur` (same geometry, frame unused).
 struct ImgSrc {
-    const uint8_t *l0;
+    const uint8_t *l0;             // caller's frames (read once by k_pyr0)
     long long l0FrameStride;
     int l0Pitch;
     uint8_t *pyr;
     uint8_t *blur;
 };
 
+void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,

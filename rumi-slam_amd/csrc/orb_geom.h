@@ -16,12 +16,14 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD
 constexpr int kBorder = kEdge - 3; // minBorderX/Y = 16
 constexpr int kMaxLevels = 16;
 constexpr int kCellTileMax = 96;   // largest FAST sub-image side the cell kernel stages in LDS
+constexpr int kPadX = 32;          // REFLECT_101 frame kept around every pyramid level in HBM: >= EDGE_THRESHOLD, keeps rows 4-B aligned
+constexpr int kPadY = kEdge;       // 19 rows, as the reference's copyMakeBorder
 
 inline int cv_round_host(double v) { return (int)std::lrint(v); }
 
 struct LevelGeom {
-    int w, h, pitch;            // level size, row pitch in bytes (64-B aligned)
-    long long off;              // byte offset of the level inside one frame's pyramid arena
+    int w, h, pitch;            // level size, row pitch in bytes (64-B aligned, includes the 2 x kPadX frame)
+    long long off;              // byte offset of the level's pixel (0,0) inside one frame's arena (the frame lies before / around it)
     int nCols, nRows, wCell, hCell;
     int cellBase, nCells;       // first cell id of this level in the frame's cell list
     int maxBX, maxBY;           // w-16, h-16
@@ -84,9 +86,9 @@ inline bool make_geometry(const OrbTables &t, int w, int h, std::vector<LevelGeo
         LevelGeom &L = g[l];
         L.w = cv_round_host((float)w * t.invScale[l]);
         L.h = cv_round_host((float)h * t.invScale[l]);
-        L.pitch = (L.w + 63) & ~63;
-        L.off = off;
-        off += (long long)L.pitch * L.h;
+        L.pitch = (L.w + 2 * kPadX + 63) & ~63;
+        L.off = off + (long long)kPadY * L.pitch + kPadX;
+        off += (long long)L.pitch * (L.h + 2 * kPadY);
         L.maxBX = L.w - kBorder; L.maxBY = L.h - kBorder;
         const float width = (float)(L.maxBX - kBorder), height = (float)(L.maxBY - kBorder);
         L.nCols = (int)(width / 35.f); L.nRows = (int)(height / 35.f);

@@ -281,6 +281,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     // Stage A (all frames): pyramid + blur.  Levels depend on each other, frames do not.
     HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
     if (prof) HIP_TRY(hipEventRecord(h->ev[0], st));
+    launch_pyr0(h->dP, P, src, nframes, st);
     for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
     for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, st);
@@ -383,28 +384,11 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
     if (!out) return RUMI_OK;
     if (out_stride < L.w + 2 * border) return RUMI_E_CAPACITY;
     HIP_TRY(hipSetDevice(h->device));
-    const uint8_t *srcp;
-    size_t pitch;
-    if (which == 0 && level == 0) { srcp = h->lastSrc.l0 + (long long)frame * h->lastSrc.l0FrameStride; pitch = h->lastSrc.l0Pitch; }
-    else {
-        srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off;
-        pitch = L.pitch;
-    }
-    HIP_TRY(hipMemcpy2D(out + (size_t)border * out_stride + border, out_stride, srcp, pitch, L.w, L.h, hipMemcpyDeviceToHost));
-    // copyMakeBorder(..., BORDER_REFLECT_101) around the level (ORBextractor.cc:1105-1110)
-    auto refl = [](int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; return i; };
-    for (int y = 0; y < L.h; y++) {
-        uint8_t *row = out + (size_t)(y + border) * out_stride;
-        for (int x = 0; x < border; x++) {
-            row[x] = row[border + refl(x - border, L.w)];
-            row[border + L.w + x] = row[border + refl(L.w + x, L.w)];
-        }
-    }
-    for (int y = 0; y < border; y++) {
-        std::memcpy(out + (size_t)y * out_stride, out + (size_t)(border + refl(y - border, L.h)) * out_stride, L.w + 2 * border);
-        std::memcpy(out + (size_t)(border + L.h + y) * out_stride, out + (size_t)(border + refl(L.h + y, L.h)) * out_stride,
-                    L.w + 2 * border);
-    }
+    // the pyramid arena already holds the level inside its REFLECT_101 frame (kPadX x kPadY); the blurred arena has no frame
+    if (border > (which ? 0 : std::min(kPadX, kPadY))) { g_lastError = which ? "blurred levels carry no border" : "border larger than the stored frame (19)"; return RUMI_E_INVALID; }
+    const uint8_t *srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off -
+                          (long long)border * L.pitch - border;
+    HIP_TRY(hipMemcpy2D(out, out_stride, srcp, L.pitch, L.w + 2 * border, L.h + 2 * border, hipMemcpyDeviceToHost));
     return RUMI_OK;
 }
 

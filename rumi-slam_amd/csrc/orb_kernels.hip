@@ -19,48 +19,78 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
+// pixel (0,0) of a pyramid level; a REFLECT_101 frame of kPadX x kPadY pixels surrounds it in memory
 __device__ __forceinline__ const uint8_t *level_base(const ImgSrc &s, const DevParams *P, int level, int frame,
                                                       int *pitch) {
-    if (level == 0) {
-        *pitch = s.l0Pitch;
-        return s.l0 + (long long)frame * s.l0FrameStride;
-    }
     *pitch = P->lv[level].pitch;
     return s.pyr + (long long)frame * P->arenaStride + P->lv[level].off;
 }
 
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
 // ------------------------------------------------------------------------------------------------
-// Pyramid: one thread per destination pixel of level `level`; taps come from host-built tables that
-// follow cv::resize's coefficient rule exactly (orb_geom.h).  HBM-bound: 1 B written, ~1.44 B read.
+// Pyramid.  Every level is stored with the reference's BORDER_REFLECT_101 frame (copyMakeBorder,
+// ORBextractor.cc:1105-1110) so that the blur and every gather run without edge cases.
+//   k_pyr0    level 0 = the caller's frame + frame; a lane moves 4 pixels.
+//   k_resize  level l from level l-1 (cv::resize INTER_LINEAR 8U; taps from host tables that follow cv's coefficient
+//             rule, orb_geom.h); a lane produces 4 horizontally adjacent pixels of the FRAMED output (frame pixels
+//             recompute their mirror pixel) and stores one dword.  HBM-bound: 1.19 B written, ~1.44 B read per pixel.
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, ImgSrc src) {
+    const DevLevel &D = P->lv[0];
+    const int frame = blockIdx.z;
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;     // first of my 4 framed columns
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
+    if (ox >= D.w + kPadX || oy >= D.h + kPadY) return;
+    const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch;
+    uint8_t *out = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
+    uint32_t v;
+    if (ox >= 0 && ox + 3 < D.w && ((reinterpret_cast<uintptr_t>(in) + ox) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(in + ox);
+    else
+        v = (uint32_t)in[reflect101(ox, D.w)] | ((uint32_t)in[reflect101(ox + 1, D.w)] << 8) |
+            ((uint32_t)in[reflect101(ox + 2, D.w)] << 16) | ((uint32_t)in[reflect101(ox + 3, D.w)] << 24);
+    *reinterpret_cast<uint32_t *>(out) = v;                                  // kPadX and the pitch are multiples of 4
+}
+
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
                                                 const int16_t *__restrict__ coef, int level) {
     const DevLevel &D = P->lv[level];
     const DevLevel &S = P->lv[level - 1];
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int frame = blockIdx.z;
-    if (dx >= D.w || dy >= D.h) return;
-    int sp;
-    const uint8_t *sb = level_base(src, P, level - 1, frame, &sp);
-    uint8_t *db = src.pyr + (long long)frame * P->arenaStride + D.off;
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
+    if (ox >= D.w + kPadX || oy >= D.h + kPadY) return;
+    const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
+    uint8_t *db = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
     const int16_t *yofs = coef + D.coefY, *ya = yofs + D.h;
-    const int sx = xofs[dx], a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
+    const int dy = reflect101(oy, D.h);
     const int sy = yofs[dy], b0 = ya[dy * 2], b1 = ya[dy * 2 + 1];
     const int sy0 = sy >= 0 ? (sy < S.h ? sy : S.h - 1) : 0;
     const int sy1r = sy + 1;
     const int sy1 = sy1r >= 0 ? (sy1r < S.h ? sy1r : S.h - 1) : 0;
-    const uint8_t *r0p = sb + (long long)sy0 * sp + sx, *r1p = sb + (long long)sy1 * sp + sx;
-    int r0, r1;
-    if (dx < D.xmax) {
-        r0 = r0p[0] * a0 + r0p[1] * a1;
-        r1 = r1p[0] * a0 + r1p[1] * a1;
-    } else {
-        r0 = r0p[0] * 2048;
-        r1 = r1p[0] * 2048;
+    const uint8_t *r0p = sb + (long long)sy0 * S.pitch, *r1p = sb + (long long)sy1 * S.pitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = reflect101(ox + i, D.w);
+        const int sx = xofs[dx];
+        int r0, r1;
+        if (dx < D.xmax) {
+            const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
+            r0 = r0p[sx] * a0 + r0p[sx + 1] * a1;
+            r1 = r1p[sx] * a0 + r1p[sx + 1] * a1;
+        } else {
+            r0 = r0p[sx] * 2048;
+            r1 = r1p[sx] * 2048;
+        }
+        packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
     }
-    db[(long long)dy * D.pitch + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    *reinterpret_cast<uint32_t *>(db) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,43 +280,61 @@ __global__ __launch_bounds__(256) void k_compact(const DevParams *__restrict__ P
 
 // ------------------------------------------------------------------------------------------------
 // Gaussian blur 7x7, sigma 2, fixed point: taps {18,34,48,56,48,34,18}/256, row pass to u16, column
-// pass to u32, (v + 32768) >> 16.  One workgroup = 64 x 16 output pixels of one level of one frame;
-// the 70 x 22 source patch (REFLECT_101 at the level's own edges) is staged in LDS.
+// pass to u32, (v + 32768) >> 16, REFLECT_101 at the level's own edges.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int i, int n) {
-    if (n == 1) return 0;
-    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
-    return i;
-}
+// Register formulation: a lane owns a 4-pixel column strip, a wave walks kBlurRows output rows top to bottom.
+// Per source row: ONE aligned dword load per lane; the left / right neighbours' dwords arrive by DPP shuffles (the two
+// outer lanes load their halo dwords); the 7-tap row pass runs on the 10 unpacked bytes, the column pass on a 7-deep
+// register ring of row results; 4 output pixels leave as one dword store.  No LDS, no barriers, and no edge cases: the
+// REFLECT_101 frame stored around every level IS the border GaussianBlur(..., BORDER_REFLECT_101) would synthesise.
+constexpr int kBlurRows = 16;
 
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, int level) {
-    __shared__ uint8_t in[22][72];
-    __shared__ uint16_t hz[22][64];
     const DevLevel &L = P->lv[level];
-    const int tid = threadIdx.x, frame = blockIdx.z;
-    const int ox = blockIdx.x * 64, oy = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frame = blockIdx.z;
+    const int xa = blockIdx.x * 256 + lane * 4;                  // first pixel of my strip
+    const int y0 = (blockIdx.y * 4 + wave) * kBlurRows;
+    if (y0 >= L.h) return;                                       // whole wave (wave-uniform)
     int pitch;
     const uint8_t *img = level_base(src, P, level, frame, &pitch);
-    for (int idx = tid; idx < 22 * 70; idx += 256) {
-        const int r = idx / 70, c = idx - r * 70;
-        const int y = reflect101(oy + r - 3, L.h), x = reflect101(ox + c - 3, L.w);
-        in[r][c] = img[(long long)y * pitch + x];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 22 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        const uint8_t *p = &in[r][c];
-        hz[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-    }
-    __syncthreads();
     uint8_t *out = src.blur + (long long)frame * P->arenaStride + L.off;
-    const int c = tid & 63;
-    for (int r = tid >> 6; r < 16; r += 4) {
-        const int x = ox + c, y = oy + r;
-        if (x < L.w && y < L.h) {
-            const uint32_t acc = 18u * (hz[r][c] + hz[r + 6][c]) + 34u * (hz[r + 1][c] + hz[r + 5][c]) +
-                                 48u * (hz[r + 2][c] + hz[r + 4][c]) + 56u * hz[r + 3][c];
-            out[(long long)y * L.pitch + x] = (uint8_t)((acc + 32768u) >> 16);
+    const int w = L.w, h = L.h;
+    // strips that start beyond the row still feed their neighbours' halos; clamp their address inside the framed row
+    const int xl = min(xa, ((w + kPadX - 4) & ~3));
+    int ring[7][4];
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) ring[k][i] = 0;
+    const int yEnd = min(y0 + kBlurRows, h);
+    for (int r = y0 - 3; r < yEnd + 3; r++) {
+        const uint8_t *row = img + (long long)r * pitch;         // rows -3..-1 and h..h+2 are frame rows
+        const uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
+        uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
+        if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
+        if (lane == 63) Rw = *reinterpret_cast<const uint32_t *>(row + min(xl + 4, (w + kPadX - 4) & ~3));
+        int b[10];
+        b[0] = (Lw >> 8) & 255; b[1] = (Lw >> 16) & 255; b[2] = Lw >> 24;
+        b[3] = C & 255; b[4] = (C >> 8) & 255; b[5] = (C >> 16) & 255; b[6] = C >> 24;
+        b[7] = Rw & 255; b[8] = (Rw >> 8) & 255; b[9] = (Rw >> 16) & 255;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) ring[k][i] = ring[k + 1][i];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            ring[6][i] = 18 * (b[i] + b[i + 6]) + 34 * (b[i + 1] + b[i + 5]) + 48 * (b[i + 2] + b[i + 4]) + 56 * b[i + 3];
+        const int y = r - 3;                                     // the ring now holds rows y-3 .. y+3
+        if (y >= y0 && xa < w) {
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t acc = 18u * (uint32_t)(ring[0][i] + ring[6][i]) + 34u * (uint32_t)(ring[1][i] + ring[5][i]) +
+                                     48u * (uint32_t)(ring[2][i] + ring[4][i]) + 56u * (uint32_t)ring[3][i];
+                o[i] = (acc + 32768u) >> 16;
+            }
+            // the blurred arena has the same framed geometry, so a whole dword always fits in the row
+            *reinterpret_cast<uint32_t *>(out + (long long)y * L.pitch + xa) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
         }
     }
 }
@@ -375,9 +423,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
 }
 
 // ---- launch wrappers (called from orb_host.hip) ----
+void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
+    dim3 g((hP.lv[0].w + 2 * kPadX + 255) / 256, (hP.lv[0].h + 2 * kPadY + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_pyr0, g, dim3(256), 0, st, dP, src);
+}
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st) {
-    dim3 g((hP.lv[level].w + 63) / 64, (hP.lv[level].h + 3) / 4, nframes);
+    dim3 g((hP.lv[level].w + 2 * kPadX + 255) / 256, (hP.lv[level].h + 2 * kPadY + 3) / 4, nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
@@ -390,7 +442,7 @@ void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *ce
                        cand, levelStart, overflow);
 }
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int level, int nframes, hipStream_t st) {
-    dim3 g((hP.lv[level].w + 63) / 64, (hP.lv[level].h + 15) / 16, nframes);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kBlurRows - 1) / (4 * kBlurRows), nframes);
     hipLaunchKernelGGL(k_blur, g, dim3(256), 0, st, dP, src, level);
 }
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
