@@ -41,6 +41,7 @@ struct ImgSrc {
 };
 
 void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
+void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,

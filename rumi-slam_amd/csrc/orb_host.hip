@@ -283,6 +283,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     if (prof) HIP_TRY(hipEventRecord(h->ev[0], st));
     launch_pyr0(h->dP, P, src, nframes, st);
     for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
+    launch_frame_cols(h->dP, P, src, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
     for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[2], st));

@@ -19,6 +19,8 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
+struct __attribute__((packed)) U64 { uint64_t v; };      // possibly unaligned 8-byte global access
+
 // pixel (0,0) of a pyramid level; a REFLECT_101 frame of kPadX x kPadY pixels surrounds it in memory
 __device__ __forceinline__ const uint8_t *level_base(const ImgSrc &s, const DevParams *P, int level, int frame,
                                                       int *pitch) {
@@ -40,20 +42,26 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 //             rule, orb_geom.h); a lane produces 4 horizontally adjacent pixels of the FRAMED output (frame pixels
 //             recompute their mirror pixel) and stores one dword.  HBM-bound: 1.19 B written, ~1.44 B read per pixel.
 // ------------------------------------------------------------------------------------------------
+// k_pyr0 / k_resize write the pixel columns [0, w) of the rows [-kPadY, h + kPadY) (the frame rows above and below are
+// computed like any other row, from the mirrored source row); k_frame_cols then mirrors the left / right frame columns of
+// every level of every frame in ONE launch (no level reads another level's frame columns).
 __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, ImgSrc src) {
     const DevLevel &D = P->lv[0];
     const int frame = blockIdx.z;
-    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;     // first of my 4 framed columns
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
-    if (ox >= D.w + kPadX || oy >= D.h + kPadY) return;
-    const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch;
+    if (ox >= D.w || oy >= D.h + kPadY) return;
+    const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch + ox;
     uint8_t *out = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
     uint32_t v;
-    if (ox >= 0 && ox + 3 < D.w && ((reinterpret_cast<uintptr_t>(in) + ox) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(in + ox);
-    else
-        v = (uint32_t)in[reflect101(ox, D.w)] | ((uint32_t)in[reflect101(ox + 1, D.w)] << 8) |
-            ((uint32_t)in[reflect101(ox + 2, D.w)] << 16) | ((uint32_t)in[reflect101(ox + 3, D.w)] << 24);
-    *reinterpret_cast<uint32_t *>(out) = v;                                  // kPadX and the pitch are multiples of 4
+    if (ox + 3 < D.w && (reinterpret_cast<uintptr_t>(in) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(in);
+    else {
+        v = in[0];
+        if (ox + 1 < D.w) v |= (uint32_t)in[1] << 8;
+        if (ox + 2 < D.w) v |= (uint32_t)in[2] << 16;
+        if (ox + 3 < D.w) v |= (uint32_t)in[3] << 24;
+    }
+    *reinterpret_cast<uint32_t *>(out) = v;                                  // columns >= w are rewritten by k_frame_cols
 }
 
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
@@ -61,9 +69,9 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const DevLevel &D = P->lv[level];
     const DevLevel &S = P->lv[level - 1];
     const int frame = blockIdx.z;
-    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
-    if (ox >= D.w + kPadX || oy >= D.h + kPadY) return;
+    if (ox >= D.w || oy >= D.h + kPadY) return;
     const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
     uint8_t *db = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
@@ -75,22 +83,57 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const int sy1 = sy1r >= 0 ? (sy1r < S.h ? sy1r : S.h - 1) : 0;
     const uint8_t *r0p = sb + (long long)sy0 * S.pitch, *r1p = sb + (long long)sy1 * S.pitch;
     uint32_t packed = 0;
+    const bool whole = ox + 3 < D.w;
+    const int sx0 = xofs[ox];
+    if (whole && ox + 3 < D.xmax && xofs[ox + 3] + 1 - sx0 <= 7) {
+        // the 4 outputs read source bytes sx0 .. sx0+7 of two rows -> two (unaligned) 8-byte loads; offsets and taps come
+        // as one 8-byte and one 16-byte table load
+        const uint64_t ofs = reinterpret_cast<const U64 *>(xofs + ox)->v;
+        const U64 *t8 = reinterpret_cast<const U64 *>(xa + 2 * ox);
+        const uint64_t ta = t8[0].v, tb = t8[1].v;
+        const uint64_t s0 = reinterpret_cast<const U64 *>(r0p + sx0)->v, s1 = reinterpret_cast<const U64 *>(r1p + sx0)->v;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = reflect101(ox + i, D.w);
-        const int sx = xofs[dx];
-        int r0, r1;
-        if (dx < D.xmax) {
-            const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
-            r0 = r0p[sx] * a0 + r0p[sx + 1] * a1;
-            r1 = r1p[sx] * a0 + r1p[sx + 1] * a1;
-        } else {
-            r0 = r0p[sx] * 2048;
-            r1 = r1p[sx] * 2048;
+        for (int i = 0; i < 4; i++) {
+            const int sh = 8 * ((int)(int16_t)(ofs >> (16 * i)) - sx0);
+            const uint64_t tt = i < 2 ? ta : tb;
+            const int a0 = (int16_t)(tt >> (32 * (i & 1))), a1 = (int16_t)(tt >> (32 * (i & 1) + 16));
+            const int r0 = (int)((s0 >> sh) & 255) * a0 + (int)((s0 >> (sh + 8)) & 255) * a1;
+            const int r1 = (int)((s1 >> sh) & 255) * a0 + (int)((s1 >> (sh + 8)) & 255) * a1;
+            packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
         }
-        packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+    } else {
+        for (int i = 0; i < 4 && ox + i < D.w; i++) {
+            const int dx = ox + i;
+            const int sx = xofs[dx];
+            int r0, r1;
+            if (dx < D.xmax) {
+                const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
+                r0 = r0p[sx] * a0 + r0p[sx + 1] * a1;
+                r1 = r1p[sx] * a0 + r1p[sx + 1] * a1;
+            } else {
+                r0 = r0p[sx] * 2048;
+                r1 = r1p[sx] * 2048;
+            }
+            packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+        }
     }
     *reinterpret_cast<uint32_t *>(db) = packed;
+}
+
+// left / right REFLECT_101 frame columns of all levels: thread = (frame, level, framed row, one of 17 aligned dword strips)
+__global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict__ P, ImgSrc src) {
+    const int level = blockIdx.y, frame = blockIdx.z;
+    const DevLevel &D = P->lv[level];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t % 17, row = t / 17 - kPadY;
+    if (row >= D.h + kPadY) return;
+    uint8_t *rp = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)row * D.pitch;
+    // strips 0..7: x = -32..-1; strips 8..16: x = (w & ~3) .. (w & ~3) + 35 (covers w .. w+31 and re-writes <= 3 interior pixels)
+    const int x0 = strip < 8 ? -kPadX + 4 * strip : (D.w & ~3) + 4 * (strip - 8);
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (uint32_t)rp[reflect101(x0 + i, D.w)] << (8 * i);
+    if (x0 + 3 < D.w + kPadX + 4) *reinterpret_cast<uint32_t *>(rp + x0) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,12 +175,17 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *t /* centre, pitch 
     return max(A, -Bn) - 1;
 }
 
+// idx / d for 0 <= idx < 10900 and 1 <= d <= 96 without an integer divide: M = floor(2^20 / d) + 1, q = (idx * M) >> 20
+// (error analysis in DESIGN.md §5; exhaustively checked by tests/test_hostcode_cpu.py through rumi_hook_magic_div).
+__host__ __device__ __forceinline__ unsigned magic_of(unsigned d) { return (1u << 20) / d + 1u; }
+__host__ __device__ __forceinline__ int magic_div(int idx, unsigned M) { return (int)(((unsigned)idx * M) >> 20); }
+
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src,
                                                     uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
-    __shared__ uint8_t tile[kCellTileMax * kTP];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kCellTileMax * kTP];
     __shared__ uint8_t sc[(kCellTileMax - 6 + 2) * kSP];
     __shared__ unsigned long long balIni[kMaxIters][4], balMin[kMaxIters][4];
-    __shared__ int prefix[kMaxIters][4];
+    __shared__ int prefix[kMaxIters * 4];
     __shared__ int sTotal[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,57 +206,74 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
         if (tid == 0) cellCnt[cellIdx] = 0;
         return;
     }
+    // stage the sub-image as aligned dwords (level rows are 4-byte aligned at x = 0 in the framed arena)
     int pitch;
-    const uint8_t *img = level_base(src, P, level, frame, &pitch) + (long long)iniY * pitch + iniX;
-    for (int idx = tid; idx < rows * cols; idx += 256) {
-        const int r = idx / cols, c = idx - r * cols;
-        tile[r * kTP + c] = img[(long long)r * pitch + c];
+    const int shx = iniX & 3;                                   // tile column of sub-image column 0
+    const uint8_t *img = level_base(src, P, level, frame, &pitch) + (long long)iniY * pitch + (iniX - shx);
+    const int nd = (shx + cols + 3) >> 2;
+    const unsigned Mnd = magic_of(nd);
+    for (int idx = tid; idx < rows * nd; idx += 256) {
+        const int r = magic_div(idx, Mnd), c = idx - r * nd;
+        *reinterpret_cast<uint32_t *>(&tile[r * kTP + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + (long long)r * pitch + 4 * c);
     }
     const int dw = cols - 6, dh = rows - 6;
+    const unsigned Mdw = magic_of(dw), Mdw2 = magic_of(dw + 2);
     for (int idx = tid; idx < (dw + 2) * (dh + 2); idx += 256) {
-        const int r = idx / (dw + 2), c = idx - r * (dw + 2);
+        const int r = magic_div(idx, Mdw2), c = idx - r * (dw + 2);
         sc[r * kSP + c] = 0;
     }
     __syncthreads();
     const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
     for (int idx = tid; idx < npx; idx += 256) {
-        const int py = idx / dw, px = idx - py * dw;
-        const int s = fast_score_lds(&tile[(py + 3) * kTP + px + 3]);
+        const int py = magic_div(idx, Mdw), px = idx - py * dw;
+        const int s = fast_score_lds(&tile[(py + 3) * kTP + px + 3 + shx]);
         if (s >= tlow) sc[(py + 1) * kSP + px + 1] = (uint8_t)s;
     }
     __syncthreads();
     const int iters = (npx + 255) >> 8;
+    const int iniTh = P->iniTh, minTh = P->minTh;
     for (int it = 0; it < iters; it++) {
         const int idx = it * 256 + tid;
         bool isMax = false;
         int v = 0;
         if (idx < npx) {
-            const int py = idx / dw, px = idx - py * dw;
+            const int py = magic_div(idx, Mdw), px = idx - py * dw;
             const uint8_t *s = &sc[(py + 1) * kSP + px + 1];
             v = s[0];
             isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-kSP - 1] && v > s[-kSP] && v > s[-kSP + 1] &&
                     v > s[kSP - 1] && v > s[kSP] && v > s[kSP + 1];
         }
-        const unsigned long long bi = __ballot(isMax && v >= P->iniTh);
-        const unsigned long long bm = __ballot(isMax && v >= P->minTh);
+        const unsigned long long bi = __ballot(isMax && v >= iniTh);
+        const unsigned long long bm = __ballot(isMax && v >= minTh);
         if (lane == 0) { balIni[it][wave] = bi; balMin[it][wave] = bm; }
     }
     __syncthreads();
-    if (tid == 0) {
-        int ti = 0;
-        for (int it = 0; it < iters; it++)
-            for (int w = 0; w < 4; w++) ti += __popcll(balIni[it][w]);
-        const bool useMin = ti == 0;          // retry with minThFAST only if the first call found nothing
-        int run = 0;
-        for (int it = 0; it < iters; it++)
-            for (int w = 0; w < 4; w++) {
-                prefix[it][w] = run;
-                run += __popcll(useMin ? balMin[it][w] : balIni[it][w]);
-            }
-        sTotal[0] = run;
-        sTotal[1] = useMin;
-        cellCnt[cellIdx] = run;
+    // prefix over the (iteration, wave) ballots on wave 0: lane l owns entries l and l + 64 (iters * 4 <= 128)
+    if (wave == 0) {
+        const int ne = iters * 4;
+        const unsigned long long *bI = &balIni[0][0], *bM = &balMin[0][0];
+        const int ci0 = lane < ne ? __popcll(bI[lane]) : 0, ci1 = lane + 64 < ne ? __popcll(bI[lane + 64]) : 0;
+        const int cm0 = lane < ne ? __popcll(bM[lane]) : 0, cm1 = lane + 64 < ne ? __popcll(bM[lane + 64]) : 0;
+        int ti = ci0 + ci1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ti += __shfl_xor(ti, o);
+        const bool useMin = ti == 0;              // retry with minThFAST only if the first call found nothing (:783)
+        const int c0 = useMin ? cm0 : ci0, c1 = useMin ? cm1 : ci1;
+        int inc0 = c0, inc1 = c1;                 // inclusive scans of the two halves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(inc0, o), b = __shfl_up(inc1, o);
+            if (lane >= o) { inc0 += a; inc1 += b; }
+        }
+        const int tot0 = __shfl(inc0, 63), tot1 = __shfl(inc1, 63);
+        if (lane < ne) prefix[lane] = inc0 - c0;
+        if (lane + 64 < ne) prefix[lane + 64] = tot0 + inc1 - c1;
+        if (lane == 0) {
+            const int run = tot0 + tot1;
+            sTotal[0] = run; sTotal[1] = useMin;
+            cellCnt[cellIdx] = run;
+        }
     }
     __syncthreads();
     const bool useMin = sTotal[1] != 0;
@@ -217,8 +282,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
         const unsigned long long b = useMin ? balMin[it][wave] : balIni[it][wave];
         if ((b >> lane) & 1ull) {
             const int idx = it * 256 + tid;
-            const int py = idx / dw, px = idx - py * dw;
-            const int pos = prefix[it][wave] + __popcll(b & ((1ull << lane) - 1ull));
+            const int py = magic_div(idx, Mdw), px = idx - py * dw;
+            const int pos = prefix[it * 4 + wave] + __popcll(b & ((1ull << lane) - 1ull));
             const uint32_t x = (uint32_t)(px + 3 + ci_j * L.wCell), y = (uint32_t)(py + 3 + ci_i * L.hCell);
             out[pos] = x | (y << 12) | ((uint32_t)sc[(py + 1) * kSP + px + 1] << 24);
         }
@@ -424,12 +489,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
 
 // ---- launch wrappers (called from orb_host.hip) ----
 void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
-    dim3 g((hP.lv[0].w + 2 * kPadX + 255) / 256, (hP.lv[0].h + 2 * kPadY + 3) / 4, nframes);
+    dim3 g((hP.lv[0].w + 255) / 256, (hP.lv[0].h + 2 * kPadY + 3) / 4, nframes);
     hipLaunchKernelGGL(k_pyr0, g, dim3(256), 0, st, dP, src);
+}
+void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
+    dim3 g(((hP.lv[0].h + 2 * kPadY) * 17 + 255) / 256, hP.nlevels, nframes);
+    hipLaunchKernelGGL(k_frame_cols, g, dim3(256), 0, st, dP, src);
 }
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st) {
-    dim3 g((hP.lv[level].w + 2 * kPadX + 255) / 256, (hP.lv[level].h + 2 * kPadY + 3) / 4, nframes);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kPadY + 3) / 4, nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
