@@ -94,6 +94,9 @@ struct RumiOrb {
     bool profiling = false;
     float stageMs[8] = {0};
     hipEvent_t ev[8] = {nullptr};
+    // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
+    hipStream_t sideStream = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 static int set_geometry(RumiOrb *h, int w, int hgt) {
@@ -173,6 +176,9 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     void *pin[] = {h->hOverflow, h->hErr};
     for (void *p : pin) if (p) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
     delete h;
 }
 
@@ -244,6 +250,9 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
 #undef TRY_ALLOC
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "side stream"; return RUMI_E_NO_DEVICE; }
     *out = h;
     return RUMI_OK;
 }
@@ -285,7 +294,11 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
     launch_frame_cols(h->dP, P, src, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
-    for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, st);
+    // fork: blur on the side stream (in profiling mode it stays on the main stream so that stage times do not overlap)
+    hipStream_t bs = prof ? st : h->sideStream;
+    if (!prof) { HIP_TRY(hipEventRecord(h->evFork, st)); HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0)); }
+    for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, bs);
+    if (!prof) HIP_TRY(hipEventRecord(h->evJoin, bs));
     if (prof) HIP_TRY(hipEventRecord(h->ev[2], st));
     HIP_TRY(hipGetLastError());
 
@@ -307,6 +320,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         launch_assemble(h->dP, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, lap0, lap1, h->dSelPacked, h->dSelMeta,
                         h->dSelCount, h->capSel, (int32_t *)d_counts + 2 * base, h->dErr, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[6], st));
+        if (!prof && base == 0) HIP_TRY(hipStreamWaitEvent(st, h->evJoin, 0));      // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, h->capSel,
                            (RumiKeyPoint *)d_kp + (size_t)base * cap, (uint8_t *)d_desc + (size_t)base * cap * 32, cap, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[7], st));

@@ -416,23 +416,60 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+constexpr int kDiscP = 36, kPatchP = 40;       // LDS row pitches: 31 (+3 alignment slack) and 37 (+3) bytes as whole dwords
+
 __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
                                                      RumiKeyPoint *__restrict__ kpOut, uint8_t *__restrict__ descOut,
                                                      int outCap) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
-    if (k >= selCount[frame]) return;
-    const uint32_t pk = selPacked[(long long)frame * selCap + k], meta = selMeta[(long long)frame * selCap + k];
-    const int level = meta & 0xFF, slot = (int)(meta >> 8);
+    // per wave: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged
+    // with aligned dword loads that are all in flight together (one memory latency instead of 24 dependent byte gathers)
+    __shared__ __attribute__((aligned(16))) uint8_t sDisc[4][31 * kDiscP];
+    __shared__ __attribute__((aligned(16))) uint8_t sPatch[4][37 * kPatchP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave, frame = blockIdx.y;
+    const bool live = k < selCount[frame];
+    int level = 0, slot = 0, x = kEdge, y = kEdge, score = 0;
+    if (live) {
+        const uint32_t pk = selPacked[(long long)frame * selCap + k], meta = selMeta[(long long)frame * selCap + k];
+        level = meta & 0xFF; slot = (int)(meta >> 8);
+        x = (int)(pk & 0xFFF) + kBorder; y = (int)((pk >> 12) & 0xFFF) + kBorder; score = (int)(pk >> 24);
+    }
     const DevLevel &L = P->lv[level];
-    const int x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder, score = (int)(pk >> 24);
+    const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;     // aligned first columns of the two staged windows
+    if (live) {
+        int pitch;
+        const uint8_t *c = level_base(src, P, level, frame, &pitch) + (long long)(y - kHalfPatch) * pitch + xd;
+        const uint8_t *b = src.blur + (long long)frame * P->arenaStride + L.off + (long long)(y - 18) * L.pitch + xp;
+        uint32_t vd[5], vp[6];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int idx = lane + 64 * q, r = idx / 9, cc = idx - r * 9;
+            vd[q] = idx < 31 * 9 ? *reinterpret_cast<const uint32_t *>(c + (long long)r * pitch + 4 * cc) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int idx = lane + 64 * q, r = idx / 10, cc = idx - r * 10;
+            vp[q] = idx < 37 * 10 ? *reinterpret_cast<const uint32_t *>(b + (long long)r * L.pitch + 4 * cc) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int idx = lane + 64 * q, r = idx / 9, cc = idx - r * 9;
+            if (idx < 31 * 9) *reinterpret_cast<uint32_t *>(&sDisc[wave][r * kDiscP + 4 * cc]) = vd[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int idx = lane + 64 * q, r = idx / 10, cc = idx - r * 10;
+            if (idx < 37 * 10) *reinterpret_cast<uint32_t *>(&sPatch[wave][r * kPatchP + 4 * cc]) = vp[q];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
 
-    // IC_Angle (ORBextractor.cc:73-97)
-    int pitch;
-    const uint8_t *c = level_base(src, P, level, frame, &pitch) + (long long)y * pitch + x;
+    // IC_Angle (ORBextractor.cc:73-97): two disc rows per step
+    const uint8_t *dc = &sDisc[wave][kHalfPatch * kDiscP + (x - xd)];
     const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
     int m10 = 0, m01 = 0;
 #pragma unroll 4
@@ -442,7 +479,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
         if (v <= kHalfPatch && (lane & 31) < 31) {
             const int d = P->umax[av];
             if (u >= -d && u <= d) {
-                const int val = c[(long long)v * pitch + u];
+                const int val = dc[v * kDiscP + u];
                 m10 += u * val;
                 m01 += v * val;
             }
@@ -456,8 +493,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = angle * factorPI;
     const float a = cosf_glibc(ang), b = sinf_glibc(ang);
-    const uint8_t *bc = src.blur + (long long)frame * P->arenaStride + L.off + (long long)y * L.pitch + x;
-    const int bp = L.pitch;
+    const uint8_t *bc = &sPatch[wave][18 * kPatchP + (x - xp)];
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -465,7 +501,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
         const int r0 = cv_round_f(x0 * b + y0 * a), c0 = cv_round_f(x0 * a - y0 * b);
         const int r1 = cv_round_f(x1 * b + y1 * a), c1 = cv_round_f(x1 * a - y1 * b);
-        const int t0 = bc[r0 * bp + c0], t1 = bc[r1 * bp + c1];
+        const int t0 = bc[r0 * kPatchP + c0], t1 = bc[r1 * kPatchP + c1];
         bits[j] = __ballot(t0 < t1);
     }
     if (slot < outCap) {
