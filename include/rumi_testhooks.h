@@ -24,6 +24,7 @@ float rumi_hook_sinf(float x);           /* restated glibc sinf  (orb_math.h) */
 float rumi_hook_cosf(float x);           /* restated glibc cosf  (orb_math.h) */
 float rumi_hook_fast_atan2(float y, float x);   /* cv::fastAtan2, degrees */
 int rumi_hook_cv_round(float v);         /* cvRound */
+int rumi_hook_magic_div(int32_t idx, int32_t d);   /* divide-free idx / d used by the FAST cell kernel (orb_geom.h) */
 
 #ifdef __cplusplus
 }

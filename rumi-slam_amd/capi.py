@@ -88,7 +88,7 @@ OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", 
                "rumi_opt_stage_ms"]
 
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
-                "rumi_hook_fast_atan2", "rumi_hook_cv_round"]
+                "rumi_hook_fast_atan2", "rumi_hook_cv_round", "rumi_hook_magic_div"]
 
 
 def hooks():
@@ -105,5 +105,6 @@ def hooks():
     L.rumi_hook_fast_atan2.restype = C.c_float
     L.rumi_hook_fast_atan2.argtypes = [C.c_float, C.c_float]
     L.rumi_hook_cv_round.argtypes = [C.c_float]
+    L.rumi_hook_magic_div.argtypes = [i32, i32]
     L._hooks_ready = True
     return L

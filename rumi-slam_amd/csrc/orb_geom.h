@@ -21,6 +21,18 @@ constexpr int kPadY = kEdge;       // 19 rows, as the reference's copyMakeBorder
 
 inline int cv_round_host(double v) { return (int)std::lrint(v); }
 
+// idx / d without an integer divide, for an index into a tile of at most 98 rows of d <= 98 elements (idx < 99 d):
+// M = floor(2^20 / d) + 1, q = (idx * M) >> 20.  With M d = 2^20 + f, 0 < f <= d, and idx = q d + r:
+// idx M = q 2^20 + (q f + r M) with q f + r M < 2^20 because q <= 98 and f <= d <= 98; idx M < 99 * 2^20 * 1.0001 < 2^32.
+// Checked exhaustively by tests/test_hostcode_cpu.py through rumi_hook_magic_div.
+#if defined(__HIPCC__)
+#define RUMI_GEOM_HD __host__ __device__ inline
+#else
+#define RUMI_GEOM_HD inline
+#endif
+RUMI_GEOM_HD unsigned magic_of(unsigned d) { return (1u << 20) / d + 1u; }
+RUMI_GEOM_HD int magic_div(int idx, unsigned M) { return (int)(((unsigned)idx * M) >> 20); }
+
 struct LevelGeom {
     int w, h, pitch;            // level size, row pitch in bytes (64-B aligned, includes the 2 x kPadX frame)
     long long off;              // byte offset of the level's pixel (0,0) inside one frame's arena (the frame lies before / around it)

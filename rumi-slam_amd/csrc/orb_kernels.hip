@@ -175,11 +175,6 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *t /* centre, pitch 
     return max(A, -Bn) - 1;
 }
 
-// idx / d for 0 <= idx < 10900 and 1 <= d <= 96 without an integer divide: M = floor(2^20 / d) + 1, q = (idx * M) >> 20
-// (error analysis in DESIGN.md §5; exhaustively checked by tests/test_hostcode_cpu.py through rumi_hook_magic_div).
-__host__ __device__ __forceinline__ unsigned magic_of(unsigned d) { return (1u << 20) / d + 1u; }
-__host__ __device__ __forceinline__ int magic_div(int idx, unsigned M) { return (int)(((unsigned)idx * M) >> 20); }
-
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src,
                                                     uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[kCellTileMax * kTP];

@@ -3,6 +3,7 @@
 
 #include <vector>
 
+#include "orb_geom.h"
 #include "orb_math.h"
 #include "orb_octree.h"
 #include "rumi_orb.h"
@@ -35,3 +36,4 @@ extern "C" float rumi_hook_sinf(float x) { return sinf_glibc(x); }
 extern "C" float rumi_hook_cosf(float x) { return cosf_glibc(x); }
 extern "C" float rumi_hook_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 extern "C" int rumi_hook_cv_round(float v) { return cv_round_f(v); }
+extern "C" int rumi_hook_magic_div(int32_t idx, int32_t d) { return magic_div(idx, magic_of((unsigned)d)); }

@@ -137,3 +137,12 @@ def test_pattern_tables_identical():
     nums = [int(v) for v in re.findall(r"-?\d+", re.sub(r"//.*", "", a))]
     assert len(nums) == 1024 and max(map(abs, nums)) <= 13
     assert nums[:8] == [8, -3, 9, 5, 4, 2, 7, -12]          # first two test pairs of the ORB pattern
+
+
+def test_divide_free_indexing_is_exact():
+    """The FAST cell kernel replaces idx / d by a multiply-shift.  Its index always satisfies idx < 98 * d (an index
+    into a tile of at most 98 rows of d elements): exhaustive over that domain."""
+    H = capi.hooks()
+    for d in range(1, 99):
+        for idx in range(0, 98 * d + d):
+            assert H.rumi_hook_magic_div(idx, d) == idx // d, (idx, d)
