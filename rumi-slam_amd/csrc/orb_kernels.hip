@@ -145,21 +145,29 @@ __global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict_
 // exactly as cv::FAST's zero-initialised score rows make them.
 // The sub-image (<= 96x96 B) is staged in LDS; scores never touch HBM.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTP = kCellTileMax + 4;                 // LDS pitch of the pixel tile
-constexpr int kSP = kCellTileMax - 6 + 2;             // LDS pitch of the score tile (1-px zero ring)
-constexpr int kMaxIters = (kCellTileMax - 6) * (kCellTileMax - 6) / 256 + 1;
-
+#include <algorithm>
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-__device__ __forceinline__ int fast_score_lds(const uint8_t *t /* centre, pitch kTP */) {
+// One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
+// sub-image as aligned dwords, scores 64 pixels per step, and emits in index order with a running offset.  LDS per wave is
+// sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
+struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TP>
+__device__ __forceinline__ int fast_score_tp(const uint8_t *t) {
     const int v = t[0];
     int d[16];
-    d[0] = v - t[3 * kTP];       d[1] = v - t[3 * kTP + 1];   d[2] = v - t[2 * kTP + 2];   d[3] = v - t[kTP + 3];
-    d[4] = v - t[3];             d[5] = v - t[-kTP + 3];      d[6] = v - t[-2 * kTP + 2];  d[7] = v - t[-3 * kTP + 1];
-    d[8] = v - t[-3 * kTP];      d[9] = v - t[-3 * kTP - 1];  d[10] = v - t[-2 * kTP - 2]; d[11] = v - t[-kTP - 3];
-    d[12] = v - t[-3];           d[13] = v - t[kTP - 3];      d[14] = v - t[2 * kTP - 2];  d[15] = v - t[3 * kTP - 1];
-    // windows of 3, then of 9 = three windows of 3 (indices mod 16)
+    d[0] = v - t[3 * TP];       d[1] = v - t[3 * TP + 1];   d[2] = v - t[2 * TP + 2];   d[3] = v - t[TP + 3];
+    d[4] = v - t[3];            d[5] = v - t[-TP + 3];      d[6] = v - t[-2 * TP + 2];  d[7] = v - t[-3 * TP + 1];
+    d[8] = v - t[-3 * TP];      d[9] = v - t[-3 * TP - 1];  d[10] = v - t[-2 * TP - 2]; d[11] = v - t[-TP - 3];
+    d[12] = v - t[-3];          d[13] = v - t[TP - 3];      d[14] = v - t[2 * TP - 2];  d[15] = v - t[3 * TP - 1];
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -175,16 +183,15 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *t /* centre, pitch 
     return max(A, -Bn) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src,
+__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
                                                     uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kCellTileMax * kTP];
-    __shared__ uint8_t sc[(kCellTileMax - 6 + 2) * kSP];
-    __shared__ unsigned long long balIni[kMaxIters][4], balMin[kMaxIters][4];
-    __shared__ int prefix[kMaxIters * 4];
-    __shared__ int sTotal[2];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cell = blockIdx.x, frame = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cell = blockIdx.x * 4 + wave, frame = blockIdx.y;
+    if (cell >= P->totalCells) return;
+    uint8_t *tile = fl + (size_t)wave * F.perWave;
+    uint8_t *sc = tile + F.tileBytes;
+    unsigned long long *balI = reinterpret_cast<unsigned long long *>(sc + F.scBytes), *balM = balI + F.maxIters;
     int level = 0;
     for (int l = 1; l < P->nlevels; l++)
         if (cell >= P->lv[l].cellBase) level = l;
@@ -192,96 +199,95 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int ci = cell - L.cellBase;
     const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
     const long long cellIdx = (long long)frame * P->totalCells + cell;
-
     const int iniY = kBorder + ci_i * L.hCell, iniX = kBorder + ci_j * L.wCell;
     const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
     const int cols = maxX - iniX, rows = maxY - iniY;
     // skip rules of ORBextractor.cc:752,760 and cv::FAST's 3-px margins
     if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || cols < 7 || rows < 7) {
-        if (tid == 0) cellCnt[cellIdx] = 0;
+        if (lane == 0) cellCnt[cellIdx] = 0;
         return;
     }
-    // stage the sub-image as aligned dwords (level rows are 4-byte aligned at x = 0 in the framed arena)
+    const int TP = F.tp, SP = F.sp;
     int pitch;
-    const int shx = iniX & 3;                                   // tile column of sub-image column 0
+    const int shx = iniX & 3;
     const uint8_t *img = level_base(src, P, level, frame, &pitch) + (long long)iniY * pitch + (iniX - shx);
     const int nd = (shx + cols + 3) >> 2;
     const unsigned Mnd = magic_of(nd);
-    for (int idx = tid; idx < rows * nd; idx += 256) {
+    for (int idx = lane; idx < rows * nd; idx += 64) {
         const int r = magic_div(idx, Mnd), c = idx - r * nd;
-        *reinterpret_cast<uint32_t *>(&tile[r * kTP + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + (long long)r * pitch + 4 * c);
+        *reinterpret_cast<uint32_t *>(&tile[r * TP + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + (long long)r * pitch + 4 * c);
     }
     const int dw = cols - 6, dh = rows - 6;
-    const unsigned Mdw = magic_of(dw), Mdw2 = magic_of(dw + 2);
-    for (int idx = tid; idx < (dw + 2) * (dh + 2); idx += 256) {
-        const int r = magic_div(idx, Mdw2), c = idx - r * (dw + 2);
-        sc[r * kSP + c] = 0;
-    }
-    __syncthreads();
+    const unsigned Mdw = magic_of(dw);
+    for (int idx = lane * 4; idx < (dh + 2) * SP; idx += 256) *reinterpret_cast<uint32_t *>(&sc[idx]) = 0;
+    wave_lds_fence();
     const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
-    for (int idx = tid; idx < npx; idx += 256) {
+    for (int idx = lane; idx < npx; idx += 64) {
         const int py = magic_div(idx, Mdw), px = idx - py * dw;
-        const int s = fast_score_lds(&tile[(py + 3) * kTP + px + 3 + shx]);
-        if (s >= tlow) sc[(py + 1) * kSP + px + 1] = (uint8_t)s;
+        const uint8_t *t = &tile[(py + 3) * TP + px + 3 + shx];
+        int s;
+        switch (TP) {                                            // compile-time pitches for the common geometries
+            case 48: s = fast_score_tp<48>(t); break;
+            case 52: s = fast_score_tp<52>(t); break;
+            case 56: s = fast_score_tp<56>(t); break;
+            default: {
+                const int v = t[0];
+                int d[16];
+                d[0] = v - t[3 * TP];       d[1] = v - t[3 * TP + 1];   d[2] = v - t[2 * TP + 2];   d[3] = v - t[TP + 3];
+                d[4] = v - t[3];            d[5] = v - t[-TP + 3];      d[6] = v - t[-2 * TP + 2];  d[7] = v - t[-3 * TP + 1];
+                d[8] = v - t[-3 * TP];      d[9] = v - t[-3 * TP - 1];  d[10] = v - t[-2 * TP - 2]; d[11] = v - t[-TP - 3];
+                d[12] = v - t[-3];          d[13] = v - t[TP - 3];      d[14] = v - t[2 * TP - 2];  d[15] = v - t[3 * TP - 1];
+                int A = -256, Bn = 256, lo3[16], hi3[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    A = max(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+                    Bn = min(Bn, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+                }
+                s = max(A, -Bn) - 1;
+            }
+        }
+        if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
     }
-    __syncthreads();
-    const int iters = (npx + 255) >> 8;
+    wave_lds_fence();
+    const int iters = (npx + 63) >> 6;
     const int iniTh = P->iniTh, minTh = P->minTh;
+    int ti = 0, tm = 0;
     for (int it = 0; it < iters; it++) {
-        const int idx = it * 256 + tid;
+        const int idx = it * 64 + lane;
         bool isMax = false;
         int v = 0;
         if (idx < npx) {
             const int py = magic_div(idx, Mdw), px = idx - py * dw;
-            const uint8_t *s = &sc[(py + 1) * kSP + px + 1];
+            const uint8_t *s = &sc[(py + 1) * SP + px + 1];
             v = s[0];
-            isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-kSP - 1] && v > s[-kSP] && v > s[-kSP + 1] &&
-                    v > s[kSP - 1] && v > s[kSP] && v > s[kSP + 1];
+            isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
+                    v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
         }
         const unsigned long long bi = __ballot(isMax && v >= iniTh);
         const unsigned long long bm = __ballot(isMax && v >= minTh);
-        if (lane == 0) { balIni[it][wave] = bi; balMin[it][wave] = bm; }
+        ti += __popcll(bi); tm += __popcll(bm);
+        if (lane == 0) { balI[it] = bi; balM[it] = bm; }
     }
-    __syncthreads();
-    // prefix over the (iteration, wave) ballots on wave 0: lane l owns entries l and l + 64 (iters * 4 <= 128)
-    if (wave == 0) {
-        const int ne = iters * 4;
-        const unsigned long long *bI = &balIni[0][0], *bM = &balMin[0][0];
-        const int ci0 = lane < ne ? __popcll(bI[lane]) : 0, ci1 = lane + 64 < ne ? __popcll(bI[lane + 64]) : 0;
-        const int cm0 = lane < ne ? __popcll(bM[lane]) : 0, cm1 = lane + 64 < ne ? __popcll(bM[lane + 64]) : 0;
-        int ti = ci0 + ci1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ti += __shfl_xor(ti, o);
-        const bool useMin = ti == 0;              // retry with minThFAST only if the first call found nothing (:783)
-        const int c0 = useMin ? cm0 : ci0, c1 = useMin ? cm1 : ci1;
-        int inc0 = c0, inc1 = c1;                 // inclusive scans of the two halves
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int a = __shfl_up(inc0, o), b = __shfl_up(inc1, o);
-            if (lane >= o) { inc0 += a; inc1 += b; }
-        }
-        const int tot0 = __shfl(inc0, 63), tot1 = __shfl(inc1, 63);
-        if (lane < ne) prefix[lane] = inc0 - c0;
-        if (lane + 64 < ne) prefix[lane + 64] = tot0 + inc1 - c1;
-        if (lane == 0) {
-            const int run = tot0 + tot1;
-            sTotal[0] = run; sTotal[1] = useMin;
-            cellCnt[cellIdx] = run;
-        }
-    }
-    __syncthreads();
-    const bool useMin = sTotal[1] != 0;
+    wave_lds_fence();
+    const bool useMin = ti == 0;                  // retry with minThFAST only if the first call found nothing (:783)
+    if (lane == 0) cellCnt[cellIdx] = useMin ? tm : ti;
     uint32_t *out = cellBuf + cellIdx * P->maxCellCand;
+    int run = 0;
     for (int it = 0; it < iters; it++) {
-        const unsigned long long b = useMin ? balMin[it][wave] : balIni[it][wave];
+        const unsigned long long b = useMin ? balM[it] : balI[it];
         if ((b >> lane) & 1ull) {
-            const int idx = it * 256 + tid;
+            const int idx = it * 64 + lane;
             const int py = magic_div(idx, Mdw), px = idx - py * dw;
-            const int pos = prefix[it * 4 + wave] + __popcll(b & ((1ull << lane) - 1ull));
             const uint32_t x = (uint32_t)(px + 3 + ci_j * L.wCell), y = (uint32_t)(py + 3 + ci_i * L.hCell);
-            out[pos] = x | (y << 12) | ((uint32_t)sc[(py + 1) * kSP + px + 1] << 24);
+            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[(py + 1) * SP + px + 1] << 24);
         }
+        run += __popcll(b);
     }
 }
 
@@ -534,7 +540,19 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st) {
-    hipLaunchKernelGGL(k_fast_cells, dim3(hP.totalCells, nframes), dim3(256), 0, st, dP, src, cellBuf, cellCnt);
+    // LDS per wave from the largest cell of this geometry
+    int wMax = 0, hMax = 0;
+    for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
+    FastLds F;
+    F.tp = (wMax + 6 + 3 + 3 + 3) & ~3;                   // + alignment shift (<= 3) + dword tail, rounded to 4
+    F.sp = (wMax + 2 + 3) & ~3;
+    F.tileBytes = (hMax + 6) * F.tp;
+    F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
+    F.maxIters = (wMax * hMax + 63) / 64 + 1;
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 15) & ~15;
+    F.tileBytes = (F.tileBytes + 15) & ~15;
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 15) & ~15;
+    hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st) {
