@@ -6,6 +6,9 @@
  *   R/lib_src/ORBmatcher.cc:39-196      SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
  *   R/lib_src/ORBmatcher.cc:198-370     SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)
  *   R/lib_src/ORBmatcher.cc:1498-1683   SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)
+ *   R/lib_src/ORBmatcher.cc:372-579     SearchByProjection(KeyFrame*, Sim3f&, points[, pointKFs], matched[, matchedKF], th, ratioHamming)
+ *   R/lib_src/ORBmatcher.cc:1685-1793   SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist)
+ *   R/lib_src/ORBmatcher.cc:682-804     SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)
  *   R/lib_src/ORBmatcher.cc:1830-1844   DescriptorDistance
  *   R/lib_src/Frame.cc:441-466,695-761  AssignFeaturesToGrid / GetFeaturesInArea / PosInGrid (candidate order)
  * The facade marshals Frame / KeyFrame / MapPoint pointers into the flat views below: a MapPoint* becomes an
@@ -85,6 +88,36 @@ int rumi_search_by_projection_frame(RumiMatcher *m, const RumiFrameFeatures *Cur
 int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, const RumiFeatureVector *kf_fv, const int32_t *kf_mp,
                        int32_t nmp, const uint8_t *mp_bad, const RumiFrameFeatures *F, const RumiFeatureVector *f_fv,
                        float nnratio, int32_t check_orientation, int32_t *matches, int32_t *nmatches_out);
+
+/* SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) — loop / merge detection (ORBmatcher.cc:682-804).
+ * kf1_mp / kf2_mp: GetMapPointMatches() of the two key-frames as ids (-1 NULL) into mp_bad[nmp].
+ * matches12[KF1->n] out: index of the KF2 FEATURE whose map point the reference stores in vpMatches12[idx1] (-1 = NULL). */
+int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFeatureVector *fv1, const int32_t *kf1_mp,
+                          const RumiFrameFeatures *KF2, const RumiFeatureVector *fv2, const int32_t *kf2_mp, int32_t nmp,
+                          const uint8_t *mp_bad, float nnratio, int32_t check_orientation, int32_t *matches12,
+                          int32_t *nmatches_out);
+
+/* SearchByProjection(KeyFrame *pKF, Sophus::Sim3f &Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th,
+ * float ratioHamming)                                        (ORBmatcher.cc:372-471, explicit_invz = 0) and its overload with
+ * vpPointsKFs / vpMatchedKF                                  (ORBmatcher.cc:473-579, explicit_invz = 1: u = fx * (x * (1/z)) + cx).
+ * Tcw7 / Ow3: the SE3 and camera centre the reference derives from Scw (:380-381), computed by the facade with Sophus.
+ * Per candidate point i (nmp): skip = isBad() || already in vpMatched; GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance,
+ * GetDescriptor.  log_scale_factor = pKF->mfLogScaleFactor.
+ * matched[KF->n] in/out: -1 = free, any other value = the feature already holds a point; on return newly matched features
+ * hold the INDEX i of their point (the facade maps it to vpPoints[i] / vpPointsKFs[i]). */
+int rumi_search_by_projection_sim3(RumiMatcher *m, const RumiFrameFeatures *KF, float log_scale_factor, const float *Tcw7,
+                                   const float *Ow3, const float *K4, int32_t nmp, const uint8_t *skip, const float *mp_pos,
+                                   const float *mp_normal, const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc,
+                                   int32_t th, float ratio_hamming, int32_t explicit_invz, int32_t *matched, int32_t *nmatches_out);
+
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)
+ * — Relocalization (ORBmatcher.cc:1685-1793; Tracking.cc:3315,3327).  kf_mp[nkf] = pKF->GetMapPointMatches() as ids into the
+ * per-point arrays (skip = isBad() || sAlreadyFound.count()); Ow3 = camera centre of CurrentFrame.  cur_mp in/out. */
+int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur, float log_scale_factor, const float *Tcw7,
+                                    const float *Ow3, const float *K4, const RumiKeyPoint *kf_keys, int32_t nkf, const int32_t *kf_mp,
+                                    int32_t nmp, const uint8_t *skip, const float *mp_pos, const float *mp_min_dist,
+                                    const float *mp_max_dist, const uint8_t *mp_desc, float th, int32_t orb_dist,
+                                    int32_t check_orientation, int32_t *cur_mp, int32_t *nmatches_out);
 
 /* Brute-force all-pairs 256-bit Hamming (the GPU formulation of BASELINE.json config 3), device pointers:
  * for each of B frame pairs, every query descriptor against every train descriptor; best index (first train index

@@ -6,6 +6,10 @@
 //   SearchByProjection(Frame&, vector<MapPoint*>&)  R/lib_src/ORBmatcher.cc:39-196        (mono branch)
 //   SearchByBoW(KeyFrame*, Frame&, ...)             R/lib_src/ORBmatcher.cc:198-370       (mono branch)
 //   SearchByProjection(Frame& Cur, const Frame& Last) R/lib_src/ORBmatcher.cc:1498-1683   (mono branch)
+//   SearchByProjection(KeyFrame*, Sim3f&, points[, pointKFs], matched[, matchedKF], th, ratioHamming)  :372-471, :473-579
+//   SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist)   R/lib_src/ORBmatcher.cc:1685-1793
+//   SearchByBoW(KeyFrame*, KeyFrame*, ...)          R/lib_src/ORBmatcher.cc:682-804
+//   KeyFrame::GetFeaturesInArea / IsInImage         R/lib_src/KeyFrame.cc:887-929;  MapPoint::PredictScale  R/lib_src/MapPoint.cc:538-570
 //   ComputeThreeMaxima                              R/lib_src/ORBmatcher.cc:1795-1826
 //   Sophus SE3f * point, Pinhole::project           R/Thirdparty/Sophus/sophus/so3.hpp:358-367, R/lib_src/CameraModels/Pinhole.cpp:43-49
 // PARITY STATUS: pinned by source only (the reference has no tests for this path); integer logic is exact,
@@ -268,6 +272,163 @@ int orc_search_by_bow(const KeyPoint *kfKeys, const uint8_t *kfDesc, int nkf, co
             if (i == ind1 || i == ind2 || i == ind3) continue;
             for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
         }
+    }
+    return nmatches;
+}
+
+// MapPoint::PredictScale (R/lib_src/MapPoint.cc:538-570): ceil(log(mfMaxDistance / dist) / mfLogScaleFactor), clamped.
+// `log` is called unqualified on a float in a file without `using namespace std`: it binds to ::log(double) unless a header
+// pulls libstdc++'s <math.h> overloads in; the double form is restated here (they differ only when the quotient is within
+// one float ulp of an integer) — unpinned.
+static int predict_scale(float maxDistance, float dist, float logScaleFactor, int nLevels) {
+    const float ratio = maxDistance / dist;
+    int nScale = (int)std::ceil(std::log((double)ratio) / logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nLevels) nScale = nLevels - 1;
+    return nScale;
+}
+
+// SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), mono  (ORBmatcher.cc:682-804).
+// matches12[n1]: index of the KF2 FEATURE matched to each KF1 feature (-1 none); the caller maps it to vpMapPoints2[.].
+int orc_search_by_bow_kf(const KeyPoint *k1, const uint8_t *d1, int n1, const int32_t *mp1, const uint32_t *nodes1, const int32_t *off1,
+                         const uint32_t *idx1, int nn1, const KeyPoint *k2, const uint8_t *d2, int n2, const int32_t *mp2,
+                         const uint32_t *nodes2, const int32_t *off2, const uint32_t *idx2, int nn2, const uint8_t *mpBad,
+                         float nnratio, int checkOri, int32_t *matches12) {
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<char> matched2(n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int p = off1[a]; p < off1[a + 1]; p++) {
+                const int i1 = (int)idx1[p];
+                const int pMP1 = mp1[i1];
+                if (pMP1 < 0 || mpBad[pMP1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int q = off2[b]; q < off2[b + 1]; q++) {
+                    const int i2 = (int)idx2[q];
+                    const int pMP2 = mp2[i2];
+                    if (matched2[i2] || pMP2 < 0) continue;
+                    if (mpBad[pMP2]) continue;
+                    const int dist = descriptor_distance(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                    matches12[i1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    if (checkOri) rotHist[rot_bin(k1[i1].angle, k2[bestIdx2].angle)].push_back(i1);
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) a = (int)(std::lower_bound(nodes1, nodes1 + nn1, nodes2[b]) - nodes1);
+        else b = (int)(std::lower_bound(nodes2, nodes2 + nn2, nodes1[a]) - nodes2);
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(KeyFrame *pKF, Sim3f &Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming)
+// (ORBmatcher.cc:372-471 with variant = 0: camera->project; :473-579 with variant = 1: explicit invz form).
+// Tcw7 / Ow3 are the SE3 and camera centre the reference derives from Scw (:380-381); skip[i] = isBad() || spAlreadyFound.count().
+// matched[nkf] in/out: index of the POINT (into vpPoints) matched to each key-frame feature, -2 = already held a point, -1 = free.
+int orc_search_by_projection_sim3(const KeyPoint *keys, const uint8_t *desc, int n, float minX, float minY, float maxX, float maxY,
+                                  const float *scaleFactors, int nLevels, float logScaleFactor, const float *Tcw7, const float *Ow3,
+                                  const float *K4, int nmp, const uint8_t *skip, const float *mpPos, const float *mpNormal,
+                                  const float *mpMinDist, const float *mpMaxDist, const uint8_t *mpDesc, int th, float ratioHamming,
+                                  int variant, int32_t *matched) {
+    FrameGrid KF(keys, desc, n, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nmp; iMP++) {
+        if (skip[iMP]) continue;
+        const float *p3Dw = mpPos + (size_t)iMP * 3;
+        float p3Dc[3];
+        se3_mul(Tcw7, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0) continue;
+        float u, v;
+        if (variant == 0) { u = K4[0] * p3Dc[0] / p3Dc[2] + K4[2]; v = K4[1] * p3Dc[1] / p3Dc[2] + K4[3]; }
+        else { const float invz = 1 / p3Dc[2]; const float x = p3Dc[0] * invz, y = p3Dc[1] * invz; u = K4[0] * x + K4[2]; v = K4[1] * y + K4[3]; }
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;                 // KeyFrame::IsInImage
+        const float maxDistance = 1.2f * mpMaxDist[iMP], minDistance = 0.8f * mpMinDist[iMP];
+        const float PO[3] = {p3Dw[0] - Ow3[0], p3Dw[1] - Ow3[1], p3Dw[2] - Ow3[2]};
+        const float dist = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = mpNormal + (size_t)iMP * 3;
+        if ((PO[0] * Pn[0] + PO[1] * Pn[1]) + PO[2] * Pn[2] < 0.5 * dist) continue;        // viewing angle < 60 deg
+        const int nPredictedLevel = predict_scale(mpMaxDist[iMP], dist, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        KF.in_area(u, v, radius, -1, -1, vIndices);                                         // KeyFrame::GetFeaturesInArea: no level filter
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = mpDesc + (size_t)iMP * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (matched[idx] != -1) continue;
+            const int kpLevel = keys[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int d = descriptor_distance(dMP, desc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW * ratioHamming) { matched[bestIdx] = iMP; nmatches++; }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1685-1793).
+// kfMp[nkf]: map point id of each key-frame feature (-1 none); skip[id] = isBad() || sAlreadyFound.count(); per id: pos, min/max distance,
+// descriptor.  cur_mp[ncur] in/out (-1 NULL).
+int orc_search_by_projection_reloc(const KeyPoint *curKeys, const uint8_t *curDesc, int ncur, float minX, float minY, float maxX, float maxY,
+                                   const float *scaleFactors, int nLevels, float logScaleFactor, const float *Tcw7, const float *Ow3,
+                                   const float *K4, const KeyPoint *kfKeys, int nkf, const int32_t *kfMp, const uint8_t *skip,
+                                   const float *mpPos, const float *mpMinDist, const float *mpMaxDist, const uint8_t *mpDesc, float th,
+                                   int ORBdist, int checkOri, int32_t *cur_mp) {
+    FrameGrid C(curKeys, curDesc, ncur, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH], vIndices2;
+    for (int i = 0; i < nkf; i++) {
+        const int pMP = kfMp[i];
+        if (pMP < 0 || skip[pMP]) continue;
+        const float *x3Dw = mpPos + (size_t)pMP * 3;
+        float x3Dc[3];
+        se3_mul(Tcw7, x3Dw, x3Dc);
+        const float u = K4[0] * x3Dc[0] / x3Dc[2] + K4[2], v = K4[1] * x3Dc[1] / x3Dc[2] + K4[3];
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const float PO[3] = {x3Dw[0] - Ow3[0], x3Dw[1] - Ow3[1], x3Dw[2] - Ow3[2]};
+        const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+        const float maxDistance = 1.2f * mpMaxDist[pMP], minDistance = 0.8f * mpMinDist[pMP];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = predict_scale(mpMaxDist[pMP], dist3D, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        C.in_area(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = mpDesc + (size_t)pMP * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (cur_mp[i2] >= 0) continue;
+            const int d = descriptor_distance(dMP, curDesc + (size_t)i2 * 32);
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            cur_mp[bestIdx2] = pMP;
+            nmatches++;
+            if (checkOri) rotHist[rot_bin(kfKeys[i].angle, curKeys[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { cur_mp[idx] = -1; nmatches--; }
     }
     return nmatches;
 }

@@ -27,7 +27,7 @@ namespace rumi {
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // Frame.h:42-43
 constexpr int kMaxSortN = 8192;
 
-enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2 };
+enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5 };
 
 struct Query {           // 48 bytes
     float u, v, r;       // window centre / half-size (MODE_BOW: unused)
@@ -172,6 +172,85 @@ __global__ void k_queries_bow(int nnKF, const uint32_t *kfNodes, const int32_t *
     }
 }
 
+// MapPoint::PredictScale (MapPoint.cc:538-570); log in double (oracle/match_oracle.cc explains the choice)
+__device__ __forceinline__ int predict_scale(float maxDistance, float dist, float logScaleFactor, int nLevels) {
+    const float ratio = maxDistance / dist;
+    int nScale = (int)ceil(log((double)ratio) / (double)logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nLevels) nScale = nLevels - 1;
+    return nScale;
+}
+__device__ __forceinline__ void se3f_mul(const float *T, const float *p, float *o) {   // Sophus::SE3f * p (so3.hpp:358-367)
+    const float qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+    float u0 = qy * p[2] - qz * p[1], u1 = qz * p[0] - qx * p[2], u2 = qx * p[1] - qy * p[0];
+    u0 += u0; u1 += u1; u2 += u2;
+    const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+    o[0] = ((p[0] + qw * u0) + c0) + T[4]; o[1] = ((p[1] + qw * u1) + c1) + T[5]; o[2] = ((p[2] + qw * u2) + c2) + T[6];
+}
+
+// SearchByProjection(KeyFrame*, Sim3f&, points, ...): ORBmatcher.cc:389-436 (variant 0) / :491-539 (variant 1)
+__global__ void k_queries_sim3(int nmp, const uint8_t *skip, const float *mpPos, const float *mpNormal, const float *mpMinDist,
+                               const float *mpMaxDist, const float *pose /*Tcw7, K4, Ow3*/, const float *scaleFactors, int nLevels,
+                               float logScaleFactor, int th, int variant, float minX, float minY, float maxX, float maxY, Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nmp) return;
+    Query o{};
+    o.descId = i; o.mpId = i; o.blocks = 1;
+    const float *Tcw = pose, *K = pose + 7, *Ow = pose + 11;
+    if (!skip[i]) {
+        const float *p3Dw = mpPos + (size_t)i * 3;
+        float pc[3];
+        se3f_mul(Tcw, p3Dw, pc);
+        if (!(pc[2] < 0.0f)) {
+            float u, v;
+            if (variant == 0) { u = K[0] * pc[0] / pc[2] + K[2]; v = K[1] * pc[1] / pc[2] + K[3]; }
+            else { const float invz = 1 / pc[2]; const float x = pc[0] * invz, y = pc[1] * invz; u = K[0] * x + K[2]; v = K[1] * y + K[3]; }
+            if (u >= minX && u < maxX && v >= minY && v < maxY) {                       // KeyFrame::IsInImage
+                const float maxD = 1.2f * mpMaxDist[i], minD = 0.8f * mpMinDist[i];
+                const float P0 = p3Dw[0] - Ow[0], P1 = p3Dw[1] - Ow[1], P2 = p3Dw[2] - Ow[2];
+                const float dist = sqrtf((P0 * P0 + P1 * P1) + P2 * P2);
+                const float *Pn = mpNormal + (size_t)i * 3;
+                if (!(dist < minD || dist > maxD) && !((double)((P0 * Pn[0] + P1 * Pn[1]) + P2 * Pn[2]) < 0.5 * (double)dist)) {
+                    const int lvl = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
+                    o.valid = 1; o.u = u; o.v = v; o.r = (float)th * scaleFactors[lvl];
+                    o.minLevel = lvl - 1; o.maxLevel = lvl;                              // the level test of :445-448 / :553-556
+                }
+            }
+        }
+    }
+    q[i] = o;
+}
+
+// SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist): ORBmatcher.cc:1700-1733
+__global__ void k_queries_reloc(int nkf, const RumiKeyPoint *kfKeys, const int32_t *kfMp, const uint8_t *skip, const float *mpPos,
+                                const float *mpMinDist, const float *mpMaxDist, const float *pose, const float *scaleFactors, int nLevels,
+                                float logScaleFactor, float th, float minX, float minY, float maxX, float maxY, Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nkf) return;
+    Query o{};
+    const int mp = kfMp[i];
+    const float *Tcw = pose, *K = pose + 7, *Ow = pose + 11;
+    if (mp >= 0 && !skip[mp]) {
+        const float *xw = mpPos + (size_t)mp * 3;
+        float pc[3];
+        se3f_mul(Tcw, xw, pc);
+        const float u = K[0] * pc[0] / pc[2] + K[2], v = K[1] * pc[1] / pc[2] + K[3];
+        if (!(u < minX || u > maxX) && !(v < minY || v > maxY)) {
+            const float P0 = xw[0] - Ow[0], P1 = xw[1] - Ow[1], P2 = xw[2] - Ow[2];
+            const float dist3D = sqrtf((P0 * P0 + P1 * P1) + P2 * P2);
+            const float maxD = 1.2f * mpMaxDist[mp], minD = 0.8f * mpMinDist[mp];
+            if (!(dist3D < minD || dist3D > maxD)) {
+                const int lvl = predict_scale(mpMaxDist[mp], dist3D, logScaleFactor, nLevels);
+                o.valid = 1; o.u = u; o.v = v; o.r = th * scaleFactors[lvl];
+                o.minLevel = lvl - 1; o.maxLevel = lvl + 1;
+            }
+        }
+        o.descId = mp; o.mpId = mp; o.blocks = 1;
+    }
+    o.angle = kfKeys[i].angle;
+    q[i] = o;
+}
+
 // ---- 3. candidates: one wave per query -----------------------------------------------------------------------------
 // list entry: feature (16 bit) | distance (9 bit) << 16 | octave (4 bit) << 25
 template <bool FILL>
@@ -196,7 +275,7 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
     }
     uint32_t *out = FILL ? lists + offsets[qi] : nullptr;
     int count = 0;
-    if (mode == MODE_BOW) {
+    if (mode == MODE_BOW || mode == MODE_BOW_KF) {
         for (int p = Q.c0 + lane; p - lane < Q.c1; p += 64) {
             const bool ok = p < Q.c1;
             if (FILL && ok) {
@@ -272,6 +351,9 @@ struct ResolveArgs {
     int32_t *nmatches;              // out
     float nnratio;
     int checkOri;
+    const uint8_t *featBlocked0;   // optional [nfeat]: feature unavailable from the start (overrides the featMp/mpObs rule)
+    float thrF;                    // MODE_SIM3: TH_LOW * ratioHamming
+    int thrI;                      // MODE_RELOC: ORBdist
 };
 
 __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatcher.cc:1592-1599
@@ -295,7 +377,8 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
         // occupancy as the previous round's assignments imply it
         for (int f = tid; f < A.nfeat; f += nt) {
             int b = kFree;
-            if (A.mode != MODE_BOW) {
+            if (A.featBlocked0) { if (A.featBlocked0[f]) b = -1; }
+            else if (A.mode != MODE_BOW) {
                 const int id = A.featMp[f];
                 if (id >= 0 && A.mpObs[id] > 0) b = -1;
             }
@@ -327,8 +410,14 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
                     if (bestDist <= RUMI_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) pick = bestIdx;
                 } else if (A.mode == MODE_FRAME) {                      // :1577
                     if (bestDist <= RUMI_TH_HIGH) pick = bestIdx;
-                } else {                                                // :283-285
+                } else if (A.mode == MODE_BOW) {                        // :283-285
                     if (bestDist <= RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
+                } else if (A.mode == MODE_BOW_KF) {                     // :753-754
+                    if (bestDist < RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
+                } else if (A.mode == MODE_SIM3) {                       // :463 / :571
+                    if ((float)bestDist <= A.thrF) pick = bestIdx;
+                } else {                                                // MODE_RELOC :1757
+                    if (bestDist <= A.thrI) pick = bestIdx;
                 }
             }
             if (pick != A.assign[i]) { changed = 1; A.assign[i] = pick; }
@@ -343,7 +432,7 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
     int32_t *last = blockedFrom;                                        // reuse LDS: last assigning query per feature
     for (int f = tid; f < A.nfeat; f += nt) last[f] = -1;
     __syncthreads();
-    const bool useHist = A.checkOri && A.mode != MODE_MAPPOINTS;
+    const bool useHist = A.checkOri && A.mode != MODE_MAPPOINTS && A.mode != MODE_SIM3;
     int local = 0;
     for (int i = tid; i < A.nq; i += nt) {
         const int f = A.assign[i];
@@ -380,13 +469,17 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
     if (A.mode == MODE_BOW)
         for (int f = tid; f < A.nfeat; f += nt) A.featMp[f] = -1;
     __syncthreads();
-    for (int f = tid; f < A.nfeat; f += nt)
-        if (last[f] >= 0) A.featMp[f] = A.q[last[f]].mpId;
+    if (A.mode != MODE_BOW_KF)
+        for (int f = tid; f < A.nfeat; f += nt)
+            if (last[f] >= 0) A.featMp[f] = A.q[last[f]].mpId;
     __syncthreads();
     if (useHist)                                                        // entries of the rejected bins are set to NULL
         for (int i = tid; i < A.nq; i += nt) {
             const int f = A.assign[i];
-            if (f >= 0 && !sKeep[rot_bin(A.q[i].angle, A.featKeys[f].angle)]) A.featMp[f] = -1;
+            if (f >= 0 && !sKeep[rot_bin(A.q[i].angle, A.featKeys[f].angle)]) {
+                if (A.mode == MODE_BOW_KF) A.assign[i] = -1;           // SearchByBoW(KF,KF) reports per QUERY (vpMatches12[idx1])
+                else A.featMp[f] = -1;
+            }
         }
 }
 
@@ -535,7 +628,8 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
 
 // count pass, scan, (grow the list arena if needed), fill pass, resolve
 static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
-                      float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut) {
+                      float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
+                      float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
     if (nq > 0) {
         hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists);
@@ -553,11 +647,12 @@ static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, cons
                            m->dCounts, m->dOffsets, m->dLists);
     }
     ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
-                  nnratio, checkOri};
+                  nnratio, checkOri, dBlocked0, thrF, thrI};
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(nmatchesOut, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (fd.n > 0) HIP_TRY(hipMemcpy(hostFeatMp, m->dFeatMp, (size_t)fd.n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (fd.n > 0 && hostFeatMp) HIP_TRY(hipMemcpy(hostFeatMp, m->dFeatMp, (size_t)fd.n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nq > 0 && hostAssign) HIP_TRY(hipMemcpy(hostAssign, m->dAssign, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RUMI_OK;
 }
 
@@ -633,6 +728,96 @@ extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, c
         hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
+}
+
+extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFeatureVector *fv1, const int32_t *kf1_mp,
+                                     const RumiFrameFeatures *KF2, const RumiFeatureVector *fv2, const int32_t *kf2_mp, int32_t nmp,
+                                     const uint8_t *mp_bad, float nnratio, int32_t check_orientation, int32_t *matches12,
+                                     int32_t *nmatches_out) {
+    if (!m || !KF1 || !KF2 || !fv1 || !fv2 || !kf1_mp || !kf2_mp || !matches12 || !nmatches_out || nmp < 0) return RUMI_E_INVALID;
+    const int nqe = fv1->n_nodes > 0 ? fv1->offsets[fv1->n_nodes] : 0, nfe = fv2->n_nodes > 0 ? fv2->offsets[fv2->n_nodes] : 0;
+    if (KF1->n > m->maxQ || nqe > m->maxQ || nmp > m->maxQ || fv1->n_nodes > m->maxQ || nfe > m->maxFeat || fv2->n_nodes > m->maxFeat) {
+        g_lastError = "SearchByBoW(KF,KF): sizes exceed the matcher's capacities";
+        return RUMI_E_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, KF2, &fd);
+    if (rc != RUMI_OK) return rc;
+    // a KF2 feature is a candidate only if it holds a good map point (:732-736): everything else starts blocked
+    std::vector<uint8_t> blocked(std::max(KF2->n, 1)), kf1bad(std::max(nmp, 1), 0);
+    for (int f = 0; f < KF2->n; f++) blocked[f] = kf2_mp[f] < 0 || kf2_mp[f] >= nmp || mp_bad[kf2_mp[f]];
+    if (KF2->n > 0) H2D(m->dU8b, blocked.data(), KF2->n);
+    if (KF1->n > 0) { H2D(m->dQKeys, KF1->keys_un, KF1->n); H2D(m->dQDesc, KF1->desc, (size_t)KF1->n * 32); H2D(m->dI[0], kf1_mp, KF1->n); }
+    if (nmp > 0) H2D(m->dU8a, mp_bad, nmp);
+    if (fv1->n_nodes > 0) { H2D(m->dNodesA, fv1->node_ids, fv1->n_nodes); H2D(m->dOffA, fv1->offsets, fv1->n_nodes + 1); }
+    if (nqe > 0) H2D(m->dIdxA, fv1->indices, nqe);
+    if (fv2->n_nodes > 0) { H2D(m->dNodesB, fv2->node_ids, fv2->n_nodes); H2D(m->dOffB, fv2->offsets, fv2->n_nodes + 1); }
+    if (nfe > 0) H2D(m->dFvIdx, fv2->indices, nfe);
+    if (fv1->n_nodes > 0)
+        hipLaunchKernelGGL(k_queries_bow, dim3((fv1->n_nodes + 255) / 256), dim3(256), 0, nullptr, fv1->n_nodes, m->dNodesA, m->dOffA, m->dIdxA,
+                           m->dI[0], m->dU8a, m->dQKeys, fv2->n_nodes, m->dNodesB, m->dOffB, m->dQ);
+    std::vector<int32_t> assign(std::max(nqe, 1), -1);
+    rc = run_search(m, MODE_BOW_KF, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, nullptr, nmatches_out, m->dU8b, 0.f, 0, assign.data());
+    if (rc != RUMI_OK) return rc;
+    for (int i = 0; i < KF1->n; i++) matches12[i] = -1;
+    for (int p = 0; p < nqe; p++) if (assign[p] >= 0) matches12[fv1->indices[p]] = assign[p];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_search_by_projection_sim3(RumiMatcher *m, const RumiFrameFeatures *KF, float log_scale_factor, const float *Tcw7,
+                                              const float *Ow3, const float *K4, int32_t nmp, const uint8_t *skip, const float *mp_pos,
+                                              const float *mp_normal, const float *mp_min_dist, const float *mp_max_dist,
+                                              const uint8_t *mp_desc, int32_t th, float ratio_hamming, int32_t explicit_invz,
+                                              int32_t *matched, int32_t *nmatches_out) {
+    if (!m || !KF || !Tcw7 || !Ow3 || !K4 || !matched || !nmatches_out || nmp < 0) return RUMI_E_INVALID;
+    if (nmp > m->maxQ) { g_lastError = "more candidate points than max_queries"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, KF, &fd);
+    if (rc != RUMI_OK) return rc;
+    std::vector<uint8_t> blocked(std::max(KF->n, 1));
+    for (int f = 0; f < KF->n; f++) blocked[f] = matched[f] != -1;                 // vpMatched[idx] != NULL (:442)
+    if (KF->n > 0) { H2D(m->dU8b, blocked.data(), KF->n); H2D(m->dFeatMp, matched, KF->n); }
+    float pose[14];
+    std::memcpy(pose, Tcw7, 28); std::memcpy(pose + 7, K4, 16); std::memcpy(pose + 11, Ow3, 12);
+    H2D(m->dPose, pose, 14);
+    if (nmp > 0) {
+        H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3);
+        H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+        hipLaunchKernelGGL(k_queries_sim3, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
+                           m->dPose, m->dScale, KF->nlevels, log_scale_factor, th, explicit_invz, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    }
+    return run_search(m, MODE_SIM3, nmp, fd, m->dQDesc, nullptr, 0.f, 0, matched, nmatches_out, m->dU8b, (float)RUMI_TH_LOW * ratio_hamming, 0);
+}
+
+extern "C" int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur, float log_scale_factor, const float *Tcw7,
+                                               const float *Ow3, const float *K4, const RumiKeyPoint *kf_keys, int32_t nkf,
+                                               const int32_t *kf_mp, int32_t nmp, const uint8_t *skip, const float *mp_pos,
+                                               const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc, float th,
+                                               int32_t orb_dist, int32_t check_orientation, int32_t *cur_mp, int32_t *nmatches_out) {
+    if (!m || !Cur || !Tcw7 || !Ow3 || !K4 || !cur_mp || !nmatches_out || nkf < 0 || nmp < 0) return RUMI_E_INVALID;
+    if (nkf > m->maxQ || nmp > m->maxQ) { g_lastError = "more key-frame features / map points than max_queries"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, Cur, &fd);
+    if (rc != RUMI_OK) return rc;
+    std::vector<uint8_t> blocked(std::max(Cur->n, 1));
+    for (int f = 0; f < Cur->n; f++) blocked[f] = cur_mp[f] >= 0;                  // CurrentFrame.mvpMapPoints[i2] != NULL (:1746)
+    if (Cur->n > 0) { H2D(m->dU8b, blocked.data(), Cur->n); H2D(m->dFeatMp, cur_mp, Cur->n); }
+    float pose[14];
+    std::memcpy(pose, Tcw7, 28); std::memcpy(pose + 7, K4, 16); std::memcpy(pose + 11, Ow3, 12);
+    H2D(m->dPose, pose, 14);
+    if (nmp > 0) {
+        H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp);
+        H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+    }
+    if (nkf > 0) {
+        H2D(m->dQKeys, kf_keys, nkf); H2D(m->dI[0], kf_mp, nkf);
+        hipLaunchKernelGGL(k_queries_reloc, dim3((nkf + 255) / 256), dim3(256), 0, nullptr, nkf, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dF[2],
+                           m->dF[3], m->dPose, m->dScale, Cur->nlevels, log_scale_factor, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    }
+    return run_search(m, MODE_RELOC, nkf, fd, m->dQDesc, nullptr, 0.f, check_orientation, cur_mp, nmatches_out, m->dU8b, 0.f, orb_dist);
 }
 
 extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,

@@ -21,7 +21,8 @@ class RumiFeatureVector(C.Structure):
 
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
-                 "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
+                 "rumi_search_by_projection_reloc", "rumi_match_bruteforce_batch_device"]
 
 
 def _lib():
@@ -37,6 +38,12 @@ def _lib():
     L.rumi_search_by_projection_frame.argtypes = [vp, C.POINTER(RumiFrameFeatures), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, f32, i32, vp, C.POINTER(i32)]
     L.rumi_search_by_bow.argtypes = [vp, C.POINTER(RumiFrameFeatures), C.POINTER(RumiFeatureVector), vp, i32, vp,
                                      C.POINTER(RumiFrameFeatures), C.POINTER(RumiFeatureVector), f32, i32, vp, C.POINTER(i32)]
+    L.rumi_search_by_bow_kf.argtypes = [vp, C.POINTER(RumiFrameFeatures), C.POINTER(RumiFeatureVector), vp, C.POINTER(RumiFrameFeatures),
+                                        C.POINTER(RumiFeatureVector), vp, i32, vp, f32, i32, vp, C.POINTER(i32)]
+    L.rumi_search_by_projection_sim3.argtypes = [vp, C.POINTER(RumiFrameFeatures), f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32,
+                                                 vp, C.POINTER(i32)]
+    L.rumi_search_by_projection_reloc.argtypes = [vp, C.POINTER(RumiFrameFeatures), f32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32,
+                                                  i32, i32, vp, C.POINTER(i32)]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
     return L
@@ -129,6 +136,51 @@ class ORBmatcher:
                                                 C.byref(F.c), C.byref(f_fv.c), self.mfNNratio, int(self.mbCheckOrientation),
                                                 capi.ptr(matches), C.byref(nm)))
         return nm.value, matches
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def SearchByBoW_KF(m, KF1, fv1, kf1_mp, KF2, fv2, kf2_mp, mp_bad):
+    """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12): returns (nmatches, matches12[KF1.n] = KF2 feature index or -1)."""
+    k1 = np.ascontiguousarray(kf1_mp, np.int32); k2 = np.ascontiguousarray(kf2_mp, np.int32); mb = _u8(mp_bad)
+    out = np.full(KF1.n, -1, np.int32)
+    nm = C.c_int32()
+    capi.check(m._lib.rumi_search_by_bow_kf(m._h, C.byref(KF1.c), C.byref(fv1.c), capi.ptr(k1), C.byref(KF2.c), C.byref(fv2.c), capi.ptr(k2),
+                                            len(mb), capi.ptr(mb), m.mfNNratio, int(m.mbCheckOrientation), capi.ptr(out), C.byref(nm)))
+    return nm.value, out
+
+
+def SearchByProjection_Sim3(m, KF, log_sf, Tcw7, Ow3, K4, pts, matched, th, ratio_hamming, explicit_invz=False):
+    """pts: dict skip u8, pos [n,3], normal [n,3], min_dist, max_dist f32, desc [n,32].  matched in/out (-1 free)."""
+    a = dict(skip=_u8(pts["skip"]), pos=_f32(pts["pos"]), normal=_f32(pts["normal"]), mn=_f32(pts["min_dist"]), mx=_f32(pts["max_dist"]),
+             desc=_u8(pts["desc"]))
+    matched = np.ascontiguousarray(matched, np.int32).copy()
+    T, O, K = _f32(Tcw7), _f32(Ow3), _f32(K4)
+    nm = C.c_int32()
+    capi.check(m._lib.rumi_search_by_projection_sim3(m._h, C.byref(KF.c), float(log_sf), capi.ptr(T), capi.ptr(O), capi.ptr(K), len(a["skip"]),
+                                                     capi.ptr(a["skip"]), capi.ptr(a["pos"]), capi.ptr(a["normal"]), capi.ptr(a["mn"]),
+                                                     capi.ptr(a["mx"]), capi.ptr(a["desc"]), int(th), float(ratio_hamming), int(explicit_invz),
+                                                     capi.ptr(matched), C.byref(nm)))
+    return nm.value, matched
+
+
+def SearchByProjection_Reloc(m, Cur, log_sf, Tcw7, Ow3, K4, kf_keys, kf_mp, pts, cur_mp, th, orb_dist):
+    a = dict(skip=_u8(pts["skip"]), pos=_f32(pts["pos"]), mn=_f32(pts["min_dist"]), mx=_f32(pts["max_dist"]), desc=_u8(pts["desc"]))
+    kk = np.ascontiguousarray(kf_keys, KP_DTYPE); km = np.ascontiguousarray(kf_mp, np.int32)
+    cur_mp = np.ascontiguousarray(cur_mp, np.int32).copy()
+    T, O, K = _f32(Tcw7), _f32(Ow3), _f32(K4)
+    nm = C.c_int32()
+    capi.check(m._lib.rumi_search_by_projection_reloc(m._h, C.byref(Cur.c), float(log_sf), capi.ptr(T), capi.ptr(O), capi.ptr(K), capi.ptr(kk),
+                                                      len(kk), capi.ptr(km), len(a["skip"]), capi.ptr(a["skip"]), capi.ptr(a["pos"]),
+                                                      capi.ptr(a["mn"]), capi.ptr(a["mx"]), capi.ptr(a["desc"]), float(th), int(orb_dist),
+                                                      int(m.mbCheckOrientation), capi.ptr(cur_mp), C.byref(nm)))
+    return nm.value, cur_mp
 
 
 def bruteforce_batch(desc_q, counts_q, desc_t, counts_t, stream=None):

@@ -139,6 +139,9 @@ def _mlib():
     L.orc_search_by_projection_frame.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp]
     L.orc_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
     L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    L.orc_search_by_bow_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
+    L.orc_search_by_projection_sim3.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp]
+    L.orc_search_by_projection_reloc.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp]
     L._m_ready = True
     return L
 
@@ -229,3 +232,38 @@ def local_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, sto
     sp = _p(stop) if stop is not None else None
     its = _olib().orc_local_ba(len(kfix), _p(kp), _p(kfix), len(mp), _p(mp), len(em), _p(em), _p(ek), _p(eo), _p(ew), _p(K4), sp, _p(erase))
     return its, kp, mp, erase
+
+
+def search_by_bow_kf(k1, d1, mp1, fv1, k2, d2, mp2, fv2, mp_bad, nnratio, check_ori):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8); m1 = np.ascontiguousarray(mp1, np.int32)
+    k2 = np.ascontiguousarray(k2, KP_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8); m2 = np.ascontiguousarray(mp2, np.int32)
+    mb = np.ascontiguousarray(mp_bad, np.uint8)
+    out = np.full(len(k1), -1, np.int32)
+    n = _mlib().orc_search_by_bow_kf(_p(k1), _p(d1), len(k1), _p(m1), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(k2), _p(d2), len(k2),
+                                     _p(m2), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), len(fv2[0]), _p(mb), nnratio, int(check_ori), _p(out))
+    return n, out
+
+
+def search_by_projection_sim3(keys, desc, w, h, sf, log_sf, Tcw7, Ow3, K4, pts, matched, th, ratio, variant):
+    keys = np.ascontiguousarray(keys, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); sf = np.ascontiguousarray(sf, np.float32)
+    a = [np.ascontiguousarray(pts["skip"], np.uint8), np.ascontiguousarray(pts["pos"], np.float32), np.ascontiguousarray(pts["normal"], np.float32),
+         np.ascontiguousarray(pts["min_dist"], np.float32), np.ascontiguousarray(pts["max_dist"], np.float32), np.ascontiguousarray(pts["desc"], np.uint8)]
+    T = np.ascontiguousarray(Tcw7, np.float32); Ow = np.ascontiguousarray(Ow3, np.float32); K = np.ascontiguousarray(K4, np.float32)
+    m = np.ascontiguousarray(matched, np.int32).copy()
+    n = _mlib().orc_search_by_projection_sim3(_p(keys), _p(desc), len(keys), 0.0, 0.0, float(w), float(h), _p(sf), len(sf), float(log_sf), _p(T), _p(Ow),
+                                              _p(K), len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), int(th), float(ratio),
+                                              int(variant), _p(m))
+    return n, m
+
+
+def search_by_projection_reloc(cur_keys, cur_desc, w, h, sf, log_sf, Tcw7, Ow3, K4, kf_keys, kf_mp, pts, cur_mp, th, orb_dist, check_ori):
+    ck = np.ascontiguousarray(cur_keys, KP_DTYPE); cd = np.ascontiguousarray(cur_desc, np.uint8); sf = np.ascontiguousarray(sf, np.float32)
+    kk = np.ascontiguousarray(kf_keys, KP_DTYPE); km = np.ascontiguousarray(kf_mp, np.int32)
+    a = [np.ascontiguousarray(pts["skip"], np.uint8), np.ascontiguousarray(pts["pos"], np.float32), np.ascontiguousarray(pts["min_dist"], np.float32),
+         np.ascontiguousarray(pts["max_dist"], np.float32), np.ascontiguousarray(pts["desc"], np.uint8)]
+    T = np.ascontiguousarray(Tcw7, np.float32); Ow = np.ascontiguousarray(Ow3, np.float32); K = np.ascontiguousarray(K4, np.float32)
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    n = _mlib().orc_search_by_projection_reloc(_p(ck), _p(cd), len(ck), 0.0, 0.0, float(w), float(h), _p(sf), len(sf), float(log_sf), _p(T), _p(Ow), _p(K),
+                                               _p(kk), len(kk), _p(km), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), float(th), int(orb_dist),
+                                               int(check_ori), _p(cm))
+    return n, cm

@@ -92,3 +92,19 @@ class TrackingScene:
                 m.setdefault(int(nd) * 7 + 3, []).append(idx)      # non-contiguous ids
             return m
         return group(node_last), group(node_cur)
+
+    def point_geometry(self):
+        """Per map point: viewing normal and scale-invariance distances as MapPoint::UpdateNormalAndDepth leaves them
+        (mfMaxDistance = dist * scale[level], mfMinDistance = mfMaxDistance / scale[nLevels-1]) plus the current camera centre."""
+        rng = self.rng
+        q = self.Tcw7[:4].astype(np.float64); t = self.Tcw7[4:].astype(np.float64)
+        _, R = quat_rotate(q, np.zeros((1, 3)))
+        Ow = -(R.T @ t)
+        PO = self.mp_pos.astype(np.float64) - Ow
+        dist = np.linalg.norm(PO, axis=1)
+        lvl = np.clip(self.last_keys["octave"] + rng.integers(-1, 2, len(dist)), 0, 7)
+        max_d = (dist * self.sf[lvl] * rng.uniform(0.9, 1.1, len(dist))).astype(np.float32)
+        min_d = (max_d / self.sf[7]).astype(np.float32)
+        normal = PO / dist[:, None] + rng.normal(size=PO.shape) * 0.3
+        normal /= np.linalg.norm(normal, axis=1)[:, None]
+        return dict(Ow=Ow.astype(np.float32), normal=normal.astype(np.float32), min_dist=min_d, max_dist=max_d)

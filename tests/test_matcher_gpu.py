@@ -125,3 +125,60 @@ def test_bruteforce_batch():
         assert np.array_equal(bi[b, :n].cpu().numpy(), rbi) and np.array_equal(bd[b, :n].cpu().numpy(), rbd)
         assert np.array_equal(sd[b, :n].cpu().numpy(), rsd)
     assert bi[1, 0].item() == 5 and bd[1, 0].item() == 0 and sd[1, 0].item() == 0
+
+
+@pytest.mark.parametrize("seed,nn", [(0, 0.75), (2, 0.9)])
+def test_search_by_bow_keyframe_keyframe(matcher, seed, nn):
+    from rumi_slam_amd.matcher import FrameView, SearchByBoW_KF
+    s = TrackingScene(seed)
+    KF1 = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    KF2 = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    fv1, fv2 = s.feature_vectors()
+    a, b = _fv(fv1), _fv(fv2)
+    rng = np.random.default_rng(seed)
+    nmp = len(s.mp_obs) + 500
+    kf2_mp = np.where(rng.random(KF2.n) < 0.85, rng.integers(0, nmp, KF2.n), -1).astype(np.int32)
+    mp_bad = (rng.random(nmp) < 0.05).astype(np.uint8)
+    for ori in (True, False):
+        n_ref, ref = O.search_by_bow_kf(s.last_keys, s.last_desc, s.last_mp, (a.node_ids, a.offsets, a.indices), s.cur_keys, s.cur_desc, kf2_mp,
+                                        (b.node_ids, b.offsets, b.indices), mp_bad, nn, ori)
+        n_gpu, got = SearchByBoW_KF(matcher(nn, ori), KF1, a, s.last_mp, KF2, b, kf2_mp, mp_bad)
+        assert n_ref > 30
+        assert n_gpu == n_ref and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("seed,th,variant", [(0, 8, 0), (1, 4, 1), (3, 10, 1)])
+def test_search_by_projection_sim3(matcher, seed, th, variant):
+    from rumi_slam_amd.matcher import FrameView, SearchByProjection_Sim3
+    s = TrackingScene(seed)
+    g = s.point_geometry()
+    KF = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    rng = np.random.default_rng(seed)
+    n = len(s.mp_pos)
+    pts = dict(skip=(rng.random(n) < 0.1).astype(np.uint8), pos=s.mp_pos, normal=g["normal"], min_dist=g["min_dist"], max_dist=g["max_dist"],
+               desc=s.mp_desc)
+    matched0 = np.where(rng.random(KF.n) < 0.1, -2, -1).astype(np.int32)
+    log_sf = float(np.log(np.float32(1.2)))
+    n_ref, ref = O.search_by_projection_sim3(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, log_sf, s.Tcw7, g["Ow"], K_TUM3, pts, matched0, th, 1.0, variant)
+    n_gpu, got = SearchByProjection_Sim3(matcher(), KF, log_sf, s.Tcw7, g["Ow"], K_TUM3, pts, matched0, th, 1.0, bool(variant))
+    assert n_ref > 50
+    assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
+
+
+@pytest.mark.parametrize("seed,th,dist", [(0, 10.0, 100), (2, 3.0, 64)])
+def test_search_by_projection_relocalisation(matcher, seed, th, dist):
+    from rumi_slam_amd.matcher import FrameView, SearchByProjection_Reloc
+    s = TrackingScene(seed)
+    g = s.point_geometry()
+    Cur = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    rng = np.random.default_rng(seed)
+    n = len(s.mp_pos)
+    pts = dict(skip=(rng.random(n) < 0.1).astype(np.uint8), pos=s.mp_pos, min_dist=g["min_dist"], max_dist=g["max_dist"], desc=s.mp_desc)
+    cur_mp0 = np.where(rng.random(Cur.n) < 0.2, rng.integers(0, n, Cur.n), -1).astype(np.int32)
+    log_sf = float(np.log(np.float32(1.2)))
+    for ori in (True, False):
+        n_ref, ref = O.search_by_projection_reloc(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, log_sf, s.Tcw7, g["Ow"], K_TUM3, s.last_keys, s.last_mp, pts,
+                                                  cur_mp0, th, dist, ori)
+        n_gpu, got = SearchByProjection_Reloc(matcher(0.9, ori), Cur, log_sf, s.Tcw7, g["Ow"], K_TUM3, s.last_keys, s.last_mp, pts, cur_mp0, th, dist)
+        assert n_ref > 50
+        assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
