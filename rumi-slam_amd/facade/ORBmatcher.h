@@ -5,6 +5,7 @@
 // tests/cpp.  Everything here is marshalling: pointers become indices, results are written back into the caller's vectors.
 #pragma once
 #include <map>
+#include <set>
 #include <unordered_map>
 #include <vector>
 
@@ -132,7 +133,134 @@ public:
         return nmatches;
     }
 
+    // Search matches between MapPoints seen in KF1 and KF2 by vocabulary node (loop / merge detection)   ORBmatcher.cc:682-804
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches12) {
+        const std::vector<MapPointT *> v1 = pKF1->GetMapPointMatches(), v2 = pKF2->GetMapPointMatches();
+        // ids: 0..n1-1 = KF1's points, n1.. = KF2's points (only isBad() is needed per id)
+        std::vector<int32_t> m1(v1.size(), -1), m2(v2.size(), -1);
+        std::vector<uint8_t> bad(v1.size() + v2.size(), 0);
+        for (size_t i = 0; i < v1.size(); i++) if (v1[i]) { m1[i] = (int32_t)i; bad[i] = v1[i]->isBad(); }
+        for (size_t i = 0; i < v2.size(); i++) if (v2[i]) { m2[i] = (int32_t)(v1.size() + i); bad[v1.size() + i] = v2[i]->isBad(); }
+        Csr a = csr(pKF1->mFeatVec), b = csr(pKF2->mFeatVec);
+        RumiFrameFeatures k1 = view(*pKF1), k2 = view(*pKF2);
+        std::vector<int32_t> m12(pKF1->N, -1);
+        int32_t nmatches = 0;
+        if (rumi_search_by_bow_kf(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), (int)bad.size(), bad.data(), mfNNratio,
+                                  mbCheckOrientation, m12.data(), &nmatches) != RUMI_OK)
+            return -1;
+        vpMatches12.assign(v1.size(), static_cast<MapPointT *>(nullptr));
+        for (size_t i = 0; i < v1.size() && i < m12.size(); i++) if (m12[i] >= 0) vpMatches12[i] = v2[m12[i]];
+        return nmatches;
+    }
+
+    // Project MapPoints seen in a key-frame into the frame and search matches (Relocalization)            ORBmatcher.cc:1685-1793
+    // Needs two one-line accessors on MapPoint: GetMinDistance() / GetMaxDistance() returning mfMinDistance / mfMaxDistance
+    // (the reference only exposes the 0.8x / 1.2x invariance values; PredictScale needs the raw one).  INTEGRATION.md §3.
+    template <class FrameT, class KeyFrameT, class SetT>
+    int SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const SetT &sAlreadyFound, const float th, const int ORBdist) {
+        using MapPointT = typename std::remove_pointer<typename std::decay<decltype(CurrentFrame.mvpMapPoints[0])>::type>::type;
+        const std::vector<MapPointT *> vpMPs = pKF->GetMapPointMatches();
+        const int nkf = (int)vpMPs.size();
+        std::vector<int32_t> kfMp(nkf, -1), curMp(CurrentFrame.N, -1);
+        std::vector<uint8_t> skip(nkf, 1), desc((size_t)nkf * 32, 0);
+        std::vector<float> pos((size_t)nkf * 3, 0.f), mn(nkf, 0.f), mx(nkf, 0.f);
+        for (int i = 0; i < nkf; i++) {
+            MapPointT *p = vpMPs[i];
+            if (!p) continue;
+            kfMp[i] = i;                                              // id = key-frame feature index
+            skip[i] = p->isBad() || sAlreadyFound.count(p);
+            const auto P = p->GetWorldPos();
+            pos[3 * i] = P(0); pos[3 * i + 1] = P(1); pos[3 * i + 2] = P(2);
+            mn[i] = p->GetMinDistance(); mx[i] = p->GetMaxDistance();
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+        }
+        for (int f = 0; f < CurrentFrame.N; f++) if (CurrentFrame.mvpMapPoints[f]) curMp[f] = nkf;      // any non-NULL blocks the feature
+        const auto Tcw = CurrentFrame.GetPose();
+        const auto q = Tcw.unit_quaternion();
+        const auto t = Tcw.translation();
+        const float T7[7] = {q.x(), q.y(), q.z(), q.w(), t(0), t(1), t(2)};
+        float Ow[3];
+        camera_centre(T7, Ow);
+        const float K4[4] = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy};
+        RumiFrameFeatures cv_ = view(CurrentFrame);
+        int32_t nmatches = 0;
+        if (rumi_search_by_projection_reloc(arena(), &cv_, CurrentFrame.mfLogScaleFactor, T7, Ow, K4,
+                                            reinterpret_cast<const RumiKeyPoint *>(pKF->mvKeysUn.data()), nkf, kfMp.data(), nkf, skip.data(),
+                                            pos.data(), mn.data(), mx.data(), desc.data(), th, ORBdist, mbCheckOrientation, curMp.data(),
+                                            &nmatches) != RUMI_OK)
+            return -1;
+        for (int f = 0; f < CurrentFrame.N; f++) {
+            if (curMp[f] == nkf) continue;                            // untouched pre-existing association
+            CurrentFrame.mvpMapPoints[f] = curMp[f] >= 0 ? vpMPs[curMp[f]] : nullptr;
+        }
+        return nmatches;
+    }
+
+#ifdef RUMI_HAVE_SOPHUS
+    // Project MapPoints using a Similarity Transformation and search matches (loop detection / merging)   ORBmatcher.cc:372-471
+    template <class KeyFrameT, class MapPointT>
+    int SearchByProjection(KeyFrameT *pKF, Sophus::Sim3f &Scw, const std::vector<MapPointT *> &vpPoints, std::vector<MapPointT *> &vpMatched,
+                           int th, float ratioHamming = 1.0) {
+        std::vector<KeyFrameT *> noKFs, noMatchedKF;
+        return searchSim3(pKF, Scw, vpPoints, noKFs, vpMatched, noMatchedKF, th, ratioHamming, false);
+    }
+    // ... and its overload that also reports the key-frame each point came from                            ORBmatcher.cc:473-579
+    template <class KeyFrameT, class MapPointT>
+    int SearchByProjection(KeyFrameT *pKF, Sophus::Sim3<float> &Scw, const std::vector<MapPointT *> &vpPoints,
+                           const std::vector<KeyFrameT *> &vpPointsKFs, std::vector<MapPointT *> &vpMatched,
+                           std::vector<KeyFrameT *> &vpMatchedKF, int th, float ratioHamming = 1.0) {
+        return searchSim3(pKF, Scw, vpPoints, vpPointsKFs, vpMatched, vpMatchedKF, th, ratioHamming, true);
+    }
+#endif
+
 protected:
+#ifdef RUMI_HAVE_SOPHUS
+    template <class KeyFrameT, class MapPointT>
+    int searchSim3(KeyFrameT *pKF, Sophus::Sim3f &Scw, const std::vector<MapPointT *> &vpPoints, const std::vector<KeyFrameT *> &vpPointsKFs,
+                   std::vector<MapPointT *> &vpMatched, std::vector<KeyFrameT *> &vpMatchedKF, int th, float ratioHamming, bool withKFs) {
+        const Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());      // :380
+        const Eigen::Vector3f Owv = Tcw.inverse().translation();
+        const auto q = Tcw.unit_quaternion();
+        const float T7[7] = {q.x(), q.y(), q.z(), q.w(), Tcw.translation()(0), Tcw.translation()(1), Tcw.translation()(2)};
+        const float Ow[3] = {Owv(0), Owv(1), Owv(2)};
+        std::set<MapPointT *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPointT *>(nullptr));
+        const int nmp = (int)vpPoints.size();
+        std::vector<uint8_t> skip(nmp), desc((size_t)nmp * 32);
+        std::vector<float> pos((size_t)nmp * 3), nrm((size_t)nmp * 3), mn(nmp), mx(nmp);
+        for (int i = 0; i < nmp; i++) {
+            MapPointT *p = vpPoints[i];
+            skip[i] = p->isBad() || spAlreadyFound.count(p);
+            const Eigen::Vector3f P = p->GetWorldPos(), N = p->GetNormal();
+            for (int c = 0; c < 3; c++) { pos[3 * i + c] = P(c); nrm[3 * i + c] = N(c); }
+            mn[i] = p->GetMinDistance(); mx[i] = p->GetMaxDistance();
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+        }
+        std::vector<int32_t> matched(pKF->N, -1);
+        for (int f = 0; f < pKF->N; f++) if (vpMatched[f]) matched[f] = -2;
+        const float K4[4] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy};
+        RumiFrameFeatures kv = view(*pKF);
+        int32_t nmatches = 0;
+        if (rumi_search_by_projection_sim3(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(),
+                                           mx.data(), desc.data(), th, ratioHamming, withKFs ? 1 : 0, matched.data(), &nmatches) != RUMI_OK)
+            return -1;
+        for (int f = 0; f < pKF->N; f++)
+            if (matched[f] >= 0) { vpMatched[f] = vpPoints[matched[f]]; if (withKFs) vpMatchedKF[f] = vpPointsKFs[matched[f]]; }
+        return nmatches;
+    }
+#endif
+    // Sophus::SE3f::inverse().translation(): conj(q) applied to -t with the same quaternion product form as so3.hpp:358-367
+    static void camera_centre(const float *T7, float *Ow) {
+        const float qx = -T7[0], qy = -T7[1], qz = -T7[2], qw = T7[3];
+        const float p[3] = {T7[4] * -1, T7[5] * -1, T7[6] * -1};
+        float u0 = qy * p[2] - qz * p[1], u1 = qz * p[0] - qx * p[2], u2 = qx * p[1] - qy * p[0];
+        u0 += u0; u1 += u1; u2 += u2;
+        const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+        Ow[0] = (p[0] + qw * u0) + c0; Ow[1] = (p[1] + qw * u1) + c1; Ow[2] = (p[2] + qw * u2) + c2;
+    }
     struct Csr {
         std::vector<uint32_t> nodes, idx;
         std::vector<int32_t> off;

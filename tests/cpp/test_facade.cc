@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <random>
+#include <set>
 #include <tuple>
 #include <vector>
 
@@ -42,6 +43,9 @@ struct MapPoint {
     std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return obs; }
     void EraseObservation(KeyFrame *k) { obs.erase(k); }
     void SetWorldPosXYZ(float x, float y, float z) { pos = V3f{{x, y, z}}; }
+    float minD = 0.5f, maxD = 60.f;
+    float GetMinDistance() { return minD; }
+    float GetMaxDistance() { return maxD; }
     void UpdateNormalAndDepth() {}
     bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
 };
@@ -52,6 +56,8 @@ struct Frame {
     std::vector<float> mvScaleFactors, mvInvLevelSigma2; std::vector<float> mvuRight;
     float mnMinX = 0, mnMinY = 0, mnMaxX = 640, mnMaxY = 480, fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
     SE3f pose;
+    float mfLogScaleFactor = 0.1823216f; int mnScaleLevels = 8;
+    std::map<unsigned, std::vector<unsigned>> mFeatVec;
     SE3f GetPose() const { return pose; }
     void SetPoseFromQuatTrans(const float *T7) { std::memcpy(pose.T, T7, 28); }
 };
@@ -137,6 +143,22 @@ int main(int argc, char **argv) {
     bool msame = true;
     for (int i = 0; i < fr[1].N; i++) msame &= (fr[1].mvpMapPoints[i] ? (int)(fr[1].mvpMapPoints[i] - mps.data()) : -1) == curRef[i];
     CHECK(msame, "SearchByProjection(Cur, Last) assignments");
+
+    // ---- the other overloads instantiate and run (their C-ABI parity is covered by tests/test_matcher_gpu.py) ----
+    {
+        KeyFrame ka, kb;
+        static_cast<Frame &>(ka) = fr[0]; static_cast<Frame &>(kb) = fr[1];
+        for (int i = 0; i < ka.N; i++) ka.mFeatVec[(unsigned)(i % 97)].push_back((unsigned)i);
+        for (int i = 0; i < kb.N; i++) kb.mFeatVec[(unsigned)(i % 97)].push_back((unsigned)i);
+        std::vector<MapPoint *> m12;
+        const int nb = matcher.SearchByBoW(&ka, &kb, m12);
+        CHECK(nb >= 0 && (int)m12.size() == ka.N, "SearchByBoW(KF,KF) runs");
+        Frame cur = fr[1];
+        cur.mvpMapPoints.assign(cur.N, nullptr);
+        std::set<MapPoint *> found;
+        const int nr = matcher.SearchByProjection(cur, &ka, found, 10.f, 100);
+        CHECK(nr >= 0, "SearchByProjection(Frame, KF, found, th, ORBdist) runs");
+    }
 
     // ---- PoseOptimization facade ~ oracle ----
     std::vector<float> Xw, ob, w;
