@@ -169,6 +169,17 @@ def main():
         kern_ms = {k: stage[k] for k in kern_bytes}
         dom = max(kern_ms, key=kern_ms.get)
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot wrap this process from inside, so the number is the
+        # committed result of `tools/pmc_summary.py` on two --pmc passes of THIS command line (profiles/r01_pmc_traffic.json);
+        # it is used only when it was taken at the same frames-per-launch.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            kname = {"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]
+            if pm.get("frames_per_launch") == B and kname in pm["kernels"]:
+                traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "frames/sec ORB extract+match", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -177,7 +188,8 @@ def main():
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": round(n_kp, 1),
                        "exchange": "all_gather(counts,keypoints,descriptors) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(kern_bytes[dom] * B),
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
                          "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},

@@ -96,7 +96,7 @@ struct RumiOrb {
     hipEvent_t ev[8] = {nullptr};
     // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
     hipStream_t sideStream = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evB0 = nullptr, evB1 = nullptr;
 };
 
 static int set_geometry(RumiOrb *h, int w, int hgt) {
@@ -178,6 +178,8 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->evB0) (void)hipEventDestroy(h->evB0);
+    if (h->evB1) (void)hipEventDestroy(h->evB1);
     if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
     delete h;
 }
@@ -252,7 +254,8 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "side stream"; return RUMI_E_NO_DEVICE; }
+        hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&h->evB0) != hipSuccess ||
+        hipEventCreate(&h->evB1) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "side stream"; return RUMI_E_NO_DEVICE; }
     *out = h;
     return RUMI_OK;
 }
@@ -294,12 +297,14 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
     launch_frame_cols(h->dP, P, src, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
-    // fork: blur on the side stream (in profiling mode it stays on the main stream so that stage times do not overlap)
-    hipStream_t bs = prof ? st : h->sideStream;
-    if (!prof) { HIP_TRY(hipEventRecord(h->evFork, st)); HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0)); }
+    // fork: blur on the side stream, next to FAST / quadtree (stage times are taken with the same overlap the timed path has)
+    hipStream_t bs = h->sideStream;
+    HIP_TRY(hipEventRecord(h->evFork, st));
+    HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0));
+    if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
     for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, bs);
-    if (!prof) HIP_TRY(hipEventRecord(h->evJoin, bs));
-    if (prof) HIP_TRY(hipEventRecord(h->ev[2], st));
+    if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
+    HIP_TRY(hipEventRecord(h->evJoin, bs));
     HIP_TRY(hipGetLastError());
 
     // Stage B (chunks of kChunk frames share the candidate / quadtree scratch; no host round trip in between)
@@ -320,7 +325,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         launch_assemble(h->dP, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, lap0, lap1, h->dSelPacked, h->dSelMeta,
                         h->dSelCount, h->capSel, (int32_t *)d_counts + 2 * base, h->dErr, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[6], st));
-        if (!prof && base == 0) HIP_TRY(hipStreamWaitEvent(st, h->evJoin, 0));      // join: rBRIEF reads the blurred levels
+        if (base == 0) HIP_TRY(hipStreamWaitEvent(st, h->evJoin, 0));               // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, h->capSel,
                            (RumiKeyPoint *)d_kp + (size_t)base * cap, (uint8_t *)d_desc + (size_t)base * cap * 32, cap, nf, st);
         if (prof) HIP_TRY(hipEventRecord(h->ev[7], st));
@@ -347,7 +352,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     if (prof) {
         float ms;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); acc[0] = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); acc[3] = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->evB0, h->evB1)); acc[3] = ms;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[7])); acc[6] = ms;
         for (int i = 0; i < 8; i++) h->stageMs[i] = acc[i];
     }

@@ -19,6 +19,15 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
+// XCD-aware workgroup placement (cdna_hip_programming.md T1): the dispatcher deals consecutive workgroups round-robin over
+// the 8 XCDs, each with a private L2.  Remapping the linear workgroup id with this bijection gives every XCD one contiguous
+// range of logical ids, so neighbouring tiles of one frame (which share 64-B lines and halo rows) meet in the same L2.
+// Placement only changes speed / HBM traffic, never results.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7, xcd = lin & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+}
+
 struct __attribute__((packed)) U64 { uint64_t v; };      // possibly unaligned 8-byte global access
 
 // pixel (0,0) of a pyramid level; a REFLECT_101 frame of kPadX x kPadY pixels surrounds it in memory
@@ -47,9 +56,10 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // every level of every frame in ONE launch (no level reads another level's frame columns).
 __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, ImgSrc src) {
     const DevLevel &D = P->lv[0];
-    const int frame = blockIdx.z;
-    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
+    const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
+    const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int oy = by * 4 + (threadIdx.x >> 6) - kPadY;
     if (ox >= D.w || oy >= D.h + kPadY) return;
     const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch + ox;
     uint8_t *out = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
@@ -68,9 +78,10 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
                                                 const int16_t *__restrict__ coef, int level) {
     const DevLevel &D = P->lv[level];
     const DevLevel &S = P->lv[level - 1];
-    const int frame = blockIdx.z;
-    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6) - kPadY;
+    const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
+    const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int oy = by * 4 + (threadIdx.x >> 6) - kPadY;
     if (ox >= D.w || oy >= D.h + kPadY) return;
     const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
     uint8_t *db = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
@@ -187,7 +198,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
                                                     uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cell = blockIdx.x * 4 + wave, frame = blockIdx.y;
+    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int cell = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
     if (cell >= P->totalCells) return;
     uint8_t *tile = fl + (size_t)wave * F.perWave;
     uint8_t *sc = tile + F.tileBytes;
@@ -357,9 +369,11 @@ constexpr int kBlurRows = 16;
 
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, int level) {
     const DevLevel &L = P->lv[level];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frame = blockIdx.z;
-    const int xa = blockIdx.x * 256 + lane * 4;                  // first pixel of my strip
-    const int y0 = (blockIdx.y * 4 + wave) * kBlurRows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
+    const int xa = bx * 256 + lane * 4;                          // first pixel of my strip
+    const int y0 = (by * 4 + wave) * kBlurRows;
     if (y0 >= L.h) return;                                       // whole wave (wave-uniform)
     int pitch;
     const uint8_t *img = level_base(src, P, level, frame, &pitch);
@@ -430,7 +444,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
     __shared__ __attribute__((aligned(16))) uint8_t sDisc[4][31 * kDiscP];
     __shared__ __attribute__((aligned(16))) uint8_t sPatch[4][37 * kPatchP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 4 + wave, frame = blockIdx.y;
+    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // a frame's key-points share one L2
+    const int k = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
     const bool live = k < selCount[frame];
     int level = 0, slot = 0, x = kEdge, y = kEdge, score = 0;
     if (live) {
