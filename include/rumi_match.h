@@ -119,6 +119,17 @@ int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur
                                     const float *mp_max_dist, const uint8_t *mp_desc, float th, int32_t orb_dist,
                                     int32_t check_orientation, int32_t *cur_mp, int32_t *nmatches_out);
 
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) for every local map point (SearchLocalPoints, Tracking.cc:2996-3055;
+ * Frame.cc:558-617, mono branch) — the step that produces the per-point inputs of rumi_search_by_projection_mappoints.
+ * Rcw9 (row-major) = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw; per point GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance.
+ * Outputs = the fields the reference writes on the MapPoint: mbTrackInView, mTrackProjX/Y (-1 when not projected inside the
+ * image), mnTrackScaleLevel, mTrackViewCos, mTrackDepth. */
+int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const float *tcw3, const float *Ow3, const float *K4, float min_x,
+                             float min_y, float max_x, float max_y, float log_scale_factor, int32_t nlevels, float viewing_cos_limit,
+                             int32_t nmp, const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                             const float *mp_max_dist, uint8_t *track_in_view, float *proj_x, float *proj_y, int32_t *scale_level,
+                             float *view_cos, float *track_depth);
+
 /* Brute-force all-pairs 256-bit Hamming (the GPU formulation of BASELINE.json config 3), device pointers:
  * for each of B frame pairs, every query descriptor against every train descriptor; best index (first train index
  * wins ties, as in every loop of the reference), best and second-best distance.

@@ -433,6 +433,35 @@ int orc_search_by_projection_reloc(const KeyPoint *curKeys, const uint8_t *curDe
     return nmatches;
 }
 
+// Frame::isInFrustum(MapPoint*, viewingCosLimit), mono branch (R/lib_src/Frame.cc:558-617): fills the tracking fields of every
+// point.  Rcw9 row-major = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw.
+void orc_is_in_frustum(const float *Rcw9, const float *tcw3, const float *Ow3, const float *K4, float minX, float minY, float maxX,
+                       float maxY, float logScaleFactor, int nLevels, float viewingCosLimit, int nmp, const float *mpPos,
+                       const float *mpNormal, const float *mpMinDist, const float *mpMaxDist, uint8_t *inView, float *projX,
+                       float *projY, int32_t *scaleLevel, float *viewCosOut, float *trackDepth) {
+    for (int i = 0; i < nmp; i++) {
+        inView[i] = 0; projX[i] = -1; projY[i] = -1; scaleLevel[i] = 0; viewCosOut[i] = 0; trackDepth[i] = 0;
+        const float *P = mpPos + (size_t)i * 3;
+        float Pc[3];
+        for (int r = 0; r < 3; r++) Pc[r] = ((Rcw9[r * 3] * P[0] + Rcw9[r * 3 + 1] * P[1]) + Rcw9[r * 3 + 2] * P[2]) + tcw3[r];
+        const float Pc_dist = std::sqrt((Pc[0] * Pc[0] + Pc[1] * Pc[1]) + Pc[2] * Pc[2]);
+        if (Pc[2] < 0.0f) continue;
+        const float u = K4[0] * Pc[0] / Pc[2] + K4[2], v = K4[1] * Pc[1] / Pc[2] + K4[3];
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        projX[i] = u; projY[i] = v;
+        const float maxDistance = 1.2f * mpMaxDist[i], minDistance = 0.8f * mpMinDist[i];
+        const float PO[3] = {P[0] - Ow3[0], P[1] - Ow3[1], P[2] - Ow3[2]};
+        const float dist = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = mpNormal + (size_t)i * 3;
+        const float viewCos = ((PO[0] * Pn[0] + PO[1] * Pn[1]) + PO[2] * Pn[2]) / dist;
+        if (viewCos < viewingCosLimit) continue;
+        scaleLevel[i] = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
+        inView[i] = 1; trackDepth[i] = Pc_dist; viewCosOut[i] = viewCos;
+    }
+}
+
 // Brute-force all-pairs best / second-best (the GPU formulation named by BASELINE.json config 3); ties keep the
 // FIRST train index, like every matcher loop of the reference (strict <).
 void orc_bruteforce_match(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *bestIdx, int32_t *bestDist,

@@ -251,6 +251,42 @@ __global__ void k_queries_reloc(int nkf, const RumiKeyPoint *kfKeys, const int32
     q[i] = o;
 }
 
+// Frame::isInFrustum (Frame.cc:558-617, mono): one lane per map point
+__global__ void k_is_in_frustum(int nmp, const float *pose /*Rcw9 tcw3 Ow3 K4*/, float minX, float minY, float maxX, float maxY,
+                                float logScaleFactor, int nLevels, float viewingCosLimit, const float *mpPos, const float *mpNormal,
+                                const float *mpMinDist, const float *mpMaxDist, uint8_t *inView, float *projX, float *projY,
+                                int32_t *scaleLevel, float *viewCosOut, float *trackDepth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nmp) return;
+    const float *R = pose, *t = pose + 9, *Ow = pose + 12, *K = pose + 15;
+    const float *P = mpPos + (size_t)i * 3;
+    uint8_t in = 0;
+    float px = -1, py = -1, vc = 0, depth = 0;
+    int lvl = 0;
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Pc[r] = ((R[r * 3] * P[0] + R[r * 3 + 1] * P[1]) + R[r * 3 + 2] * P[2]) + t[r];
+    const float Pc_dist = sqrtf((Pc[0] * Pc[0] + Pc[1] * Pc[1]) + Pc[2] * Pc[2]);
+    if (!(Pc[2] < 0.0f)) {
+        const float u = K[0] * Pc[0] / Pc[2] + K[2], v = K[1] * Pc[1] / Pc[2] + K[3];
+        if (!(u < minX || u > maxX) && !(v < minY || v > maxY)) {
+            px = u; py = v;
+            const float maxD = 1.2f * mpMaxDist[i], minD = 0.8f * mpMinDist[i];
+            const float P0 = P[0] - Ow[0], P1 = P[1] - Ow[1], P2 = P[2] - Ow[2];
+            const float dist = sqrtf((P0 * P0 + P1 * P1) + P2 * P2);
+            if (!(dist < minD || dist > maxD)) {
+                const float *Pn = mpNormal + (size_t)i * 3;
+                const float viewCos = ((P0 * Pn[0] + P1 * Pn[1]) + P2 * Pn[2]) / dist;
+                if (!(viewCos < viewingCosLimit)) {
+                    lvl = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
+                    in = 1; depth = Pc_dist; vc = viewCos;
+                }
+            }
+        }
+    }
+    inView[i] = in; projX[i] = px; projY[i] = py; scaleLevel[i] = lvl; viewCosOut[i] = vc; trackDepth[i] = depth;
+}
+
 // ---- 3. candidates: one wave per query -----------------------------------------------------------------------------
 // list entry: feature (16 bit) | distance (9 bit) << 16 | octave (4 bit) << 25
 template <bool FILL>
@@ -601,7 +637,7 @@ extern "C" int rumi_match_create(int32_t max_features, int32_t max_queries, int3
     for (auto &f : m->dF) TRYA(dalloc(&f, Q * 3));
     for (auto &i : m->dI) TRYA(dalloc(&i, Q + 1));
     TRYA(dalloc(&m->dQKeys, Q)); TRYA(dalloc(&m->dNodesA, Q)); TRYA(dalloc(&m->dNodesB, F)); TRYA(dalloc(&m->dIdxA, Q));
-    TRYA(dalloc(&m->dOffA, Q + 1)); TRYA(dalloc(&m->dOffB, F + 1)); TRYA(dalloc(&m->dPose, 16));
+    TRYA(dalloc(&m->dOffA, Q + 1)); TRYA(dalloc(&m->dOffB, F + 1)); TRYA(dalloc(&m->dPose, 32));
 #undef TRYA
     *out = m;
     return RUMI_OK;
@@ -818,6 +854,35 @@ extern "C" int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFe
                            m->dF[3], m->dPose, m->dScale, Cur->nlevels, log_scale_factor, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
     return run_search(m, MODE_RELOC, nkf, fd, m->dQDesc, nullptr, 0.f, check_orientation, cur_mp, nmatches_out, m->dU8b, 0.f, orb_dist);
+}
+
+extern "C" int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const float *tcw3, const float *Ow3, const float *K4,
+                                        float min_x, float min_y, float max_x, float max_y, float log_scale_factor, int32_t nlevels,
+                                        float viewing_cos_limit, int32_t nmp, const float *mp_pos, const float *mp_normal,
+                                        const float *mp_min_dist, const float *mp_max_dist, uint8_t *track_in_view, float *proj_x,
+                                        float *proj_y, int32_t *scale_level, float *view_cos, float *track_depth) {
+    if (!m || !Rcw9 || !tcw3 || !Ow3 || !K4 || nmp < 0) return RUMI_E_INVALID;
+    if (nmp > m->maxQ) { g_lastError = "more map points than max_queries"; return RUMI_E_CAPACITY; }
+    if (nmp == 0) return RUMI_OK;
+    if (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !track_in_view || !proj_x || !proj_y || !scale_level || !view_cos || !track_depth)
+        return RUMI_E_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    float pose[19];
+    std::memcpy(pose, Rcw9, 36); std::memcpy(pose + 9, tcw3, 12); std::memcpy(pose + 12, Ow3, 12); std::memcpy(pose + 15, K4, 16);
+    H2D(m->dPose, pose, 19);
+    H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3); H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp);
+    // outputs reuse query-side scratch: dU8a, dF[4] (x, y, cos packed as 3n), dF[5] (depth), dI[0]
+    float *dX = m->dF[4], *dY = m->dF[4] + nmp, *dC = m->dF[4] + 2 * (size_t)nmp;
+    hipLaunchKernelGGL(k_is_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dPose, min_x, min_y, max_x, max_y, log_scale_factor,
+                       nlevels, viewing_cos_limit, m->dF[0], m->dF[1], m->dF[2], m->dF[3], m->dU8a, dX, dY, m->dI[0], dC, m->dF[5]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(track_in_view, m->dU8a, (size_t)nmp, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(proj_x, dX, (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(proj_y, dY, (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(view_cos, dC, (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(track_depth, m->dF[5], (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(scale_level, m->dI[0], (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    return RUMI_OK;
 }
 
 extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,

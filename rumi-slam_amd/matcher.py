@@ -22,7 +22,7 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
 
 
 def _lib():
@@ -44,6 +44,7 @@ def _lib():
                                                  vp, C.POINTER(i32)]
     L.rumi_search_by_projection_reloc.argtypes = [vp, C.POINTER(RumiFrameFeatures), f32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32,
                                                   i32, i32, vp, C.POINTER(i32)]
+    L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
     return L
@@ -181,6 +182,20 @@ def SearchByProjection_Reloc(m, Cur, log_sf, Tcw7, Ow3, K4, kf_keys, kf_mp, pts,
                                                       capi.ptr(a["mn"]), capi.ptr(a["mx"]), capi.ptr(a["desc"]), float(th), int(orb_dist),
                                                       int(m.mbCheckOrientation), capi.ptr(cur_mp), C.byref(nm)))
     return nm.value, cur_mp
+
+
+def isInFrustum(m, Rcw9, tcw3, Ow3, K4, w, h, log_sf, nlevels, cos_limit, pts):
+    """Frame::isInFrustum for all points; returns the dict SearchByProjection_MapPoints takes (without desc / obs / is_bad)."""
+    n = len(pts["max_dist"])
+    R, t, O, K = _f32(Rcw9), _f32(tcw3), _f32(Ow3), _f32(K4)
+    a = dict(pos=_f32(pts["pos"]), normal=_f32(pts["normal"]), mn=_f32(pts["min_dist"]), mx=_f32(pts["max_dist"]))
+    out = dict(track_in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32),
+               scale_level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32), track_depth=np.zeros(n, np.float32))
+    capi.check(m._lib.rumi_frame_is_in_frustum(m._h, capi.ptr(R), capi.ptr(t), capi.ptr(O), capi.ptr(K), 0.0, 0.0, float(w), float(h), float(log_sf),
+                                               int(nlevels), float(cos_limit), n, capi.ptr(a["pos"]), capi.ptr(a["normal"]), capi.ptr(a["mn"]),
+                                               capi.ptr(a["mx"]), capi.ptr(out["track_in_view"]), capi.ptr(out["proj_x"]), capi.ptr(out["proj_y"]),
+                                               capi.ptr(out["scale_level"]), capi.ptr(out["view_cos"]), capi.ptr(out["track_depth"])))
+    return out
 
 
 def bruteforce_batch(desc_q, counts_q, desc_t, counts_t, stream=None):

@@ -139,6 +139,7 @@ def _mlib():
     L.orc_search_by_projection_frame.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp]
     L.orc_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
     L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    L.orc_is_in_frustum.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_search_by_bow_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
     L.orc_search_by_projection_sim3.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp]
     L.orc_search_by_projection_reloc.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp]
@@ -267,3 +268,15 @@ def search_by_projection_reloc(cur_keys, cur_desc, w, h, sf, log_sf, Tcw7, Ow3, 
                                                _p(kk), len(kk), _p(km), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), float(th), int(orb_dist),
                                                int(check_ori), _p(cm))
     return n, cm
+
+
+def is_in_frustum(Rcw9, tcw3, Ow3, K4, w, h, log_sf, nlevels, cos_limit, pts):
+    n = len(pts["max_dist"])
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    R, t, Ow, K, pos, nrm, mn, mx = f(Rcw9), f(tcw3), f(Ow3), f(K4), f(pts["pos"]), f(pts["normal"]), f(pts["min_dist"]), f(pts["max_dist"])
+    out = dict(track_in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32),
+               scale_level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32), track_depth=np.zeros(n, np.float32))
+    _mlib().orc_is_in_frustum(_p(R), _p(t), _p(Ow), _p(K), 0.0, 0.0, float(w), float(h), float(log_sf), int(nlevels), float(cos_limit), n, _p(pos), _p(nrm),
+                              _p(mn), _p(mx), _p(out["track_in_view"]), _p(out["proj_x"]), _p(out["proj_y"]), _p(out["scale_level"]), _p(out["view_cos"]),
+                              _p(out["track_depth"]))
+    return out

@@ -182,3 +182,28 @@ def test_search_by_projection_relocalisation(matcher, seed, th, dist):
         n_gpu, got = SearchByProjection_Reloc(matcher(0.9, ori), Cur, log_sf, s.Tcw7, g["Ow"], K_TUM3, s.last_keys, s.last_mp, pts, cur_mp0, th, dist)
         assert n_ref > 50
         assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_is_in_frustum_then_search_local_points(matcher, seed):
+    """SearchLocalPoints = Frame::isInFrustum for every local point, then SearchByProjection(F, points): both steps on the GPU."""
+    from rumi_slam_amd.matcher import FrameView, isInFrustum
+    from scene import quat_rotate
+    s = TrackingScene(seed)
+    g = s.point_geometry()
+    _, R = quat_rotate(s.Tcw7[:4].astype(np.float64), np.zeros((1, 3)))
+    R32 = R.astype(np.float32)
+    pts = dict(pos=s.mp_pos, normal=g["normal"], min_dist=g["min_dist"], max_dist=g["max_dist"])
+    log_sf = float(np.log(np.float32(1.2)))
+    ref = O.is_in_frustum(R32.ravel(), s.Tcw7[4:], g["Ow"], K_TUM3, s.w, s.h, log_sf, 8, 0.5, pts)
+    m = matcher(0.8)
+    got = isInFrustum(m, R32.ravel(), s.Tcw7[4:], g["Ow"], K_TUM3, s.w, s.h, log_sf, 8, 0.5, pts)
+    assert ref["track_in_view"].sum() > 300
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    mp = dict(got, is_bad=np.zeros(len(s.mp_obs), np.uint8), desc=s.mp_desc, obs=s.mp_obs)
+    frame_mp = np.full(F.n, -1, np.int32)
+    n_ref, fm_ref = O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, mp, frame_mp, 3.0, False, 0.0, 0.8)
+    n_gpu, fm = m.SearchByProjection_MapPoints(F, mp, frame_mp, 3.0)
+    assert n_gpu == n_ref and n_ref > 100 and np.array_equal(fm, fm_ref)
