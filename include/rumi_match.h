@@ -119,6 +119,13 @@ int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur
                                     const float *mp_max_dist, const uint8_t *mp_desc, float th, int32_t orb_dist,
                                     int32_t check_orientation, int32_t *cur_mp, int32_t *nmatches_out);
 
+/* ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12,
+ * int windowSize) — R/lib_src/ORBmatcher.cc:581-680 (monocular initialisation, Tracking.cc:1968).
+ * prev_matched [F1->n][2] is read and updated in place (:675-677); matches12 [F1->n] receives vnMatches12. */
+int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFeatures *F1, const RumiFrameFeatures *F2, float *prev_matched,
+                                   int32_t window_size, float nnratio, int32_t check_orientation, int32_t *matches12,
+                                   int32_t *nmatches_out);
+
 /* Frame::isInFrustum(MapPoint*, viewingCosLimit) for every local map point (SearchLocalPoints, Tracking.cc:2996-3055;
  * Frame.cc:558-617, mono branch) — the step that produces the per-point inputs of rumi_search_by_projection_mappoints.
  * Rcw9 (row-major) = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw; per point GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance.

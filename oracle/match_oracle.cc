@@ -15,6 +15,7 @@
 // PARITY STATUS: pinned by source only (the reference has no tests for this path); integer logic is exact,
 // the float projection follows Eigen's expression order (no FMA: build with -ffp-contract=off).
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -430,6 +431,58 @@ int orc_search_by_projection_reloc(const KeyPoint *curKeys, const uint8_t *curDe
             if (i != ind1 && i != ind2 && i != ind3)
                 for (int idx : rotHist[i]) { cur_mp[idx] = -1; nmatches--; }
     }
+    return nmatches;
+}
+
+// ORBmatcher::SearchForInitialization (R/lib_src/ORBmatcher.cc:581-680)
+int orc_search_for_initialization(const KeyPoint *keys1, const uint8_t *desc1, int n1, const KeyPoint *keys2, const uint8_t *desc2,
+                                  int n2, float minX, float minY, float maxX, float maxY, float *prevMatched, int windowSize,
+                                  float nnratio, int checkOrientation, int32_t *matches12) {
+    FrameGrid G2(keys2, desc2, n2, minX, minY, maxX, maxY);
+    std::vector<int> cand;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> matchedDistance(n2, INT_MAX), matches21(n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = keys1[i1].octave;
+        if (level1 > 0) continue;
+        G2.in_area(prevMatched[2 * i1], prevMatched[2 * i1 + 1], (float)windowSize, level1, level1, cand);
+        if (cand.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : cand) {
+            const int dist = descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+            if (matchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDistance[bestIdx2] = bestDist;
+            nmatches++;
+            if (checkOrientation) {
+                float rot = keys1[i1].angle - keys2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prevMatched[2 * i1] = keys2[matches12[i1]].x; prevMatched[2 * i1 + 1] = keys2[matches12[i1]].y; }
     return nmatches;
 }
 

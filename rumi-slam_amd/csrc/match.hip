@@ -27,7 +27,7 @@ namespace rumi {
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // Frame.h:42-43
 constexpr int kMaxSortN = 8192;
 
-enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5 };
+enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5, MODE_INIT = 6 };
 
 struct Query {           // 48 bytes
     float u, v, r;       // window centre / half-size (MODE_BOW: unused)
@@ -248,6 +248,18 @@ __global__ void k_queries_reloc(int nkf, const RumiKeyPoint *kfKeys, const int32
         o.descId = mp; o.mpId = mp; o.blocks = 1;
     }
     o.angle = kfKeys[i].angle;
+    q[i] = o;
+}
+
+// SearchForInitialization: level-0 key-points of F1, window around vbPrevMatched (ORBmatcher.cc:593-602)
+__global__ void k_queries_init(int n1, const RumiKeyPoint *keys1, const float *prevMatched, float windowSize, Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    Query o{};
+    o.valid = !(keys1[i].octave > 0);
+    o.u = prevMatched[2 * i]; o.v = prevMatched[2 * i + 1]; o.r = windowSize;
+    o.minLevel = 0; o.maxLevel = 0;
+    o.descId = i; o.mpId = i; o.angle = keys1[i].angle;
     q[i] = o;
 }
 
@@ -519,6 +531,94 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
         }
 }
 
+// SearchForInitialization resolve (ORBmatcher.cc:593-679).  The skip rule `vMatchedDistance[i2] <= dist` makes every query depend
+// on the best distance accepted so far for each candidate, so the queries are replayed IN ORDER by one wave; the lanes share the
+// candidate list of the current query.  Called once per initialisation attempt (a few thousand queries): latency, not throughput.
+struct InitArgs {
+    int n1, n2;
+    const Query *q;
+    const int32_t *counts, *offsets;
+    const uint32_t *lists;
+    const RumiKeyPoint *keys2;
+    int32_t *matches12;             // out [n1]
+    float *prevMatched;             // in/out [n1][2]
+    int32_t *nmatches;
+    float nnratio;
+    int checkOri;
+};
+
+__global__ __launch_bounds__(64) void k_resolve_init(InitArgs A) {
+    extern __shared__ int32_t sInit[];          // matchedDist[n2] | matches21[n2]
+    __shared__ int sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH];
+    int32_t *matchedDist = sInit, *matches21 = sInit + A.n2;
+    const int lane = threadIdx.x;
+    const int kInf = 0x7FFFFFFF;
+    for (int f = lane; f < A.n2; f += 64) { matchedDist[f] = kInf; matches21[f] = -1; }
+    for (int i = lane; i < A.n1; i += 64) A.matches12[i] = -1;
+    if (lane < RUMI_HISTO_LENGTH) sHist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    for (int i1 = 0; i1 < A.n1; i1++) {
+        const int cnt = A.counts[i1];
+        if (cnt == 0) continue;
+        const uint32_t *L = A.lists + A.offsets[i1];
+        int b1 = kInf, b2 = kInf, bKey = kInf;            // best, second-best distance; best as dist<<16 | list position
+        int bFeat = -1;
+        for (int k = lane; k < cnt; k += 64) {
+            const uint32_t e = L[k];
+            const int f = (int)(e & 0xFFFF), d = (int)((e >> 16) & 0x1FF);
+            if (matchedDist[f] <= d) continue;                            // :617
+            if (d < b1) { b2 = b1; b1 = d; bKey = (d << 16) | k; bFeat = f; }
+            else if (d < b2) b2 = d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int c1 = __shfl_xor(b1, o), c2 = __shfl_xor(b2, o), cKey = __shfl_xor(bKey, o), cFeat = __shfl_xor(bFeat, o);
+            b2 = min(max(b1, c1), min(b2, c2));
+            b1 = min(b1, c1);
+            if (cKey < bKey) { bKey = cKey; bFeat = cFeat; }
+        }
+        // :629-638 (uniform across the wave)
+        if (b1 <= RUMI_TH_LOW && (float)b1 < (float)b2 * A.nnratio) {
+            if (lane == 0) {
+                const int prev = matches21[bFeat];
+                if (prev >= 0) A.matches12[prev] = -1;
+                A.matches12[i1] = bFeat;
+                matches21[bFeat] = i1;
+                matchedDist[bFeat] = b1;
+                if (A.checkOri) sHist[rot_bin(A.q[i1].angle, A.keys2[bFeat].angle)]++;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = 1;
+        if (A.checkOri) {                                                   // ComputeThreeMaxima over ALL accepted (also stolen) entries
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
+                const int s = sHist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = (i == ind1 || i == ind2 || i == ind3);
+        }
+    }
+    __syncthreads();
+    // a surviving match keeps the bin it was accepted with (its feature never changes afterwards): :661-677
+    for (int i = lane; i < A.n1; i += 64) {
+        int f = A.matches12[i];
+        if (f >= 0 && A.checkOri && !sKeep[rot_bin(A.q[i].angle, A.keys2[f].angle)]) { A.matches12[i] = -1; f = -1; }
+        if (f >= 0) { nmatches++; A.prevMatched[2 * i] = A.keys2[f].x; A.prevMatched[2 * i + 1] = A.keys2[f].y; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmatches += __shfl_xor(nmatches, o);
+    if (lane == 0) *A.nmatches = nmatches;
+}
+
 // ---- brute force ----------------------------------------------------------------------------------------------------
 // grid (ceil(cap/256), B); 256 queries per workgroup in registers; train descriptors staged 256 at a time in LDS and
 // read as broadcasts (every lane reads the same address: conflict-free).
@@ -662,10 +762,8 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
     return RUMI_OK;
 }
 
-// count pass, scan, (grow the list arena if needed), fill pass, resolve
-static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
-                      float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
-                      float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
+// count pass, scan, (grow the list arena if needed), fill pass
+static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc) {
     if (nq > 0) {
         hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists);
@@ -682,6 +780,15 @@ static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, cons
         hipLaunchKernelGGL(k_candidates<true>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists);
     }
+    return RUMI_OK;
+}
+
+// candidate lists, then the fix-point resolve
+static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
+                      float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
+                      float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
+    const int rcl = build_lists(m, mode, nq, fd, dQueryDesc);
+    if (rcl != RUMI_OK) return rcl;
     ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
                   nnratio, checkOri, dBlocked0, thrF, thrI};
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
@@ -854,6 +961,32 @@ extern "C" int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFe
                            m->dF[3], m->dPose, m->dScale, Cur->nlevels, log_scale_factor, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
     return run_search(m, MODE_RELOC, nkf, fd, m->dQDesc, nullptr, 0.f, check_orientation, cur_mp, nmatches_out, m->dU8b, 0.f, orb_dist);
+}
+
+extern "C" int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFeatures *F1, const RumiFrameFeatures *F2,
+                                              float *prev_matched, int32_t window_size, float nnratio, int32_t check_orientation,
+                                              int32_t *matches12, int32_t *nmatches_out) {
+    if (!m || !F1 || !F2 || !nmatches_out || F1->n < 0) return RUMI_E_INVALID;
+    if (F1->n > m->maxQ) { g_lastError = "more F1 key-points than max_queries"; return RUMI_E_CAPACITY; }
+    if (F1->n > 0 && (!prev_matched || !matches12 || !F1->keys_un || !F1->desc)) return RUMI_E_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, F2, &fd);
+    if (rc != RUMI_OK) return rc;
+    const int n1 = F1->n;
+    *nmatches_out = 0;
+    if (n1 == 0) return RUMI_OK;
+    H2D(m->dQKeys, F1->keys_un, n1); H2D(m->dQDesc, F1->desc, (size_t)n1 * 32); H2D(m->dF[0], prev_matched, (size_t)n1 * 2);
+    hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, nullptr, n1, m->dQKeys, m->dF[0], (float)window_size, m->dQ);
+    rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc);
+    if (rc != RUMI_OK) return rc;
+    InitArgs A{n1, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dAssign, m->dF[0], m->dNmatches, nnratio, check_orientation};
+    hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), (size_t)std::max(fd.n, 1) * 2 * sizeof(int32_t), nullptr, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(nmatches_out, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(matches12, m->dAssign, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(prev_matched, m->dF[0], (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return RUMI_OK;
 }
 
 extern "C" int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const float *tcw3, const float *Ow3, const float *K4,

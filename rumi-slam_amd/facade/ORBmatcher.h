@@ -113,6 +113,20 @@ public:
         return nmatches;
     }
 
+    // Matching for the Map Initialization (only used in the monocular case) — ORBmatcher.cc:581-680
+    template <class FrameT, class Point2fT>
+    int SearchForInitialization(FrameT &F1, FrameT &F2, std::vector<Point2fT> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10) {
+        static_assert(sizeof(Point2fT) == 2 * sizeof(float), "cv::Point2f layout expected");
+        RumiFrameFeatures a = view(F1), b = view(F2);
+        a.n = (int32_t)F1.mvKeysUn.size(); b.n = (int32_t)F2.mvKeysUn.size();
+        vnMatches12.assign(F1.mvKeysUn.size(), -1);
+        int32_t nmatches = 0;
+        if (rumi_search_for_initialization(arena(), &a, &b, reinterpret_cast<float *>(vbPrevMatched.data()), windowSize, mfNNratio, mbCheckOrientation,
+                                           vnMatches12.data(), &nmatches) != RUMI_OK)
+            return -1;
+        return nmatches;
+    }
+
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame, by vocabulary node (TrackReferenceKeyFrame, Relocalization)
     template <class KeyFrameT, class FrameT, class MapPointT>
     int SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> &vpMapPointMatches) {

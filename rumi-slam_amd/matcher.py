@@ -22,7 +22,7 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
 
 
 def _lib():
@@ -44,6 +44,7 @@ def _lib():
                                                  vp, C.POINTER(i32)]
     L.rumi_search_by_projection_reloc.argtypes = [vp, C.POINTER(RumiFrameFeatures), f32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32,
                                                   i32, i32, vp, C.POINTER(i32)]
+    L.rumi_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
@@ -128,6 +129,15 @@ class ORBmatcher:
             capi.ptr(last_outlier), len(mp_obs), capi.ptr(mp_pos), capi.ptr(mp_desc), capi.ptr(mp_obs), float(th),
             int(self.mbCheckOrientation), capi.ptr(cur_mp), C.byref(nm)))
         return nm.value, cur_mp
+
+    def SearchForInitialization(self, F1, F2, prev_matched, window_size=100):
+        """Returns (nmatches, vnMatches12, updated vbPrevMatched) — ORBmatcher.cc:581-680."""
+        pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+        m12 = np.full(F1.n, -1, np.int32)
+        nm = C.c_int32()
+        capi.check(self._lib.rumi_search_for_initialization(self._h, C.byref(F1.c), C.byref(F2.c), capi.ptr(pm), int(window_size), self.mfNNratio,
+                                                            int(self.mbCheckOrientation), capi.ptr(m12), C.byref(nm)))
+        return nm.value, m12, pm
 
     def SearchByBoW(self, KF, kf_fv, kf_mp, mp_bad, F, f_fv):
         kf_mp = np.ascontiguousarray(kf_mp, np.int32); mp_bad = np.ascontiguousarray(mp_bad, np.uint8)

@@ -139,6 +139,8 @@ def _mlib():
     L.orc_search_by_projection_frame.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp]
     L.orc_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
     L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    L.orc_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, i32, vp]
+    L.orc_search_for_initialization.restype = i32
     L.orc_is_in_frustum.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_search_by_bow_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
     L.orc_search_by_projection_sim3.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp]
@@ -280,3 +282,13 @@ def is_in_frustum(Rcw9, tcw3, Ow3, K4, w, h, log_sf, nlevels, cos_limit, pts):
                               _p(mn), _p(mx), _p(out["track_in_view"]), _p(out["proj_x"]), _p(out["proj_y"]), _p(out["scale_level"]), _p(out["view_cos"]),
                               _p(out["track_depth"]))
     return out
+
+
+def search_for_initialization(keys1, desc1, keys2, desc2, w, h, prev_matched, window, nnratio, check_ori):
+    k1 = np.ascontiguousarray(keys1, KP_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8)
+    k2 = np.ascontiguousarray(keys2, KP_DTYPE); d2 = np.ascontiguousarray(desc2, np.uint8)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.full(len(k1), -1, np.int32)
+    n = _mlib().orc_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), 0.0, 0.0, float(w), float(h), _p(pm), int(window),
+                                              float(nnratio), int(check_ori), _p(m12))
+    return n, m12, pm

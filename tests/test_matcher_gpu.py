@@ -207,3 +207,22 @@ def test_is_in_frustum_then_search_local_points(matcher, seed):
     n_ref, fm_ref = O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, mp, frame_mp, 3.0, False, 0.0, 0.8)
     n_gpu, fm = m.SearchByProjection_MapPoints(F, mp, frame_mp, 3.0)
     assert n_gpu == n_ref and n_ref > 100 and np.array_equal(fm, fm_ref)
+
+
+@pytest.mark.parametrize("seed,ratio,ori,window", [(0, 0.9, True, 100), (1, 0.9, False, 100), (2, 0.7, True, 40), (3, 1.5, True, 200)])
+def test_search_for_initialization(matcher, seed, ratio, ori, window):
+    """Monocular initialisation matcher: sequential steal rule (vMatchedDistance) replayed exactly; second call reuses vbPrevMatched."""
+    from rumi_slam_amd.matcher import FrameView
+    s = TrackingScene(seed)
+    m = matcher(ratio, ori)
+    F1 = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    F2 = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    pm0 = np.stack([s.last_keys["x"], s.last_keys["y"]], 1).astype(np.float32)
+    n_ref, m_ref, pm_ref = O.search_for_initialization(s.last_keys, s.last_desc, s.cur_keys, s.cur_desc, s.w, s.h, pm0, window, ratio, ori)
+    n_gpu, m12, pm = m.SearchForInitialization(F1, F2, pm0, window)
+    assert n_ref > 50
+    assert n_gpu == n_ref and np.array_equal(m12, m_ref) and np.array_equal(pm, pm_ref)
+    # Tracking::MonocularInitialization calls it again on the next frame with the updated vbPrevMatched
+    n_ref2, m_ref2, pm_ref2 = O.search_for_initialization(s.last_keys, s.last_desc, s.cur_keys, s.cur_desc, s.w, s.h, pm_ref, window, ratio, ori)
+    n_gpu2, m12b, pmb = m.SearchForInitialization(F1, F2, pm, window)
+    assert n_gpu2 == n_ref2 and np.array_equal(m12b, m_ref2) and np.array_equal(pmb, pm_ref2)
