@@ -126,6 +126,18 @@ int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFeatures *F1, 
                                    int32_t window_size, float nnratio, int32_t check_orientation, int32_t *matches12,
                                    int32_t *nmatches_out);
 
+/* ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t,size_t>> &vMatchedPairs, bOnlyStereo,
+ * bCoarse) — R/lib_src/ORBmatcher.cc:806-1013, monocular branch (LocalMapping::CreateNewMapPoints, LocalMapping.cc:425).
+ * kf*_mp: >= 0 where the key-frame already holds a map point for the feature.  F12 (row-major 3x3) is the fundamental matrix
+ * K1^-T [t12]x R12 K2^-1 that Pinhole::epipolarConstrain (Pinhole.cpp:107-129) rebuilds for every pair, epipole2 =
+ * pKF2->mpCamera->project(T2w * pKF1->GetCameraCenter()) (:815-818): both are formed by the caller with the reference's own
+ * Eigen/Sophus expressions (facade/ORBmatcher.h), so no Eigen arithmetic is restated on this side of the ABI.
+ * matches12 [KF1->n] = vMatches12 (vMatchedPairs = its non-negative entries in index order). */
+int rumi_search_for_triangulation(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFeatureVector *fv1, const int32_t *kf1_mp,
+                                  const RumiFrameFeatures *KF2, const RumiFeatureVector *fv2, const int32_t *kf2_mp, const float *F12,
+                                  const float *epipole2, int32_t only_stereo, int32_t coarse, int32_t check_orientation,
+                                  int32_t *matches12, int32_t *nmatches_out);
+
 /* Frame::isInFrustum(MapPoint*, viewingCosLimit) for every local map point (SearchLocalPoints, Tracking.cc:2996-3055;
  * Frame.cc:558-617, mono branch) — the step that produces the per-point inputs of rumi_search_by_projection_mappoints.
  * Rcw9 (row-major) = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw; per point GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance.

@@ -486,6 +486,73 @@ int orc_search_for_initialization(const KeyPoint *keys1, const uint8_t *desc1, i
     return nmatches;
 }
 
+// ORBmatcher::SearchForTriangulation, monocular branch (R/lib_src/ORBmatcher.cc:806-1013) with Pinhole::epipolarConstrain
+// (Pinhole.cpp:107-129) evaluated from a caller-supplied F12 (the matrix the reference rebuilds per pair) and epipole.
+int orc_search_for_triangulation(const KeyPoint *keys1, const uint8_t *desc1, int n1, const int32_t *mp1, const uint32_t *nodes1,
+                                 const int32_t *off1, const uint32_t *idx1, int nn1, const KeyPoint *keys2, const uint8_t *desc2, int n2,
+                                 const int32_t *mp2, const uint32_t *nodes2, const int32_t *off2, const uint32_t *idx2, int nn2,
+                                 const float *scaleFactors2, const float *F12, const float *ep, int onlyStereo, int coarse,
+                                 int checkOrientation, int32_t *matches12) {
+    (void)n2;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int p = off1[a]; p < off1[a + 1]; p++) {
+                const int i1 = (int)idx1[p];
+                if (mp1[i1] >= 0) continue;
+                if (onlyStereo) continue;                               // bStereo1 is false for every monocular key-point
+                const KeyPoint &kp1 = keys1[i1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int c = off2[b]; c < off2[b + 1]; c++) {
+                    const int i2 = (int)idx2[c];
+                    if (mp2[i2] >= 0) continue;                         // vbMatched2 is never written upstream
+                    const int dist = descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint &kp2 = keys2[i2];
+                    const float distex = ep[0] - kp2.x, distey = ep[1] - kp2.y;
+                    if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+                    bool ok = coarse != 0;
+                    if (!ok) {
+                        const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                        const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                        const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                        const float num = la * kp2.x + lb * kp2.y + lc;
+                        const float den = la * la + lb * lb;
+                        if (den != 0) {
+                            const float dsqr = num * num / den;
+                            const float unc = scaleFactors2[kp2.octave] * scaleFactors2[kp2.octave];
+                            ok = dsqr < 3.84 * unc;
+                        }
+                    }
+                    if (ok) { bestIdx2 = i2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[i1] = bestIdx2;
+                    nmatches++;
+                    if (checkOrientation) rotHist[rot_bin(kp1.angle, keys2[bestIdx2].angle)].push_back(i1);
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;               // lower_bound
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int i1 : rotHist[i]) { matches12[i1] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // Frame::isInFrustum(MapPoint*, viewingCosLimit), mono branch (R/lib_src/Frame.cc:558-617): fills the tracking fields of every
 // point.  Rcw9 row-major = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw.
 void orc_is_in_frustum(const float *Rcw9, const float *tcw3, const float *Ow3, const float *K4, float minX, float minY, float maxX,

@@ -619,6 +619,107 @@ __global__ __launch_bounds__(64) void k_resolve_init(InitArgs A) {
     if (lane == 0) *A.nmatches = nmatches;
 }
 
+// SearchForTriangulation, monocular branch (ORBmatcher.cc:806-1013).  vbMatched2 is never set in the reference, so the queries
+// are independent: per KF1 feature without a map point, the LAST candidate of minimal distance (<= TH_LOW, `dist > bestDist`
+// rejects, so ties move to the later one) among those passing the epipole and epipolar tests.  One thread per node of KF1.
+struct TriArgs {
+    int nn1, nn2;
+    const uint32_t *nodes1; const int32_t *off1; const uint32_t *idx1;
+    const uint32_t *nodes2; const int32_t *off2; const uint32_t *idx2;
+    const RumiKeyPoint *keys1, *keys2;
+    const uint8_t *desc1, *desc2;
+    const int32_t *mp1, *mp2;
+    const float *scale2;            // KF2 mvScaleFactors
+    const float *geom;              // F12 row-major [9], epipole [2]
+    int coarse;
+    int32_t *assign;                // [entries of fv1] chosen KF2 feature or -1
+};
+
+__global__ void k_tri_match(TriArgs A) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A.nn1) return;
+    int lo = 0, hi = A.nn2;
+    const uint32_t id = A.nodes1[a];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.nodes2[mid] < id) lo = mid + 1; else hi = mid; }
+    const bool hit = lo < A.nn2 && A.nodes2[lo] == id;
+    const float *F = A.geom;
+    const float epx = A.geom[9], epy = A.geom[10];
+    for (int p = A.off1[a]; p < A.off1[a + 1]; p++) {
+        int best = -1;
+        const int i1 = (int)A.idx1[p];
+        if (hit && A.mp1[i1] < 0) {
+            const RumiKeyPoint k1 = A.keys1[i1];
+            uint32_t d1[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) d1[k] = reinterpret_cast<const uint32_t *>(A.desc1 + (size_t)i1 * 32)[k];
+            // epipolar line l = x1' F12 (Pinhole.cpp:114-117)
+            const float la = k1.x * F[0] + k1.y * F[3] + F[6];
+            const float lb = k1.x * F[1] + k1.y * F[4] + F[7];
+            const float lc = k1.x * F[2] + k1.y * F[5] + F[8];
+            const float den = la * la + lb * lb;
+            int bestDist = RUMI_TH_LOW;
+            for (int c = A.off2[lo]; c < A.off2[lo + 1]; c++) {
+                const int i2 = (int)A.idx2[c];
+                if (A.mp2[i2] >= 0) continue;
+                const int dist = hamming256(d1, reinterpret_cast<const uint32_t *>(A.desc2 + (size_t)i2 * 32));
+                if (dist > RUMI_TH_LOW || dist > bestDist) continue;
+                const RumiKeyPoint k2 = A.keys2[i2];
+                const float ex = epx - k2.x, ey = epy - k2.y;
+                if (ex * ex + ey * ey < 100 * A.scale2[k2.octave]) continue;                       // :912-918
+                if (!A.coarse) {
+                    const float num = la * k2.x + lb * k2.y + lc;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    const float s2 = A.scale2[k2.octave] * A.scale2[k2.octave];                    // mvLevelSigma2
+                    if (!((double)dsqr < 3.84 * (double)s2)) continue;
+                }
+                best = i2; bestDist = dist;
+            }
+        }
+        A.assign[p] = best;
+    }
+}
+
+// rotation-histogram filter + match count for k_tri_match (ORBmatcher.cc:964-1001); single workgroup
+__global__ __launch_bounds__(256) void k_tri_filter(int nq, const uint32_t *idx1, const RumiKeyPoint *keys1, const RumiKeyPoint *keys2,
+                                                    int32_t *assign, int checkOri, int32_t *nmatches) {
+    __shared__ int sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH], sCount;
+    const int tid = threadIdx.x;
+    if (tid < RUMI_HISTO_LENGTH) { sHist[tid] = 0; sKeep[tid] = 1; }
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    if (checkOri) {
+        for (int p = tid; p < nq; p += 256) {
+            const int f = assign[p];
+            if (f >= 0) atomicAdd(&sHist[rot_bin(keys1[idx1[p]].angle, keys2[f].angle)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
+                const int s = sHist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = (i == ind1 || i == ind2 || i == ind3);
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int p = tid; p < nq; p += 256) {
+        const int f = assign[p];
+        if (f < 0) continue;
+        if (checkOri && !sKeep[rot_bin(keys1[idx1[p]].angle, keys2[f].angle)]) assign[p] = -1;
+        else local++;
+    }
+    atomicAdd(&sCount, local);
+    __syncthreads();
+    if (tid == 0) *nmatches = sCount;
+}
+
 // ---- brute force ----------------------------------------------------------------------------------------------------
 // grid (ceil(cap/256), B); 256 queries per workgroup in registers; train descriptors staged 256 at a time in LDS and
 // read as broadcasts (every lane reads the same address: conflict-free).
@@ -904,6 +1005,44 @@ extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF
     rc = run_search(m, MODE_BOW_KF, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, nullptr, nmatches_out, m->dU8b, 0.f, 0, assign.data());
     if (rc != RUMI_OK) return rc;
     for (int i = 0; i < KF1->n; i++) matches12[i] = -1;
+    for (int p = 0; p < nqe; p++) if (assign[p] >= 0) matches12[fv1->indices[p]] = assign[p];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_search_for_triangulation(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFeatureVector *fv1, const int32_t *kf1_mp,
+                                             const RumiFrameFeatures *KF2, const RumiFeatureVector *fv2, const int32_t *kf2_mp,
+                                             const float *F12, const float *epipole2, int32_t only_stereo, int32_t coarse,
+                                             int32_t check_orientation, int32_t *matches12, int32_t *nmatches_out) {
+    if (!m || !KF1 || !KF2 || !fv1 || !fv2 || !F12 || !epipole2 || !nmatches_out) return RUMI_E_INVALID;
+    if ((KF1->n > 0 && (!kf1_mp || !matches12)) || (KF2->n > 0 && !kf2_mp)) return RUMI_E_INVALID;
+    const int nqe = fv1->n_nodes > 0 ? fv1->offsets[fv1->n_nodes] : 0, nfe = fv2->n_nodes > 0 ? fv2->offsets[fv2->n_nodes] : 0;
+    if (KF1->n > m->maxQ || nqe > m->maxQ || fv1->n_nodes > m->maxQ || nfe > m->maxFeat || fv2->n_nodes > m->maxFeat) {
+        g_lastError = "SearchForTriangulation: sizes exceed the matcher's capacities";
+        return RUMI_E_CAPACITY;
+    }
+    for (int i = 0; i < KF1->n; i++) matches12[i] = -1;
+    *nmatches_out = 0;
+    // monocular key-frames have no stereo key-points (mvuRight < 0): bOnlyStereo skips every pair (:874-876)
+    if (only_stereo || nqe == 0 || nfe == 0 || KF2->n == 0) return RUMI_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, KF2, &fd);
+    if (rc != RUMI_OK) return rc;
+    float geom[11];
+    std::memcpy(geom, F12, 36); std::memcpy(geom + 9, epipole2, 8);
+    H2D(m->dPose, geom, 11);
+    H2D(m->dFeatMp, kf2_mp, KF2->n);
+    H2D(m->dQKeys, KF1->keys_un, KF1->n); H2D(m->dQDesc, KF1->desc, (size_t)KF1->n * 32); H2D(m->dI[0], kf1_mp, KF1->n);
+    H2D(m->dNodesA, fv1->node_ids, fv1->n_nodes); H2D(m->dOffA, fv1->offsets, fv1->n_nodes + 1); H2D(m->dIdxA, fv1->indices, nqe);
+    H2D(m->dNodesB, fv2->node_ids, fv2->n_nodes); H2D(m->dOffB, fv2->offsets, fv2->n_nodes + 1); H2D(m->dFvIdx, fv2->indices, nfe);
+    TriArgs A{fv1->n_nodes, fv2->n_nodes, m->dNodesA, m->dOffA, m->dIdxA, m->dNodesB, m->dOffB, m->dFvIdx, m->dQKeys, m->dKeys,
+              m->dQDesc, m->dDesc, m->dI[0], m->dFeatMp, m->dScale, m->dPose, coarse, m->dAssign};
+    hipLaunchKernelGGL(k_tri_match, dim3((fv1->n_nodes + 63) / 64), dim3(64), 0, nullptr, A);
+    hipLaunchKernelGGL(k_tri_filter, dim3(1), dim3(256), 0, nullptr, nqe, m->dIdxA, m->dQKeys, m->dKeys, m->dAssign, check_orientation, m->dNmatches);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> assign(nqe);
+    HIP_TRY(hipMemcpy(nmatches_out, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(assign.data(), m->dAssign, (size_t)nqe * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int p = 0; p < nqe; p++) if (assign[p] >= 0) matches12[fv1->indices[p]] = assign[p];
     return RUMI_OK;
 }

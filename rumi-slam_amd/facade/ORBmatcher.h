@@ -168,6 +168,49 @@ public:
         return nmatches;
     }
 
+    // Matching to triangulate new MapPoints. Check Epipolar Constraint (LocalMapping::CreateNewMapPoints)  ORBmatcher.cc:806-1013
+    // Monocular key-frames.  The fundamental matrix and the epipole are formed here with the reference's own expressions
+    // (:812-829 and Pinhole.cpp:109-112), so they are evaluated by the very same Eigen/Sophus code as upstream.
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
+                               const bool bCoarse = false) {
+        float F[9], e[2];
+#ifdef RUMI_HAVE_SOPHUS
+        {
+            Sophus::SE3f T1w = pKF1->GetPose(), T2w = pKF2->GetPose(), Tw2 = pKF2->GetPoseInverse();
+            Eigen::Vector3f Cw = pKF1->GetCameraCenter();
+            Eigen::Vector3f C2 = T2w * Cw;
+            Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
+            Sophus::SE3f T12 = T1w * Tw2;
+            Eigen::Matrix3f R12 = T12.rotationMatrix();
+            Eigen::Vector3f t12 = T12.translation();
+            Eigen::Matrix3f t12x = Sophus::SO3f::hat(t12);
+            Eigen::Matrix3f K1 = pKF1->mpCamera->toK_();
+            Eigen::Matrix3f K2 = pKF2->mpCamera->toK_();
+            Eigen::Matrix3f F12 = K1.transpose().inverse() * t12x * R12 * K2.inverse();
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[r * 3 + c] = F12(r, c);
+            e[0] = ep(0); e[1] = ep(1);
+        }
+#else
+        pKF1->EpipolarGeometryTo(pKF2, F, e);            // adapter of the mock data model (tests/cpp/test_facade.cc)
+#endif
+        const auto v1 = pKF1->GetMapPointMatches(), v2 = pKF2->GetMapPointMatches();
+        std::vector<int32_t> m1(pKF1->N, -1), m2(pKF2->N, -1);
+        for (size_t i = 0; i < v1.size() && i < m1.size(); i++) if (v1[i]) m1[i] = 0;
+        for (size_t i = 0; i < v2.size() && i < m2.size(); i++) if (v2[i]) m2[i] = 0;
+        Csr a = csr(pKF1->mFeatVec), b = csr(pKF2->mFeatVec);
+        RumiFrameFeatures k1 = view(*pKF1), k2 = view(*pKF2);
+        std::vector<int32_t> m12(pKF1->N, -1);
+        int32_t nmatches = 0;
+        if (rumi_search_for_triangulation(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), F, e, bOnlyStereo, bCoarse, mbCheckOrientation,
+                                          m12.data(), &nmatches) != RUMI_OK)
+            return -1;
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches > 0 ? nmatches : 0);
+        for (size_t i = 0; i < m12.size(); i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+        return nmatches;
+    }
+
     // Project MapPoints seen in a key-frame into the frame and search matches (Relocalization)            ORBmatcher.cc:1685-1793
     // Needs two one-line accessors on MapPoint: GetMinDistance() / GetMaxDistance() returning mfMinDistance / mfMaxDistance
     // (the reference only exposes the 0.8x / 1.2x invariance values; PredictScale needs the raw one).  INTEGRATION.md §3.

@@ -22,7 +22,7 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
 
 
 def _lib():
@@ -45,6 +45,7 @@ def _lib():
     L.rumi_search_by_projection_reloc.argtypes = [vp, C.POINTER(RumiFrameFeatures), f32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32,
                                                   i32, i32, vp, C.POINTER(i32)]
     L.rumi_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp]
+    L.rumi_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
@@ -165,6 +166,19 @@ def SearchByBoW_KF(m, KF1, fv1, kf1_mp, KF2, fv2, kf2_mp, mp_bad):
     capi.check(m._lib.rumi_search_by_bow_kf(m._h, C.byref(KF1.c), C.byref(fv1.c), capi.ptr(k1), C.byref(KF2.c), C.byref(fv2.c), capi.ptr(k2),
                                             len(mb), capi.ptr(mb), m.mfNNratio, int(m.mbCheckOrientation), capi.ptr(out), C.byref(nm)))
     return nm.value, out
+
+
+def SearchForTriangulation(m, KF1, fv1, kf1_mp, KF2, fv2, kf2_mp, F12, epipole2, only_stereo=False, coarse=False):
+    """ORBmatcher::SearchForTriangulation (mono): returns (nmatches, vMatchedPairs as an [k,2] array of (idx1, idx2))."""
+    k1 = np.ascontiguousarray(kf1_mp, np.int32); k2 = np.ascontiguousarray(kf2_mp, np.int32)
+    F = _f32(F12).ravel(); ep = _f32(epipole2)
+    out = np.full(KF1.n, -1, np.int32)
+    nm = C.c_int32()
+    capi.check(m._lib.rumi_search_for_triangulation(m._h, C.byref(KF1.c), C.byref(fv1.c), capi.ptr(k1), C.byref(KF2.c), C.byref(fv2.c), capi.ptr(k2),
+                                                    capi.ptr(F), capi.ptr(ep), int(only_stereo), int(coarse), int(m.mbCheckOrientation),
+                                                    capi.ptr(out), C.byref(nm)))
+    idx = np.nonzero(out >= 0)[0]
+    return nm.value, np.stack([idx, out[idx]], 1).astype(np.int64)
 
 
 def SearchByProjection_Sim3(m, KF, log_sf, Tcw7, Ow3, K4, pts, matched, th, ratio_hamming, explicit_invz=False):

@@ -69,6 +69,12 @@ struct KeyFrame : Frame {
     bool isBad() { return bad; }
     Map *GetMap() { return map; }
     void EraseMapPointMatch(MapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
+    // stands in for the Sophus/Eigen expressions of the real tree: a fixed rank-2 F12 (pure x-translation) and a far epipole
+    void EpipolarGeometryTo(const KeyFrame *, float *F, float *e) const {
+        const float f[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+        for (int i = 0; i < 9; i++) F[i] = f[i];
+        e[0] = 5000.f; e[1] = 240.f;
+    }
 };
 
 static int fails = 0;
@@ -158,6 +164,18 @@ int main(int argc, char **argv) {
         std::set<MapPoint *> found;
         const int nr = matcher.SearchByProjection(cur, &ka, found, 10.f, 100);
         CHECK(nr >= 0, "SearchByProjection(Frame, KF, found, th, ORBdist) runs");
+        std::vector<std::pair<size_t, size_t>> pairs;
+        for (auto &p : ka.mvpMapPoints) p = nullptr;
+        for (auto &p : kb.mvpMapPoints) p = nullptr;
+        const int nt = matcher.SearchForTriangulation(&ka, &kb, pairs, false, true);
+        CHECK(nt >= 0 && (int)pairs.size() == nt, "SearchForTriangulation pairs == count");
+        std::vector<cv::Point2f> prev(fr[0].mvKeysUn.size());
+        for (size_t i = 0; i < prev.size(); i++) prev[i] = fr[0].mvKeysUn[i].pt;
+        std::vector<int> ini;
+        const int ni = matcher.SearchForInitialization(fr[0], fr[1], prev, ini, 100);
+        int cnt = 0;
+        for (int v : ini) cnt += v >= 0;
+        CHECK(ni > 20 && ni == cnt && ini.size() == fr[0].mvKeysUn.size(), "SearchForInitialization count == surviving vnMatches12 entries");
     }
 
     // ---- PoseOptimization facade ~ oracle ----

@@ -141,6 +141,8 @@ def _mlib():
     L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.orc_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, i32, vp]
     L.orc_search_for_initialization.restype = i32
+    L.orc_search_for_triangulation.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp]
+    L.orc_search_for_triangulation.restype = i32
     L.orc_is_in_frustum.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_search_by_bow_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
     L.orc_search_by_projection_sim3.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp]
@@ -292,3 +294,15 @@ def search_for_initialization(keys1, desc1, keys2, desc2, w, h, prev_matched, wi
     n = _mlib().orc_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), 0.0, 0.0, float(w), float(h), _p(pm), int(window),
                                               float(nnratio), int(check_ori), _p(m12))
     return n, m12, pm
+
+
+def search_for_triangulation(k1, d1, mp1, fv1, k2, d2, mp2, fv2, sf2, F12, ep, only_stereo, coarse, check_ori):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8); m1 = np.ascontiguousarray(mp1, np.int32)
+    k2 = np.ascontiguousarray(k2, KP_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8); m2 = np.ascontiguousarray(mp2, np.int32)
+    sf2 = np.ascontiguousarray(sf2, np.float32); F = np.ascontiguousarray(F12, np.float32).ravel(); e = np.ascontiguousarray(ep, np.float32)
+    out = np.full(len(k1), -1, np.int32)
+    n = _mlib().orc_search_for_triangulation(_p(k1), _p(d1), len(k1), _p(m1), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(k2), _p(d2), len(k2),
+                                             _p(m2), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), len(fv2[0]), _p(sf2), _p(F), _p(e), int(only_stereo),
+                                             int(coarse), int(check_ori), _p(out))
+    idx = np.nonzero(out >= 0)[0]
+    return n, np.stack([idx, out[idx]], 1).astype(np.int64)

@@ -34,6 +34,7 @@ class TrackingScene:
         self.sf = ext.tables()["scale"]
         img0 = synth_frame(9000 + seed, w=w, h=h)
         img1, A = warp_frame(img0, 777 + seed)
+        self.A = np.asarray(A, np.float64)
         _, self.last_keys, self.last_desc = ext.extract(img0, (0, 1000))
         _, self.cur_keys, self.cur_desc = ext.extract(img1, (0, 1000))
         nl = len(self.last_keys)
@@ -92,6 +93,17 @@ class TrackingScene:
                 m.setdefault(int(nd) * 7 + 3, []).append(idx)      # non-contiguous ids
             return m
         return group(node_last), group(node_cur)
+
+    def epipolar_geometry(self, epipole=(500.0, 200.0)):
+        """(F12 row-major float32[9], epipole float32[2]) consistent with the image warp x2 ~ H x1: F12 = H^T [e2]x^T, so that
+        x1^T F12 x2 = 0 for true correspondences and F12 e2 = 0 (what Pinhole::epipolarConstrain evaluates)."""
+        H = np.eye(3)
+        H[:self.A.shape[0], :] = self.A[:3, :3] if self.A.shape[1] == 3 else self.A
+        e = np.array([epipole[0], epipole[1], 1.0])
+        ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+        F12 = H.T @ ex.T
+        F12 /= np.abs(F12).max()
+        return F12.astype(np.float32).ravel(), np.asarray(epipole, np.float32)
 
     def point_geometry(self):
         """Per map point: viewing normal and scale-invariance distances as MapPoint::UpdateNormalAndDepth leaves them

@@ -226,3 +226,32 @@ def test_search_for_initialization(matcher, seed, ratio, ori, window):
     n_ref2, m_ref2, pm_ref2 = O.search_for_initialization(s.last_keys, s.last_desc, s.cur_keys, s.cur_desc, s.w, s.h, pm_ref, window, ratio, ori)
     n_gpu2, m12b, pmb = m.SearchForInitialization(F1, F2, pm, window)
     assert n_gpu2 == n_ref2 and np.array_equal(m12b, m_ref2) and np.array_equal(pmb, pm_ref2)
+
+
+@pytest.mark.parametrize("seed,coarse,ori", [(0, False, True), (1, False, False), (2, True, True), (3, False, True)])
+def test_search_for_triangulation(matcher, seed, coarse, ori):
+    """LocalMapping::CreateNewMapPoints matcher: BoW node walk + epipole / epipolar-line tests, pairs identical to the oracle."""
+    from rumi_slam_amd.matcher import FrameView, SearchForTriangulation
+    s = TrackingScene(seed)
+    KF1 = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    KF2 = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    fv1, fv2 = s.feature_vectors(n_nodes=150)
+    a, b = _fv(fv1), _fv(fv2)
+    rng = np.random.default_rng(seed)
+    mp1 = np.where(rng.random(KF1.n) < 0.4, 1, -1).astype(np.int32)        # only un-tracked key-points are triangulated
+    mp2 = np.where(rng.random(KF2.n) < 0.4, 1, -1).astype(np.int32)
+    F12, ep = s.epipolar_geometry()
+    m = matcher(0.6, ori)
+    n_ref, ref = O.search_for_triangulation(s.last_keys, s.last_desc, mp1, (a.node_ids, a.offsets, a.indices), s.cur_keys, s.cur_desc, mp2,
+                                            (b.node_ids, b.offsets, b.indices), s.sf, F12, ep, False, coarse, ori)
+    n_gpu, got = SearchForTriangulation(m, KF1, a, mp1, KF2, b, mp2, F12, ep, False, coarse)
+    assert n_ref > 40 and len(ref) == n_ref
+    assert n_gpu == n_ref and np.array_equal(got, ref)
+    if not coarse:      # the epipolar test must actually reject something, or the case proves nothing
+        n_c, _ = O.search_for_triangulation(s.last_keys, s.last_desc, mp1, (a.node_ids, a.offsets, a.indices), s.cur_keys, s.cur_desc, mp2,
+                                            (b.node_ids, b.offsets, b.indices), s.sf, F12, ep, False, True, False)
+        n_f, _ = O.search_for_triangulation(s.last_keys, s.last_desc, mp1, (a.node_ids, a.offsets, a.indices), s.cur_keys, s.cur_desc, mp2,
+                                            (b.node_ids, b.offsets, b.indices), s.sf, F12, ep, False, False, False)
+        assert n_f < n_c
+    n0, p0 = SearchForTriangulation(m, KF1, a, mp1, KF2, b, mp2, F12, ep, True, coarse)      # bOnlyStereo on mono key-frames
+    assert n0 == 0 and len(p0) == 0
