@@ -138,6 +138,31 @@ int rumi_search_for_triangulation(RumiMatcher *m, const RumiFrameFeatures *KF1, 
                                   const float *epipole2, int32_t only_stereo, int32_t coarse, int32_t check_orientation,
                                   int32_t *matches12, int32_t *nmatches_out);
 
+/* The search half of both ORBmatcher::Fuse overloads — R/lib_src/ORBmatcher.cc:1015-1180 (KeyFrame*, points, th, bRight=false;
+ * LocalMapping::SearchInNeighbors, LocalMapping.cc:699-727) and :1182-1291 (KeyFrame*, Sim3f&, points, th, vpReplacePoint;
+ * LoopClosing / CloudMerging): for every map point, the key-frame feature it fuses with (best_idx, -1 = none: skipped, not
+ * visible, or best Hamming distance > TH_LOW).  The points do not compete for features, so this part is data-parallel; the
+ * map mutations that follow (Replace / AddObservation / AddMapPoint, and the isBad / IsInKeyFrame skips that depend on them)
+ * are replayed in list order by the facade (facade/ORBmatcher.h), which owns the live map objects.
+ * skip[i] != 0: NULL entry.  check_reprojection = 1 for the first overload (mono chi2 gate 5.99, :1138-1145), 0 for the Sim3
+ * overload (Tcw7 = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()), Ow3 = Tcw.inverse().translation()). */
+int rumi_fuse_candidates(RumiMatcher *m, const RumiFrameFeatures *KF, float log_scale_factor, const float *Tcw7, const float *Ow3,
+                         const float *K4, int32_t nmp, const uint8_t *skip, const float *mp_pos, const float *mp_normal,
+                         const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc, float th,
+                         int32_t check_reprojection, int32_t *best_idx);
+
+/* ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const Sim3f &S12, th) —
+ * R/lib_src/ORBmatcher.cc:1293-1496 (loop / merge Sim3 refinement).  One entry per key-frame feature on each side:
+ * skip1[i] = no map point, already matched (vbAlreadyMatched1) or bad; pc1_in2[i] = S21 * (T1w * p3Dw) — the point in camera 2,
+ * formed by the caller with the reference's own Sophus expressions (:1338-1340); min/max_dist = mfMinDistance / mfMaxDistance;
+ * desc = GetDescriptor().  Likewise side 2 with pc2_in1 = S12 * (T2w * p3Dw) and vbAlreadyMatched2.  K4 = pKF1's intrinsics
+ * (the reference projects both directions with them, :1294-1297).  match12[i1] = KF2 feature whose map point agrees both
+ * ways, or -1 (then vpMatches12[i1] is left as it was). */
+int rumi_search_by_sim3(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFrameFeatures *KF2, const float *K4,
+                        float log_scale_factor, const uint8_t *skip1, const float *pc1_in2, const float *min_dist1,
+                        const float *max_dist1, const uint8_t *desc1, const uint8_t *skip2, const float *pc2_in1, const float *min_dist2,
+                        const float *max_dist2, const uint8_t *desc2, float th, int32_t *match12, int32_t *nfound_out);
+
 /* Frame::isInFrustum(MapPoint*, viewingCosLimit) for every local map point (SearchLocalPoints, Tracking.cc:2996-3055;
  * Frame.cc:558-617, mono branch) — the step that produces the per-point inputs of rumi_search_by_projection_mappoints.
  * Rcw9 (row-major) = Frame::mRcw, tcw3 = mtcw, Ow3 = mOw; per point GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance.

@@ -383,6 +383,106 @@ int orc_search_by_projection_sim3(const KeyPoint *keys, const uint8_t *desc, int
     return nmatches;
 }
 
+// The search half of ORBmatcher::Fuse (R/lib_src/ORBmatcher.cc:1058-1161 with checkReproj = 1, monocular key-points;
+// :1209-1277 with checkReproj = 0): per map point the key-frame feature of smallest Hamming distance inside the predicted-scale
+// window, -1 when the point is not visible or the distance exceeds TH_LOW.  What follows in the reference (Replace /
+// AddObservation / AddMapPoint and the isBad / IsInKeyFrame skips) acts on live map objects and is not restated here.
+void orc_fuse_candidates(const KeyPoint *keys, const uint8_t *desc, int n, float minX, float minY, float maxX, float maxY,
+                         const float *scaleFactors, int nLevels, float logScaleFactor, const float *Tcw7, const float *Ow3, const float *K4,
+                         int nmp, const uint8_t *skip, const float *mpPos, const float *mpNormal, const float *mpMinDist,
+                         const float *mpMaxDist, const uint8_t *mpDesc, float th, int checkReproj, int32_t *bestIdxOut) {
+    FrameGrid KF(keys, desc, n, minX, minY, maxX, maxY);
+    std::vector<int> vIndices;
+    for (int i = 0; i < nmp; i++) {
+        bestIdxOut[i] = -1;
+        if (skip[i]) continue;
+        const float *p3Dw = mpPos + (size_t)i * 3;
+        float p3Dc[3];
+        se3_mul(Tcw7, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float u = K4[0] * p3Dc[0] / p3Dc[2] + K4[2], v = K4[1] * p3Dc[1] / p3Dc[2] + K4[3];
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;
+        const float maxDistance = 1.2f * mpMaxDist[i], minDistance = 0.8f * mpMinDist[i];
+        const float PO[3] = {p3Dw[0] - Ow3[0], p3Dw[1] - Ow3[1], p3Dw[2] - Ow3[2]};
+        const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float *Pn = mpNormal + (size_t)i * 3;
+        if ((PO[0] * Pn[0] + PO[1] * Pn[1]) + PO[2] * Pn[2] < 0.5 * dist3D) continue;
+        const int nPredictedLevel = predict_scale(mpMaxDist[i], dist3D, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        KF.in_area(u, v, radius, -1, -1, vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = mpDesc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            const KeyPoint &kp = keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (checkReproj) {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                const float invSigma2 = 1.0f / (scaleFactors[kpLevel] * scaleFactors[kpLevel]);       // ORBextractor.cc:417-426
+                if (e2 * invSigma2 > 5.99) continue;
+            }
+            const int d = descriptor_distance(dMP, desc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) bestIdxOut[i] = bestIdx;
+    }
+}
+
+// One direction of ORBmatcher::SearchBySim3 (R/lib_src/ORBmatcher.cc:1329-1402 / :1405-1478) from camera-frame points
+static void sim3_direction(const KeyPoint *keys, const uint8_t *desc, int n, float minX, float minY, float maxX, float maxY,
+                           const float *scaleFactors, int nLevels, float logScaleFactor, const float *K4, int np, const uint8_t *skip,
+                           const float *pc, const float *mpMinDist, const float *mpMaxDist, const uint8_t *mpDesc, float th,
+                           std::vector<int> &vnMatch) {
+    FrameGrid KF(keys, desc, n, minX, minY, maxX, maxY);
+    vnMatch.assign(np, -1);
+    std::vector<int> vIndices;
+    for (int i = 0; i < np; i++) {
+        if (skip[i]) continue;
+        const float *p = pc + (size_t)i * 3;
+        if (p[2] < 0.0) continue;
+        const float invz = 1.0 / p[2];
+        const float x = p[0] * invz, y = p[1] * invz;
+        const float u = K4[0] * x + K4[2], v = K4[1] * y + K4[3];
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;
+        const float maxDistance = 1.2f * mpMaxDist[i], minDistance = 0.8f * mpMinDist[i];
+        const float dist3D = std::sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = predict_scale(mpMaxDist[i], dist3D, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        KF.in_area(u, v, radius, -1, -1, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const int oct = keys[idx].octave;
+            if (oct < nPredictedLevel - 1 || oct > nPredictedLevel) continue;
+            const int d = descriptor_distance(mpDesc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+}
+
+// ORBmatcher::SearchBySim3 (R/lib_src/ORBmatcher.cc:1293-1496); per-feature inputs as documented in include/rumi_match.h
+int orc_search_by_sim3(const KeyPoint *keys1, const uint8_t *kfDesc1, int n1, const KeyPoint *keys2, const uint8_t *kfDesc2, int n2, float minX,
+                       float minY, float maxX, float maxY, const float *scaleFactors, int nLevels, float logScaleFactor, const float *K4,
+                       const uint8_t *skip1, const float *pc1in2, const float *min1, const float *max1, const uint8_t *desc1,
+                       const uint8_t *skip2, const float *pc2in1, const float *min2, const float *max2, const uint8_t *desc2, float th,
+                       int32_t *match12) {
+    std::vector<int> vnMatch1, vnMatch2;
+    sim3_direction(keys2, kfDesc2, n2, minX, minY, maxX, maxY, scaleFactors, nLevels, logScaleFactor, K4, n1, skip1, pc1in2, min1, max1, desc1, th, vnMatch1);
+    sim3_direction(keys1, kfDesc1, n1, minX, minY, maxX, maxY, scaleFactors, nLevels, logScaleFactor, K4, n2, skip2, pc2in1, min2, max2, desc2, th, vnMatch2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    return nFound;
+}
+
 // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1685-1793).
 // kfMp[nkf]: map point id of each key-frame feature (-1 none); skip[id] = isBad() || sAlreadyFound.count(); per id: pos, min/max distance,
 // descriptor.  cur_mp[ncur] in/out (-1 NULL).

@@ -27,7 +27,7 @@ namespace rumi {
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // Frame.h:42-43
 constexpr int kMaxSortN = 8192;
 
-enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5, MODE_INIT = 6 };
+enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5, MODE_INIT = 6, MODE_FUSE = 7 };
 
 struct Query {           // 48 bytes
     float u, v, r;       // window centre / half-size (MODE_BOW: unused)
@@ -45,6 +45,7 @@ struct FrameDev {
     const RumiKeyPoint *keys;
     const uint8_t *desc;
     float minX, minY, maxX, maxY, wInv, hInv;
+    const float *scale;          // mvScaleFactors
     const uint16_t *sortedIdx;   // features sorted by (cell, index)
     const int32_t *cellStart;    // [kGridCells + 1]
 };
@@ -191,11 +192,12 @@ __device__ __forceinline__ void se3f_mul(const float *T, const float *p, float *
 // SearchByProjection(KeyFrame*, Sim3f&, points, ...): ORBmatcher.cc:389-436 (variant 0) / :491-539 (variant 1)
 __global__ void k_queries_sim3(int nmp, const uint8_t *skip, const float *mpPos, const float *mpNormal, const float *mpMinDist,
                                const float *mpMaxDist, const float *pose /*Tcw7, K4, Ow3*/, const float *scaleFactors, int nLevels,
-                               float logScaleFactor, int th, int variant, float minX, float minY, float maxX, float maxY, Query *q) {
+                               float logScaleFactor, float th, int variant, int blocks, int checkReproj, float minX, float minY, float maxX, float maxY,
+                               Query *q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nmp) return;
     Query o{};
-    o.descId = i; o.mpId = i; o.blocks = 1;
+    o.descId = i; o.mpId = i; o.blocks = blocks; o.c0 = checkReproj;
     const float *Tcw = pose, *K = pose + 7, *Ow = pose + 11;
     if (!skip[i]) {
         const float *p3Dw = mpPos + (size_t)i * 3;
@@ -212,8 +214,36 @@ __global__ void k_queries_sim3(int nmp, const uint8_t *skip, const float *mpPos,
                 const float *Pn = mpNormal + (size_t)i * 3;
                 if (!(dist < minD || dist > maxD) && !((double)((P0 * Pn[0] + P1 * Pn[1]) + P2 * Pn[2]) < 0.5 * (double)dist)) {
                     const int lvl = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
-                    o.valid = 1; o.u = u; o.v = v; o.r = (float)th * scaleFactors[lvl];
+                    o.valid = 1; o.u = u; o.v = v; o.r = th * scaleFactors[lvl];
                     o.minLevel = lvl - 1; o.maxLevel = lvl;                              // the level test of :445-448 / :553-556
+                }
+            }
+        }
+    }
+    q[i] = o;
+}
+
+// SearchBySim3, one direction (ORBmatcher.cc:1329-1371 / :1405-1447): points already in the target camera frame
+__global__ void k_queries_campoints(int n, const uint8_t *skip, const float *pc, const float *mpMinDist, const float *mpMaxDist, const float *K,
+                                    const float *scaleFactors, int nLevels, float logScaleFactor, float th, float minX, float minY, float maxX,
+                                    float maxY, Query *q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Query o{};
+    o.descId = i; o.mpId = i;
+    if (!skip[i]) {
+        const float *p = pc + (size_t)i * 3;
+        if (!((double)p[2] < 0.0)) {
+            const float invz = (float)(1.0 / (double)p[2]);
+            const float x = p[0] * invz, y = p[1] * invz;
+            const float u = K[0] * x + K[2], v = K[1] * y + K[3];
+            if (u >= minX && u < maxX && v >= minY && v < maxY) {                       // KeyFrame::IsInImage
+                const float maxD = 1.2f * mpMaxDist[i], minD = 0.8f * mpMinDist[i];
+                const float dist = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+                if (!(dist < minD || dist > maxD)) {
+                    const int lvl = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
+                    o.valid = 1; o.u = u; o.v = v; o.r = th * scaleFactors[lvl];
+                    o.minLevel = lvl - 1; o.maxLevel = lvl;
                 }
             }
         }
@@ -358,6 +388,12 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
                         }
                         const float dx = kp.x - Q.u, dy = kp.y - Q.v;
                         if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) pass = false;
+                        if (mode == MODE_FUSE && Q.c0 && pass) {                        // mono reprojection gate, ORBmatcher.cc:1138-1145
+                            const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                            const float e2 = ex * ex + ey * ey;
+                            const float s2 = F.scale[oct] * F.scale[oct];              // mvLevelSigma2; mvInvLevelSigma2 = 1.0f / it
+                            if ((double)(e2 * (1.0f / s2)) > 5.99) pass = false;
+                        }
                     }
                     const unsigned long long b = __ballot(pass);
                     if (FILL && pass) {
@@ -464,6 +500,8 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
                     if (bestDist < RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
                 } else if (A.mode == MODE_SIM3) {                       // :463 / :571
                     if ((float)bestDist <= A.thrF) pick = bestIdx;
+                } else if (A.mode == MODE_FUSE) {                       // Fuse :1161 / :1277 (TH_LOW), SearchBySim3 :1399 / :1475 (TH_HIGH)
+                    if (bestDist <= A.thrI) pick = bestIdx;
                 } else {                                                // MODE_RELOC :1757
                     if (bestDist <= A.thrI) pick = bestIdx;
                 }
@@ -857,7 +895,7 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
     fd->minX = F->min_x; fd->minY = F->min_y; fd->maxX = F->max_x; fd->maxY = F->max_y;
     fd->wInv = (float)kGridCols / (float)(F->max_x - F->min_x);     // Frame.cc:322-323
     fd->hInv = (float)kGridRows / (float)(F->max_y - F->min_y);
-    fd->sortedIdx = m->dSorted; fd->cellStart = m->dCellStart;
+    fd->sortedIdx = m->dSorted; fd->cellStart = m->dCellStart; fd->scale = m->dScale;
     hipLaunchKernelGGL(k_grid, dim3(1), dim3(256), 0, nullptr, F->n, m->dKeys, fd->minX, fd->minY, fd->wInv, fd->hInv, m->dSorted,
                        m->dCellStart);
     return RUMI_OK;
@@ -1068,9 +1106,75 @@ extern "C" int rumi_search_by_projection_sim3(RumiMatcher *m, const RumiFrameFea
         H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3);
         H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
         hipLaunchKernelGGL(k_queries_sim3, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
-                           m->dPose, m->dScale, KF->nlevels, log_scale_factor, th, explicit_invz, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+                           m->dPose, m->dScale, KF->nlevels, log_scale_factor, (float)th, explicit_invz, 1, 0, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
     return run_search(m, MODE_SIM3, nmp, fd, m->dQDesc, nullptr, 0.f, 0, matched, nmatches_out, m->dU8b, (float)RUMI_TH_LOW * ratio_hamming, 0);
+}
+
+extern "C" int rumi_fuse_candidates(RumiMatcher *m, const RumiFrameFeatures *KF, float log_scale_factor, const float *Tcw7, const float *Ow3,
+                                    const float *K4, int32_t nmp, const uint8_t *skip, const float *mp_pos, const float *mp_normal,
+                                    const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc, float th,
+                                    int32_t check_reprojection, int32_t *best_idx) {
+    if (!m || !KF || !Tcw7 || !Ow3 || !K4 || nmp < 0 || (nmp > 0 && !best_idx)) return RUMI_E_INVALID;
+    if (nmp > m->maxQ) { g_lastError = "more candidate points than max_queries"; return RUMI_E_CAPACITY; }
+    if (nmp == 0) return RUMI_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, KF, &fd);
+    if (rc != RUMI_OK) return rc;
+    HIP_TRY(hipMemsetAsync(m->dU8b, 0, std::max(KF->n, 1), nullptr));              // nothing is blocked: the points do not compete
+    float pose[14];
+    std::memcpy(pose, Tcw7, 28); std::memcpy(pose + 7, K4, 16); std::memcpy(pose + 11, Ow3, 12);
+    H2D(m->dPose, pose, 14);
+    H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3);
+    H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+    hipLaunchKernelGGL(k_queries_sim3, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
+                       m->dPose, m->dScale, KF->nlevels, log_scale_factor, th, 0, 0, check_reprojection, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    int32_t n = 0;
+    return run_search(m, MODE_FUSE, nmp, fd, m->dQDesc, nullptr, 0.f, 0, nullptr, &n, m->dU8b, 0.f, RUMI_TH_LOW, best_idx);
+}
+
+static int sim3_direction(RumiMatcher *m, const RumiFrameFeatures *KF, float logSf, const float *K4, int n, const uint8_t *skip, const float *pc,
+                          const float *mn, const float *mx, const uint8_t *desc, float th, int32_t *best) {
+    for (int i = 0; i < n; i++) best[i] = -1;
+    if (n == 0) return RUMI_OK;
+    FrameDev fd;
+    int rc = upload_frame(m, KF, &fd);
+    if (rc != RUMI_OK) return rc;
+    HIP_TRY(hipMemsetAsync(m->dU8b, 0, std::max(KF->n, 1), nullptr));
+    H2D(m->dPose, K4, 4);
+    H2D(m->dU8a, skip, n); H2D(m->dF[0], pc, (size_t)n * 3); H2D(m->dF[2], mn, n); H2D(m->dF[3], mx, n); H2D(m->dQDesc, desc, (size_t)n * 32);
+    hipLaunchKernelGGL(k_queries_campoints, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, m->dU8a, m->dF[0], m->dF[2], m->dF[3], m->dPose, m->dScale,
+                       KF->nlevels, logSf, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    int32_t cnt = 0;
+    return run_search(m, MODE_FUSE, n, fd, m->dQDesc, nullptr, 0.f, 0, nullptr, &cnt, m->dU8b, 0.f, RUMI_TH_HIGH, best);
+}
+
+extern "C" int rumi_search_by_sim3(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFrameFeatures *KF2, const float *K4,
+                                   float log_scale_factor, const uint8_t *skip1, const float *pc1_in2, const float *min_dist1,
+                                   const float *max_dist1, const uint8_t *desc1, const uint8_t *skip2, const float *pc2_in1,
+                                   const float *min_dist2, const float *max_dist2, const uint8_t *desc2, float th, int32_t *match12,
+                                   int32_t *nfound_out) {
+    if (!m || !KF1 || !KF2 || !K4 || !nfound_out) return RUMI_E_INVALID;
+    const int n1 = KF1->n, n2 = KF2->n;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!skip1 || !pc1_in2 || !min_dist1 || !max_dist1 || !desc1 || !match12)) ||
+        (n2 > 0 && (!skip2 || !pc2_in1 || !min_dist2 || !max_dist2 || !desc2)))
+        return RUMI_E_INVALID;
+    if (n1 > m->maxQ || n2 > m->maxQ) { g_lastError = "SearchBySim3: key-frame larger than max_queries"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(m->device));
+    std::vector<int32_t> vnMatch1(std::max(n1, 1)), vnMatch2(std::max(n2, 1));
+    int rc = sim3_direction(m, KF2, log_scale_factor, K4, n1, skip1, pc1_in2, min_dist1, max_dist1, desc1, th, vnMatch1.data());
+    if (rc != RUMI_OK) return rc;
+    rc = sim3_direction(m, KF1, log_scale_factor, K4, n2, skip2, pc2_in1, min_dist2, max_dist2, desc2, th, vnMatch2.data());
+    if (rc != RUMI_OK) return rc;
+    int nFound = 0;                                                                 // check agreement, :1480-1493
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    *nfound_out = nFound;
+    return RUMI_OK;
 }
 
 extern "C" int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur, float log_scale_factor, const float *Tcw7,

@@ -211,6 +211,123 @@ public:
         return nmatches;
     }
 
+    // Project MapPoints into KeyFrame and search for duplicated MapPoints (LocalMapping::SearchInNeighbors)  ORBmatcher.cc:1015-1180
+    // Monocular key-frames (bRight = false).  The window search runs on the GPU for all points at once; the map mutations are
+    // then replayed in list order with the reference's own MapPoint / KeyFrame methods, re-evaluating the isBad / IsInKeyFrame
+    // skips at the moment the reference would (a point replaced by an earlier iteration is bad by the time its turn comes).
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th = 3.0, const bool /*bRight*/ = false) {
+        const auto Tcw = pKF->GetPose();
+        const auto q = Tcw.unit_quaternion();
+        const auto t = Tcw.translation();
+        const float T7[7] = {q.x(), q.y(), q.z(), q.w(), t(0), t(1), t(2)};
+        float Ow[3];
+#ifdef RUMI_HAVE_SOPHUS
+        { const Eigen::Vector3f c = pKF->GetCameraCenter(); Ow[0] = c(0); Ow[1] = c(1); Ow[2] = c(2); }
+#else
+        camera_centre(T7, Ow);
+#endif
+        std::vector<int32_t> best;
+        if (!fuse_search(pKF, T7, Ow, vpMapPoints, [&](MapPointT *p) { return p->isBad() || p->IsInKeyFrame(pKF); }, th, 1, best)) return -1;
+        int nFused = 0;
+        for (size_t i = 0; i < vpMapPoints.size(); i++) {
+            MapPointT *pMP = vpMapPoints[i];
+            if (!pMP) continue;
+            if (pMP->isBad()) continue;
+            else if (pMP->IsInKeyFrame(pKF)) continue;
+            if (best[i] < 0) continue;
+            MapPointT *pMPinKF = pKF->GetMapPoint(best[i]);                    // :1162-1174
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, best[i]);
+                pKF->AddMapPoint(pMP, best[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+#ifdef RUMI_HAVE_SOPHUS
+    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]              ORBmatcher.cc:1293-1496
+    // The camera-frame points are formed with the reference's own Sophus expressions (:1338-1340, :1414-1416).
+    template <class KeyFrameT, class MapPointT>
+    int SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches12, const Sophus::Sim3f &S12, const float th) {
+        const Sophus::SE3f T1w = pKF1->GetPose(), T2w = pKF2->GetPose();
+        const Sophus::Sim3f S21 = S12.inverse();
+        const std::vector<MapPointT *> v1 = pKF1->GetMapPointMatches(), v2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)v1.size(), N2 = (int)v2.size();
+        std::vector<bool> already1(N1, false), already2(N2, false);
+        for (int i = 0; i < N1; i++)
+            if (MapPointT *p = vpMatches12[i]) {
+                already1[i] = true;
+                const int idx2 = std::get<0>(p->GetIndexInKeyFrame(pKF2));
+                if (idx2 >= 0 && idx2 < N2) already2[idx2] = true;
+            }
+        struct Side { std::vector<uint8_t> skip, desc; std::vector<float> pc, mn, mx; };
+        auto gather = [](const std::vector<MapPointT *> &v, const std::vector<bool> &already, const Sophus::SE3f &Tw, const Sophus::Sim3f &S) {
+            Side s;
+            const size_t n = v.size();
+            s.skip.assign(n, 1); s.desc.assign(n * 32, 0); s.pc.assign(n * 3, 0.f); s.mn.assign(n, 0.f); s.mx.assign(n, 0.f);
+            for (size_t i = 0; i < n; i++) {
+                MapPointT *p = v[i];
+                if (!p || already[i] || p->isBad()) continue;
+                s.skip[i] = 0;
+                const Eigen::Vector3f p3Dw = p->GetWorldPos();
+                const Eigen::Vector3f pa = Tw * p3Dw;
+                const Eigen::Vector3f pb = S * pa;
+                for (int c = 0; c < 3; c++) s.pc[3 * i + c] = pb(c);
+                s.mn[i] = p->GetMinDistance(); s.mx[i] = p->GetMaxDistance();
+                const cv::Mat d = p->GetDescriptor();
+                std::memcpy(&s.desc[i * 32], d.ptr(0), 32);
+            }
+            return s;
+        };
+        const Side a = gather(v1, already1, T1w, S21), b = gather(v2, already2, T2w, S12);
+        const float K4[4] = {pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy};
+        RumiFrameFeatures k1 = view(*pKF1), k2 = view(*pKF2);
+        k1.n = N1; k2.n = N2;
+        std::vector<int32_t> m12(N1 > 0 ? N1 : 1, -1);
+        int32_t nFound = 0;
+        if (rumi_search_by_sim3(arena(), &k1, &k2, K4, pKF2->mfLogScaleFactor, a.skip.data(), a.pc.data(), a.mn.data(), a.mx.data(), a.desc.data(),
+                                b.skip.data(), b.pc.data(), b.mn.data(), b.mx.data(), b.desc.data(), th, m12.data(), &nFound) != RUMI_OK)
+            return -1;
+        for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = v2[m12[i1]];
+        return nFound;
+    }
+
+    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints               ORBmatcher.cc:1182-1291
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT *pKF, Sophus::Sim3f &Scw, const std::vector<MapPointT *> &vpPoints, float th, std::vector<MapPointT *> &vpReplacePoint) {
+        const Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+        const Eigen::Vector3f Owv = Tcw.inverse().translation();
+        const auto q = Tcw.unit_quaternion();
+        const float T7[7] = {q.x(), q.y(), q.z(), q.w(), Tcw.translation()(0), Tcw.translation()(1), Tcw.translation()(2)};
+        const float Ow[3] = {Owv(0), Owv(1), Owv(2)};
+        const std::set<MapPointT *> spAlreadyFound = pKF->GetMapPoints();
+        std::vector<int32_t> best;
+        if (!fuse_search(pKF, T7, Ow, vpPoints, [&](MapPointT *p) { return p->isBad() || spAlreadyFound.count(p) > 0; }, th, 0, best)) return -1;
+        int nFused = 0;
+        for (size_t iMP = 0; iMP < vpPoints.size(); iMP++) {
+            MapPointT *pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            if (best[iMP] < 0) continue;
+            MapPointT *pMPinKF = pKF->GetMapPoint(best[iMP]);                  // :1278-1286
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, best[iMP]);
+                pKF->AddMapPoint(pMP, best[iMP]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+#endif
+
     // Project MapPoints seen in a key-frame into the frame and search matches (Relocalization)            ORBmatcher.cc:1685-1793
     // Needs two one-line accessors on MapPoint: GetMinDistance() / GetMaxDistance() returning mfMinDistance / mfMaxDistance
     // (the reference only exposes the 0.8x / 1.2x invariance values; PredictScale needs the raw one).  INTEGRATION.md §3.
@@ -309,6 +426,30 @@ protected:
         return nmatches;
     }
 #endif
+    // gather + rumi_fuse_candidates.  A point skipped at gather time (NULL, bad, already in the key-frame) stays skipped in the replay
+    // (bad is permanent; a point of the key-frame only leaves it by being replaced, i.e. by turning bad).
+    template <class KeyFrameT, class MapPointT, class SkipFn>
+    static bool fuse_search(KeyFrameT *pKF, const float *T7, const float *Ow, const std::vector<MapPointT *> &pts, SkipFn skipFn, float th, int reproj,
+                            std::vector<int32_t> &best) {
+        const int nmp = (int)pts.size();
+        best.assign(nmp, -1);
+        std::vector<uint8_t> skip(nmp, 1), desc((size_t)nmp * 32);
+        std::vector<float> pos((size_t)nmp * 3), nrm((size_t)nmp * 3), mn(nmp), mx(nmp);
+        for (int i = 0; i < nmp; i++) {
+            MapPointT *p = pts[i];
+            if (!p || skipFn(p)) continue;
+            skip[i] = 0;
+            const auto P = p->GetWorldPos(), N = p->GetNormal();
+            for (int c = 0; c < 3; c++) { pos[3 * i + c] = P(c); nrm[3 * i + c] = N(c); }
+            mn[i] = p->GetMinDistance(); mx[i] = p->GetMaxDistance();
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+        }
+        const float K4[4] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy};
+        RumiFrameFeatures kv = view(*pKF);
+        return rumi_fuse_candidates(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(), mx.data(),
+                                    desc.data(), th, reproj, best.data()) == RUMI_OK;
+    }
     // Sophus::SE3f::inverse().translation(): conj(q) applied to -t with the same quaternion product form as so3.hpp:358-367
     static void camera_centre(const float *T7, float *Ow) {
         const float qx = -T7[0], qy = -T7[1], qz = -T7[2], qw = T7[3];

@@ -22,7 +22,7 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
 
 
 def _lib():
@@ -46,6 +46,8 @@ def _lib():
                                                   i32, i32, vp, C.POINTER(i32)]
     L.rumi_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp]
     L.rumi_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.rumi_fuse_candidates.argtypes = [vp, vp, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp]
+    L.rumi_search_by_sim3.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
@@ -179,6 +181,33 @@ def SearchForTriangulation(m, KF1, fv1, kf1_mp, KF2, fv2, kf2_mp, F12, epipole2,
                                                     capi.ptr(out), C.byref(nm)))
     idx = np.nonzero(out >= 0)[0]
     return nm.value, np.stack([idx, out[idx]], 1).astype(np.int64)
+
+
+def SearchBySim3(m, KF1, KF2, K4, log_sf, side1, side2, th):
+    """ORBmatcher::SearchBySim3.  side*: dict skip u8, pc [n,3] (point in the OTHER camera), min_dist, max_dist, desc [n,32].
+    Returns (nFound, match12[KF1.n])."""
+    def prep(d):
+        return [_u8(d["skip"]), _f32(d["pc"]), _f32(d["min_dist"]), _f32(d["max_dist"]), _u8(d["desc"])]
+    a, b = prep(side1), prep(side2)
+    K = _f32(K4)
+    out = np.full(KF1.n, -1, np.int32)
+    nf = C.c_int32()
+    capi.check(m._lib.rumi_search_by_sim3(m._h, C.byref(KF1.c), C.byref(KF2.c), capi.ptr(K), float(log_sf), *[capi.ptr(x) for x in a],
+                                          *[capi.ptr(x) for x in b], float(th), capi.ptr(out), C.byref(nf)))
+    return nf.value, out
+
+
+def FuseCandidates(m, KF, log_sf, Tcw7, Ow3, K4, pts, th, check_reprojection=True):
+    """Search half of ORBmatcher::Fuse: best key-frame feature per map point (-1 none).  pts as for SearchByProjection_Sim3."""
+    a = dict(skip=_u8(pts["skip"]), pos=_f32(pts["pos"]), normal=_f32(pts["normal"]), mn=_f32(pts["min_dist"]), mx=_f32(pts["max_dist"]),
+             desc=_u8(pts["desc"]))
+    n = len(a["skip"])
+    out = np.full(n, -1, np.int32)
+    T, O, K = _f32(Tcw7), _f32(Ow3), _f32(K4)
+    capi.check(m._lib.rumi_fuse_candidates(m._h, C.byref(KF.c), float(log_sf), capi.ptr(T), capi.ptr(O), capi.ptr(K), n, capi.ptr(a["skip"]),
+                                           capi.ptr(a["pos"]), capi.ptr(a["normal"]), capi.ptr(a["mn"]), capi.ptr(a["mx"]), capi.ptr(a["desc"]),
+                                           float(th), int(check_reprojection), capi.ptr(out)))
+    return out
 
 
 def SearchByProjection_Sim3(m, KF, log_sf, Tcw7, Ow3, K4, pts, matched, th, ratio_hamming, explicit_invz=False):

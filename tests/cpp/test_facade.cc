@@ -47,6 +47,11 @@ struct MapPoint {
     float GetMinDistance() { return minD; }
     float GetMaxDistance() { return maxD; }
     void UpdateNormalAndDepth() {}
+    V3f normal{{0, 0, 1}};
+    V3f GetNormal() { return normal; }
+    bool IsInKeyFrame(KeyFrame *k) { return obs.count(k) > 0; }
+    void AddObservation(KeyFrame *k, int idx) { if (!obs.count(k)) nObs++; obs[k] = std::make_tuple(idx, -1); }
+    void Replace(MapPoint *other);                     // defined after KeyFrame
     bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
 };
 std::mutex MapPoint::mGlobalMutex;
@@ -69,6 +74,8 @@ struct KeyFrame : Frame {
     bool isBad() { return bad; }
     Map *GetMap() { return map; }
     void EraseMapPointMatch(MapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
+    MapPoint *GetMapPoint(size_t idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint *p, size_t idx) { mvpMapPoints[idx] = p; }
     // stands in for the Sophus/Eigen expressions of the real tree: a fixed rank-2 F12 (pure x-translation) and a far epipole
     void EpipolarGeometryTo(const KeyFrame *, float *F, float *e) const {
         const float f[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
@@ -76,6 +83,18 @@ struct KeyFrame : Frame {
         e[0] = 5000.f; e[1] = 240.f;
     }
 };
+
+// the part of MapPoint::Replace the Fuse loop can observe: the replaced point turns bad and hands over its key-frame slots
+void MapPoint::Replace(MapPoint *other) {
+    if (other == this) return;
+    bad = true;
+    for (auto &o : obs) {
+        KeyFrame *k = o.first;
+        if (!other->IsInKeyFrame(k)) { k->mvpMapPoints[std::get<0>(o.second)] = other; other->AddObservation(k, std::get<0>(o.second)); }
+        else k->mvpMapPoints[std::get<0>(o.second)] = nullptr;
+    }
+    obs.clear(); nObs = 0;
+}
 
 static int fails = 0;
 #define CHECK(c, msg) do { if (!(c)) { std::printf("FAIL: %s (%s:%d)\n", msg, __FILE__, __LINE__); fails++; } } while (0)
@@ -169,6 +188,26 @@ int main(int argc, char **argv) {
         for (auto &p : kb.mvpMapPoints) p = nullptr;
         const int nt = matcher.SearchForTriangulation(&ka, &kb, pairs, false, true);
         CHECK(nt >= 0 && (int)pairs.size() == nt, "SearchForTriangulation pairs == count");
+        // Fuse(KF, points, th): empty slots get an observation, occupied slots trigger Replace; replay keeps the map consistent
+        {
+            KeyFrame kf; static_cast<Frame &>(kf) = fr[1];
+            std::memcpy(kf.pose.T, T7, 28);
+            kf.mvpMapPoints.assign(kf.N, nullptr);
+            std::vector<MapPoint> resident(kf.N);
+            for (int i = 0; i < kf.N; i += 2) { resident[i].pos = V3f{{0, 0, 5}}; resident[i].nObs = 1 + i % 5; resident[i].obs[&kf] = std::make_tuple(i, -1); kf.mvpMapPoints[i] = &resident[i]; }
+            std::vector<MapPoint> cand(mps.size());
+            std::vector<MapPoint *> vp;
+            for (size_t i = 0; i < mps.size(); i++) { cand[i].pos = mps[i].pos; cand[i].desc = mps[i].desc; cand[i].nObs = 3; cand[i].obs.clear(); vp.push_back(i % 17 == 0 ? nullptr : &cand[i]); }
+            const int nf = matcher.Fuse(&kf, vp, 15.f);
+            int added = 0, replacedCand = 0, replacedResident = 0;
+            for (auto &c : cand) { if (c.bad) replacedCand++; else if (c.IsInKeyFrame(&kf)) added++; }
+            for (auto &r : resident) if (r.bad) replacedResident++;
+            bool consistent = true;
+            for (int i = 0; i < kf.N; i++) if (kf.mvpMapPoints[i] && kf.mvpMapPoints[i]->bad) consistent = false;
+            CHECK(nf > 20 && replacedCand + replacedResident > 0 && added > 0, "Fuse adds observations and replaces duplicates");
+            CHECK(consistent, "Fuse leaves no bad point in the key-frame");
+            CHECK(nf >= replacedCand + replacedResident, "Fuse count covers every replacement");
+        }
         std::vector<cv::Point2f> prev(fr[0].mvKeysUn.size());
         for (size_t i = 0; i < prev.size(); i++) prev[i] = fr[0].mvKeysUn[i].pt;
         std::vector<int> ini;

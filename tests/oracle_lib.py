@@ -143,6 +143,9 @@ def _mlib():
     L.orc_search_for_initialization.restype = i32
     L.orc_search_for_triangulation.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp]
     L.orc_search_for_triangulation.restype = i32
+    L.orc_fuse_candidates.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp]
+    L.orc_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp]
+    L.orc_search_by_sim3.restype = i32
     L.orc_is_in_frustum.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_search_by_bow_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
     L.orc_search_by_projection_sim3.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp]
@@ -306,3 +309,27 @@ def search_for_triangulation(k1, d1, mp1, fv1, k2, d2, mp2, fv2, sf2, F12, ep, o
                                              int(coarse), int(check_ori), _p(out))
     idx = np.nonzero(out >= 0)[0]
     return n, np.stack([idx, out[idx]], 1).astype(np.int64)
+
+
+def fuse_candidates(keys, desc, w, h, sf, log_sf, Tcw7, Ow3, K4, pts, th, check_reproj):
+    keys = np.ascontiguousarray(keys, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); sf = np.ascontiguousarray(sf, np.float32)
+    a = [np.ascontiguousarray(pts["skip"], np.uint8), np.ascontiguousarray(pts["pos"], np.float32), np.ascontiguousarray(pts["normal"], np.float32),
+         np.ascontiguousarray(pts["min_dist"], np.float32), np.ascontiguousarray(pts["max_dist"], np.float32), np.ascontiguousarray(pts["desc"], np.uint8)]
+    T = np.ascontiguousarray(Tcw7, np.float32); Ow = np.ascontiguousarray(Ow3, np.float32); K = np.ascontiguousarray(K4, np.float32)
+    out = np.full(len(a[0]), -1, np.int32)
+    _mlib().orc_fuse_candidates(_p(keys), _p(desc), len(keys), 0.0, 0.0, float(w), float(h), _p(sf), len(sf), float(log_sf), _p(T), _p(Ow), _p(K),
+                                len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), float(th), int(check_reproj), _p(out))
+    return out
+
+
+def search_by_sim3(k1, d1, k2, d2, w, h, sf, log_sf, K4, side1, side2, th):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8); k2 = np.ascontiguousarray(k2, KP_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8)
+    sf = np.ascontiguousarray(sf, np.float32); K = np.ascontiguousarray(K4, np.float32)
+    def prep(d):
+        return [np.ascontiguousarray(d["skip"], np.uint8), np.ascontiguousarray(d["pc"], np.float32), np.ascontiguousarray(d["min_dist"], np.float32),
+                np.ascontiguousarray(d["max_dist"], np.float32), np.ascontiguousarray(d["desc"], np.uint8)]
+    a, b = prep(side1), prep(side2)
+    out = np.full(len(k1), -1, np.int32)
+    n = _mlib().orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), 0.0, 0.0, float(w), float(h), _p(sf), len(sf), float(log_sf), _p(K),
+                                   *[_p(x) for x in a], *[_p(x) for x in b], float(th), _p(out))
+    return n, out

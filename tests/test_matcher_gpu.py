@@ -255,3 +255,56 @@ def test_search_for_triangulation(matcher, seed, coarse, ori):
         assert n_f < n_c
     n0, p0 = SearchForTriangulation(m, KF1, a, mp1, KF2, b, mp2, F12, ep, True, coarse)      # bOnlyStereo on mono key-frames
     assert n0 == 0 and len(p0) == 0
+
+
+@pytest.mark.parametrize("seed,th,reproj", [(0, 3.0, True), (1, 3.0, False), (2, 4.0, False), (3, 2.5, True)])
+def test_fuse_candidates(matcher, seed, th, reproj):
+    """Search half of both Fuse overloads (LocalMapping::SearchInNeighbors th=3; loop/merge fusion th=3..4)."""
+    from rumi_slam_amd.matcher import FrameView, FuseCandidates
+    s = TrackingScene(seed)
+    g = s.point_geometry()
+    KF = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    rng = np.random.default_rng(seed)
+    n = len(s.mp_pos)
+    pts = dict(skip=(rng.random(n) < 0.1).astype(np.uint8), pos=s.mp_pos, normal=g["normal"], min_dist=g["min_dist"], max_dist=g["max_dist"],
+               desc=s.mp_desc)
+    log_sf = float(np.log(np.float32(1.2)))
+    ref = O.fuse_candidates(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, log_sf, s.Tcw7, g["Ow"], K_TUM3, pts, th, reproj)
+    got = FuseCandidates(matcher(), KF, log_sf, s.Tcw7, g["Ow"], K_TUM3, pts, th, reproj)
+    assert np.count_nonzero(ref >= 0) > 50
+    assert np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
+    if reproj:          # the chi2 gate must bite, or the flag is untested
+        loose = O.fuse_candidates(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, log_sf, s.Tcw7, g["Ow"], K_TUM3, pts, th, False)
+        assert np.count_nonzero(loose != ref) > 0
+
+
+@pytest.mark.parametrize("seed,th", [(0, 7.5), (1, 7.5), (2, 3.0)])
+def test_search_by_sim3(matcher, seed, th):
+    """Loop/merge Sim3 refinement matcher: two window searches from camera-frame points + mutual agreement."""
+    from rumi_slam_amd.matcher import FrameView, SearchBySim3
+    s = TrackingScene(seed)
+    KF1 = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    KF2 = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    rng = np.random.default_rng(100 + seed)
+    fx, fy, cx, cy = [float(v) for v in K_TUM3]
+    sf = s.sf.astype(np.float64)
+
+    def side(keys, desc, u, v, z):
+        pc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+        dist = np.linalg.norm(pc, axis=1)
+        mx = dist * sf[keys["octave"]]
+        return dict(skip=(rng.random(len(keys)) < 0.15).astype(np.uint8), pc=pc.astype(np.float32), min_dist=(mx / sf[-1]).astype(np.float32),
+                    max_dist=mx.astype(np.float32), desc=desc)
+
+    wx, wy, z = s.proj                                   # where the last-frame points fall in the current image
+    side1 = side(s.last_keys, s.last_desc, wx, wy, z)
+    H = np.eye(3); H[:s.A.shape[0], :] = s.A
+    Hi = np.linalg.inv(H)
+    x2 = np.stack([s.cur_keys["x"], s.cur_keys["y"], np.ones(len(s.cur_keys))], 0).astype(np.float64)
+    x1 = Hi @ x2
+    side2 = side(s.cur_keys, s.cur_desc, x1[0] / x1[2], x1[1] / x1[2], rng.uniform(1, 8, len(s.cur_keys)))
+    log_sf = float(np.log(np.float32(1.2)))
+    n_ref, ref = O.search_by_sim3(s.last_keys, s.last_desc, s.cur_keys, s.cur_desc, s.w, s.h, s.sf, log_sf, K_TUM3, side1, side2, th)
+    n_gpu, got = SearchBySim3(matcher(), KF1, KF2, K_TUM3, log_sf, side1, side2, th)
+    assert n_ref > 50 and n_ref == np.count_nonzero(ref >= 0)
+    assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
