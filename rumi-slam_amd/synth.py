@@ -85,3 +85,21 @@ def warp_frame(img, seed, max_rot_deg=3.0, max_shift=8, max_scale=0.02):
     bot = im[iy1, ix0] * (65536 - fx) + im[iy1, ix1] * fx
     out = (top * (65536 - fy) + bot * fy + (1 << 31)) >> 32
     return np.clip(out, 0, 255).astype(np.uint8), A
+
+
+def warp_homography(img, H):
+    """Image of a plane under a camera motion: out(x') = img(H^-1 x'), bilinear in float64, edge-clamped.  H maps source
+    pixels to destination pixels (3x3).  Used by the closed-loop tracking substitute for BASELINE config 1."""
+    h, w = img.shape
+    Hi = np.linalg.inv(np.asarray(H, np.float64))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+    sx = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den
+    sy = (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
+    ix, iy = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = sx - ix, sy - iy
+    ix0, ix1 = np.clip(ix, 0, w - 1), np.clip(ix + 1, 0, w - 1)
+    iy0, iy1 = np.clip(iy, 0, h - 1), np.clip(iy + 1, 0, h - 1)
+    im = img.astype(np.float64)
+    out = (im[iy0, ix0] * (1 - fx) + im[iy0, ix1] * fx) * (1 - fy) + (im[iy1, ix0] * (1 - fx) + im[iy1, ix1] * fx) * fy
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
