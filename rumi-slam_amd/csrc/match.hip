@@ -58,42 +58,68 @@ __device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t *d
 }
 
 // ---- 1. grid -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_grid(int n, const RumiKeyPoint *__restrict__ keys, float minX, float minY, float wInv,
-                                              float hInv, uint16_t *__restrict__ sortedIdx, int32_t *__restrict__ cellStart) {
-    __shared__ uint32_t s[kMaxSortN];
+// Frame::AssignFeaturesToGrid as a counting sort by cell (cell = column-major ix*48+iy, the order GetFeaturesInArea walks),
+// ascending key-point index inside a cell (= push_back order).  One workgroup; the per-cell segments (a handful of entries) are
+// put in index order by an insertion sort after an unordered atomic placement.
+__global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__restrict__ keys, float minX, float minY, float wInv,
+                                               float hInv, uint16_t *__restrict__ sortedIdx, int32_t *__restrict__ cellStart) {
+    __shared__ int32_t sCnt[kGridCells + 1];
+    __shared__ uint16_t sCell[kMaxSortN], sOut[kMaxSortN];
+    __shared__ int32_t sPart[1024];
     const int tid = threadIdx.x;
-    int m = 1;
-    while (m < n) m <<= 1;
-    for (int i = tid; i < m; i += 256) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < n) {
-            // Frame::PosInGrid: round() of the float expression, dropped when outside the grid
-            const int px = (int)__builtin_roundf((keys[i].x - minX) * wInv);
-            const int py = (int)__builtin_roundf((keys[i].y - minY) * hInv);
-            if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) key = ((uint32_t)(px * kGridRows + py) << 16) | (uint32_t)i;
-        }
-        s[i] = key;
+    for (int c = tid; c <= kGridCells; c += 1024) sCnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        // Frame::PosInGrid: round() of the float expression, dropped when outside the grid
+        const int px = (int)__builtin_roundf((keys[i].x - minX) * wInv);
+        const int py = (int)__builtin_roundf((keys[i].y - minY) * hInv);
+        uint16_t cell = 0xFFFF;
+        if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) { cell = (uint16_t)(px * kGridRows + py); atomicAdd(&sCnt[cell], 1); }
+        sCell[i] = cell;
     }
     __syncthreads();
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = s[i], b = s[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    // sorted ascending: valid keys first.  cellStart[c] = first position whose cell >= c.
-    for (int i = tid; i < n; i += 256) sortedIdx[i] = (uint16_t)(s[i] & 0xFFFF);
-    for (int i = tid; i <= n; i += 256) {
-        const int cPrev = i == 0 ? -1 : (s[i - 1] == 0xFFFFFFFFu ? kGridCells : (int)(s[i - 1] >> 16));
-        const int cHere = (i == n || s[i] == 0xFFFFFFFFu) ? kGridCells : (int)(s[i] >> 16);
-        for (int c = cPrev + 1; c <= cHere; c++) cellStart[c] = i;
+    // exclusive scan of the 3072 counts: 3 cells per thread + block scan of the partial sums
+    constexpr int kPer = (kGridCells + 1023) / 1024;
+    int loc[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) { const int c = tid * kPer + k; loc[k] = c < kGridCells ? sCnt[c] : 0; sum += loc[k]; }
+    sPart[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? sPart[tid - o] : 0;
+        __syncthreads();
+        sPart[tid] += v;
+        __syncthreads();
     }
+    int run = sPart[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int c = tid * kPer + k;
+        if (c < kGridCells) { cellStart[c] = run; sCnt[c] = run; run += loc[k]; }
+    }
+    if (tid == 1023) cellStart[kGridCells] = sPart[1023];
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const uint16_t cell = sCell[i];
+        if (cell != 0xFFFF) sOut[atomicAdd(&sCnt[cell], 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    // sCnt[c] is now the END of cell c; its start is the end of cell c-1 (or 0)
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int c = tid * kPer + k;
+        if (c >= kGridCells) continue;
+        const int e = sCnt[c], b0 = e - loc[k];
+        for (int i = b0 + 1; i < e; i++) {
+            const uint16_t v = sOut[i];
+            int j = i - 1;
+            while (j >= b0 && sOut[j] > v) { sOut[j + 1] = sOut[j]; j--; }
+            sOut[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    const int valid = sPart[1023];
+    for (int i = tid; i < valid; i += 1024) sortedIdx[i] = sOut[i];
 }
 
 // ---- 2. queries ----------------------------------------------------------------------------------------------
@@ -329,21 +355,56 @@ __global__ void k_is_in_frustum(int nmp, const float *pose /*Rcw9 tcw3 Ow3 K4*/,
     inView[i] = in; projX[i] = px; projY[i] = py; scaleLevel[i] = lvl; viewCosOut[i] = vc; trackDepth[i] = depth;
 }
 
+// ---- uploads: one pinned block per call, scattered to the arrays on the device ---------------------------------------------
+struct Segment { void *dst; uint32_t off, bytes; };
+constexpr int kMaxSegments = 32;
+__global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ mirror, int nseg) {
+    const Segment sg = reinterpret_cast<const Segment *>(mirror)[blockIdx.y];
+    if ((int)blockIdx.y >= nseg) return;
+    const uint32_t words = sg.bytes >> 2;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(mirror + sg.off);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(sg.dst);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < (sg.bytes & 3)) {
+        const uint32_t k = (words << 2) + threadIdx.x;
+        reinterpret_cast<uint8_t *>(sg.dst)[k] = mirror[sg.off + k];
+    }
+}
+
 // ---- 3. candidates: one wave per query -----------------------------------------------------------------------------
 // list entry: feature (16 bit) | distance (9 bit) << 16 | octave (4 bit) << 25
+// Lists of up to kSortMax entries are stored SORTED by (distance, position in the reference's candidate order): the
+// reference's "best / second best among the candidates not yet taken" is then simply the first / second not-taken entry
+// (strict `<` keeps the earliest of equal distances, and a displaced best becomes the second), so a resolve round reads a
+// couple of entries per query instead of the whole list.  Longer lists stay in candidate order and are scanned in full.
+constexpr int kSortMax = 1024;
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Query *__restrict__ q, FrameDev F,
                                                     const uint8_t *__restrict__ qDesc, const uint32_t *__restrict__ fvIdx,
                                                     int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
-                                                    uint32_t *__restrict__ lists) {
+                                                    uint32_t *__restrict__ lists, int listCap, int32_t *__restrict__ overflow) {
+    __shared__ uint32_t sKey[FILL ? 4 * kSortMax : 1], sVal[FILL ? 4 * kSortMax : 1];
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
+    if (FILL && offsets[nq] > listCap) {                 // the arena cannot hold this call's lists: report the need, write nothing
+        if (qi == 0 && lane == 0) *overflow = offsets[nq];
+        return;
+    }
     const Query Q = q[qi];
     if (!Q.valid) {
         if (!FILL && lane == 0) counts[qi] = 0;
         return;
     }
+    const int total = FILL ? counts[qi] : 0;
+    const bool sorted = FILL && total <= kSortMax;
+    uint32_t *key = sKey + (threadIdx.x >> 6) * kSortMax, *val = sVal + (threadIdx.x >> 6) * kSortMax;
     uint32_t qd[8];
     if (FILL) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(qDesc + (size_t)Q.descId * 32);
@@ -359,7 +420,9 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
             if (FILL && ok) {
                 const int idx = (int)fvIdx[p];
                 const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
-                out[p - Q.c0] = (uint32_t)idx | ((uint32_t)d << 16);
+                const uint32_t e = (uint32_t)idx | ((uint32_t)d << 16);
+                if (sorted) { key[p - Q.c0] = ((uint32_t)d << 10) | (uint32_t)(p - Q.c0); val[p - Q.c0] = e; }
+                else out[p - Q.c0] = e;
             }
         }
         count = Q.c1 - Q.c0;
@@ -398,7 +461,10 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
                     const unsigned long long b = __ballot(pass);
                     if (FILL && pass) {
                         const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
-                        out[count + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
+                        const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+                        const uint32_t e = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
+                        if (sorted) { key[pos] = ((uint32_t)d << 10) | (uint32_t)pos; val[pos] = e; }
+                        else out[pos] = e;
                     }
                     count += __popcll(b);
                 }
@@ -406,6 +472,25 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
         }
     }
     if (!FILL && lane == 0) counts[qi] = count;
+    if (sorted && total > 0) {
+        int m = 1;
+        while (m < total) m <<= 1;
+        for (int i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
+        wave_lds_fence();
+        for (int k = 2; k <= m; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (m >> 1); t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const uint32_t a = key[i], b = key[l];
+                    if ((a > b) == ((i & k) == 0)) {
+                        key[i] = b; key[l] = a;
+                        const uint32_t va = val[i]; val[i] = val[l]; val[l] = va;
+                    }
+                }
+                wave_lds_fence();
+            }
+        for (int i = lane; i < total; i += 64) out[i] = val[i];
+    }
 }
 
 // exclusive scan of counts -> offsets (single workgroup; nq is a few thousand)
@@ -438,6 +523,7 @@ struct ResolveArgs {
     const uint8_t *featBlocked0;   // optional [nfeat]: feature unavailable from the start (overrides the featMp/mpObs rule)
     float thrF;                    // MODE_SIM3: TH_LOW * ratioHamming
     int thrI;                      // MODE_RELOC: ORBdist
+    const int32_t *overflow;       // set by the fill pass when the list arena is too small: nothing to resolve
 };
 
 __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatcher.cc:1592-1599
@@ -454,6 +540,7 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
     __shared__ int sChanged, sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH], sCount;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int kFree = 0x7FFFFFFF;
+    if (A.nq > 0 && *A.overflow != 0) return;
     for (int i = tid; i < A.nq; i += nt) A.assign[i] = -1;
     if (tid < RUMI_HISTO_LENGTH) sHist[tid] = 0;
     if (tid == 0) sCount = 0;
@@ -482,13 +569,15 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
             if (cnt > 0) {
                 const uint32_t *L = A.lists + A.offsets[i];
                 int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
+                const bool sortedList = cnt <= kSortMax;                // then entries come in (distance, candidate order)
                 for (int k = 0; k < cnt; k++) {
                     const uint32_t e = L[k];
                     const int f = (int)(e & 0xFFFF);
                     if (blockedFrom[f] < i) continue;                  // taken by an earlier query (or before the call)
                     const int d = (int)((e >> 16) & 0x1FF), lv = (int)((e >> 25) & 15);
                     if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = f; }
-                    else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; }
+                    else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; if (sortedList) break; }
+                    else if (sortedList) break;                         // equal to the second best: nothing later can change either
                 }
                 if (A.mode == MODE_MAPPOINTS) {                         // ORBmatcher.cc:106-111
                     if (bestDist <= RUMI_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) pick = bestIdx;
@@ -583,6 +672,7 @@ struct InitArgs {
     int32_t *nmatches;
     float nnratio;
     int checkOri;
+    const int32_t *overflow;
 };
 
 __global__ __launch_bounds__(64) void k_resolve_init(InitArgs A) {
@@ -591,6 +681,7 @@ __global__ __launch_bounds__(64) void k_resolve_init(InitArgs A) {
     int32_t *matchedDist = sInit, *matches21 = sInit + A.n2;
     const int lane = threadIdx.x;
     const int kInf = 0x7FFFFFFF;
+    if (*A.overflow != 0) return;
     for (int f = lane; f < A.n2; f += 64) { matchedDist[f] = kInf; matches21[f] = -1; }
     for (int i = lane; i < A.n1; i += 64) A.matches12[i] = -1;
     if (lane < RUMI_HISTO_LENGTH) sHist[lane] = 0;
@@ -810,18 +901,27 @@ struct RumiMatcher {
     size_t listCap = 0;
     // frame (train) side
     RumiKeyPoint *dKeys = nullptr; uint8_t *dDesc = nullptr; float *dScale = nullptr;
-    uint16_t *dSorted = nullptr; int32_t *dCellStart = nullptr; int32_t *dFeatMp = nullptr;
+    uint16_t *dSorted = nullptr; int32_t *dCellStart = nullptr;
     uint32_t *dFvIdx = nullptr;      // frame FeatureVector indices (BoW)
     // query side
-    Query *dQ = nullptr; uint8_t *dQDesc = nullptr; int32_t *dCounts = nullptr, *dOffsets = nullptr, *dAssign = nullptr;
+    Query *dQ = nullptr; uint8_t *dQDesc = nullptr; int32_t *dCounts = nullptr, *dOffsets = nullptr;
     uint32_t *dLists = nullptr;
-    int32_t *dNmatches = nullptr;
+    // results, one block so that one copy brings them back: [nmatches, list overflow, -, -][featMp maxFeat][assign maxQ]
+    int32_t *dOut = nullptr, *hOut = nullptr;
+    int32_t *dNmatches = nullptr, *dOverflow = nullptr, *dFeatMp = nullptr, *dAssign = nullptr;     // views into dOut
     // raw inputs of the query builders
     uint8_t *dU8a = nullptr, *dU8b = nullptr; float *dF[6] = {nullptr}; int32_t *dI[4] = {nullptr};
     RumiKeyPoint *dQKeys = nullptr; uint32_t *dNodesA = nullptr, *dNodesB = nullptr, *dIdxA = nullptr;
     int32_t *dOffA = nullptr, *dOffB = nullptr;
     float *dPose = nullptr;
+    // uploads of one call: packed into a pinned block, copied once, scattered on the device (k_scatter)
+    uint8_t *hStage = nullptr, *dStage = nullptr;
+    size_t stageCap = 0, stageUsed = 0;
+    int nseg = 0;
+    // k_grid of the uploaded frame, launched by flush_uploads once the key-points are in place
+    bool gridPending = false; int gridN = 0; float gridMinX = 0, gridMinY = 0, gridWInv = 0, gridHInv = 0;
 };
+constexpr size_t kStageHeader = kMaxSegments * sizeof(Segment);
 
 extern "C" int rumi_descriptor_distance(const uint8_t *a, const uint8_t *b) {
     uint64_t x[4], y[4];
@@ -833,11 +933,13 @@ extern "C" int rumi_descriptor_distance(const uint8_t *a, const uint8_t *b) {
 extern "C" void rumi_match_destroy(RumiMatcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void *p[] = {m->dKeys, m->dDesc, m->dScale, m->dSorted, m->dCellStart, m->dFeatMp, m->dFvIdx, m->dQ, m->dQDesc, m->dCounts,
-                 m->dOffsets, m->dAssign, m->dLists, m->dNmatches, m->dU8a, m->dU8b, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
+    void *p[] = {m->dKeys, m->dDesc, m->dScale, m->dSorted, m->dCellStart, m->dFvIdx, m->dQ, m->dQDesc, m->dCounts,
+                 m->dOffsets, m->dLists, m->dOut, m->dU8a, m->dU8b, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
                  m->dF[4], m->dF[5], m->dI[0], m->dI[1], m->dI[2], m->dI[3], m->dQKeys, m->dNodesA, m->dNodesB, m->dIdxA,
-                 m->dOffA, m->dOffB, m->dPose};
+                 m->dOffA, m->dOffB, m->dPose, m->dStage};
     for (void *q : p) if (q) (void)hipFree(q);
+    if (m->hStage) (void)hipHostFree(m->hStage);
+    if (m->hOut) (void)hipHostFree(m->hOut);
     delete m;
 }
 
@@ -868,23 +970,68 @@ extern "C" int rumi_match_create(int32_t max_features, int32_t max_queries, int3
     int rc;
 #define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_match_destroy(m); return rc; }
     TRYA(dalloc(&m->dKeys, F)); TRYA(dalloc(&m->dDesc, F * 32)); TRYA(dalloc(&m->dScale, 64));
-    TRYA(dalloc(&m->dSorted, F)); TRYA(dalloc(&m->dCellStart, kGridCells + 2)); TRYA(dalloc(&m->dFeatMp, F));
+    TRYA(dalloc(&m->dSorted, F)); TRYA(dalloc(&m->dCellStart, kGridCells + 2));
     TRYA(dalloc(&m->dFvIdx, F));
     TRYA(dalloc(&m->dQ, Q)); TRYA(dalloc(&m->dQDesc, Q * 32)); TRYA(dalloc(&m->dCounts, Q + 1)); TRYA(dalloc(&m->dOffsets, Q + 1));
-    TRYA(dalloc(&m->dAssign, Q)); TRYA(dalloc(&m->dLists, m->listCap)); TRYA(dalloc(&m->dNmatches, 1));
-    TRYA(dalloc(&m->dU8a, Q)); TRYA(dalloc(&m->dU8b, Q));
+    TRYA(dalloc(&m->dLists, m->listCap));
+    TRYA(dalloc(&m->dOut, 4 + F + Q));
+    m->dNmatches = m->dOut; m->dOverflow = m->dOut + 1; m->dFeatMp = m->dOut + 4; m->dAssign = m->dOut + 4 + F;
+    TRYA(dalloc(&m->dU8a, Q)); TRYA(dalloc(&m->dU8b, std::max(Q, F)));
     for (auto &f : m->dF) TRYA(dalloc(&f, Q * 3));
     for (auto &i : m->dI) TRYA(dalloc(&i, Q + 1));
     TRYA(dalloc(&m->dQKeys, Q)); TRYA(dalloc(&m->dNodesA, Q)); TRYA(dalloc(&m->dNodesB, F)); TRYA(dalloc(&m->dIdxA, Q));
     TRYA(dalloc(&m->dOffA, Q + 1)); TRYA(dalloc(&m->dOffB, F + 1)); TRYA(dalloc(&m->dPose, 32));
+    m->stageCap = kStageHeader + F * 112 + Q * 224 + 65536;
+    TRYA(dalloc(&m->dStage, m->stageCap));
+    if (hipHostMalloc((void **)&m->hStage, m->stageCap, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&m->hOut, (4 + F + Q) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        g_lastError = "rumi_match_create: pinned host allocation failed";
+        rumi_match_destroy(m);
+        return RUMI_E_NO_DEVICE;
+    }
+    m->stageUsed = kStageHeader;
 #undef TRYA
     *out = m;
     return RUMI_OK;
 }
 
-#define H2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(n) * sizeof(*(dst)), hipMemcpyHostToDevice, nullptr))
+// Queue `bytes` of host data for the array `dst`; nothing moves until flush_uploads.
+static int stage_add(RumiMatcher *m, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return RUMI_OK;
+    const size_t off = (m->stageUsed + 15) & ~(size_t)15;
+    if (m->nseg >= kMaxSegments || off + bytes > m->stageCap) {
+        g_lastError = "matcher upload block exhausted (raise max_features / max_queries)";
+        return RUMI_E_CAPACITY;
+    }
+    std::memcpy(m->hStage + off, src, bytes);
+    reinterpret_cast<Segment *>(m->hStage)[m->nseg++] = Segment{dst, (uint32_t)off, (uint32_t)bytes};
+    m->stageUsed = off + bytes;
+    return RUMI_OK;
+}
+#define H2D(dst, src, n) do { const int rcS_ = stage_add(m, (dst), (src), (size_t)(n) * sizeof(*(dst))); if (rcS_ != RUMI_OK) return rcS_; } while (0)
+
+// One host-to-device copy for everything queued, the scatter, then the grid of the uploaded frame.
+static int flush_uploads(RumiMatcher *m) {
+    if (m->nseg > 0) {
+        HIP_TRY(hipMemcpyAsync(m->dStage, m->hStage, m->stageUsed, hipMemcpyHostToDevice, nullptr));
+        hipLaunchKernelGGL(k_scatter, dim3(8, m->nseg), dim3(256), 0, nullptr, m->dStage, m->nseg);
+        m->nseg = 0;
+        m->stageUsed = kStageHeader;
+    }
+    if (m->gridPending) {
+        hipLaunchKernelGGL(k_grid, dim3(1), dim3(1024), 0, nullptr, m->gridN, m->dKeys, m->gridMinX, m->gridMinY, m->gridWInv, m->gridHInv,
+                           m->dSorted, m->dCellStart);
+        m->gridPending = false;
+    }
+    return RUMI_OK;
+}
+#define FLUSH(m) do { const int rcF_ = flush_uploads(m); if (rcF_ != RUMI_OK) return rcF_; } while (0)
+
+// A call that fails between stage_add and flush must not leak its queue into the next one.
+static void reset_uploads(RumiMatcher *m) { m->nseg = 0; m->stageUsed = kStageHeader; m->gridPending = false; }
 
 static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd) {
+    reset_uploads(m);
     if (!F || F->n < 0 || F->n > m->maxFeat || F->nlevels < 1 || F->nlevels > 64 || !(F->max_x > F->min_x) || !(F->max_y > F->min_y)) {
         g_lastError = "bad RumiFrameFeatures (n, nlevels or bounds)";
         return RUMI_E_INVALID;
@@ -896,45 +1043,61 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
     fd->wInv = (float)kGridCols / (float)(F->max_x - F->min_x);     // Frame.cc:322-323
     fd->hInv = (float)kGridRows / (float)(F->max_y - F->min_y);
     fd->sortedIdx = m->dSorted; fd->cellStart = m->dCellStart; fd->scale = m->dScale;
-    hipLaunchKernelGGL(k_grid, dim3(1), dim3(256), 0, nullptr, F->n, m->dKeys, fd->minX, fd->minY, fd->wInv, fd->hInv, m->dSorted,
-                       m->dCellStart);
+    m->gridPending = true; m->gridN = F->n; m->gridMinX = fd->minX; m->gridMinY = fd->minY; m->gridWInv = fd->wInv; m->gridHInv = fd->hInv;
     return RUMI_OK;
 }
 
-// count pass, scan, (grow the list arena if needed), fill pass
+// count pass, scan, fill pass.  The fill pass refuses to write past the list arena and raises the overflow word instead; the
+// caller sees it in the result block, grows the arena and repeats the call (run_search) — no mid-pipeline read-back.
 static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc) {
+    FLUSH(m);
+    HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));
     if (nq > 0) {
         hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
-                           m->dCounts, m->dOffsets, m->dLists);
+                           m->dCounts, m->dOffsets, m->dLists, 0, m->dOverflow);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, nullptr, nq, m->dCounts, m->dOffsets);
-        int32_t total = 0;
-        HIP_TRY(hipMemcpy(&total, m->dOffsets + nq, sizeof total, hipMemcpyDeviceToHost));
-        if ((size_t)total > m->listCap) {
-            (void)hipFree(m->dLists);
-            m->dLists = nullptr;
-            m->listCap = (size_t)total * 2;
-            int rc = dalloc(&m->dLists, m->listCap);
-            if (rc != RUMI_OK) return rc;
-        }
         hipLaunchKernelGGL(k_candidates<true>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
-                           m->dCounts, m->dOffsets, m->dLists);
+                           m->dCounts, m->dOffsets, m->dLists, (int)std::min<size_t>(m->listCap, 0x7FFFFFFF), m->dOverflow);
     }
     return RUMI_OK;
+}
+
+// bring back [header | featMp | assign] with one copy; returns RUMI_E_CAPACITY-like signal through *overflowTotal
+static int fetch_results(RumiMatcher *m, int nfeat, int nq, bool wantAssign) {
+    const size_t ints = wantAssign ? (size_t)4 + m->maxFeat + std::max(nq, 0) : (size_t)4 + std::max(nfeat, 0);
+    HIP_TRY(hipMemcpy(m->hOut, m->dOut, ints * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RUMI_OK;
+}
+
+static int grow_lists(RumiMatcher *m, size_t need) {
+    (void)hipFree(m->dLists);
+    m->dLists = nullptr;
+    m->listCap = need * 2;
+    return dalloc(&m->dLists, m->listCap);
 }
 
 // candidate lists, then the fix-point resolve
 static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
                       float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
                       float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
-    const int rcl = build_lists(m, mode, nq, fd, dQueryDesc);
-    if (rcl != RUMI_OK) return rcl;
-    ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
-                  nnratio, checkOri, dBlocked0, thrF, thrI};
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(nmatchesOut, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (fd.n > 0 && hostFeatMp) HIP_TRY(hipMemcpy(hostFeatMp, m->dFeatMp, (size_t)fd.n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (nq > 0 && hostAssign) HIP_TRY(hipMemcpy(hostAssign, m->dAssign, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int rcl = build_lists(m, mode, nq, fd, dQueryDesc);
+        if (rcl != RUMI_OK) return rcl;
+        ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
+                      nnratio, checkOri, dBlocked0, thrF, thrI, m->dOverflow};
+        hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
+        HIP_TRY(hipGetLastError());
+        const int rcf = fetch_results(m, fd.n, nq, hostAssign != nullptr);
+        if (rcf != RUMI_OK) return rcf;
+        if (m->hOut[1] == 0) break;
+        // list arena too small: the resolve did not run and the frame's map-point vector is untouched
+        if (attempt == 1) { g_lastError = "candidate list arena overflow after growing"; return RUMI_E_CAPACITY; }
+        const int rcg = grow_lists(m, (size_t)m->hOut[1]);
+        if (rcg != RUMI_OK) return rcg;
+    }
+    *nmatchesOut = m->hOut[0];
+    if (fd.n > 0 && hostFeatMp) std::memcpy(hostFeatMp, m->hOut + 4, (size_t)fd.n * sizeof(int32_t));
+    if (nq > 0 && hostAssign) std::memcpy(hostAssign, m->hOut + 4 + m->maxFeat, (size_t)nq * sizeof(int32_t));
     return RUMI_OK;
 }
 
@@ -956,6 +1119,7 @@ extern "C" int rumi_search_by_projection_mappoints(RumiMatcher *m, const RumiFra
         H2D(m->dF[0], proj_x, nmp); H2D(m->dF[1], proj_y, nmp); H2D(m->dF[2], view_cos, nmp); H2D(m->dF[3], track_depth, nmp);
         H2D(m->dI[0], scale_level, nmp); H2D(m->dI[1], mp_obs, nmp);
         H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1],
                            m->dI[0], m->dF[2], m->dF[3], m->dU8b, m->dI[1], m->dScale, th, far_points, th_far_points, m->dQ);
     }
@@ -980,6 +1144,7 @@ extern "C" int rumi_search_by_projection_frame(RumiMatcher *m, const RumiFrameFe
     if (nmp > 0) { H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dI[1], mp_obs, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32); }
     if (nlast > 0) {
         H2D(m->dQKeys, last_keys, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast);
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a,
                            m->dF[0], m->dI[1], m->dPose, m->dPose + 7, m->dScale, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
@@ -1007,6 +1172,7 @@ extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, c
     if (f_fv->n_nodes > 0) { H2D(m->dNodesB, f_fv->node_ids, f_fv->n_nodes); H2D(m->dOffB, f_fv->offsets, f_fv->n_nodes + 1); }
     if (nfe > 0) H2D(m->dFvIdx, f_fv->indices, nfe);
     if (kf_fv->n_nodes > 0)
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
@@ -1037,6 +1203,7 @@ extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF
     if (fv2->n_nodes > 0) { H2D(m->dNodesB, fv2->node_ids, fv2->n_nodes); H2D(m->dOffB, fv2->offsets, fv2->n_nodes + 1); }
     if (nfe > 0) H2D(m->dFvIdx, fv2->indices, nfe);
     if (fv1->n_nodes > 0)
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_bow, dim3((fv1->n_nodes + 255) / 256), dim3(256), 0, nullptr, fv1->n_nodes, m->dNodesA, m->dOffA, m->dIdxA,
                            m->dI[0], m->dU8a, m->dQKeys, fv2->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     std::vector<int32_t> assign(std::max(nqe, 1), -1);
@@ -1075,12 +1242,14 @@ extern "C" int rumi_search_for_triangulation(RumiMatcher *m, const RumiFrameFeat
     H2D(m->dNodesB, fv2->node_ids, fv2->n_nodes); H2D(m->dOffB, fv2->offsets, fv2->n_nodes + 1); H2D(m->dFvIdx, fv2->indices, nfe);
     TriArgs A{fv1->n_nodes, fv2->n_nodes, m->dNodesA, m->dOffA, m->dIdxA, m->dNodesB, m->dOffB, m->dFvIdx, m->dQKeys, m->dKeys,
               m->dQDesc, m->dDesc, m->dI[0], m->dFeatMp, m->dScale, m->dPose, coarse, m->dAssign};
+    FLUSH(m);
     hipLaunchKernelGGL(k_tri_match, dim3((fv1->n_nodes + 63) / 64), dim3(64), 0, nullptr, A);
     hipLaunchKernelGGL(k_tri_filter, dim3(1), dim3(256), 0, nullptr, nqe, m->dIdxA, m->dQKeys, m->dKeys, m->dAssign, check_orientation, m->dNmatches);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> assign(nqe);
-    HIP_TRY(hipMemcpy(nmatches_out, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(assign.data(), m->dAssign, (size_t)nqe * sizeof(int32_t), hipMemcpyDeviceToHost));
+    rc = fetch_results(m, 0, nqe, true);
+    if (rc != RUMI_OK) return rc;
+    *nmatches_out = m->hOut[0];
+    const int32_t *assign = m->hOut + 4 + m->maxFeat;
     for (int p = 0; p < nqe; p++) if (assign[p] >= 0) matches12[fv1->indices[p]] = assign[p];
     return RUMI_OK;
 }
@@ -1105,6 +1274,7 @@ extern "C" int rumi_search_by_projection_sim3(RumiMatcher *m, const RumiFrameFea
     if (nmp > 0) {
         H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3);
         H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_sim3, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
                            m->dPose, m->dScale, KF->nlevels, log_scale_factor, (float)th, explicit_invz, 1, 0, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
@@ -1128,6 +1298,7 @@ extern "C" int rumi_fuse_candidates(RumiMatcher *m, const RumiFrameFeatures *KF,
     H2D(m->dPose, pose, 14);
     H2D(m->dU8a, skip, nmp); H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3);
     H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+    FLUSH(m);
     hipLaunchKernelGGL(k_queries_sim3, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dU8a, m->dF[0], m->dF[1], m->dF[2], m->dF[3],
                        m->dPose, m->dScale, KF->nlevels, log_scale_factor, th, 0, 0, check_reprojection, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     int32_t n = 0;
@@ -1144,6 +1315,7 @@ static int sim3_direction(RumiMatcher *m, const RumiFrameFeatures *KF, float log
     HIP_TRY(hipMemsetAsync(m->dU8b, 0, std::max(KF->n, 1), nullptr));
     H2D(m->dPose, K4, 4);
     H2D(m->dU8a, skip, n); H2D(m->dF[0], pc, (size_t)n * 3); H2D(m->dF[2], mn, n); H2D(m->dF[3], mx, n); H2D(m->dQDesc, desc, (size_t)n * 32);
+    FLUSH(m);
     hipLaunchKernelGGL(k_queries_campoints, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, m->dU8a, m->dF[0], m->dF[2], m->dF[3], m->dPose, m->dScale,
                        KF->nlevels, logSf, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     int32_t cnt = 0;
@@ -1200,6 +1372,7 @@ extern "C" int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFe
     }
     if (nkf > 0) {
         H2D(m->dQKeys, kf_keys, nkf); H2D(m->dI[0], kf_mp, nkf);
+        FLUSH(m);
         hipLaunchKernelGGL(k_queries_reloc, dim3((nkf + 255) / 256), dim3(256), 0, nullptr, nkf, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dF[2],
                            m->dF[3], m->dPose, m->dScale, Cur->nlevels, log_scale_factor, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
     }
@@ -1220,14 +1393,24 @@ extern "C" int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFea
     *nmatches_out = 0;
     if (n1 == 0) return RUMI_OK;
     H2D(m->dQKeys, F1->keys_un, n1); H2D(m->dQDesc, F1->desc, (size_t)n1 * 32); H2D(m->dF[0], prev_matched, (size_t)n1 * 2);
+    FLUSH(m);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, nullptr, n1, m->dQKeys, m->dF[0], (float)window_size, m->dQ);
-    rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc);
-    if (rc != RUMI_OK) return rc;
-    InitArgs A{n1, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dAssign, m->dF[0], m->dNmatches, nnratio, check_orientation};
-    hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), (size_t)std::max(fd.n, 1) * 2 * sizeof(int32_t), nullptr, A);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(nmatches_out, m->dNmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(matches12, m->dAssign, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc);
+        if (rc != RUMI_OK) return rc;
+        InitArgs A{n1, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dAssign, m->dF[0], m->dNmatches, nnratio, check_orientation,
+                   m->dOverflow};
+        hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), (size_t)std::max(fd.n, 1) * 2 * sizeof(int32_t), nullptr, A);
+        HIP_TRY(hipGetLastError());
+        rc = fetch_results(m, 0, n1, true);
+        if (rc != RUMI_OK) return rc;
+        if (m->hOut[1] == 0) break;
+        if (attempt == 1) { g_lastError = "candidate list arena overflow after growing"; return RUMI_E_CAPACITY; }
+        rc = grow_lists(m, (size_t)m->hOut[1]);
+        if (rc != RUMI_OK) return rc;
+    }
+    *nmatches_out = m->hOut[0];
+    std::memcpy(matches12, m->hOut + 4 + m->maxFeat, (size_t)n1 * sizeof(int32_t));
     HIP_TRY(hipMemcpy(prev_matched, m->dF[0], (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
     return RUMI_OK;
 }
@@ -1243,21 +1426,27 @@ extern "C" int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const
     if (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !track_in_view || !proj_x || !proj_y || !scale_level || !view_cos || !track_depth)
         return RUMI_E_INVALID;
     HIP_TRY(hipSetDevice(m->device));
+    reset_uploads(m);
     float pose[19];
     std::memcpy(pose, Rcw9, 36); std::memcpy(pose + 9, tcw3, 12); std::memcpy(pose + 12, Ow3, 12); std::memcpy(pose + 15, K4, 16);
     H2D(m->dPose, pose, 19);
     H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3); H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp);
-    // outputs reuse query-side scratch: dU8a, dF[4] (x, y, cos packed as 3n), dF[5] (depth), dI[0]
-    float *dX = m->dF[4], *dY = m->dF[4] + nmp, *dC = m->dF[4] + 2 * (size_t)nmp;
+    // outputs are packed into the upload mirror (its contents have been scattered by then) and come back with one copy
+    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+    if (n16 * 21 > m->stageCap) { g_lastError = "isInFrustum: result block exceeds the staging block"; return RUMI_E_CAPACITY; }
+    uint8_t *dIn = m->dStage;
+    float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
+    int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
+    FLUSH(m);
     hipLaunchKernelGGL(k_is_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dPose, min_x, min_y, max_x, max_y, log_scale_factor,
-                       nlevels, viewing_cos_limit, m->dF[0], m->dF[1], m->dF[2], m->dF[3], m->dU8a, dX, dY, m->dI[0], dC, m->dF[5]);
+                       nlevels, viewing_cos_limit, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dIn, dX, dY, dL, dC, dD);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(track_in_view, m->dU8a, (size_t)nmp, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(proj_x, dX, (size_t)nmp * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(proj_y, dY, (size_t)nmp * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(view_cos, dC, (size_t)nmp * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(track_depth, m->dF[5], (size_t)nmp * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(scale_level, m->dI[0], (size_t)nmp * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(m->hStage, m->dStage, n16 * 21, hipMemcpyDeviceToHost));
+    const uint8_t *h = m->hStage;
+    std::memcpy(track_in_view, h, (size_t)nmp);
+    std::memcpy(proj_x, h + n16, (size_t)nmp * 4); std::memcpy(proj_y, h + n16 * 5, (size_t)nmp * 4);
+    std::memcpy(view_cos, h + n16 * 9, (size_t)nmp * 4); std::memcpy(track_depth, h + n16 * 13, (size_t)nmp * 4);
+    std::memcpy(scale_level, h + n16 * 17, (size_t)nmp * 4);
     return RUMI_OK;
 }
 

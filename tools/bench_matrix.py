@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Measurement matrix of SURVEY.md §8(d) beyond the single bench.py line: batch sweep (single-stream .. 1024 frames), feature
+count sweep (1000 / 2000 = TUM3.yaml / 5000 = mono-init extractor), the low-texture retry set, the windowed matchers M1-M3
+through the host C ABI, brute force in pairs/s and Gpopc/s, and the all-cores CPU baseline of config 5.
+Writes one JSON document (default gpurun_out/bench_matrix.json; the judged copy lives in profiles/)."""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timed(fn, reps, sync):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def median_call(fn, reps=50):
+    """Median latency of a synchronous call (a mean is dominated by the interpreter's occasional gen-2 GC pause, ~50 ms with torch loaded)."""
+    import numpy as np
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_matrix.json"))
+    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.matcher import FrameView, FeatureVector, ORBmatcher, bruteforce_batch
+    from rumi_slam_amd.synth import synth_frame
+    from scene import K_TUM3, TrackingScene
+    dev = torch.device("cuda", 0)
+    sync = torch.cuda.synchronize
+    doc = {"device": torch.cuda.get_device_name(0), "host_cpus": os.cpu_count()}
+    uniq = np.stack([synth_frame(1234 + i) for i in range(32)])
+
+    def frames_for(B, src=uniq):
+        t = torch.from_numpy(src).to(dev)
+        return t.repeat((B + len(src) - 1) // len(src), 1, 1)[:B].contiguous()
+
+    # ---- batch sweep, 1000 features ----
+    rows = []
+    for B in (1, 16, 64, 256, 1024):
+        ext = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+        fr = frames_for(B)
+        cap = 1000 + 96
+        reps = max(3, min(50, 2048 // B))
+        t_e = timed(lambda: ext.extract_batch(fr, (0, 1000), cap=cap), reps, sync)
+
+        def both():
+            kp, d, c = ext.extract_batch(fr, (0, 1000), cap=cap)
+            bruteforce_batch(d, c, torch.roll(d, -1, 0), torch.roll(c, -1, 0))
+        t_b = timed(both, reps, sync)
+        rows.append({"frames_per_launch": B, "extract_fps": round(B / t_e, 1), "extract_match_fps": round(B / t_b, 1),
+                     "ms_per_batch_extract": round(t_e * 1e3, 3)})
+        ext.close()
+    doc["batch_sweep_1000_features"] = rows
+
+    # ---- single stream through the host API (PCIe both ways) ----
+    ext = ORBextractor(1000, 1.2, 8, 20, 7)
+    t1 = timed(lambda: ext(uniq[0]), 100, sync)
+    doc["single_frame_host_api"] = {"ms_per_frame": round(t1 * 1e3, 3), "fps": round(1 / t1, 1), "note": "rumi_orb_extract: H2D image, kernels, D2H key-points + descriptors"}
+    ext.close()
+
+    # ---- feature-count sweep and the low-texture set at 256 frames per launch ----
+    rows = []
+    low = np.stack([synth_frame(3000 + i, n_rect=60, contrast=(8, 19)) for i in range(16)])
+    for nf, src, tag in ((1000, uniq, "textured"), (2000, uniq, "textured"), (5000, uniq, "textured"), (1000, low, "low texture (minThFAST retry)")):
+        B = 256
+        ext = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+        fr = frames_for(B, src)
+        cap = nf + 96
+        t_e = timed(lambda: ext.extract_batch(fr, (0, 1000), cap=cap), 5, sync)
+        kp, d, c = ext.extract_batch(fr, (0, 1000), cap=cap)
+        sync()
+        rows.append({"nfeatures": nf, "input": tag, "frames_per_launch": B, "extract_fps": round(B / t_e, 1),
+                     "mean_keypoints": round(float(c[:, 0].float().mean().item()), 1)})
+        ext.close()
+    doc["feature_sweep"] = rows
+
+    # ---- brute force alone ----
+    ext = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=256)
+    fr = frames_for(256)
+    kp, d, c = ext.extract_batch(fr, (0, 1000), cap=1096)
+    d2, c2 = torch.roll(d, -1, 0).contiguous(), torch.roll(c, -1, 0).contiguous()
+    t_m = timed(lambda: bruteforce_batch(d, c, d2, c2), 20, sync)
+    n = c[:, 0].double()
+    pairs = float((n * torch.roll(n, -1, 0)).sum().item())
+    doc["bruteforce"] = {"frame_pairs_per_s": round(256 / t_m, 1), "descriptor_pairs_per_s": round(pairs / t_m, 1),
+                         "Gpopc64_per_s": round(pairs * 4 / t_m / 1e9, 2), "ms_per_256_pairs": round(t_m * 1e3, 3)}
+    ext.close()
+
+    # ---- windowed matchers through the host C ABI (uploads included) vs the oracle, one frame pair ----
+    s = TrackingScene(0)
+    m = ORBmatcher(0.8, True)
+    F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    mp = s.mappoint_view()
+    fm0 = np.full(F.n, -1, np.int32)
+    nosync = lambda: None
+    cpu_time = lambda fn: median_call(fn, 20)
+    g1 = median_call(lambda: m.SearchByProjection_MapPoints(F, mp, fm0, 3.0))
+    c1 = cpu_time(lambda: O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, mp, fm0, 3.0, False, 0.0, 0.8))
+    a2 = (s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos, s.mp_desc, s.mp_obs, fm0)
+    g2 = median_call(lambda: m.SearchByProjection_Frame(F, *a2, 15.0))
+    c2_ = cpu_time(lambda: O.search_by_projection_frame(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, *a2, 15.0, True))
+    fv1, fv2 = s.feature_vectors()
+    A, Bv = FeatureVector(fv1), FeatureVector(fv2)
+    KF = FrameView(s.last_keys, s.last_desc, s.w, s.h, s.sf)
+    bad = np.zeros(len(s.mp_obs), np.uint8)
+    g3 = median_call(lambda: m.SearchByBoW(KF, A, s.last_mp, bad, F, Bv))
+    c3 = cpu_time(lambda: O.search_by_bow(s.last_keys, s.last_desc, s.last_mp, bad, (A.node_ids, A.offsets, A.indices), s.cur_keys, s.cur_desc,
+                                          (Bv.node_ids, Bv.offsets, Bv.indices), 0.8, True))
+    doc["windowed_matchers_host_api"] = {
+        "note": "median latency of one call per frame pair, host arrays in/out (one pinned upload, kernels, one read-back); oracle = scalar CPU restatement",
+        "M1_SearchByProjection_mappoints": {"queries": int(len(mp["obs"])), "gpu_us": round(g1 * 1e6, 1), "cpu_oracle_us": round(c1 * 1e6, 1)},
+        "M2_SearchByProjection_frame": {"queries": int(len(s.last_keys)), "gpu_us": round(g2 * 1e6, 1), "cpu_oracle_us": round(c2_ * 1e6, 1)},
+        "M3_SearchByBoW": {"queries": int(len(s.last_keys)), "gpu_us": round(g3 * 1e6, 1), "cpu_oracle_us": round(c3 * 1e6, 1)}}
+
+    # ---- CPU oracle, all cores (config 5: one frame per thread) ----
+    T = args.cpu_threads
+    orcs = [O.OracleExtractor(1000, 1.2, 8, 20, 7) for _ in range(T)]
+    def work(k):
+        for i in range(6):
+            orcs[k].extract(uniq[(k * 6 + i) % len(uniq)], (0, 1000))
+    with ThreadPoolExecutor(T) as ex:
+        t0 = time.perf_counter(); list(ex.map(work, range(T))); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); work(0); dt1 = time.perf_counter() - t0
+    doc["cpu_oracle_extract"] = {"threads": T, "fps_all_threads": round(T * 6 / dt, 1), "fps_one_thread": round(6 / dt1, 1), "flags": "g++ -O2 -ffp-contract=off"}
+
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(doc, open(args.out, "w"), indent=1)
+    print(json.dumps(doc))
+
+
+if __name__ == "__main__":
+    main()
