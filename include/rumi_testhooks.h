@@ -14,6 +14,9 @@ extern "C" {
 /* Sort (key, id) pairs exactly as std::sort(first,last,compareNodes) of libstdc++ would
  * (ORBextractor.cc:524-536,658); ids are permuted in place alongside keys. */
 int rumi_hook_sort_like_std(uint32_t *keys, uint16_t *ids, int32_t n);
+/* The same through the workgroup-parallel replay on the GPU (n <= 4096; needs a device) and through the real std::sort. */
+int rumi_hook_sort_device(uint32_t *keys, uint16_t *ids, int32_t n);
+int rumi_hook_std_sort(uint32_t *keys, uint16_t *ids, int32_t n);
 
 /* DistributeOctTree (ORBextractor.cc:538-724) on packed candidates x | y<<12 | score<<24 (coordinates
  * relative to (minX,minY)); writes indices into `cand` in the reference's result order. */

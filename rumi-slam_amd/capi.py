@@ -88,7 +88,7 @@ MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_de
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba",
                "rumi_opt_stage_ms"]
 
-HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
+HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_sort_device", "rumi_hook_std_sort", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
                 "rumi_hook_fast_atan2", "rumi_hook_cv_round", "rumi_hook_magic_div"]
 
 
@@ -99,6 +99,8 @@ def hooks():
         return L
     vp, i32 = C.c_void_p, C.c_int32
     L.rumi_hook_sort_like_std.argtypes = [vp, vp, i32]
+    L.rumi_hook_sort_device.argtypes = [vp, vp, i32]
+    L.rumi_hook_std_sort.argtypes = [vp, vp, i32]
     L.rumi_hook_quadtree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32)]
     for name in ("rumi_hook_sinf", "rumi_hook_cosf"):
         getattr(L, name).restype = C.c_float

@@ -7,6 +7,10 @@
 #include "orb_math.h"
 #include "orb_octree.h"
 #include "rumi_orb.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "rumi_testhooks.h"
 
 using namespace rumi;
@@ -18,6 +22,19 @@ extern "C" int rumi_hook_sort_like_std(uint32_t *keys, uint16_t *ids, int32_t n)
     sort_like_libstdcxx(e.data(), n);
     for (int i = 0; i < n; i++) { keys[i] = e[i].key; ids[i] = e[i].id; }
     return RUMI_OK;
+}
+
+namespace rumi { int launch_sort_hook(uint32_t *keys, uint16_t *ids, int n); }
+// the same entries through the workgroup-parallel replay on the GPU (orb_octree_kernel.hip)
+extern "C" int rumi_hook_sort_device(uint32_t *keys, uint16_t *ids, int32_t n) { return rumi::launch_sort_hook(keys, ids, n); }
+// ... and through the real std::sort of the libstdc++ this library is built against (what the reference's compareNodes sort does)
+extern "C" int rumi_hook_std_sort(uint32_t *keys, uint16_t *ids, int32_t n) {
+    if (n < 0) return -1;
+    std::vector<std::pair<uint32_t, uint16_t>> v(n);
+    for (int i = 0; i < n; i++) v[i] = {keys[i], ids[i]};
+    std::sort(v.begin(), v.end(), [](const std::pair<uint32_t, uint16_t> &a, const std::pair<uint32_t, uint16_t> &b) { return a.first < b.first; });
+    for (int i = 0; i < n; i++) { keys[i] = v[i].first; ids[i] = v[i].second; }
+    return 0;
 }
 
 extern "C" int rumi_hook_quadtree(const uint32_t *cand, int32_t n, int32_t minX, int32_t maxX, int32_t minY,

@@ -121,3 +121,36 @@ def test_golden_fixtures_on_gpu():
         assert mono == int(g["mono"]), path
         assert np.array_equal(kps.view(np.uint8).reshape(-1, 28), g["kps"]), path
         assert np.array_equal(desc, g["desc"]), path
+
+
+def test_workgroup_sort_replays_std_sort():
+    """The quadtree's fine rounds sort (size, UL.x) keys with std::sort; equal keys are frequent and their order is whatever
+    libstdc++'s introsort leaves.  The workgroup-parallel replay (parallel Hoare partitions + windowed stable rank) must give
+    the very same permutation as the real std::sort, including the heap-sort fallback on adversarial inputs."""
+    from rumi_slam_amd import capi
+    H = capi.hooks()
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in [0, 1, 2, 15, 16, 17, 18, 31, 33, 64, 65, 100, 257, 700, 1000, 2189, 4096]:
+        for hi in (2, 5, 40, 100000):
+            cases.append(rng.integers(0, hi, n).astype(np.uint32))
+    cases.append(np.arange(3000, dtype=np.uint32))                              # sorted
+    cases.append(np.arange(3000, dtype=np.uint32)[::-1].copy())                # reversed
+    cases.append(np.concatenate([np.arange(1500), np.arange(1500)[::-1]]).astype(np.uint32))   # organ pipe
+    k = np.zeros(4096, np.uint32); k[::2] = np.arange(2048); k[1::2] = np.arange(2048)[::-1]
+    cases.append(k)
+    # median-of-3 killer (drives introsort into its depth limit -> heap-sort fallback)
+    n = 2048; killer = np.zeros(n, np.uint32); h = n // 2
+    for i in range(h):
+        killer[2 * i] = i + 1 if i % 2 == 0 else 0
+        killer[2 * i + 1] = h + i + 1
+    cases.append(killer)
+    for keys in cases:
+        n = len(keys)
+        ids = np.arange(n, dtype=np.uint16)
+        k1, i1 = keys.copy(), ids.copy()
+        k2, i2 = keys.copy(), ids.copy()
+        assert H.rumi_hook_std_sort(capi.ptr(k1), capi.ptr(i1), n) == 0
+        assert H.rumi_hook_sort_device(capi.ptr(k2), capi.ptr(i2), n) == 0
+        assert np.array_equal(k1, k2), f"keys not sorted alike, n={n}"
+        assert np.array_equal(i1, i2), f"tie order differs from std::sort, n={n}: {np.count_nonzero(i1 != i2)} positions"

@@ -71,6 +71,9 @@ def test_sort_replay_equals_libstdcxx():
             assert (np.diff(k2.astype(np.int64)) >= 0).all()
             assert sorted(i2.tolist()) == list(range(n))
             assert np.array_equal(keys[i2], k2)
+            k3, i3 = keys.copy(), ids.copy()                     # the real std::sort of the libstdc++ in this image
+            assert H.rumi_hook_std_sort(capi.ptr(k3), capi.ptr(i3), n) == 0
+            assert np.array_equal(i2, i3), f"tie order differs from std::sort at n={n}"
 
 
 def _pack(x, y, s):
