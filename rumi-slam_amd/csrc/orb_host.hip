@@ -2,6 +2,8 @@
 // Reference behaviour: ORBextractor::operator() R/lib_src/ORBextractor.cc:1014-1091.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -298,7 +300,9 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     launch_frame_cols(h->dP, P, src, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
     // fork: blur on the side stream, next to FAST / quadtree (stage times are taken with the same overlap the timed path has)
-    hipStream_t bs = h->sideStream;
+    // RUMI_SERIAL=1 (profiling aid): blur on the main stream, so that every kernel's duration is its stand-alone duration
+    static const bool serial = std::getenv("RUMI_SERIAL") != nullptr;
+    hipStream_t bs = serial ? st : h->sideStream;
     HIP_TRY(hipEventRecord(h->evFork, st));
     HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0));
     if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));

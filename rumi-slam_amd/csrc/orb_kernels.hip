@@ -171,8 +171,9 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int TP>
-__device__ __forceinline__ int fast_score_tp(const uint8_t *t) {
+// FAST 9/16 corner score of the pixel at t (tile pitch TP): max over the 16 arcs of 9 contiguous circle pixels of the
+// minimum contrast, minus 1 (cv::cornerScore<16>; a pixel is a corner at threshold T iff score >= T).
+__device__ __forceinline__ int fast_score_at(const uint8_t *t, const int TP) {
     const int v = t[0];
     int d[16];
     d[0] = v - t[3 * TP];       d[1] = v - t[3 * TP + 1];   d[2] = v - t[2 * TP + 2];   d[3] = v - t[TP + 3];
@@ -192,6 +193,63 @@ __device__ __forceinline__ int fast_score_tp(const uint8_t *t) {
         Bn = min(Bn, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
     }
     return max(A, -Bn) - 1;
+}
+
+// Necessary condition for score >= thr - 1: every arc of 9 contains 4 consecutive of the 8 EVEN circle positions, so the best
+// "4 consecutive even positions" contrast bounds the score from above.  A third of the work of the full score; the pixels that
+// pass (edges and corners) are compacted and scored exactly afterwards, the rest can never reach the threshold.
+__device__ __forceinline__ bool fast_quick_at(const uint8_t *t, const int TP, const int thr) {
+    const int v = t[0];
+    int e[8];
+    e[0] = v - t[3 * TP];  e[1] = v - t[2 * TP + 2];  e[2] = v - t[3];   e[3] = v - t[-2 * TP + 2];
+    e[4] = v - t[-3 * TP]; e[5] = v - t[-2 * TP - 2]; e[6] = v - t[-3];  e[7] = v - t[2 * TP - 2];
+    int lo2[8], hi2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { lo2[k] = min(e[k], e[(k + 1) & 7]); hi2[k] = max(e[k], e[(k + 1) & 7]); }
+    int lo4[8], hi4[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 7]); hi4[k] = max(hi2[k], hi2[(k + 2) & 7]); }
+    const int A = max3i(max3i(lo4[0], lo4[1], lo4[2]), max3i(lo4[3], lo4[4], lo4[5]), max(lo4[6], lo4[7]));
+    const int Bn = min3i(min3i(hi4[0], hi4[1], hi4[2]), min3i(hi4[3], hi4[4], hi4[5]), min(hi4[6], hi4[7]));
+    return max(A, -Bn) >= thr;
+}
+
+// score map of one cell: quick test on every pixel, exact score on the compacted survivors (CTP != 0: compile-time tile pitch)
+template <int CTP>
+__device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, int tp, int SP, int shx, int dw, unsigned Mdw,
+                                                int npx, int tlow, int lane) {
+    const int TP = CTP ? CTP : tp;
+    int pending = 0;                                   // survivors waiting in cl[0..pending), pending < 128
+    for (int base = 0; base < npx; base += 64) {
+        const int idx = base + lane;
+        bool pass = false;
+        if (idx < npx) {
+            const int py = magic_div(idx, Mdw), px = idx - py * dw;
+            pass = fast_quick_at(&tile[(py + 3) * TP + px + 3 + shx], TP, tlow + 1);
+        }
+        const unsigned long long b = __ballot(pass);
+        if (pass) cl[pending + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+        pending += __popcll(b);
+        if (pending >= 64) {                           // a full wave of survivors: score them exactly
+            wave_lds_fence();
+            const int i2 = cl[lane];
+            const int rest = pending - 64;
+            const int mv = lane < rest ? cl[64 + lane] : 0;
+            const int py = magic_div(i2, Mdw), px = i2 - py * dw;
+            const int s = fast_score_at(&tile[(py + 3) * TP + px + 3 + shx], TP);
+            if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+            wave_lds_fence();
+            if (lane < rest) cl[lane] = (uint16_t)mv;
+            pending = rest;
+        }
+    }
+    wave_lds_fence();
+    if (lane < pending) {
+        const int i2 = cl[lane];
+        const int py = magic_div(i2, Mdw), px = i2 - py * dw;
+        const int s = fast_score_at(&tile[(py + 3) * TP + px + 3 + shx], TP);
+        if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
@@ -235,36 +293,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     wave_lds_fence();
     const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
-    for (int idx = lane; idx < npx; idx += 64) {
-        const int py = magic_div(idx, Mdw), px = idx - py * dw;
-        const uint8_t *t = &tile[(py + 3) * TP + px + 3 + shx];
-        int s;
-        switch (TP) {                                            // compile-time pitches for the common geometries
-            case 48: s = fast_score_tp<48>(t); break;
-            case 52: s = fast_score_tp<52>(t); break;
-            case 56: s = fast_score_tp<56>(t); break;
-            default: {
-                const int v = t[0];
-                int d[16];
-                d[0] = v - t[3 * TP];       d[1] = v - t[3 * TP + 1];   d[2] = v - t[2 * TP + 2];   d[3] = v - t[TP + 3];
-                d[4] = v - t[3];            d[5] = v - t[-TP + 3];      d[6] = v - t[-2 * TP + 2];  d[7] = v - t[-3 * TP + 1];
-                d[8] = v - t[-3 * TP];      d[9] = v - t[-3 * TP - 1];  d[10] = v - t[-2 * TP - 2]; d[11] = v - t[-TP - 3];
-                d[12] = v - t[-3];          d[13] = v - t[TP - 3];      d[14] = v - t[2 * TP - 2];  d[15] = v - t[3 * TP - 1];
-                int A = -256, Bn = 256, lo3[16], hi3[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    A = max(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-                    Bn = min(Bn, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-                }
-                s = max(A, -Bn) - 1;
-            }
-        }
-        if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+    uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
+    switch (TP) {                                                // compile-time pitches for the common geometries
+        case 48: fast_score_cell<48>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
+        case 52: fast_score_cell<52>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
+        case 56: fast_score_cell<56>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
+        default: fast_score_cell<0>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
     }
     wave_lds_fence();
     const int iters = (npx + 63) >> 6;
@@ -564,9 +598,9 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.tileBytes = (hMax + 6) * F.tp;
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 15) & ~15;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 15) & ~15;
+    // tile | score map | two ballot arrays | ring of pixels that passed the quick test (128 x uint16)
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 128 * 2 + 15) & ~15;
     hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,

@@ -82,7 +82,9 @@ def main():
     # ---- feature-count sweep and the low-texture set at 256 frames per launch ----
     rows = []
     low = np.stack([synth_frame(3000 + i, n_rect=60, contrast=(8, 19)) for i in range(16)])
-    for nf, src, tag in ((1000, uniq, "textured"), (2000, uniq, "textured"), (5000, uniq, "textured"), (1000, low, "low texture (minThFAST retry)")):
+    sparse = np.stack([synth_frame(5000 + i, n_rect=40) for i in range(16)])
+    for nf, src, tag in ((1000, uniq, "textured"), (2000, uniq, "textured"), (5000, uniq, "textured"), (1000, low, "low texture (minThFAST retry)"),
+                         (1000, sparse, "sparse texture (40 rectangles: corner density of natural images)")):
         B = 256
         ext = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
         fr = frames_for(B, src)
