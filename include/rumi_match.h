@@ -120,7 +120,7 @@ int rumi_search_by_projection_reloc(RumiMatcher *m, const RumiFrameFeatures *Cur
                                     int32_t check_orientation, int32_t *cur_mp, int32_t *nmatches_out);
 
 /* ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12,
- * int windowSize) — R/lib_src/ORBmatcher.cc:581-680 (monocular initialisation, Tracking.cc:1968).
+ * int windowSize) — R/lib_src/ORBmatcher.cc:581-680 (monocular initialisation, Tracking.cc:2115).
  * prev_matched [F1->n][2] is read and updated in place (:675-677); matches12 [F1->n] receives vnMatches12. */
 int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFeatures *F1, const RumiFrameFeatures *F2, float *prev_matched,
                                    int32_t window_size, float nnratio, int32_t check_orientation, int32_t *matches12,
