@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, I
     *reinterpret_cast<uint32_t *>(out) = v;                                  // columns >= w are rewritten by k_frame_cols
 }
 
+// Each lane produces 4 pixels of kResizeRows consecutive rows: the column tables are loaded once and the 2 x kResizeRows
+// source-row loads are issued back to back, so a wave has 8 x more bytes in flight per dependent round trip than with one row
+// (the kernel is latency-bound: two dependent table -> pixel round trips per wave).
+constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
                                                 const int16_t *__restrict__ coef, int level) {
     const DevLevel &D = P->lv[level];
@@ -81,54 +85,80 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
     const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oy = by * 4 + (threadIdx.x >> 6) - kPadY;
-    if (ox >= D.w || oy >= D.h + kPadY) return;
+    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows - kPadY;
+    if (ox >= D.w || oyBase >= D.h + kPadY) return;
     const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
-    uint8_t *db = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
+    uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
     const int16_t *yofs = coef + D.coefY, *ya = yofs + D.h;
-    const int dy = reflect101(oy, D.h);
-    const int sy = yofs[dy], b0 = ya[dy * 2], b1 = ya[dy * 2 + 1];
-    const int sy0 = sy >= 0 ? (sy < S.h ? sy : S.h - 1) : 0;
-    const int sy1r = sy + 1;
-    const int sy1 = sy1r >= 0 ? (sy1r < S.h ? sy1r : S.h - 1) : 0;
-    const uint8_t *r0p = sb + (long long)sy0 * S.pitch, *r1p = sb + (long long)sy1 * S.pitch;
-    uint32_t packed = 0;
+    const uint8_t *r0p[kResizeRows], *r1p[kResizeRows];
+    int b0[kResizeRows], b1[kResizeRows];
+    bool live[kResizeRows];
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) {
+        const int oy = oyBase + r;
+        live[r] = oy < D.h + kPadY;
+        const int dy = reflect101(live[r] ? oy : 0, D.h);
+        const int sy = yofs[dy];
+        b0[r] = ya[dy * 2]; b1[r] = ya[dy * 2 + 1];
+        const int sy0 = sy >= 0 ? (sy < S.h ? sy : S.h - 1) : 0;
+        const int sy1r = sy + 1;
+        const int sy1 = sy1r >= 0 ? (sy1r < S.h ? sy1r : S.h - 1) : 0;
+        r0p[r] = sb + (long long)sy0 * S.pitch; r1p[r] = sb + (long long)sy1 * S.pitch;
+    }
     const bool whole = ox + 3 < D.w;
     const int sx0 = xofs[ox];
     if (whole && ox + 3 < D.xmax && xofs[ox + 3] + 1 - sx0 <= 7) {
-        // the 4 outputs read source bytes sx0 .. sx0+7 of two rows -> two (unaligned) 8-byte loads; offsets and taps come
-        // as one 8-byte and one 16-byte table load
+        // the 4 outputs read source bytes sx0 .. sx0+7 of two rows -> two (unaligned) 8-byte loads per row; offsets and taps
+        // come as one 8-byte and one 16-byte table load
         const uint64_t ofs = reinterpret_cast<const U64 *>(xofs + ox)->v;
         const U64 *t8 = reinterpret_cast<const U64 *>(xa + 2 * ox);
         const uint64_t ta = t8[0].v, tb = t8[1].v;
-        const uint64_t s0 = reinterpret_cast<const U64 *>(r0p + sx0)->v, s1 = reinterpret_cast<const U64 *>(r1p + sx0)->v;
+        uint64_t s0[kResizeRows], s1[kResizeRows];
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            s0[r] = reinterpret_cast<const U64 *>(r0p[r] + sx0)->v;
+            s1[r] = reinterpret_cast<const U64 *>(r1p[r] + sx0)->v;
+        }
+        int sh[4], a0[4], a1[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int sh = 8 * ((int)(int16_t)(ofs >> (16 * i)) - sx0);
+            sh[i] = 8 * ((int)(int16_t)(ofs >> (16 * i)) - sx0);
             const uint64_t tt = i < 2 ? ta : tb;
-            const int a0 = (int16_t)(tt >> (32 * (i & 1))), a1 = (int16_t)(tt >> (32 * (i & 1) + 16));
-            const int r0 = (int)((s0 >> sh) & 255) * a0 + (int)((s0 >> (sh + 8)) & 255) * a1;
-            const int r1 = (int)((s1 >> sh) & 255) * a0 + (int)((s1 >> (sh + 8)) & 255) * a1;
-            packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+            a0[i] = (int16_t)(tt >> (32 * (i & 1))); a1[i] = (int16_t)(tt >> (32 * (i & 1) + 16));
+        }
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int q0 = (int)((s0[r] >> sh[i]) & 255) * a0[i] + (int)((s0[r] >> (sh[i] + 8)) & 255) * a1[i];
+                const int q1 = (int)((s1[r] >> sh[i]) & 255) * a0[i] + (int)((s1[r] >> (sh[i] + 8)) & 255) * a1[i];
+                packed |= (uint32_t)((((b0[r] * (q0 >> 4)) >> 16) + ((b1[r] * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+            }
+            if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
     } else {
-        for (int i = 0; i < 4 && ox + i < D.w; i++) {
-            const int dx = ox + i;
-            const int sx = xofs[dx];
-            int r0, r1;
-            if (dx < D.xmax) {
-                const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
-                r0 = r0p[sx] * a0 + r0p[sx + 1] * a1;
-                r1 = r1p[sx] * a0 + r1p[sx + 1] * a1;
-            } else {
-                r0 = r0p[sx] * 2048;
-                r1 = r1p[sx] * 2048;
+        for (int r = 0; r < kResizeRows; r++) {
+            if (!live[r]) continue;
+            uint32_t packed = 0;
+            for (int i = 0; i < 4 && ox + i < D.w; i++) {
+                const int dx = ox + i;
+                const int sx = xofs[dx];
+                int q0, q1;
+                if (dx < D.xmax) {
+                    const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
+                    q0 = r0p[r][sx] * a0 + r0p[r][sx + 1] * a1;
+                    q1 = r1p[r][sx] * a0 + r1p[r][sx + 1] * a1;
+                } else {
+                    q0 = r0p[r][sx] * 2048;
+                    q1 = r1p[r][sx] * 2048;
+                }
+                packed |= (uint32_t)((((b0[r] * (q0 >> 4)) >> 16) + ((b1[r] * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
             }
-            packed |= (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+            *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
     }
-    *reinterpret_cast<uint32_t *>(db) = packed;
 }
 
 // left / right REFLECT_101 frame columns of all levels: thread = (frame, level, framed row, one of 17 aligned dword strips)
@@ -584,7 +614,7 @@ void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int
 }
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st) {
-    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kPadY + 3) / 4, nframes);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kPadY + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
