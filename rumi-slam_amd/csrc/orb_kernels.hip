@@ -201,34 +201,31 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// FAST 9/16 corner score of the pixel at t (tile pitch TP): max over the 16 arcs of 9 contiguous circle pixels of the
-// minimum contrast, minus 1 (cv::cornerScore<16>; a pixel is a corner at threshold T iff score >= T).
-__device__ __forceinline__ int fast_score_at(const uint8_t *t, const int TP) {
-    const int v = t[0];
+// FAST 9/16 corner score of the pixel at t (tile pitch TP) for ONE polarity: sign = +1 scores the "darker ring" arcs
+// (contrast v - p), sign = -1 the "brighter ring" arcs (p - v).  cv::cornerScore<16> = max of the two, minus 1: max over the 16
+// arcs of 9 contiguous circle pixels of the minimum contrast (a pixel is a corner at threshold T iff score >= T).
+__device__ __forceinline__ int fast_score_polar(const uint8_t *t, const int TP, const int sign) {
+    const int sv = sign * (int)t[0], ns = -sign;
     int d[16];
-    d[0] = v - t[3 * TP];       d[1] = v - t[3 * TP + 1];   d[2] = v - t[2 * TP + 2];   d[3] = v - t[TP + 3];
-    d[4] = v - t[3];            d[5] = v - t[-TP + 3];      d[6] = v - t[-2 * TP + 2];  d[7] = v - t[-3 * TP + 1];
-    d[8] = v - t[-3 * TP];      d[9] = v - t[-3 * TP - 1];  d[10] = v - t[-2 * TP - 2]; d[11] = v - t[-TP - 3];
-    d[12] = v - t[-3];          d[13] = v - t[TP - 3];      d[14] = v - t[2 * TP - 2];  d[15] = v - t[3 * TP - 1];
-    int lo3[16], hi3[16];
+    d[0] = sv + ns * t[3 * TP];       d[1] = sv + ns * t[3 * TP + 1];   d[2] = sv + ns * t[2 * TP + 2];   d[3] = sv + ns * t[TP + 3];
+    d[4] = sv + ns * t[3];            d[5] = sv + ns * t[-TP + 3];      d[6] = sv + ns * t[-2 * TP + 2];  d[7] = sv + ns * t[-3 * TP + 1];
+    d[8] = sv + ns * t[-3 * TP];      d[9] = sv + ns * t[-3 * TP - 1];  d[10] = sv + ns * t[-2 * TP - 2]; d[11] = sv + ns * t[-TP - 3];
+    d[12] = sv + ns * t[-3];          d[13] = sv + ns * t[TP - 3];      d[14] = sv + ns * t[2 * TP - 2];  d[15] = sv + ns * t[3 * TP - 1];
+    int lo3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    }
-    int A = -256, Bn = 256;
+    for (int k = 0; k < 16; k++) lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    int A = -256;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        A = max(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        Bn = min(Bn, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-    }
-    return max(A, -Bn) - 1;
+    for (int k = 0; k < 16; k += 2)
+        A = max3i(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]), min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
+    return A - 1;
 }
 
-// Necessary condition for score >= thr - 1: every arc of 9 contains 4 consecutive of the 8 EVEN circle positions, so the best
-// "4 consecutive even positions" contrast bounds the score from above.  A third of the work of the full score; the pixels that
-// pass (edges and corners) are compacted and scored exactly afterwards, the rest can never reach the threshold.
-__device__ __forceinline__ bool fast_quick_at(const uint8_t *t, const int TP, const int thr) {
+// Necessary condition for score >= thr - 1, per polarity: every arc of 9 contains 4 consecutive of the 8 EVEN circle positions,
+// so the best "4 consecutive even positions" contrast bounds that polarity's score from above.  Returns bit 0 = the darker-ring
+// polarity can reach thr, bit 1 = the brighter-ring polarity can.  Pixels with no bit set can never reach the threshold; the
+// others are compacted (one entry per polarity) and scored exactly for that polarity only.
+__device__ __forceinline__ int fast_quick_at(const uint8_t *t, const int TP, const int thr) {
     const int v = t[0];
     int e[8];
     e[0] = v - t[3 * TP];  e[1] = v - t[2 * TP + 2];  e[2] = v - t[3];   e[3] = v - t[-2 * TP + 2];
@@ -241,7 +238,24 @@ __device__ __forceinline__ bool fast_quick_at(const uint8_t *t, const int TP, co
     for (int k = 0; k < 8; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 7]); hi4[k] = max(hi2[k], hi2[(k + 2) & 7]); }
     const int A = max3i(max3i(lo4[0], lo4[1], lo4[2]), max3i(lo4[3], lo4[4], lo4[5]), max(lo4[6], lo4[7]));
     const int Bn = min3i(min3i(hi4[0], hi4[1], hi4[2]), min3i(hi4[3], hi4[4], hi4[5]), min(hi4[6], hi4[7]));
-    return max(A, -Bn) >= thr;
+    return (A >= thr ? 1 : 0) | (-Bn >= thr ? 2 : 0);
+}
+
+// exact scores of up to 64 ring entries (entry = pixel index | polarity << 15).  A pixel that passed both quick tests has two
+// entries, darker first; darker entries store their score, then brighter entries keep the maximum (their darker twin sits
+// earlier in the ring, i.e. in this batch or a previous one).
+template <int CTP>
+__device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *sc, int entry, bool active, int tp, int SP, int shx, int dw,
+                                                 unsigned Mdw, int tlow) {
+    const int TP = CTP ? CTP : tp;
+    const int i2 = entry & 0x7FFF, bright = entry >> 15;
+    const int py = magic_div(i2, Mdw), px = i2 - py * dw;
+    int s = 0;
+    if (active) s = fast_score_polar(&tile[(py + 3) * TP + px + 3 + shx], TP, bright ? -1 : 1);
+    uint8_t *dst = &sc[(py + 1) * SP + px + 1];
+    if (active && !bright && s >= tlow) *dst = (uint8_t)s;
+    wave_lds_fence();
+    if (active && bright && s >= tlow && s > (int)*dst) *dst = (uint8_t)s;
 }
 
 // score map of one cell: quick test on every pixel, exact score on the compacted survivors (CTP != 0: compile-time tile pitch)
@@ -249,37 +263,35 @@ template <int CTP>
 __device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, int tp, int SP, int shx, int dw, unsigned Mdw,
                                                 int npx, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
-    int pending = 0;                                   // survivors waiting in cl[0..pending), pending < 128
+    int pending = 0;                                   // entries waiting in cl[0..pending), pending < 64 between steps
     for (int base = 0; base < npx; base += 64) {
         const int idx = base + lane;
-        bool pass = false;
+        int pass = 0;
         if (idx < npx) {
             const int py = magic_div(idx, Mdw), px = idx - py * dw;
             pass = fast_quick_at(&tile[(py + 3) * TP + px + 3 + shx], TP, tlow + 1);
         }
-        const unsigned long long b = __ballot(pass);
-        if (pass) cl[pending + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)idx;
-        pending += __popcll(b);
-        if (pending >= 64) {                           // a full wave of survivors: score them exactly
+        // ring positions: entries of lower lanes first, darker before brighter within a lane
+        const unsigned long long bd = __ballot(pass & 1), bb = __ballot(pass & 2);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int pos = pending + __popcll(bd & below) + __popcll(bb & below);
+        if (pass & 1) cl[pos++] = (uint16_t)idx;
+        if (pass & 2) cl[pos] = (uint16_t)(idx | 0x8000);
+        pending += __popcll(bd) + __popcll(bb);
+        while (pending >= 64) {                        // a full wave of entries: score them exactly
             wave_lds_fence();
-            const int i2 = cl[lane];
+            const int e = cl[lane];
             const int rest = pending - 64;
-            const int mv = lane < rest ? cl[64 + lane] : 0;
-            const int py = magic_div(i2, Mdw), px = i2 - py * dw;
-            const int s = fast_score_at(&tile[(py + 3) * TP + px + 3 + shx], TP);
-            if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+            const int mv0 = lane < rest ? cl[64 + lane] : 0, mv1 = lane + 64 < rest ? cl[128 + lane] : 0;
+            fast_score_batch<CTP>(tile, sc, e, true, tp, SP, shx, dw, Mdw, tlow);
             wave_lds_fence();
-            if (lane < rest) cl[lane] = (uint16_t)mv;
+            if (lane < rest) cl[lane] = (uint16_t)mv0;
+            if (lane + 64 < rest) cl[64 + lane] = (uint16_t)mv1;
             pending = rest;
         }
     }
     wave_lds_fence();
-    if (lane < pending) {
-        const int i2 = cl[lane];
-        const int py = magic_div(i2, Mdw), px = i2 - py * dw;
-        const int s = fast_score_at(&tile[(py + 3) * TP + px + 3 + shx], TP);
-        if (s >= tlow) sc[(py + 1) * SP + px + 1] = (uint8_t)s;
-    }
+    fast_score_batch<CTP>(tile, sc, lane < pending ? cl[lane] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow);
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
@@ -373,15 +385,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
 // A level that would exceed its capacity is truncated and flagged (levelStart keeps the true count in
 // overflow[frame]); the host turns that into RUMI_E_CAPACITY.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(const DevParams *__restrict__ P, const uint32_t *__restrict__ cellBuf,
+constexpr int kCompactThreads = 1024;
+__global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__restrict__ P, const uint32_t *__restrict__ cellBuf,
                                                  const int32_t *__restrict__ cellCnt, uint32_t *__restrict__ cand,
                                                  int32_t *__restrict__ levelStart, int32_t *__restrict__ overflow) {
     extern __shared__ int sStart[];          // totalCells + 1 exclusive prefix
-    __shared__ int part[256];
+    __shared__ int part[kCompactThreads];
     const int tid = threadIdx.x, frame = blockIdx.x;
     const int nc = P->totalCells;
     const int32_t *cnt = cellCnt + (long long)frame * nc;
-    const int chunk = (nc + 255) / 256;
+    const int chunk = (nc + kCompactThreads - 1) / kCompactThreads;
     int sum = 0;
     for (int k = 0; k < chunk; k++) {
         const int c = tid * chunk + k;
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256) void k_compact(const DevParams *__restrict__ P
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; }
+        for (int i = 0; i < kCompactThreads; i++) { const int t = part[i]; part[i] = run; run += t; }
         sStart[nc] = run;
     }
     __syncthreads();
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256) void k_compact(const DevParams *__restrict__ P
     }
     uint32_t *out = cand + (long long)frame * P->totalCand;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < nc; c += 4) {
+    for (int c = wave; c < nc; c += kCompactThreads / 64) {
         const int n = cnt[c], s0 = sStart[c];
         const uint32_t *in = cellBuf + ((long long)frame * nc + c) * P->maxCellCand;
         for (int k = lane; k < n; k += 64)
@@ -629,13 +642,13 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    // tile | score map | two ballot arrays | ring of pixels that passed the quick test (128 x uint16)
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 128 * 2 + 15) & ~15;
+    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (192 x uint16)
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 192 * 2 + 15) & ~15;
     hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(256), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
+    hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
                        cand, levelStart, overflow);
 }
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int level, int nframes, hipStream_t st) {
