@@ -88,6 +88,8 @@ MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_de
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba",
                "rumi_opt_stage_ms"]
 
+VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_transform_features",
+               "rumi_voc_transform_batch_device", "rumi_voc_transform"]
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_sort_device", "rumi_hook_std_sort", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
                 "rumi_hook_fast_atan2", "rumi_hook_cv_round", "rumi_hook_magic_div"]
 

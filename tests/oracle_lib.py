@@ -333,3 +333,41 @@ def search_by_sim3(k1, d1, k2, d2, w, h, sf, log_sf, K4, side1, side2, th):
     n = _mlib().orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), 0.0, 0.0, float(w), float(h), _p(sf), len(sf), float(log_sf), _p(K),
                                    *[_p(x) for x in a], *[_p(x) for x in b], float(th), _p(out))
     return n, out
+
+
+class OracleVocabulary:
+    """DBoW2 vocabulary tree + transform restated on the CPU (oracle/voc_oracle.cc)."""
+
+    def __init__(self, parent, is_leaf, desc, weight, weighting=0, scoring=0):
+        L = lib()
+        vp, i32 = C.c_void_p, C.c_int32
+        L.orc_voc_create.restype = vp
+        L.orc_voc_create.argtypes = [i32, vp, vp, vp, vp, i32, i32]
+        L.orc_voc_destroy.argtypes = [vp]
+        L.orc_voc_transform_features.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.orc_voc_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        self._L = L
+        a = [np.ascontiguousarray(parent, np.int32), np.ascontiguousarray(is_leaf, np.uint8), np.ascontiguousarray(desc, np.uint8),
+             np.ascontiguousarray(weight, np.float64)]
+        self._h = L.orc_voc_create(len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(weighting), int(scoring))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_voc_destroy(self._h)
+            self._h = None
+
+    def transform_features(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = len(d)
+        word, node, w = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        self._L.orc_voc_transform_features(self._h, _p(d), n, int(levelsup), _p(word), _p(w), _p(node))
+        return word, w, node
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = len(d)
+        bi, bv = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fn, fo, fi = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+        nw, nn = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        self._L.orc_voc_transform(self._h, _p(d), n, int(levelsup), _p(bi), _p(bv), _p(nw), _p(fn), _p(fo), _p(fi), _p(nn))
+        return (bi[:nw[0]].copy(), bv[:nw[0]].copy()), (fn[:nn[0]].copy(), fo[:nn[0] + 1].copy(), fi[:fo[nn[0]]].copy())

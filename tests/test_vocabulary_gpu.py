@@ -1,0 +1,89 @@
+"""GPU parity of the bag-of-words transform (DBoW2 tree descent + BowVector / FeatureVector assembly) against the CPU oracle:
+word ids, node ids and the FeatureVector bit-exact; BowVector values bit-identical doubles (same additions in the same order)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from voc_scene import synthetic_vocabulary, write_text
+
+pytestmark = pytest.mark.gpu
+
+
+def _features(voc, rng, n):
+    """Descriptors near random leaves (plus pure noise), with duplicates so that words repeat inside one frame."""
+    parent, leaf, desc, weight = voc
+    leaves = np.nonzero(leaf)[0]
+    pick = desc[rng.choice(leaves, n)].copy()
+    for i in range(n):
+        for b in rng.integers(0, 256, int(rng.integers(0, 30))):
+            pick[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    pick[rng.random(n) < 0.1] = rng.integers(0, 256, (int((rng.random(n) < 0.1).sum()) or 1, 32), dtype=np.uint8)[0]
+    return pick
+
+
+@pytest.mark.parametrize("seed,k,L,ragged,levelsup", [(0, 10, 3, False, 1), (1, 10, 4, False, 2), (2, 7, 4, True, 2), (3, 16, 3, True, 4), (4, 20, 2, False, 0)])
+def test_transform_matches_oracle(seed, k, L, ragged, levelsup):
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary(seed, k, L, ragged)
+    g, o = ORBVocabulary(*voc), O.OracleVocabulary(*voc)
+    assert g.size() == int(voc[1].sum())
+    rng = np.random.default_rng(100 + seed)
+    d = _features(voc, rng, 1500)
+    w1, v1, n1 = g.transform_features(d, levelsup)
+    w2, v2, n2 = o.transform_features(d, levelsup)
+    assert np.array_equal(w1, w2) and np.array_equal(n1, n2) and np.array_equal(v1, v2)
+    (bi, bv), (fn, fo, fi) = g.transform(d, levelsup)
+    (bi2, bv2), (fn2, fo2, fi2) = o.transform(d, levelsup)
+    assert len(bi2) > 50 and len(bi2) < len(d), "words must repeat inside the frame for the sum order to matter"
+    assert np.array_equal(bi, bi2) and bv.tobytes() == bv2.tobytes()
+    assert np.array_equal(fn, fn2) and np.array_equal(fo, fo2) and np.array_equal(fi, fi2)
+    assert abs(bv.sum() - 1.0) < 1e-12                                   # L1-normalised
+
+
+@pytest.mark.parametrize("weighting,scoring", [(1, 0), (2, 1), (3, 5), (0, 5), (0, 1)])
+def test_weighting_and_scoring_variants(weighting, scoring):
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary(9, 8, 3)
+    g, o = ORBVocabulary(*voc, weighting=weighting, scoring=scoring), O.OracleVocabulary(*voc, weighting=weighting, scoring=scoring)
+    d = _features(voc, np.random.default_rng(5), 800)
+    (bi, bv), fv = g.transform(d, 2)
+    (bi2, bv2), fv2 = o.transform(d, 2)
+    assert np.array_equal(bi, bi2) and bv.tobytes() == bv2.tobytes()
+    for a, b in zip(fv, fv2):
+        assert np.array_equal(a, b)
+
+
+def test_text_file_loader_and_empty_input(tmp_path):
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary(3, 5, 3)
+    write_text(tmp_path / "voc.txt", voc, 5, 3)
+    g, o = ORBVocabulary(path=tmp_path / "voc.txt"), O.OracleVocabulary(*voc)
+    d = _features(voc, np.random.default_rng(1), 300)
+    a, b = g.transform(d, 1), o.transform(d, 1)
+    assert np.array_equal(a[0][0], b[0][0]) and a[0][1].tobytes() == b[0][1].tobytes()
+    (bi, bv), (fn, fo, fi) = g.transform(np.zeros((0, 32), np.uint8))
+    assert len(bi) == 0 and len(fn) == 0 and list(fo) == [0]
+
+
+def test_batch_transform_feeds_search_by_bow():
+    """Rumination batch: extract_batch -> transform_batch (all frames in one launch) == per-frame oracle transform; the
+    resulting FeatureVectors drive SearchByBoW with the same matches as the oracle's."""
+    import torch
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.synth import synth_frame, warp_frame
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary(11, 10, 3)
+    g, o = ORBVocabulary(*voc), O.OracleVocabulary(*voc)
+    img0 = synth_frame(31)
+    img1, _ = warp_frame(img0, 32)
+    frames = torch.from_numpy(np.stack([img0, img1, synth_frame(33)])).cuda()
+    ext = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=3)
+    kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=1100)
+    word, w, node = g.transform_batch(desc, counts, levelsup=2)
+    torch.cuda.synchronize()
+    for f in range(3):
+        n = int(counts[f, 0])
+        w2, v2, n2 = o.transform_features(desc[f, :n].cpu().numpy(), 2)
+        assert np.array_equal(word[f, :n].cpu().numpy().view(np.uint32), w2)
+        assert np.array_equal(node[f, :n].cpu().numpy().view(np.uint32), n2)
+        assert np.array_equal(w[f, :n].cpu().numpy(), v2)
