@@ -1,7 +1,7 @@
 /* rumi_voc.h — C ABI of the MI355X bag-of-words transform.
  *
  * Replaces, for the hot call `mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)` of Frame::ComputeBoW /
- * KeyFrame::ComputeBoW (R/lib_src/Frame.cc:763-768, KeyFrame.cc:305-313):
+ * KeyFrame::ComputeBoW (R/lib_src/Frame.cc:763-768, KeyFrame.cc:245-252):
  *   DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
  *     R/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1126-1199, the per-feature tree descent :1217-1260,
  *   DBoW2::FORB::distance               R/Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101,

@@ -1,4 +1,4 @@
-// Facade for the one call the hot path makes on the vocabulary (R/lib_src/Frame.cc:763-768, KeyFrame.cc:305-313):
+// Facade for the one call the hot path makes on the vocabulary (R/lib_src/Frame.cc:763-768, KeyFrame.cc:245-252):
 //     mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4);
 // Class surface: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (R/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:33-290),
 // typedef'd to ORBVocabulary in R/include/cloud_edge_slam_lib/ORBVocabulary.h.  The tree descent runs on the GPU
