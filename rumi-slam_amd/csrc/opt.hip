@@ -81,29 +81,46 @@ __device__ __forceinline__ bool chol6_solve(const double *H /*upper 21, row-majo
 struct PoseArgs {
     const int32_t *start;
     const float *Xw, *obs, *w, *K4;
-    float *Tcw7;
+    const float *Tin;     // initial poses [nbatch][7]
+    float *Tout;          // optimised poses [nbatch][7] (left as Tin where the reference returns early)
     uint8_t *outlier;
     int32_t *nGood;
     uint8_t *active;      // scratch, one per correspondence
     double *lastChi2;     // scratch, one per correspondence
+    int skipSmall;        // the global-memory instantiation leaves the frames the LDS instantiation solves
 };
 
+// LDS = true (frames of up to kPoseLdsEdges correspondences): the edge data, the active flags and the last chi2 of every edge
+// live in LDS for the whole solve, so none of the ~60 passes over the edges waits for global memory.
+constexpr int kPoseLdsEdges = 1024;
+template <bool LDS>
 __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
     __shared__ double red[4 * 28];
-    __shared__ double bc[16];          // broadcast: trial pose (7), ok flag
+    __shared__ float sXw[LDS ? 3 * kPoseLdsEdges : 1], sObs[LDS ? 2 * kPoseLdsEdges : 1], sW[LDS ? kPoseLdsEdges : 1];
+    __shared__ double sChi[LDS ? kPoseLdsEdges : 1];
+    __shared__ uint8_t sAct[LDS ? kPoseLdsEdges : 1];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int s0 = A.start[b], n = A.start[b + 1] - s0;
-    const float *Xw = A.Xw + (size_t)s0 * 3, *obs = A.obs + (size_t)s0 * 2, *wgt = A.w + s0;
-    uint8_t *outlier = A.outlier + s0, *active = A.active + s0;
-    double *lastChi2 = A.lastChi2 + s0;
+    if (LDS && n > kPoseLdsEdges) return;                                  // such frames are solved by the global-memory instantiation
+    if (!LDS && n <= kPoseLdsEdges && A.skipSmall) return;
+    const float *Xw = LDS ? sXw : A.Xw + (size_t)s0 * 3, *obs = LDS ? sObs : A.obs + (size_t)s0 * 2, *wgt = LDS ? sW : A.w + s0;
+    uint8_t *outlier = A.outlier + s0, *active = LDS ? sAct : A.active + s0;
+    double *lastChi2 = LDS ? sChi : A.lastChi2 + s0;
+    if (LDS) {
+        for (int i = tid; i < 3 * n; i += 256) sXw[i] = A.Xw[(size_t)s0 * 3 + i];
+        for (int i = tid; i < 2 * n; i += 256) sObs[i] = A.obs[(size_t)s0 * 2 + i];
+        for (int i = tid; i < n; i += 256) sW[i] = A.w[s0 + i];
+    }
     for (int i = tid; i < n; i += 256) { outlier[i] = 0; active[i] = 1; }
-    if (n < 3) {                                                            // Optimizer.cc:899-900
+    if (LDS) __syncthreads();
+    if (n < 3) {                                                            // Optimizer.cc:899-900: returns 0, pose untouched
         if (tid == 0) A.nGood[b] = 0;
+        if (tid < 7) A.Tout[(size_t)b * 7 + tid] = A.Tin[(size_t)b * 7 + tid];
         return;
     }
     const DCam cam{A.K4[0], A.K4[1], A.K4[2], A.K4[3]};
     const double delta = (double)(float)sqrt(5.991), dsqr = delta * delta;  // const float deltaMono = sqrt(5.991)
-    const DSE3 T0 = se3_from_float7(A.Tcw7 + (size_t)b * 7);
+    const DSE3 T0 = se3_from_float7(A.Tin + (size_t)b * 7);
     DSE3 T = T0;
     bool robust = true;
     int nBadRound = 0;
@@ -141,17 +158,19 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
             double lambda = -1, ni = 2;
             int nBad = 0;
             for (int itl = 0; itl < 10; itl++) {
-                double currentChi = robust_chi2(T);
-                const double iniChi = currentChi;
-                double hb[27];                                             // buildSystem: 21 upper entries of H, 6 of b
+                // computeActiveErrors + activeRobustChi2 and buildSystem evaluate every edge at the same estimate: one pass, the
+                // robust chi2 rides along as the 28th reduced value (same per-edge values, same reduction tree as robust_chi2)
+                double hb[28];                                             // 21 upper entries of H, 6 of b, robust chi2
 #pragma unroll
-                for (int k = 0; k < 27; k++) hb[k] = 0;
+                for (int k = 0; k < 28; k++) hb[k] = 0;
                 for (int i = tid; i < n; i += 256) {
                     if (!active[i]) continue;
                     double e0, e1; D3 pc;
                     const double c = edge_chi2(i, T, e0, e1, pc);
+                    lastChi2[i] = c;
                     double r0 = c, r1 = 1;
                     if (robust) huber(c, delta, dsqr, r0, r1);
+                    hb[27] += r0;
                     double J0[6], J1[6];
                     jac_pose(cam, pc, J0, J1);
                     const double w = (double)wgt[i], rw = r1 * w;
@@ -164,7 +183,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                     for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
                 }
-                block_sum<27>(hb, red);
+                block_sum<28>(hb, red);
+                double currentChi = hb[27];
+                const double iniChi = currentChi;
                 if (itl == 0) {                                            // computeLambdaInit: tau * max |H_jj|
                     double m = 0;
                     int p = 0;
@@ -217,10 +238,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
         if (n < 10) break;                                                 // optimizer.edges().size() < 10
     }
     if (tid == 0) {
-        se3_to_float7(T, A.Tcw7 + (size_t)b * 7);
+        se3_to_float7(T, A.Tout + (size_t)b * 7);
         A.nGood[b] = n - nBadRound;
     }
-    (void)bc;
 }
 
 // ==================================================================================================================
@@ -650,6 +670,7 @@ struct RumiOptimizer {
     int npCap = 0;
     uint8_t *dErase = nullptr;
     double *hScal = nullptr;
+    uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     float stageMs[8] = {0};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -669,6 +690,10 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
                  o->dAglob, o->dErase, o->dYt, o->dG, o->dLp};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->hScal) (void)hipHostFree(o->hScal);
+    if (o->hPose) (void)hipHostFree(o->hPose);
+    if (o->hPoseOut) (void)hipHostFree(o->hPoseOut);
+    if (o->dPoseIn) (void)hipFree(o->dPoseIn);
+    if (o->dPoseOut) (void)hipFree(o->dPoseOut);
     for (auto &e : o->ev) if (e) (void)hipEventDestroy(e);
     delete o;
 }
@@ -702,6 +727,15 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     TRYA(oalloc(&o->dYt, 3 * M * (size_t)o->npCap)); TRYA(oalloc(&o->dG, (size_t)o->npCap * o->npCap)); TRYA(oalloc(&o->dLp, M * 6));
 #undef TRYA
     if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    {
+        const size_t inCap = (PB + 1) * 4 + 16 + PB * 28 + PE * 24 + 256, outCap = PB * 32 + PE + 256;
+        if (hipHostMalloc((void **)&o->hPose, inCap, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&o->hPoseOut, outCap, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&o->dPoseIn, inCap) != hipSuccess || hipMalloc((void **)&o->dPoseOut, outCap) != hipSuccess) {
+            rumi_opt_destroy(o);
+            return RUMI_E_NO_DEVICE;
+        }
+    }
     for (auto &e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
     *out = o;
     return RUMI_OK;
@@ -721,24 +755,31 @@ extern "C" int rumi_pose_optimization_batch(RumiOptimizer *o, int32_t nbatch, co
     if (nbatch > o->maxPoseBatch || total > o->maxPoseEdges) { g_lastError = "pose optimisation: batch larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
     if (total > 0 && (!Xw || !obs || !inv_sigma2 || !outlier_out)) return RUMI_E_INVALID;
     HIP_TRY(hipSetDevice(o->device));
-    HIP_TRY(hipMemcpy(o->dStart, start, (size_t)(nbatch + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    // one pinned block up: [start | K4 | T | Xw | obs | w]; one block back: [nGood | T | outlier]
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t oStart = 0, oK = al(oStart + (size_t)(nbatch + 1) * 4), oT = al(oK + 16), oX = al(oT + (size_t)nbatch * 28),
+                 oO = al(oX + (size_t)total * 12), oW = al(oO + (size_t)total * 8), inBytes = al(oW + (size_t)total * 4);
+    const size_t rG = 0, rT = al(rG + (size_t)nbatch * 4), rO = al(rT + (size_t)nbatch * 28), outBytes = al(rO + (size_t)total);
+    uint8_t *hs = o->hPose;
+    std::memcpy(hs + oStart, start, (size_t)(nbatch + 1) * 4);
+    std::memcpy(hs + oK, K4, 16);
+    std::memcpy(hs + oT, Tcw7, (size_t)nbatch * 28);
     if (total > 0) {
-        HIP_TRY(hipMemcpy(o->dXw, Xw, (size_t)total * 3 * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(o->dObs, obs, (size_t)total * 2 * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(o->dW, inv_sigma2, (size_t)total * sizeof(float), hipMemcpyHostToDevice));
+        std::memcpy(hs + oX, Xw, (size_t)total * 12); std::memcpy(hs + oO, obs, (size_t)total * 8); std::memcpy(hs + oW, inv_sigma2, (size_t)total * 4);
     }
-    HIP_TRY(hipMemcpy(o->dK, K4, 4 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(o->dT7, Tcw7, (size_t)nbatch * 7 * sizeof(float), hipMemcpyHostToDevice));
-    PoseArgs A{o->dStart, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dNGood, o->dActive, o->dLastChi2};
-    hipLaunchKernelGGL(k_pose_opt, dim3(nbatch), dim3(256), 0, nullptr, A);
+    HIP_TRY(hipMemcpyAsync(o->dPoseIn, hs, inBytes, hipMemcpyHostToDevice, nullptr));
+    uint8_t *di = o->dPoseIn, *dout = o->dPoseOut;
+    PoseArgs A{(const int32_t *)(di + oStart), (const float *)(di + oX), (const float *)(di + oO), (const float *)(di + oW), (const float *)(di + oK),
+               (const float *)(di + oT), (float *)(dout + rT), dout + rO, (int32_t *)(dout + rG), o->dActive, o->dLastChi2, 1};
+    bool anyBig = false, anySmall = false;
+    for (int b = 0; b < nbatch; b++) { const int nb = start[b + 1] - start[b]; anyBig |= nb > kPoseLdsEdges; anySmall |= nb <= kPoseLdsEdges; }
+    if (anySmall) hipLaunchKernelGGL(k_pose_opt<true>, dim3(nbatch), dim3(256), 0, nullptr, A);
+    if (anyBig) hipLaunchKernelGGL(k_pose_opt<false>, dim3(nbatch), dim3(256), 0, nullptr, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(n_good_out, o->dNGood, (size_t)nbatch * sizeof(int32_t), hipMemcpyDeviceToHost));
-    // the reference leaves the pose untouched when it returns early with < 3 correspondences
-    std::vector<float> T((size_t)nbatch * 7);
-    HIP_TRY(hipMemcpy(T.data(), o->dT7, T.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (int b = 0; b < nbatch; b++)
-        if (start[b + 1] - start[b] >= 3) std::memcpy(Tcw7 + (size_t)b * 7, T.data() + (size_t)b * 7, 7 * sizeof(float));
-    if (total > 0) HIP_TRY(hipMemcpy(outlier_out, o->dOutlier, (size_t)total, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o->hPoseOut, dout, outBytes, hipMemcpyDeviceToHost));
+    std::memcpy(n_good_out, o->hPoseOut + rG, (size_t)nbatch * 4);
+    std::memcpy(Tcw7, o->hPoseOut + rT, (size_t)nbatch * 28);           // early returns (< 3 correspondences) carry the input pose
+    if (total > 0) std::memcpy(outlier_out, o->hPoseOut + rO, (size_t)total);
     return RUMI_OK;
 }
 

@@ -135,6 +135,44 @@ def main():
         "M2_SearchByProjection_frame": {"queries": int(len(s.last_keys)), "gpu_us": round(g2 * 1e6, 1), "cpu_oracle_us": round(c2_ * 1e6, 1)},
         "M3_SearchByBoW": {"queries": int(len(s.last_keys)), "gpu_us": round(g3 * 1e6, 1), "cpu_oracle_us": round(c3 * 1e6, 1)}}
 
+    # ---- one Tracking-thread frame through the host API: extract -> SearchByProjection(Cur, Last) -> PoseOptimization ->
+    #      SearchByProjection(F, local points) -> PoseOptimization (TrackWithMotionModel + TrackLocalMap, Tracking.cc:2434-2560)
+    from rumi_slam_amd.optimizer import Optimizer
+    ext1 = ORBextractor(1000, 1.2, 8, 20, 7)
+    orc1 = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    opt = Optimizer()
+    inv_s2 = ext1.GetInverseScaleSigmaSquares()
+    img = synth_frame(9000)                       # the frame TrackingScene(0) calls "last"; its warped successor is s.cur_*
+    from rumi_slam_amd.synth import warp_frame
+    img_cur, _ = warp_frame(img, 777)
+
+    def track_gpu():
+        _, keys, desc = ext1(img_cur)
+        Fc = FrameView(keys, desc, s.w, s.h, s.sf)
+        nm, cur_mp = m.SearchByProjection_Frame(Fc, *a2[:-1], np.full(Fc.n, -1, np.int32), 15.0)
+        idx = np.nonzero(cur_mp >= 0)[0]
+        ng, T, out = opt.PoseOptimization(s.mp_pos[cur_mp[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_s2[keys["octave"][idx]], K_TUM3, s.Tcw7)
+        n2, fm = m.SearchByProjection_MapPoints(Fc, mp, cur_mp, 3.0)
+        idx = np.nonzero((fm >= 0) & (fm < len(s.mp_pos)))[0]
+        opt.PoseOptimization(s.mp_pos[fm[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_s2[keys["octave"][idx]], K_TUM3, T)
+        return ng
+
+    def track_cpu():
+        _, keys, desc = orc1.extract(img_cur)
+        nm, cur_mp = O.search_by_projection_frame(keys, desc, s.w, s.h, s.sf, *a2[:-1], np.full(len(keys), -1, np.int32), 15.0, True)
+        idx = np.nonzero(cur_mp >= 0)[0]
+        ng, T, out = O.pose_optimization(s.mp_pos[cur_mp[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_s2[keys["octave"][idx]], K_TUM3, s.Tcw7)
+        n2, fm = O.search_by_projection_mappoints(keys, desc, s.w, s.h, s.sf, mp, cur_mp, 3.0, False, 0.0, 0.8)
+        idx = np.nonzero((fm >= 0) & (fm < len(s.mp_pos)))[0]
+        O.pose_optimization(s.mp_pos[fm[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_s2[keys["octave"][idx]], K_TUM3, T)
+        return ng
+
+    assert track_gpu() == track_cpu()
+    tg, tc = median_call(track_gpu, 30), median_call(track_cpu, 5)
+    doc["tracking_frame_host_api"] = {"sequence": "ORBextractor() -> SearchByProjection(Cur,Last) -> PoseOptimization -> SearchByProjection(F, local points) -> PoseOptimization",
+                                      "gpu_ms": round(tg * 1e3, 3), "cpu_oracle_ms": round(tc * 1e3, 2), "gpu_fps": round(1 / tg, 1), "cpu_fps": round(1 / tc, 1),
+                                      "note": "one 640x480 frame, host arrays in and out at every call (PCIe included), python wrapper overhead included on both sides"}
+
     # ---- CPU oracle, all cores (config 5: one frame per thread) ----
     T = args.cpu_threads
     orcs = [O.OracleExtractor(1000, 1.2, 8, 20, 7) for _ in range(T)]
