@@ -65,6 +65,8 @@ struct RumiOrb {
     int16_t *dCoef = nullptr;
     // HBM arenas (sized for max_batch frames unless noted)
     uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame)
+    uint8_t *hIn = nullptr, *hOut1 = nullptr, *dOut1 = nullptr;   // pinned image / pinned + device [counts | kp | desc] block of that API
+    size_t out1Bytes = 0;             // > 0 while rumi_orb_extract wants the block copied back before the call's one synchronisation
     uint8_t *dPyr = nullptr, *dBlur = nullptr;
     uint32_t *dCellBuf = nullptr;    // kChunk frames
     int32_t *dCellCnt = nullptr;
@@ -183,6 +185,9 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (h->evB0) (void)hipEventDestroy(h->evB0);
     if (h->evB1) (void)hipEventDestroy(h->evB1);
     if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
+    if (h->hIn) (void)hipHostFree(h->hIn);
+    if (h->hOut1) (void)hipHostFree(h->hOut1);
+    if (h->dOut1) (void)hipFree(h->dOut1);
     delete h;
 }
 
@@ -242,6 +247,11 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dKp, (size_t)h->capSel));
     TRY_ALLOC(dev_alloc(&h->dDesc, (size_t)h->capSel * 32));
     TRY_ALLOC(dev_alloc(&h->dCounts, 2));
+    TRY_ALLOC(dev_alloc(&h->dOut1, (size_t)16 + (size_t)h->capSel * 60));
+    if (hipHostMalloc((void **)&h->hIn, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->hOut1, (size_t)16 + (size_t)h->capSel * 60, hipHostMallocDefault) != hipSuccess) {
+        rumi_orb_destroy(h); g_lastError = "pinned staging"; return RUMI_E_NO_DEVICE;
+    }
     int maxN = 0;
     for (int l = 0; l < cfg->nlevels; l++) maxN = std::max(maxN, h->tab.featuresPerLevel[l]);
     h->selLevelCap = maxN + 4 * 16 + 8;
@@ -350,7 +360,9 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         }
         h->lastChunkBase = base; h->lastChunkFrames = nf;
     }
-    // One synchronisation per call: the error word and the overflow words of the last chunk.
+    // One synchronisation per call: the error word and the overflow words of the last chunk (and, for the single-frame host
+    // API, its result block).
+    if (h->out1Bytes) HIP_TRY(hipMemcpyAsync(h->hOut1, h->dOut1, h->out1Bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (prof) {
@@ -381,19 +393,24 @@ extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32
     if (!img || w <= 0 || hgt <= 0) return RUMI_E_EMPTY;            // operator() returns -1 on an empty image
     if (stride < w || w > h->cfg.max_width || hgt > h->cfg.max_height) { g_lastError = "image size"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy2D(h->dIn, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)hgt, hipMemcpyHostToDevice));
-    int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, w, (int64_t)w * hgt, lap0, lap1, h->dKp, h->dDesc,
-                                           h->dCounts, h->capSel, nullptr);
+    // image -> pinned -> device (async), kernels, [counts | key-points | descriptors] -> pinned: one synchronisation in all
+    for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+    HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)w * hgt, hipMemcpyHostToDevice, nullptr));
+    int32_t *dC = reinterpret_cast<int32_t *>(h->dOut1);
+    RumiKeyPoint *dK = reinterpret_cast<RumiKeyPoint *>(h->dOut1 + 16);
+    uint8_t *dD = h->dOut1 + 16 + (size_t)h->capSel * sizeof(RumiKeyPoint);
+    h->out1Bytes = (size_t)16 + (size_t)h->capSel * 60;
+    const int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, w, (int64_t)w * hgt, lap0, lap1, dK, dD, dC, h->capSel, nullptr);
+    h->out1Bytes = 0;
     if (rc != RUMI_OK) return rc;
-    int32_t counts[2];
-    HIP_TRY(hipMemcpy(counts, h->dCounts, sizeof counts, hipMemcpyDeviceToHost));
+    const int32_t *counts = reinterpret_cast<const int32_t *>(h->hOut1);
     *n_out = counts[0];
     *mono_out = counts[1];
     if (counts[0] > cap) { g_lastError = "kp_out/desc_out capacity"; return RUMI_E_CAPACITY; }
     if (counts[0] > 0) {
         if (!kp_out || !desc_out) return RUMI_E_INVALID;
-        HIP_TRY(hipMemcpy(kp_out, h->dKp, (size_t)counts[0] * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(desc_out, h->dDesc, (size_t)counts[0] * 32, hipMemcpyDeviceToHost));
+        std::memcpy(kp_out, h->hOut1 + 16, (size_t)counts[0] * sizeof(RumiKeyPoint));
+        std::memcpy(desc_out, h->hOut1 + 16 + (size_t)h->capSel * sizeof(RumiKeyPoint), (size_t)counts[0] * 32);
     }
     return RUMI_OK;
 }
