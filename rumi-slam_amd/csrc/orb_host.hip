@@ -316,7 +316,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     HIP_TRY(hipEventRecord(h->evFork, st));
     HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0));
     if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
-    for (int l = 0; l < P.nlevels; l++) launch_blur(h->dP, P, src, l, nframes, bs);
+    launch_blur(h->dP, P, src, nframes, bs);
     if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
     HIP_TRY(hipEventRecord(h->evJoin, bs));
     HIP_TRY(hipGetLastError());

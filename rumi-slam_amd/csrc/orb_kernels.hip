@@ -444,11 +444,18 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
 // REFLECT_101 frame stored around every level IS the border GaussianBlur(..., BORDER_REFLECT_101) would synthesise.
 constexpr int kBlurRows = 16;
 
-__global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, int level) {
-    const DevLevel &L = P->lv[level];
+// all levels in one launch: workgroup `lin` of a frame belongs to the level whose [base, base + gx * gy) range holds it
+struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; };
+
+__global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
-    const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
+    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = wg / gridDim.x, lin = wg % gridDim.x;
+    int level = 0;
+    for (int l = 1; l < P->nlevels; l++)
+        if (lin >= G.base[l]) level = l;
+    const DevLevel &L = P->lv[level];
+    const int bx = (lin - G.base[level]) % G.gx[level], by = (lin - G.base[level]) / G.gx[level];
     const int xa = bx * 256 + lane * 4;                          // first pixel of my strip
     const int y0 = (by * 4 + wave) * kBlurRows;
     if (y0 >= L.h) return;                                       // whole wave (wave-uniform)
@@ -651,9 +658,16 @@ void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *ce
     hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
                        cand, levelStart, overflow);
 }
-void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int level, int nframes, hipStream_t st) {
-    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kBlurRows - 1) / (4 * kBlurRows), nframes);
-    hipLaunchKernelGGL(k_blur, g, dim3(256), 0, st, dP, src, level);
+void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
+    BlurGrid G{};
+    int run = 0;
+    for (int l = 0; l < hP.nlevels; l++) {
+        G.gx[l] = (hP.lv[l].w + 255) / 256;
+        G.base[l] = run;
+        run += G.gx[l] * ((hP.lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows));
+    }
+    G.base[hP.nlevels] = run;
+    hipLaunchKernelGGL(k_blur, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
 }
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
