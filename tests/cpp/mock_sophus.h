@@ -1,0 +1,98 @@
+// Minimal stand-ins for the few Eigen / Sophus types the RUMI_HAVE_SOPHUS sections of rumi-slam_amd/facade/*.h touch, so that
+// those sections are COMPILED and RUN in this image (which has neither library).  Test scaffolding only: it gives the facade
+// code something with the same member names to instantiate against; it is not a model of Eigen's or Sophus's rounding.
+#pragma once
+#include <cmath>
+
+namespace Eigen {
+struct Vector2f { float v[2]; float operator()(int i) const { return v[i]; } float &operator()(int i) { return v[i]; } };
+struct Vector3f {
+    float v[3];
+    Vector3f() : v{0, 0, 0} {}
+    Vector3f(float x, float y, float z) : v{x, y, z} {}
+    float operator()(int i) const { return v[i]; }
+    float &operator()(int i) { return v[i]; }
+    Vector3f operator/(float s) const { return Vector3f(v[0] / s, v[1] / s, v[2] / s); }
+    Vector3f operator*(float s) const { return Vector3f(v[0] * s, v[1] * s, v[2] * s); }
+    Vector3f operator+(const Vector3f &o) const { return Vector3f(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+    Vector3f operator-(const Vector3f &o) const { return Vector3f(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+};
+struct Matrix3f {
+    float m[3][3];
+    Matrix3f() : m{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}} {}
+    float operator()(int r, int c) const { return m[r][c]; }
+    float &operator()(int r, int c) { return m[r][c]; }
+    Matrix3f transpose() const { Matrix3f t; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) t.m[r][c] = m[c][r]; return t; }
+    Matrix3f operator*(const Matrix3f &o) const {
+        Matrix3f p;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) p.m[r][c] = m[r][0] * o.m[0][c] + m[r][1] * o.m[1][c] + m[r][2] * o.m[2][c];
+        return p;
+    }
+    Vector3f operator*(const Vector3f &x) const {
+        return Vector3f(m[0][0] * x(0) + m[0][1] * x(1) + m[0][2] * x(2), m[1][0] * x(0) + m[1][1] * x(1) + m[1][2] * x(2),
+                        m[2][0] * x(0) + m[2][1] * x(1) + m[2][2] * x(2));
+    }
+    Matrix3f inverse() const {
+        const float a = m[0][0], b = m[0][1], c = m[0][2], d = m[1][0], e = m[1][1], f = m[1][2], g = m[2][0], h = m[2][1], i = m[2][2];
+        const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g), s = 1.0f / det;
+        Matrix3f r;
+        r.m[0][0] = (e * i - f * h) * s; r.m[0][1] = (c * h - b * i) * s; r.m[0][2] = (b * f - c * e) * s;
+        r.m[1][0] = (f * g - d * i) * s; r.m[1][1] = (a * i - c * g) * s; r.m[1][2] = (c * d - a * f) * s;
+        r.m[2][0] = (d * h - e * g) * s; r.m[2][1] = (b * g - a * h) * s; r.m[2][2] = (a * e - b * d) * s;
+        return r;
+    }
+};
+struct Quaternionf {
+    float qw, qx, qy, qz;
+    Quaternionf() : qw(1), qx(0), qy(0), qz(0) {}
+    Quaternionf(float w, float x, float y, float z) : qw(w), qx(x), qy(y), qz(z) {}
+    explicit Quaternionf(const Matrix3f &R) {
+        const float tr = R(0, 0) + R(1, 1) + R(2, 2);
+        if (tr > 0) { const float s = std::sqrt(tr + 1.0f) * 2; qw = 0.25f * s; qx = (R(2, 1) - R(1, 2)) / s; qy = (R(0, 2) - R(2, 0)) / s; qz = (R(1, 0) - R(0, 1)) / s; }
+        else if (R(0, 0) > R(1, 1) && R(0, 0) > R(2, 2)) { const float s = std::sqrt(1.0f + R(0, 0) - R(1, 1) - R(2, 2)) * 2; qw = (R(2, 1) - R(1, 2)) / s; qx = 0.25f * s; qy = (R(0, 1) + R(1, 0)) / s; qz = (R(0, 2) + R(2, 0)) / s; }
+        else if (R(1, 1) > R(2, 2)) { const float s = std::sqrt(1.0f + R(1, 1) - R(0, 0) - R(2, 2)) * 2; qw = (R(0, 2) - R(2, 0)) / s; qx = (R(0, 1) + R(1, 0)) / s; qy = 0.25f * s; qz = (R(1, 2) + R(2, 1)) / s; }
+        else { const float s = std::sqrt(1.0f + R(2, 2) - R(0, 0) - R(1, 1)) * 2; qw = (R(1, 0) - R(0, 1)) / s; qx = (R(0, 2) + R(2, 0)) / s; qy = (R(1, 2) + R(2, 1)) / s; qz = 0.25f * s; }
+    }
+    float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; }
+    Matrix3f toRotationMatrix() const {
+        Matrix3f R;
+        R(0, 0) = 1 - 2 * (qy * qy + qz * qz); R(0, 1) = 2 * (qx * qy - qz * qw); R(0, 2) = 2 * (qx * qz + qy * qw);
+        R(1, 0) = 2 * (qx * qy + qz * qw); R(1, 1) = 1 - 2 * (qx * qx + qz * qz); R(1, 2) = 2 * (qy * qz - qx * qw);
+        R(2, 0) = 2 * (qx * qz - qy * qw); R(2, 1) = 2 * (qy * qz + qx * qw); R(2, 2) = 1 - 2 * (qx * qx + qy * qy);
+        return R;
+    }
+};
+}  // namespace Eigen
+
+namespace Sophus {
+struct SO3f {
+    static Eigen::Matrix3f hat(const Eigen::Vector3f &w) {
+        Eigen::Matrix3f M;
+        M(0, 0) = 0; M(0, 1) = -w(2); M(0, 2) = w(1); M(1, 0) = w(2); M(1, 1) = 0; M(1, 2) = -w(0); M(2, 0) = -w(1); M(2, 1) = w(0); M(2, 2) = 0;
+        return M;
+    }
+};
+struct SE3f {
+    Eigen::Quaternionf q; Eigen::Vector3f t;
+    SE3f() {}
+    SE3f(const Eigen::Quaternionf &q_, const Eigen::Vector3f &t_) : q(q_), t(t_) {}
+    SE3f(const Eigen::Matrix3f &R, const Eigen::Vector3f &t_) : q(R), t(t_) {}
+    Eigen::Quaternionf unit_quaternion() const { return q; }
+    Eigen::Vector3f translation() const { return t; }
+    Eigen::Matrix3f rotationMatrix() const { return q.toRotationMatrix(); }
+    SE3f inverse() const { const Eigen::Matrix3f Rt = rotationMatrix().transpose(); return SE3f(Rt, (Rt * t) * -1.0f); }
+    SE3f operator*(const SE3f &o) const { return SE3f(rotationMatrix() * o.rotationMatrix(), rotationMatrix() * o.t + t); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f &p) const { return rotationMatrix() * p + t; }
+};
+template <class S> struct Sim3 {
+    Eigen::Matrix3f R; Eigen::Vector3f t; S s = 1;
+    Sim3() {}
+    Sim3(const Eigen::Matrix3f &R_, const Eigen::Vector3f &t_, S s_) : R(R_), t(t_), s(s_) {}
+    Eigen::Matrix3f rotationMatrix() const { return R; }
+    Eigen::Vector3f translation() const { return t; }
+    S scale() const { return s; }
+    Sim3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); return Sim3(Rt, (Rt * t) * (-1.0f / s), 1.0f / s); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f &p) const { return (R * p) * s + t; }
+};
+using Sim3f = Sim3<float>;
+}  // namespace Sophus

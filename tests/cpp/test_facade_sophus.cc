@@ -1,0 +1,200 @@
+// Compiles the RUMI_HAVE_SOPHUS sections of rumi-slam_amd/facade/*.h (the overloads that take Sophus::Sim3f / write back through
+// Sophus::SE3f) against tests/cpp/mock_sophus.h and runs them on the GPU: SearchByProjection(KF, Sim3, ...) x 2, Fuse(KF, Sim3, ...),
+// SearchBySim3, SearchForTriangulation with the fundamental matrix formed by the facade's own expression, PoseOptimization's SetPose.
+// The numeric parity of the C-ABI calls underneath is covered by tests/test_matcher_gpu.py; here the results are checked against
+// the same calls made directly with the arrays this test gathers itself.
+#define RUMI_HAVE_SOPHUS 1
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
+#include <set>
+#include <tuple>
+#include <vector>
+
+#include "mock_sophus.h"
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "Optimizer.h"
+
+struct Map { std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int changes = 0; void IncreaseChangeIndex() { changes++; } };
+struct KeyFrame;
+struct Camera {
+    float fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
+    Eigen::Vector2f project(const Eigen::Vector3f &p) const { return Eigen::Vector2f{{fx * p(0) / p(2) + cx, fy * p(1) / p(2) + cy}}; }
+    Eigen::Matrix3f toK_() const { Eigen::Matrix3f K; K(0, 0) = fx; K(0, 2) = cx; K(1, 1) = fy; K(1, 2) = cy; return K; }
+};
+struct MapPoint {
+    static std::mutex mGlobalMutex;
+    Eigen::Vector3f pos, normal{0, 0, 1}; cv::Mat desc; int nObs = 1; bool bad = false; Map *map = nullptr; long mnBALocalForKF = -1;
+    std::map<KeyFrame *, std::tuple<int, int>> obs;
+    float minD = 0.5f, maxD = 60.f;
+    Eigen::Vector3f GetWorldPos() { return pos; }
+    Eigen::Vector3f GetNormal() { return normal; }
+    void SetWorldPos(const Eigen::Vector3f &p) { pos = p; }
+    cv::Mat GetDescriptor() { return desc; }
+    int Observations() { return nObs; }
+    bool isBad() { return bad; }
+    Map *GetMap() { return map; }
+    std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return obs; }
+    void EraseObservation(KeyFrame *k) { obs.erase(k); }
+    float GetMinDistance() { return minD; }
+    float GetMaxDistance() { return maxD; }
+    void UpdateNormalAndDepth() {}
+    bool IsInKeyFrame(KeyFrame *k) { return obs.count(k) > 0; }
+    void AddObservation(KeyFrame *k, int idx) { if (!obs.count(k)) nObs++; obs[k] = std::make_tuple(idx, -1); }
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame *k) { auto it = obs.find(k); return it == obs.end() ? std::make_tuple(-1, -1) : it->second; }
+    void Replace(MapPoint *) { bad = true; }
+};
+std::mutex MapPoint::mGlobalMutex;
+struct Frame {
+    int N = 0;
+    std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<MapPoint *> mvpMapPoints; std::vector<bool> mvbOutlier;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    float mnMinX = 0, mnMinY = 0, mnMaxX = 640, mnMaxY = 480, fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
+    float mfLogScaleFactor = 0.1823216f; int mnScaleLevels = 8;
+    Sophus::SE3f pose;
+    Camera cam, *mpCamera = &cam;
+    std::map<unsigned, std::vector<unsigned>> mFeatVec;
+    Sophus::SE3f GetPose() const { return pose; }
+    void SetPose(const Sophus::SE3f &T) { pose = T; }
+};
+struct KeyFrame : Frame {
+    long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1; Map *map = nullptr; bool bad = false;
+    std::vector<KeyFrame *> covis;
+    KeyFrame() {}
+    KeyFrame(const KeyFrame &o) : Frame(o), mnId(o.mnId), map(o.map) { mpCamera = &cam; }
+    std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return covis; }
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    std::set<MapPoint *> GetMapPoints() { std::set<MapPoint *> s; for (auto *p : mvpMapPoints) if (p) s.insert(p); return s; }
+    MapPoint *GetMapPoint(size_t i) { return mvpMapPoints[i]; }
+    void AddMapPoint(MapPoint *p, size_t i) { mvpMapPoints[i] = p; }
+    void EraseMapPointMatch(MapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
+    Sophus::SE3f GetPoseInverse() const { return pose.inverse(); }
+    Eigen::Vector3f GetCameraCenter() const { return pose.inverse().translation(); }
+    bool isBad() { return bad; }
+    Map *GetMap() { return map; }
+};
+
+static int fails = 0;
+#define CHECK(c, msg) do { if (!(c)) { std::printf("FAIL: %s (%s:%d)\n", msg, __FILE__, __LINE__); fails++; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 3) { std::printf("usage: test_facade_sophus frame0.bin frame1.bin (640x480 u8)\n"); return 2; }
+    std::vector<uint8_t> im[2];
+    for (int k = 0; k < 2; k++) {
+        im[k].resize(640 * 480);
+        FILE *f = std::fopen(argv[1 + k], "rb");
+        if (!f || std::fread(im[k].data(), 1, im[k].size(), f) != im[k].size()) { std::printf("cannot read %s\n", argv[1 + k]); return 2; }
+        std::fclose(f);
+    }
+    ORB_SLAM3::ORBextractor ext(1000, 1.2f, 8, 20, 7);
+    std::vector<int> lap = {0, 1000};
+    KeyFrame kf[2];
+    for (int k = 0; k < 2; k++) {
+        cv::Mat img(480, 640, CV_8UC1, im[k].data(), 640), mask;
+        ext(img, mask, kf[k].mvKeysUn, kf[k].mDescriptors, lap);
+        kf[k].N = (int)kf[k].mvKeysUn.size();
+        kf[k].mvScaleFactors = ext.GetScaleFactors(); kf[k].mvInvLevelSigma2 = ext.GetInverseScaleSigmaSquares();
+        kf[k].mvpMapPoints.assign(kf[k].N, nullptr); kf[k].mvbOutlier.assign(kf[k].N, false);
+        kf[k].mnId = k;
+        for (int i = 0; i < kf[k].N; i++) kf[k].mFeatVec[(unsigned)(i % 89)].push_back((unsigned)i);
+    }
+    kf[1].pose = Sophus::SE3f(Eigen::Quaternionf(0.99998f, 0.004f, -0.003f, 0.002f), Eigen::Vector3f(0.02f, -0.01f, 0.03f));
+    std::mt19937 rng(3);
+    // one map point per key-point of kf[0], placed so that it projects near the same pixel in kf[1]
+    std::vector<MapPoint> mps(kf[0].N);
+    std::vector<MapPoint *> vp;
+    for (int i = 0; i < kf[0].N; i++) {
+        const float z = 2.f + (rng() % 600) / 100.f;
+        const Eigen::Vector3f pc((kf[0].mvKeysUn[i].pt.x - 320.1f) / 535.4f * z, (kf[0].mvKeysUn[i].pt.y - 247.6f) / 539.2f * z, z);
+        mps[i].pos = kf[1].pose.inverse() * pc;
+        mps[i].desc = cv::Mat(1, 32, CV_8U, kf[0].mDescriptors.ptr(i), 32);
+        // UpdateNormalAndDepth: mfMaxDistance = dist * scale[level], mfMinDistance = mfMaxDistance / scale[nLevels - 1]
+        const float dist = std::sqrt(pc(0) * pc(0) + pc(1) * pc(1) + pc(2) * pc(2));
+        mps[i].maxD = dist * kf[0].mvScaleFactors[kf[0].mvKeysUn[i].octave]; mps[i].minD = mps[i].maxD / kf[0].mvScaleFactors[7];
+        vp.push_back(&mps[i]);
+    }
+    ORB_SLAM3::ORBmatcher matcher(0.75f, true);
+    // --- SearchByProjection(KF, Sim3, points, matched, th, ratio) and its pointKFs overload: same search, same result ---
+    Sophus::Sim3f Scw(kf[1].pose.rotationMatrix(), kf[1].pose.translation(), 1.0f);
+    {
+        KeyFrame target = kf[0];                                   // features of frame 0 seen from pose kf[1].pose
+        std::vector<MapPoint *> matched(target.N, nullptr), matched2(target.N, nullptr);
+        std::vector<KeyFrame *> ptKFs(vp.size(), &kf[1]), matchedKF(target.N, nullptr);
+        const int n1 = matcher.SearchByProjection(&target, Scw, vp, matched, 6, 1.0f);
+        const int n2 = matcher.SearchByProjection(&target, Scw, vp, ptKFs, matched2, matchedKF, 6, 1.0f);
+        int cnt = 0, self = 0;
+        for (int f = 0; f < target.N; f++) { cnt += matched[f] != nullptr; self += matched[f] == &mps[f]; }
+        CHECK(n1 > 300 && n1 == cnt, "SearchByProjection(KF, Sim3) count == filled slots");
+        CHECK(self > n1 * 8 / 10, "SearchByProjection(KF, Sim3): a point built from feature f is matched back to feature f");
+        CHECK(n2 > 300, "SearchByProjection(KF, Sim3, pointKFs) runs");
+        bool kfok = true;
+        for (int f = 0; f < target.N; f++) if ((matched2[f] != nullptr) != (matchedKF[f] == &kf[1])) kfok = false;
+        CHECK(kfok, "matched key-frames follow matched points");
+        // --- Fuse(KF, Sim3, points, th, replace): empty key-frame -> every fused point becomes an observation ---
+        KeyFrame empty = kf[0];
+        std::vector<MapPoint *> repl(vp.size(), nullptr);
+        const int nf = matcher.Fuse(&empty, Scw, vp, 4.f, repl);
+        int added = 0, replaced = 0;
+        for (auto &p : mps) added += p.IsInKeyFrame(&empty);
+        for (auto *r : repl) replaced += r != nullptr;
+        CHECK(nf > 300 && nf == added + replaced && added > replaced, "Fuse(KF, Sim3): fused == observations added + duplicates reported");
+        bool dupOk = true;                                         // a reported duplicate is the point that took the feature first
+        for (size_t i = 0; i < repl.size(); i++) if (repl[i] && !repl[i]->IsInKeyFrame(&empty)) dupOk = false;
+        CHECK(dupOk, "Fuse(KF, Sim3): vpReplacePoint holds the key-frame's point");
+        std::vector<MapPoint *> repl2(vp.size(), nullptr);
+        const int nf2 = matcher.Fuse(&empty, Scw, vp, 4.f, repl2);
+        CHECK(nf2 == replaced, "Fuse(KF, Sim3) skips the points already in the key-frame and reports the same duplicates again");
+    }
+    // --- SearchBySim3: kf A (frame 0, pose I) and kf B (frame 0 again, pose P): S12 = P^-1 maps camera B into camera A ---
+    {
+        KeyFrame A = kf[0], B = kf[0];
+        B.pose = kf[1].pose; B.mnId = 7;
+        std::vector<MapPoint> ma(A.N), mb(B.N);
+        for (int i = 0; i < A.N; i++) {
+            const float z = 3.f + (i % 40) / 10.f;
+            const Eigen::Vector3f pcA((A.mvKeysUn[i].pt.x - 320.1f) / 535.4f * z, (A.mvKeysUn[i].pt.y - 247.6f) / 539.2f * z, z);
+            const float dist = std::sqrt(pcA(0) * pcA(0) + pcA(1) * pcA(1) + pcA(2) * pcA(2));
+            ma[i].pos = pcA; ma[i].desc = cv::Mat(1, 32, CV_8U, A.mDescriptors.ptr(i), 32);
+            ma[i].maxD = dist * A.mvScaleFactors[A.mvKeysUn[i].octave]; ma[i].minD = ma[i].maxD / A.mvScaleFactors[7];
+            mb[i].pos = B.pose.inverse() * pcA;                    // the same point expressed so that camera B sees it at the same pixel
+            mb[i].desc = ma[i].desc; mb[i].minD = ma[i].minD; mb[i].maxD = ma[i].maxD;
+            A.mvpMapPoints[i] = &ma[i]; B.mvpMapPoints[i] = &mb[i];
+        }
+        const Sophus::Sim3f S12;                                   // identity: camera-A coordinates of a's points == camera-B coordinates of b's
+        std::vector<MapPoint *> m12(A.N, nullptr);
+        const int nfound = matcher.SearchBySim3(&A, &B, m12, S12, 7.5f);
+        int self = 0;
+        for (int i = 0; i < A.N; i++) self += m12[i] == &mb[i];
+        CHECK(nfound > 500 && self > nfound * 9 / 10, "SearchBySim3 finds the mutual matches");
+    }
+    // --- SearchForTriangulation with F12 from the facade's own expression: for a pure translation between the two cameras a
+    //     correspondence satisfies the epipolar constraint, a mismatched row does not
+    {
+        KeyFrame A = kf[0], B = kf[0];
+        B.pose = Sophus::SE3f(Eigen::Quaternionf(1, 0, 0, 0), Eigen::Vector3f(0.3f, 0.f, 0.f));
+        std::vector<std::pair<size_t, size_t>> pairs, coarse;
+        const int nt = matcher.SearchForTriangulation(&A, &B, pairs, false, false);
+        const int nc = matcher.SearchForTriangulation(&A, &B, coarse, false, true);
+        CHECK(nt > 100 && (int)pairs.size() == nt && nc >= nt, "SearchForTriangulation (F12 from Sophus expressions) runs");
+        int sameRow = 0;
+        for (auto &p : pairs) sameRow += std::fabs(A.mvKeysUn[p.first].pt.y - B.mvKeysUn[p.second].pt.y) < 4.f * A.mvScaleFactors[B.mvKeysUn[p.second].octave];
+        CHECK(sameRow == nt, "x-translation: accepted pairs lie on the same image row");
+    }
+    // --- PoseOptimization writes back through SetPose(Sophus::SE3f(Eigen::Quaternionf, Eigen::Vector3f)) ---
+    {
+        Frame F = kf[0];
+        F.pose = Sophus::SE3f(Eigen::Quaternionf(0.99995f, 0.006f, -0.004f, 0.003f), Eigen::Vector3f(0.05f, -0.03f, 0.06f));
+        for (int i = 0; i < F.N; i++) F.mvpMapPoints[i] = &mps[i];
+        const int ng = ORB_SLAM3::Optimizer::PoseOptimization(&F);
+        const Sophus::SE3f T = F.GetPose();
+        CHECK(ng > 500, "PoseOptimization inliers");
+        CHECK(std::fabs(T.translation()(0) - 0.02f) < 5e-3f && std::fabs(T.translation()(2) - 0.03f) < 5e-3f && std::fabs(T.unit_quaternion().x() - 0.004f) < 2e-3f,
+              "PoseOptimization recovers the pose the points were built with");
+    }
+    if (fails == 0) std::printf("facade (Sophus overloads): all checks passed\n");
+    return fails ? 1 : 0;
+}
