@@ -400,15 +400,25 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
         const int c = tid * chunk + k;
         if (c < nc) sum += cnt[c];
     }
-    part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < kCompactThreads; i++) { const int t = part[i]; part[i] = run; run += t; }
-        sStart[nc] = run;
+    // exclusive scan of the per-thread sums: shuffles inside a wave, the 16 wave totals through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
     }
+    if (lane == 63) part[wave] = inc;
     __syncthreads();
-    int run = part[tid];
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactThreads / 64; w++) {
+        const int t = part[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    if (tid == 0) sStart[nc] = total;
+    int run = base + inc - sum;
     for (int k = 0; k < chunk; k++) {
         const int c = tid * chunk + k;
         if (c < nc) { sStart[c] = run; run += cnt[c]; }
@@ -424,12 +434,17 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
         if (sStart[c1] - sStart[c0] > P->lv[tid].candCap) atomicOr(&overflow[frame], 1 << tid);
     }
     uint32_t *out = cand + (long long)frame * P->totalCand;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < nc; c += kCompactThreads / 64) {
-        const int n = cnt[c], s0 = sStart[c];
-        const uint32_t *in = cellBuf + ((long long)frame * nc + c) * P->maxCellCand;
-        for (int k = lane; k < n; k += 64)
-            if (s0 + k < P->totalCand) out[s0 + k] = in[k];
+    // one lane per output element: its cell is the last one whose start is <= j (binary search in the LDS prefix), so every
+    // lane has an independent load in flight instead of a wave walking its cells one round trip at a time
+    const int nOut = min(sStart[nc], P->totalCand);
+    const uint32_t *inBase = cellBuf + (long long)frame * nc * P->maxCellCand;
+    for (int j = tid; j < nOut; j += kCompactThreads) {
+        int lo = 0, hi = nc;                       // invariant: sStart[lo] <= j < sStart[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sStart[mid] <= j) lo = mid; else hi = mid;
+        }
+        out[j] = inBase[(long long)lo * P->maxCellCand + (j - sStart[lo])];
     }
 }
 
