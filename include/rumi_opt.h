@@ -60,6 +60,17 @@ int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t 
                   int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
                   const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats);
 
+/* Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vector<KeyFrame*> vpAdjustKF, vector<KeyFrame*> vpFixedKF, bool *pbStopFlag)
+ * — the merge / welding-window bundle adjustment, R/lib_src/Optimizer.cc:3768-4183 (LoopClosing::MergeLocal, CloudMerging),
+ * monocular edges.  Same flattened graph and the same outputs as rumi_local_ba; what differs is the procedure: optimize(5) with
+ * Huber(sqrt(5.99)), then — unless *stop_flag — edges with chi2 > 5.991 or non-positive depth leave the optimisation (level 1),
+ * the robust kernels are removed and optimize(10) runs again (:3986-4031); erase_out is the final test of :4042-4056.  A graph
+ * without fixed key-frames is accepted, as upstream.  stats = {iterations of the first optimize, LM trials in total, optimised
+ * key-frames, iterations of the second optimize}. */
+int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                  int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                  const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats);
+
 /* Device time of the last rumi_local_ba call by stage, in ms (HIP events):
  * [0] linearise+Hll/Hpl, [1] pose block J^T W J on f64 MFMA, [2] Schur complement, [3] reduced solve, [4] update+chi2, [5] total */
 int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);

@@ -275,8 +275,11 @@ struct BAProblem : LMProblem {
     std::vector<double> Hpp, bp, Hll, bl, Hpl, x, Dinv;  // Hpp: nOpt x 36, Hll: nMP x 9, Hpl: nE x 18 (6x3), x: 6nOpt + 3nMP
     std::vector<std::vector<int>> edgesOfPoint;
     std::vector<double> lastChi2;                 // per edge, as of the last computeActiveErrors()
+    std::vector<uint8_t> level1;                  // edge moved to level 1 (merge BA second pass): not an active edge any more
+    bool robust = true;                           // Huber kernel attached to the edges
 
     void init() {
+        level1.assign(nE, 0);
         poseCol.assign(nKF, -1);
         for (int k = 0; k < nKF; k++) if (!fixedKF[k]) poseCol[k] = nOpt++;
         edgesOfPoint.assign(nMP, {});
@@ -295,7 +298,13 @@ struct BAProblem : LMProblem {
     double robust_chi2() override {
         double chi = 0;
         lastChi2.resize(nE);
-        for (int e = 0; e < nE; e++) { double r[2], rho[3]; lastChi2[e] = edge_err(e, r); huber(lastChi2[e], delta, dsqr, rho); chi += rho[0]; }
+        for (int e = 0; e < nE; e++) {
+            if (level1[e]) continue;                                      // computeActiveErrors() visits active edges only
+            double r[2], rho[3];
+            lastChi2[e] = edge_err(e, r);
+            if (robust) { huber(lastChi2[e], delta, dsqr, rho); chi += rho[0]; }
+            else chi += lastChi2[e];
+        }
         return chi;
     }
     void build() override {
@@ -304,8 +313,9 @@ struct BAProblem : LMProblem {
         for (int e = 0; e < nE; e++) {
             double r[2], rho[3];
             V3 pc;
+            if (level1[e]) continue;
             const double c = edge_err(e, r, &pc);
-            huber(c, delta, dsqr, rho);
+            if (robust) huber(c, delta, dsqr, rho); else { rho[0] = c; rho[1] = 1; rho[2] = 0; }
             const double w = rho[1] * info[e];
             double B[2][6], A[2][3], R[3][3];
             jac_pose(cam, pc, B);                                        // d e / d pose
@@ -478,6 +488,53 @@ int orc_local_ba(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float 
     }
     for (int k = 0; k < nKF; k++) if (!kfFixed[k]) se3_to_float7(P.T[k], kfPose + 7 * k);
     for (int p = 0; p < nMP; p++) { mpPos[3 * p] = (float)P.X[p].x; mpPos[3 * p + 1] = (float)P.X[p].y; mpPos[3 * p + 2] = (float)P.X[p].z; }
+    return its;
+}
+
+// Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vpAdjustKF, vpFixedKF, bool *pbStopFlag), monocular edges
+// (R/lib_src/Optimizer.cc:3768-4183), on the same flattened graph as orc_local_ba.  its2[0] / its2[1] receive the LM iterations
+// of the two optimize() calls.  Returns -1 when the stop flag is already set (:3982-3984).
+int orc_merge_ba(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float *mpPos, int nE, const int32_t *eMP, const int32_t *eKF,
+                 const float *eObs, const float *eInvSigma2, const float *K4, const volatile uint8_t *stop, uint8_t *eraseOut, int32_t *its2) {
+    if (its2) its2[0] = its2[1] = 0;
+    if (stop && *stop) return -1;
+    BAProblem P;
+    P.nKF = nKF; P.nMP = nMP; P.nE = nE; P.fixedKF = kfFixed; P.eMP = eMP; P.eKF = eKF; P.stop = stop;
+    P.T.resize(nKF); P.X.resize(nMP);
+    for (int k = 0; k < nKF; k++) P.T[k] = se3_from_float7(kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) P.X[p] = {mpPos[3 * p], mpPos[3 * p + 1], mpPos[3 * p + 2]};
+    std::vector<double> o(2 * (size_t)nE), w(nE);
+    for (int e = 0; e < nE; e++) { o[2 * e] = eObs[2 * e]; o[2 * e + 1] = eObs[2 * e + 1]; w[e] = eInvSigma2[e]; }
+    P.obs = o.data(); P.info = w.data();
+    P.cam = {K4[0], K4[1], K4[2], K4[3]};
+    const float thHuber2D = (float)std::sqrt(5.99);                       // :3871
+    P.delta = thHuber2D; P.dsqr = P.delta * P.delta;
+    P.init();
+    const int its1 = lm_optimize(P, 5);                                   // :3986-3987
+    int its = its1, itsSecond = 0;
+    const bool bDoMore = !(stop && *stop);
+    if (bDoMore) {                                                        // :3996-4031
+        for (int e = 0; e < nE; e++) {
+            double r[2];
+            V3 pc;
+            P.edge_err(e, r, &pc);
+            const double chi2 = its1 > 0 ? P.lastChi2[e] : P.edge_err(e, r);
+            if (chi2 > 5.991 || !(pc.z > 0.0)) P.level1[e] = 1;           // e->setLevel(1)
+        }
+        P.robust = false;                                                 // e->setRobustKernel(0)
+        itsSecond = lm_optimize(P, 10);                                   // initializeOptimization(0); optimize(10)
+        its += itsSecond;
+    }
+    for (int e = 0; e < nE; e++) {                                        // :4042-4056
+        double r[2];
+        V3 pc;
+        P.edge_err(e, r, &pc);
+        const double chi2 = its > 0 ? P.lastChi2[e] : P.edge_err(e, r);
+        eraseOut[e] = (chi2 > 5.991 || !(pc.z > 0.0)) ? 1 : 0;
+    }
+    for (int k = 0; k < nKF; k++) if (!kfFixed[k]) se3_to_float7(P.T[k], kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) { mpPos[3 * p] = (float)P.X[p].x; mpPos[3 * p + 1] = (float)P.X[p].y; mpPos[3 * p + 2] = (float)P.X[p].z; }
+    if (its2) { its2[0] = its1; its2[1] = itsSecond; }
     return its;
 }
 

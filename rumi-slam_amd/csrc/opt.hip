@@ -257,6 +257,8 @@ struct BADev {
     double delta, dsqr;
     double *Hll, *bl, *Hpl, *panel, *Hpp, *bp, *Dinv, *S, *bs, *x, *lastChi2;
     double *scal;                              // [0] chi2, [1] scale, [2] max diag (as bits), [3] ok flag
+    const uint8_t *off;                        // edge at level 1 (excluded from the optimisation), merge BA second pass
+    int robust;                                // Huber kernel on the edges (off in the merge BA second pass)
 };
 
 __device__ __forceinline__ DSE3 load_pose(const double *T, int k) {
@@ -279,10 +281,12 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BADev B, const double *T, const
         cam_project(B.cam, pc, u, v);
         const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, w = B.info[e];
         const double c = e0 * w * e0 + e1 * w * e1;
-        B.lastChi2[e] = c;
-        double r0, r1;
-        huber(c, B.delta, B.dsqr, r0, r1);
-        acc[0] = r0;
+        if (!B.off[e]) {                                                    // level-1 edges keep the error of their last active pass
+            B.lastChi2[e] = c;
+            double r0 = c, r1 = 1;
+            if (B.robust) huber(c, B.delta, B.dsqr, r0, r1);
+            acc[0] = r0;
+        }
     }
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) atomicAdd(&B.scal[0], acc[0]);
@@ -298,8 +302,19 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
     cam_project(B.cam, pc, u, v);
     const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, info = B.info[e];
     const double c = e0 * info * e0 + e1 * info * e1;
-    double r0, r1;
-    huber(c, B.delta, B.dsqr, r0, r1);
+    if (B.off[e]) {                                                         // inactive edge: contributes nothing to H, b, Y
+        const int slot0 = B.rowSlot[e];
+        if (slot0 >= 0) {
+            double *hp = B.Hpl + (size_t)e * 18, *rp = B.panel + (size_t)slot0 * 8;
+#pragma unroll
+            for (int k = 0; k < 18; k++) hp[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) rp[k] = 0;
+        }
+        return;
+    }
+    double r0 = c, r1 = 1;
+    if (B.robust) huber(c, B.delta, B.dsqr, r0, r1);
     const double w = r1 * info;
     double J0[6], J1[6], R[3][3], A0[3], A1[3];
     jac_pose(B.cam, pc, J0, J1);
@@ -633,6 +648,15 @@ __global__ __launch_bounds__(256) void k_ba_update(BADev B, double lambda, const
     if (threadIdx.x == 0 && acc[0] != 0.0) atomicAdd(&B.scal[1], acc[0]);
 }
 
+// merge BA, between its two optimisations (Optimizer.cc:3996-4010): edges with chi2 > 5.991 or non-positive depth go to level 1
+__global__ void k_ba_mark(BADev B, const double *T, const double *X, uint8_t *off) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B.nE) return;
+    const int p = B.eMP[e];
+    const D3 pc = se3_map(load_pose(T, B.eKF[e]), D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
+    off[e] = (B.lastChi2[e] > 5.991 || !(pc.z > 0.0)) ? 1 : 0;
+}
+
 __global__ void k_ba_finalize(BADev B, const double *T, const double *X, int useLast, uint8_t *erase) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B.nE) return;
@@ -659,7 +683,7 @@ struct RumiOptimizer {
     // pose optimisation
     int32_t *dStart = nullptr, *dNGood = nullptr;
     float *dXw = nullptr, *dObs = nullptr, *dW = nullptr, *dK = nullptr, *dT7 = nullptr;
-    uint8_t *dOutlier = nullptr, *dActive = nullptr;
+    uint8_t *dOutlier = nullptr, *dActive = nullptr, *dEOff = nullptr;
     double *dLastChi2 = nullptr;
     // BA
     int32_t *dEMP = nullptr, *dEKF = nullptr, *dPoseCol = nullptr, *dPtStart = nullptr, *dPtEdge = nullptr, *dRowSlot = nullptr,
@@ -687,7 +711,7 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     void *p[] = {o->dStart, o->dNGood, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dActive, o->dLastChi2, o->dEMP, o->dEKF,
                  o->dPoseCol, o->dPtStart, o->dPtEdge, o->dRowSlot, o->dKfRowStart, o->dObsD, o->dInfo, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
-                 o->dAglob, o->dErase, o->dYt, o->dG, o->dLp};
+                 o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hPose) (void)hipHostFree(o->hPose);
@@ -723,7 +747,7 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     TRYA(oalloc(&o->dHpp, K * 36)); TRYA(oalloc(&o->dBp, N)); TRYA(oalloc(&o->dDinv, M * 9)); TRYA(oalloc(&o->dS, N * N));
     TRYA(oalloc(&o->dBs, N)); TRYA(oalloc(&o->dXv, N + M * 3)); TRYA(oalloc(&o->dChi, E)); TRYA(oalloc(&o->dScal, 8));
     o->npCap = (int)std::min<size_t>((N + 1 + 15) / 16 * 16, 256);
-    TRYA(oalloc(&o->dAglob, (N + 2) * (N + 2) + 2 * N)); TRYA(oalloc(&o->dErase, E));
+    TRYA(oalloc(&o->dAglob, (N + 2) * (N + 2) + 2 * N)); TRYA(oalloc(&o->dErase, E)); TRYA(oalloc(&o->dEOff, E));
     TRYA(oalloc(&o->dYt, 3 * M * (size_t)o->npCap)); TRYA(oalloc(&o->dG, (size_t)o->npCap * o->npCap)); TRYA(oalloc(&o->dLp, M * 6));
 #undef TRYA
     if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
@@ -790,9 +814,13 @@ extern "C" int rumi_pose_optimization(RumiOptimizer *o, const float *Xw, const f
     return rumi_pose_optimization_batch(o, 1, start, Xw, obs, inv_sigma2, K4, Tcw7, outlier_out, n_good_out);
 }
 
-extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
-                             int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
-                             const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
+// mode 0: Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, ...) — one optimize(10) with Huber(sqrt(5.991)).
+// mode 1: Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vpAdjustKF, vpFixedKF, bool*) (merge window, Optimizer.cc:3768-4183) —
+//         optimize(5) with Huber(sqrt(5.99)); unless stopped: outlier edges to level 1, kernels off, initializeOptimization(0) +
+//         optimize(10); the erase test reads every edge's stored error (level-1 edges: the one they had when they left).
+static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                  int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                  const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
     if (!o || nKF < 1 || nMP < 0 || nE < 0 || !kf_pose7 || !kf_fixed || !K4 || (nMP > 0 && !mp_pos3) ||
         (nE > 0 && (!e_mp || !e_kf || !e_obs || !e_inv_sigma2 || !erase_out)))
         return RUMI_E_INVALID;
@@ -800,7 +828,7 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     int nFixed = 0;
     for (int k = 0; k < nKF; k++) nFixed += kf_fixed[k] ? 1 : 0;
-    if (nFixed == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
+    if (nFixed == 0 && mode == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
     if (stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                                     // :1274-1276
     for (int e = 0; e < nE; e++)
         if (e_mp[e] < 0 || e_mp[e] >= nMP || e_kf[e] < 0 || e_kf[e] >= nKF) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
@@ -841,7 +869,10 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
     B.eMP = o->dEMP; B.eKF = o->dEKF; B.poseCol = o->dPoseCol; B.ptStart = o->dPtStart; B.ptEdge = o->dPtEdge; B.rowSlot = o->dRowSlot;
     B.kfRowStart = o->dKfRowStart; B.obs = o->dObsD; B.info = o->dInfo;
     B.cam = DCam{K4[0], K4[1], K4[2], K4[3]};
-    B.delta = (double)(float)std::sqrt(5.991); B.dsqr = B.delta * B.delta;          // const float thHuberMono = sqrt(5.991)
+    B.delta = mode == 0 ? (double)(float)std::sqrt(5.991) : (double)(float)std::sqrt(5.99);   // thHuberMono = sqrt(5.991) / thHuber2D = sqrt(5.99)
+    B.dsqr = B.delta * B.delta;
+    B.off = o->dEOff; B.robust = 1;
+    if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, nullptr));
     B.Hll = o->dHll; B.bl = o->dBl; B.Hpl = o->dHpl; B.panel = o->dPanel; B.Hpp = o->dHpp; B.bp = o->dBp; B.Dinv = o->dDinv; B.S = o->dS;
     B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
 
@@ -867,11 +898,12 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
     if (nMP > 0) HIP_TRY(hipMemsetAsync(o->dYt, 0, (size_t)K3 * NP * sizeof(double), st));   // pattern of Y is fixed: zero once, live entries are rewritten per trial
     HIP_TRY(hipEventRecord(o->ev[0], st));
     int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
+    bool ranChi2 = false;
+    auto lm = [&](int maxIt) -> int {                       // g2o optimize(maxIt)
     double lambda = -1, ni = 2;
     int nBad = 0;
-    bool ranChi2 = false;
     double currentChi = 0;
-    for (int it = 0; it < 10 && !(stop_flag && *stop_flag); it++) {
+    for (int it = 0; it < maxIt && !(stop_flag && *stop_flag); it++) {
         // g2o recomputes the active errors here; the value is already known after the first iteration (an accepted trial
         // left it in tempChi, a rejected one did not change the state), so only the first iteration launches the kernel.
         if (it == 0 && (rc = chi2_of(cur, &currentChi)) != RUMI_OK) return rc;
@@ -938,6 +970,16 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) break;
     }
+    return RUMI_OK;
+    };
+    int itersFirst = 0;
+    if ((rc = lm(mode == 0 ? 10 : 5)) != RUMI_OK) return rc;
+    itersFirst = iters;
+    if (mode == 1 && !(stop_flag && *stop_flag)) {          // bDoMore
+        if (nE > 0 && ranChi2) hipLaunchKernelGGL(k_ba_mark, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], o->dEOff);
+        B.robust = 0;
+        if ((rc = lm(10)) != RUMI_OK) return rc;
+    }
     if (nE > 0) hipLaunchKernelGGL(k_ba_finalize, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dErase);
     HIP_TRY(hipEventRecord(o->ev[1], st));
     HIP_TRY(hipGetLastError());
@@ -952,6 +994,18 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
         se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
     }
     for (size_t i = 0; i < X1.size(); i++) mp_pos3[i] = (float)X1[i];
-    if (stats) { stats[0] = iters; stats[1] = trials; stats[2] = nOpt; stats[3] = 0; }
+    if (stats) { stats[0] = mode == 0 ? iters : itersFirst; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 0 ? 0 : iters - itersFirst; }
     return RUMI_OK;
+}
+
+extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                             int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                             const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
+    return ba_run(o, 0, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats);
+}
+
+extern "C" int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                             int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                             const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
+    return ba_run(o, 1, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats);
 }

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import capi
 
-OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba",
+OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba",
                "rumi_opt_stage_ms"]
 
 
@@ -21,6 +21,7 @@ def _lib():
     L.rumi_pose_optimization.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.rumi_pose_optimization_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_local_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
     L._opt_ready = True
     return L
@@ -62,7 +63,7 @@ class Optimizer:
                                                           capi.ptr(T), capi.ptr(out), capi.ptr(ng)))
         return ng, T, out[:len(w)]
 
-    def LocalBundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag=None):
+    def LocalBundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag=None, merge=False):
         """Returns (stats[4], kf_pose, mp_pos, erase[nE])."""
         kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
         mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32)
@@ -71,9 +72,14 @@ class Optimizer:
         erase = np.zeros(max(len(em), 1), np.uint8)
         stats = np.zeros(4, np.int32)
         sp = capi.ptr(stop_flag) if stop_flag is not None else None
-        capi.check(self._lib.rumi_local_ba(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
-                                           capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
+        fn = self._lib.rumi_merge_ba if merge else self._lib.rumi_local_ba
+        capi.check(fn(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
+                      capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
         return stats, kp, mp, erase[:len(em)]
+
+    def MergeBundleAdjustment(self, *args, **kw):
+        """Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag): the two-pass merge-window BA."""
+        return self.LocalBundleAdjustment(*args, merge=True, **kw)
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)

@@ -23,6 +23,8 @@ int orc_search_by_projection_frame(const orc::KeyPoint *, const uint8_t *, int, 
 int orc_pose_optimization(const float *, const float *, const float *, int, const float *, float *, uint8_t *);
 int orc_local_ba(int, float *, const uint8_t *, int, float *, int, const int32_t *, const int32_t *, const float *, const float *, const float *,
                  const volatile uint8_t *, uint8_t *);
+int orc_merge_ba(int, float *, const uint8_t *, int, float *, int, const int32_t *, const int32_t *, const float *, const float *, const float *,
+                 const volatile uint8_t *, uint8_t *, int32_t *);
 }
 
 // ---- mock data model: only the members the facades touch, named as in the reference ----
@@ -33,7 +35,7 @@ struct Map { std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int ch
 struct KeyFrame;
 struct MapPoint {
     static std::mutex mGlobalMutex;
-    V3f pos; cv::Mat desc; int nObs = 1; bool bad = false; Map *map = nullptr; long mnBALocalForKF = -1;
+    V3f pos; cv::Mat desc; int nObs = 1; bool bad = false; Map *map = nullptr; long mnBALocalForKF = -1, mnBALocalForMerge = -1;
     std::map<KeyFrame *, std::tuple<int, int>> obs;
     V3f GetWorldPos() { return pos; }
     cv::Mat GetDescriptor() { return desc; }
@@ -67,8 +69,9 @@ struct Frame {
     void SetPoseFromQuatTrans(const float *T7) { std::memcpy(pose.T, T7, 28); }
 };
 struct KeyFrame : Frame {
-    long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1; Map *map = nullptr; bool bad = false;
+    long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1, mnBALocalForMerge = -1; Map *map = nullptr; bool bad = false;
     std::vector<KeyFrame *> covis;
+    std::set<MapPoint *> GetMapPoints() { std::set<MapPoint *> s; for (auto *p : mvpMapPoints) if (p) s.insert(p); return s; }
     std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return covis; }
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     bool isBad() { return bad; }
@@ -297,6 +300,43 @@ int main(int argc, char **argv) {
     size_t remaining = 0; for (auto *p : plist) remaining += p->obs.size();
     CHECK(remaining + erasedRef == eMp.size(), "LBA erased observations");
     CHECK(map.changes == 1, "IncreaseChangeIndex");
+    // ---- merge-window LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) facade ~ oracle on the same map ----
+    {
+        std::vector<KeyFrame *> adjust = {&kfs[5], &kfs[4], &kfs[3]}, fixedK = {&kfs[0], &kfs[1], &kfs[2]};
+        for (int k = 3; k < nKF; k++) { kfs[k].pose.T[4] += 0.02f * g(rng); kfs[k].pose.T[5] += 0.01f * g(rng); }
+        std::vector<KeyFrame *> ord(fixedK); ord.insert(ord.end(), adjust.begin(), adjust.end());
+        std::map<KeyFrame *, int> kid2;
+        std::vector<float> kp2, mp2, ob2v, w2; std::vector<uint8_t> fx2; std::vector<int32_t> em2, ek2;
+        for (size_t i = 0; i < ord.size(); i++) { kid2[ord[i]] = (int)i; kp2.insert(kp2.end(), ord[i]->pose.T, ord[i]->pose.T + 7); fx2.push_back(i < fixedK.size()); }
+        std::vector<MapPoint *> pl2; std::set<MapPoint *> seen2;
+        for (KeyFrame *k : ord) for (MapPoint *p : k->GetMapPoints()) if (seen2.insert(p).second) pl2.push_back(p);
+        for (size_t p = 0; p < pl2.size(); p++) {
+            mp2.insert(mp2.end(), pl2[p]->pos.v, pl2[p]->pos.v + 3);
+            for (auto &o2 : pl2[p]->obs) {
+                if (!o2.first->GetMapPoint(std::get<0>(o2.second))) continue;
+                em2.push_back((int)p); ek2.push_back(kid2[o2.first]);
+                const cv::KeyPoint &kp = o2.first->mvKeysUn[std::get<0>(o2.second)];
+                ob2v.push_back(kp.pt.x); ob2v.push_back(kp.pt.y); w2.push_back(o2.first->mvInvLevelSigma2[kp.octave]);
+            }
+        }
+        std::vector<uint8_t> er2(em2.size() + 1);
+        std::vector<float> kpR(kp2), mpR(mp2);
+        int32_t its2[2];
+        orc_merge_ba((int)ord.size(), kpR.data(), fx2.data(), (int)pl2.size(), mpR.data(), (int)em2.size(), em2.data(), ek2.data(), ob2v.data(), w2.data(), K4,
+                     nullptr, er2.data(), its2);
+        bool stop2 = false;
+        ORB_SLAM3::Optimizer::LocalBundleAdjustment(&kfs[5], adjust, fixedK, &stop2);
+        double dK2 = 0, dP2 = 0;
+        for (size_t i = 0; i < ord.size(); i++) for (int c = 0; c < 7; c++) dK2 = std::fmax(dK2, std::fabs(ord[i]->pose.T[c] - kpR[i * 7 + c]));
+        for (size_t p = 0; p < pl2.size(); p++) for (int c = 0; c < 3; c++) dP2 = std::fmax(dP2, std::fabs(pl2[p]->pos.v[c] - mpR[p * 3 + c]));
+        CHECK(its2[0] > 0 && its2[1] > 0 && dK2 < 2e-4 && dP2 < 1e-3, "merge BA poses / points vs oracle");
+        int erasedRef2 = 0;
+        for (size_t e = 0; e < em2.size(); e++) erasedRef2 += er2[e];
+        size_t remaining2 = 0;
+        for (auto *p : pl2) for (auto &o2 : p->obs) remaining2 += kid2.count(o2.first) && o2.first->GetMapPoint(std::get<0>(o2.second)) ? 1 : 0;
+        CHECK(remaining2 + erasedRef2 == em2.size(), "merge BA erased observations");
+        std::printf("merge BA: edges %zu, iterations %d + %d, erased %d, dK %.2e dP %.2e\n", em2.size(), its2[0], its2[1], erasedRef2, dK2, dP2);
+    }
     std::printf("facade test: %d failure(s); matches %d, pose inliers %d, LBA edges %d (erased %d) dK %.2e dP %.2e\n", fails, ngpu, good, nEdges, erasedRef, dK, dP);
     (void)erased;
     return fails ? 1 : 0;

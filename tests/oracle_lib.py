@@ -242,6 +242,21 @@ def local_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, sto
     return its, kp, mp, erase
 
 
+def merge_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop=None):
+    """Returns (its of the two optimize() calls, kf_pose, mp_pos, erase)."""
+    kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
+    mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32); ek = np.ascontiguousarray(e_kf, np.int32)
+    eo = np.ascontiguousarray(e_obs, np.float32); ew = np.ascontiguousarray(e_inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+    erase = np.zeros(len(em), np.uint8)
+    its2 = np.zeros(2, np.int32)
+    sp = _p(stop) if stop is not None else None
+    L = _olib()
+    L.orc_merge_ba.restype = C.c_int32
+    L.orc_merge_ba.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 8
+    L.orc_merge_ba(len(kfix), _p(kp), _p(kfix), len(mp), _p(mp), len(em), _p(em), _p(ek), _p(eo), _p(ew), _p(K4), sp, _p(erase), _p(its2))
+    return its2, kp, mp, erase
+
+
 def search_by_bow_kf(k1, d1, mp1, fv1, k2, d2, mp2, fv2, mp_bad, nnratio, check_ori):
     k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8); m1 = np.ascontiguousarray(mp1, np.int32)
     k2 = np.ascontiguousarray(k2, KP_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8); m2 = np.ascontiguousarray(mp2, np.int32)

@@ -81,3 +81,35 @@ def test_local_ba_stop_flag_and_no_fixed(opt):
     assert stats[3] == 1 and np.array_equal(kp, b["kf_pose"]) and np.array_equal(mp, b["mp_pos"])   # aborted before optimising
     with pytest.raises(capi.RumiError):
         opt.LocalBundleAdjustment(b["kf_pose"], np.zeros_like(b["kf_fixed"]), b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=5, n_opt=15, n_fixed=10, n_points=2000, outlier_frac=0.08), dict(seed=6, n_opt=8, n_fixed=0, n_points=600),
+                                 dict(seed=7, n_opt=30, n_fixed=12, n_points=1500, outlier_frac=0.2)])
+def test_merge_window_bundle_adjustment(opt, cfg):
+    """Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag): optimize(5) with Huber, outlier edges to level 1,
+    kernels off, optimize(10).  Same iteration counts in both passes, same erase flags, poses / landmarks at 1e-4."""
+    b = ba_problem(**cfg)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    its2, kp_ref, mp_ref, er_ref = O.merge_ba(*a)
+    stats, kp, mp, er = opt.MergeBundleAdjustment(*a)
+    assert (stats[0], stats[3]) == (its2[0], its2[1]), f"LM iterations of the two passes: {stats} vs {its2}"
+    assert its2[0] > 0 and its2[1] > 0
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    scale = np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-2)
+    assert (np.linalg.norm(mp - mp_ref, axis=1) <= RTOL * scale).all(), "landmarks"
+    assert np.count_nonzero(er != er_ref) == 0, "erase flags"
+    if cfg.get("outlier_frac"):
+        assert er_ref.sum() > 0
+    # differs from the single-pass local BA on the same graph (otherwise the second pass is untested)
+    if cfg["n_fixed"] > 0:
+        _, kp1, _, _ = opt.LocalBundleAdjustment(*a)
+        assert np.abs(kp1 - kp).max() > 0
+
+
+def test_merge_ba_stop_flag(opt):
+    b = ba_problem(seed=8, n_opt=4, n_fixed=2, n_points=200)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    stop = np.ones(1, np.uint8)
+    stats, kp, mp, er = opt.MergeBundleAdjustment(*a, stop_flag=stop)
+    assert stats[0] == 0 and np.array_equal(kp, b["kf_pose"]) and np.array_equal(mp, b["mp_pos"])
