@@ -42,6 +42,8 @@ def all_gather_records(counts, kp, desc, n_frames, group=None):
         g = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenated form: accepted by RCCL and gloo
         dist.all_gather_into_tensor(g, t, group=group)
         outs.append(g.view((world, per) + tuple(t.shape[1:])))
+    if n_frames % world == 0:                       # even split: the gathered buffers already ARE the queue, in order
+        return tuple(g.view((world * per,) + tuple(g.shape[2:])) for g in outs)
     keep = []
     for r in range(world):
         lo, hi = shard_bounds(n_frames, r, world)
