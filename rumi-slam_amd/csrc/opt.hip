@@ -383,6 +383,14 @@ __global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
     }
 }
 
+// one launch instead of a memset per array
+struct ZeroList { double *p[4]; int n[4]; };
+__global__ void k_ba_zero(ZeroList Z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (i < Z.n[s]) Z.p[s][i] = 0.0;
+}
+
 __global__ void k_ba_maxdiag(BADev B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double m = 0;
@@ -695,6 +703,7 @@ struct RumiOptimizer {
     uint8_t *dErase = nullptr;
     double *hScal = nullptr;
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
+    uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
     float stageMs[8] = {0};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -715,6 +724,9 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hPose) (void)hipHostFree(o->hPose);
+    if (o->hBa) (void)hipHostFree(o->hBa);
+    if (o->dBa) (void)hipFree(o->dBa);
+    if (o->dBaOut) (void)hipFree(o->dBaOut);
     if (o->hPoseOut) (void)hipHostFree(o->hPoseOut);
     if (o->dPoseIn) (void)hipFree(o->dPoseIn);
     if (o->dPoseOut) (void)hipFree(o->dPoseOut);
@@ -751,6 +763,12 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     TRYA(oalloc(&o->dYt, 3 * M * (size_t)o->npCap)); TRYA(oalloc(&o->dG, (size_t)o->npCap * o->npCap)); TRYA(oalloc(&o->dLp, M * 6));
 #undef TRYA
     if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    o->baStageCap = E * 48 + M * 32 + K * 80 + 1024;
+    if (hipHostMalloc((void **)&o->hBa, o->baStageCap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&o->dBa, o->baStageCap) != hipSuccess ||
+        hipMalloc((void **)&o->dBaOut, o->baStageCap) != hipSuccess) {
+        rumi_opt_destroy(o);
+        return RUMI_E_NO_DEVICE;
+    }
     {
         const size_t inCap = (PB + 1) * 4 + 16 + PB * 28 + PE * 24 + 256, outCap = PB * 32 + PE + 256;
         if (hipHostMalloc((void **)&o->hPose, inCap, hipHostMallocDefault) != hipSuccess ||
@@ -846,28 +864,39 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) kfRowStart[c + 1] += 2; }
     for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
     { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; fill[c] += 2; } } }
-    std::vector<double> T0((size_t)nKF * 8), X0((size_t)nMP * 3), obsD((size_t)nE * 2), info(nE);
-    for (int k = 0; k < nKF; k++) {
-        const DSE3 P = se3_from_float7(kf_pose7 + (size_t)k * 7);
-        double *t = &T0[(size_t)k * 8];
-        t[0] = P.r.x; t[1] = P.r.y; t[2] = P.r.z; t[3] = P.r.w; t[4] = P.t.x; t[5] = P.t.y; t[6] = P.t.z; t[7] = 0;
-    }
-    for (size_t i = 0; i < X0.size(); i++) X0[i] = mp_pos3[i];
-    for (int e = 0; e < nE; e++) { obsD[2 * e] = e_obs[2 * e]; obsD[2 * e + 1] = e_obs[2 * e + 1]; info[e] = e_inv_sigma2[e]; }
-#define UP(dst, v) HIP_TRY(hipMemcpy((dst), (v).data(), (v).size() * sizeof((v)[0]), hipMemcpyHostToDevice))
-    UP(o->dPoseCol, poseCol); UP(o->dPtStart, ptStart); UP(o->dKfRowStart, kfRowStart);
+    // one pinned block up: the kernels read the graph arrays straight from its device mirror; the initial state is copied on the
+    // device into the first of the two state buffers
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t oPC = 0, oPS = al(oPC + (size_t)nKF * 4), oKR = al(oPS + (size_t)(nMP + 1) * 4), oPE = al(oKR + (size_t)(nOpt + 1) * 4),
+                 oRS = al(oPE + (size_t)nE * 4), oEM = al(oRS + (size_t)nE * 4), oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4),
+                 oIn = al(oOb + (size_t)nE * 16), oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), upBytes = al(oX + (size_t)nMP * 24);
+    if (upBytes > o->baStageCap) { g_lastError = "local BA: upload block larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    uint8_t *hs = o->hBa;
+    std::memcpy(hs + oPC, poseCol.data(), (size_t)nKF * 4); std::memcpy(hs + oPS, ptStart.data(), (size_t)(nMP + 1) * 4);
+    std::memcpy(hs + oKR, kfRowStart.data(), (size_t)(nOpt + 1) * 4);
     if (nE > 0) {
-        UP(o->dPtEdge, ptEdge); UP(o->dRowSlot, rowSlot); UP(o->dObsD, obsD); UP(o->dInfo, info);
-        HIP_TRY(hipMemcpy(o->dEMP, e_mp, (size_t)nE * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(o->dEKF, e_kf, (size_t)nE * sizeof(int32_t), hipMemcpyHostToDevice));
+        std::memcpy(hs + oPE, ptEdge.data(), (size_t)nE * 4); std::memcpy(hs + oRS, rowSlot.data(), (size_t)nE * 4);
+        std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4);
+        double *ob = reinterpret_cast<double *>(hs + oOb), *inf = reinterpret_cast<double *>(hs + oIn);
+        for (int e = 0; e < nE; e++) { ob[2 * e] = e_obs[2 * e]; ob[2 * e + 1] = e_obs[2 * e + 1]; inf[e] = e_inv_sigma2[e]; }
     }
-    UP(o->dT[0], T0);
-    if (nMP > 0) UP(o->dX[0], X0);
-#undef UP
+    {
+        double *T0 = reinterpret_cast<double *>(hs + oT), *X0 = reinterpret_cast<double *>(hs + oX);
+        for (int k = 0; k < nKF; k++) {
+            const DSE3 P = se3_from_float7(kf_pose7 + (size_t)k * 7);
+            double *t = T0 + (size_t)k * 8;
+            t[0] = P.r.x; t[1] = P.r.y; t[2] = P.r.z; t[3] = P.r.w; t[4] = P.t.x; t[5] = P.t.y; t[6] = P.t.z; t[7] = 0;
+        }
+        for (size_t i = 0; i < (size_t)nMP * 3; i++) X0[i] = mp_pos3[i];
+    }
+    HIP_TRY(hipMemcpyAsync(o->dBa, hs, upBytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(o->dT[0], o->dBa + oT, (size_t)nKF * 64, hipMemcpyDeviceToDevice, nullptr));
+    if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dX[0], o->dBa + oX, (size_t)nMP * 24, hipMemcpyDeviceToDevice, nullptr));
     BADev B{};
     B.nKF = nKF; B.nMP = nMP; B.nE = nE; B.nOpt = nOpt; B.n = n;
-    B.eMP = o->dEMP; B.eKF = o->dEKF; B.poseCol = o->dPoseCol; B.ptStart = o->dPtStart; B.ptEdge = o->dPtEdge; B.rowSlot = o->dRowSlot;
-    B.kfRowStart = o->dKfRowStart; B.obs = o->dObsD; B.info = o->dInfo;
+    B.eMP = (const int32_t *)(o->dBa + oEM); B.eKF = (const int32_t *)(o->dBa + oEK); B.poseCol = (const int32_t *)(o->dBa + oPC);
+    B.ptStart = (const int32_t *)(o->dBa + oPS); B.ptEdge = (const int32_t *)(o->dBa + oPE); B.rowSlot = (const int32_t *)(o->dBa + oRS);
+    B.kfRowStart = (const int32_t *)(o->dBa + oKR); B.obs = (const double *)(o->dBa + oOb); B.info = (const double *)(o->dBa + oIn);
     B.cam = DCam{K4[0], K4[1], K4[2], K4[3]};
     B.delta = mode == 0 ? (double)(float)std::sqrt(5.991) : (double)(float)std::sqrt(5.99);   // thHuberMono = sqrt(5.991) / thHuber2D = sqrt(5.99)
     B.dsqr = B.delta * B.delta;
@@ -910,14 +939,13 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         ranChi2 = true;
         const double iniChi = currentChi;
         // buildSystem
-        HIP_TRY(hipMemsetAsync(o->dHll, 0, (size_t)nMP * 9 * sizeof(double), st));
-        HIP_TRY(hipMemsetAsync(o->dBl, 0, (size_t)nMP * 3 * sizeof(double), st));
-        if (nE > 0) hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur]);
-        if (nOpt > 0) {
-            HIP_TRY(hipMemsetAsync(o->dHpp, 0, (size_t)nOpt * 36 * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(o->dBp, 0, (size_t)n * sizeof(double), st));
-            hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt, kHppSlices), dim3(256), 0, st, B);
+        {
+            const ZeroList Z{{o->dHll, o->dBl, o->dHpp, o->dBp}, {nMP * 9, nMP * 3, nOpt * 36, n}};
+            const int zmax = std::max(std::max(nMP * 9, nOpt * 36), 1);
+            hipLaunchKernelGGL(k_ba_zero, dim3((zmax + 255) / 256), dim3(256), 0, st, Z);
         }
+        if (nE > 0) hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur]);
+        if (nOpt > 0) hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt, kHppSlices), dim3(256), 0, st, B);
         if (it == 0) {
             HIP_TRY(hipMemsetAsync(o->dScal + 2, 0, sizeof(double), st));
             const int nd = nOpt * 6 + nMP * 3;
@@ -930,8 +958,10 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         int qmax = 0;
         do {
             const int trial = cur ^ 1;
-            HIP_TRY(hipMemsetAsync(o->dG, 0, (size_t)NP * NP * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(o->dScal, 0, 2 * sizeof(double), st));
+            {
+                const ZeroList Z{{o->dG, o->dScal, nullptr, nullptr}, {NP * NP, 2, 0, 0}};
+                hipLaunchKernelGGL(k_ba_zero, dim3((NP * NP + 255) / 256), dim3(256), 0, st, Z);
+            }
             if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
             if (nE > 0) hipLaunchKernelGGL(k_ba_yfill, dim3(gE), dim3(256), 0, st, B, o->dYt, NP, o->dLp);
             if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
@@ -983,17 +1013,21 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     if (nE > 0) hipLaunchKernelGGL(k_ba_finalize, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dErase);
     HIP_TRY(hipEventRecord(o->ev[1], st));
     HIP_TRY(hipGetLastError());
-    std::vector<double> T1((size_t)nKF * 8), X1((size_t)nMP * 3);
-    HIP_TRY(hipMemcpy(T1.data(), o->dT[cur], T1.size() * sizeof(double), hipMemcpyDeviceToHost));
-    if (nMP > 0) HIP_TRY(hipMemcpy(X1.data(), o->dX[cur], X1.size() * sizeof(double), hipMemcpyDeviceToHost));
-    if (nE > 0) HIP_TRY(hipMemcpy(erase_out, o->dErase, (size_t)nE, hipMemcpyDeviceToHost));
+    // results gathered on the device into the (now idle) upload mirror and read back with one copy: [T | X | erase]
+    const size_t rT = 0, rX = al(rT + (size_t)nKF * 64), rE = al(rX + (size_t)nMP * 24), dnBytes = al(rE + (size_t)nE);
+    HIP_TRY(hipMemcpyAsync(o->dBaOut + rT, o->dT[cur], (size_t)nKF * 64, hipMemcpyDeviceToDevice, st));
+    if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rX, o->dX[cur], (size_t)nMP * 24, hipMemcpyDeviceToDevice, st));
+    if (nE > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rE, o->dErase, (size_t)nE, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy(o->hBa, o->dBaOut, dnBytes, hipMemcpyDeviceToHost));
+    const double *T1 = reinterpret_cast<const double *>(o->hBa + rT), *X1 = reinterpret_cast<const double *>(o->hBa + rX);
+    if (nE > 0) std::memcpy(erase_out, o->hBa + rE, (size_t)nE);
     HIP_TRY(hipEventElapsedTime(&o->stageMs[5], o->ev[0], o->ev[1]));
     for (int k = 0; k < nKF; k++) {
         if (kf_fixed[k]) continue;
-        const double *t = &T1[(size_t)k * 8];
+        const double *t = T1 + (size_t)k * 8;
         se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
     }
-    for (size_t i = 0; i < X1.size(); i++) mp_pos3[i] = (float)X1[i];
+    for (size_t i = 0; i < (size_t)nMP * 3; i++) mp_pos3[i] = (float)X1[i];
     if (stats) { stats[0] = mode == 0 ? iters : itersFirst; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 0 ? 0 : iters - itersFirst; }
     return RUMI_OK;
 }
