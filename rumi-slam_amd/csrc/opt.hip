@@ -563,6 +563,14 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
         __syncthreads();
         if (sFail) break;
         // rows below the block: L[r][c0..] = A[r][c0..] * Ld^-T  (one thread per row)
+        if (c0 + w + tid <= n) {                              // the block's factor, once per thread, into registers
+            double lb[kPW][kPW], rb[kPW];
+#pragma unroll
+            for (int b = 0; b < kPW; b++) {
+                rb[b] = rdb[b];
+#pragma unroll
+                for (int k = 0; k < kPW; k++) lb[b][k] = k < b ? ldb[b * kPW + k] : 0.0;
+            }
         for (int r = c0 + w + tid; r <= n; r += nt) {
             double x[kPW];
 #pragma unroll
@@ -571,24 +579,31 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
             for (int b = 0; b < kPW; b++) {
                 double t = x[b];
 #pragma unroll
-                for (int k = 0; k < kPW; k++) if (k < b) t -= x[k] * ldb[b * kPW + k];
-                x[b] = t * rdb[b];
+                for (int k = 0; k < kPW; k++) if (k < b) t -= x[k] * lb[b][k];
+                x[b] = t * rb[b];
             }
 #pragma unroll
             for (int b = 0; b < kPW; b++) if (b < w) A[(size_t)r * ld + c0 + b] = x[b];
         }
+        }
         __syncthreads();
         // trailing update: A[i][k] -= sum_q L[i][c0+q] L[k][c0+q] for c0+w <= k <= i <= n, k < n
+        // 32 x 32 thread grid over the lower triangle: thread (ty, tx) owns rows i = t0 + ty + 32 a, columns k = t0 + tx + 32 b, k <= i;
+        // the panel entries of its rows / columns are read once per (a, b) tile row / column, no integer division
         const int t0 = c0 + w, m = n + 1 - t0;
-        for (int idx = tid; idx < m * m; idx += nt) {
-            const int ii = idx / m, kk = idx - ii * m;
-            const int i = t0 + ii, k = t0 + kk;
-            if (kk > ii || k >= n) continue;
-            double acc = 0;
+        const int ty = tid >> 5, tx = tid & 31;
+        for (int i = t0 + ty; i <= n; i += 32) {
+            double li[kPW];
 #pragma unroll
-            for (int q = 0; q < kPW; q++) if (q < w) acc += A[(size_t)i * ld + c0 + q] * A[(size_t)k * ld + c0 + q];
-            A[(size_t)i * ld + k] -= acc;
+            for (int q = 0; q < kPW; q++) li[q] = q < w ? A[(size_t)i * ld + c0 + q] : 0.0;
+            for (int k = t0 + tx; k <= i && k < n; k += 32) {
+                double acc = 0;
+#pragma unroll
+                for (int q = 0; q < kPW; q++) if (q < w) acc += li[q] * A[(size_t)k * ld + c0 + q];
+                A[(size_t)i * ld + k] -= acc;
+            }
         }
+        (void)m;
         __syncthreads();
     }
     if (sFail) {
@@ -622,27 +637,37 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
 }
 
 // x_l = D^-1 (b_l - H_pl^T x_p); trial state = oplus(current, x); scale += x^T (lambda x + b)
+// Landmark back-substitution x_l = D^-1 (b_l - H_pl^T x_p) (block_solver.hpp:468-481), oplus of points and poses, and the
+// gain-ratio denominator.  Eight lanes share a landmark (its ~15 edges are two rounds instead of fifteen dependent ones); the
+// first nKF * 8 lanes past the landmarks carry the poses (one per group of eight).
+constexpr int kLmLanes = 8;
 __global__ __launch_bounds__(256) void k_ba_update(BADev B, double lambda, const double *T, const double *X, double *Tt, double *Xt) {
     __shared__ double red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int gi = (blockIdx.x * 256 + threadIdx.x) / kLmLanes, sub = threadIdx.x & (kLmLanes - 1);
     double acc[1] = {0};
-    if (i < B.nMP) {
-        const int p = i;
-        double c0 = B.bl[3 * p], c1 = B.bl[3 * p + 1], c2 = B.bl[3 * p + 2];
-        for (int s = B.ptStart[p]; s < B.ptStart[p + 1]; s++) {
+    if (gi < B.nMP) {
+        const int p = gi;
+        double c0 = 0, c1 = 0, c2 = 0;
+        for (int s = B.ptStart[p] + sub; s < B.ptStart[p + 1]; s += kLmLanes) {
             const int e = B.ptEdge[s], col = B.poseCol[B.eKF[e]];
             if (col < 0) continue;
             const double *h = B.Hpl + (size_t)e * 18, *xp = B.x + col * 6;
 #pragma unroll
             for (int a = 0; a < 6; a++) { c0 -= h[a * 3] * xp[a]; c1 -= h[a * 3 + 1] * xp[a]; c2 -= h[a * 3 + 2] * xp[a]; }
         }
-        const double *I = B.Dinv + (size_t)p * 9;
-        const double x0 = I[0] * c0 + I[1] * c1 + I[2] * c2, x1 = I[3] * c0 + I[4] * c1 + I[5] * c2, x2 = I[6] * c0 + I[7] * c1 + I[8] * c2;
-        B.x[B.n + 3 * p] = x0; B.x[B.n + 3 * p + 1] = x1; B.x[B.n + 3 * p + 2] = x2;
-        Xt[3 * p] = X[3 * p] + x0; Xt[3 * p + 1] = X[3 * p + 1] + x1; Xt[3 * p + 2] = X[3 * p + 2] + x2;
-        acc[0] = x0 * (lambda * x0 + B.bl[3 * p]) + x1 * (lambda * x1 + B.bl[3 * p + 1]) + x2 * (lambda * x2 + B.bl[3 * p + 2]);
-    } else if (i < B.nMP + B.nKF) {
-        const int k = i - B.nMP, col = B.poseCol[k];
+#pragma unroll
+        for (int o = kLmLanes / 2; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, kLmLanes); c1 += __shfl_xor(c1, o, kLmLanes); c2 += __shfl_xor(c2, o, kLmLanes); }
+        if (sub == 0) {
+            const double b0 = B.bl[3 * p], b1 = B.bl[3 * p + 1], b2 = B.bl[3 * p + 2];
+            c0 += b0; c1 += b1; c2 += b2;
+            const double *I = B.Dinv + (size_t)p * 9;
+            const double x0 = I[0] * c0 + I[1] * c1 + I[2] * c2, x1 = I[3] * c0 + I[4] * c1 + I[5] * c2, x2 = I[6] * c0 + I[7] * c1 + I[8] * c2;
+            B.x[B.n + 3 * p] = x0; B.x[B.n + 3 * p + 1] = x1; B.x[B.n + 3 * p + 2] = x2;
+            Xt[3 * p] = X[3 * p] + x0; Xt[3 * p + 1] = X[3 * p + 1] + x1; Xt[3 * p + 2] = X[3 * p + 2] + x2;
+            acc[0] = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        }
+    } else if (gi < B.nMP + B.nKF && sub == 0) {
+        const int k = gi - B.nMP, col = B.poseCol[k];
         DSE3 P = load_pose(T, k);
         if (col >= 0) {
             const double *xp = B.x + col * 6;
@@ -970,7 +995,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
                 else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(1024), 0, st, B, lambda, o->dG, NP, o->dAglob);
             }
             else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
-            hipLaunchKernelGGL(k_ba_update, dim3((nMP + nKF + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
+            hipLaunchKernelGGL(k_ba_update, dim3(((nMP + nKF) * kLmLanes + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
             hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
