@@ -14,6 +14,7 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
+#include "FrameFrustum.h"
 #include "orb_oracle.h"
 
 extern "C" {
@@ -67,6 +68,14 @@ struct Frame {
     std::map<unsigned, std::vector<unsigned>> mFeatVec;
     SE3f GetPose() const { return pose; }
     void SetPoseFromQuatTrans(const float *T7) { std::memcpy(pose.T, T7, 28); }
+    void PoseMatrices(float *R, float *t, float *Ow) const {          // mRcw, mtcw, mOw = -Rcw^T tcw
+        const float x = pose.T[0], y = pose.T[1], z = pose.T[2], w = pose.T[3];
+        const float r[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+        for (int i = 0; i < 9; i++) R[i] = r[i];
+        for (int i = 0; i < 3; i++) t[i] = pose.T[4 + i];
+        for (int i = 0; i < 3; i++) Ow[i] = -(r[i] * t[0] + r[3 + i] * t[1] + r[6 + i] * t[2]);
+    }
 };
 struct KeyFrame : Frame {
     long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1, mnBALocalForMerge = -1; Map *map = nullptr; bool bad = false;
@@ -210,6 +219,23 @@ int main(int argc, char **argv) {
             CHECK(nf > 20 && replacedCand + replacedResident > 0 && added > 0, "Fuse adds observations and replaces duplicates");
             CHECK(consistent, "Fuse leaves no bad point in the key-frame");
             CHECK(nf >= replacedCand + replacedResident, "Fuse count covers every replacement");
+        }
+        // batched isInFrustum -> SearchByProjection(F, local points): the fields written on the points drive the search
+        {
+            Frame cur2 = fr[1];
+            cur2.mvpMapPoints.assign(cur2.N, nullptr);
+            std::vector<MapPoint *> local;
+            for (auto &p : mps) local.push_back(&p);
+            const std::vector<uint8_t> in = rumi_facade::IsInFrustum(cur2, local, 0.5f);
+            int nin = 0; bool consistent = true;
+            for (size_t i = 0; i < local.size(); i++) {
+                nin += in[i];
+                if ((in[i] != 0) != local[i]->mbTrackInView) consistent = false;
+                if (in[i] && !(local[i]->mTrackProjX >= 0 && local[i]->mTrackProjX <= 640 && local[i]->mnTrackScaleLevel >= 0 && local[i]->mnTrackScaleLevel < 8)) consistent = false;
+            }
+            CHECK(nin > 300 && consistent, "IsInFrustum fills the tracking fields");
+            const int nl = matcher.SearchByProjection(cur2, local, 3.f, false, 50.f);
+            CHECK(nl > 100, "SearchByProjection(F, local points) after the batched isInFrustum");
         }
         std::vector<cv::Point2f> prev(fr[0].mvKeysUn.size());
         for (size_t i = 0; i < prev.size(); i++) prev[i] = fr[0].mvKeysUn[i].pt;
