@@ -17,7 +17,9 @@ constexpr int kBorder = kEdge - 3; // minBorderX/Y = 16
 constexpr int kMaxLevels = 16;
 constexpr int kCellTileMax = 96;   // largest FAST sub-image side the cell kernel stages in LDS
 constexpr int kPadX = 32;          // REFLECT_101 frame kept around every pyramid level in HBM: >= EDGE_THRESHOLD, keeps rows 4-B aligned
-constexpr int kPadY = kEdge;       // 19 rows, as the reference's copyMakeBorder
+constexpr int kPadY = kEdge;       // 19 rows reserved, as the reference's copyMakeBorder
+constexpr int kFrameRows = 3;      // frame rows / columns actually MATERIALISED around a level: the only reader outside the level is the
+constexpr int kFrameCols = 4;      // 7x7 blur (3 px); the 19-px border of mvImagePyramid is synthesised on export (rumi_orb_pyramid_level)
 
 inline int cv_round_host(double v) { return (int)std::lrint(v); }
 

@@ -425,11 +425,21 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
     if (!out) return RUMI_OK;
     if (out_stride < L.w + 2 * border) return RUMI_E_CAPACITY;
     HIP_TRY(hipSetDevice(h->device));
-    // the pyramid arena already holds the level inside its REFLECT_101 frame (kPadX x kPadY); the blurred arena has no frame
-    if (border > (which ? 0 : std::min(kPadX, kPadY))) { g_lastError = which ? "blurred levels carry no border" : "border larger than the stored frame (19)"; return RUMI_E_INVALID; }
-    const uint8_t *srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off -
-                          (long long)border * L.pitch - border;
-    HIP_TRY(hipMemcpy2D(out, out_stride, srcp, L.pitch, L.w + 2 * border, L.h + 2 * border, hipMemcpyDeviceToHost));
+    // the arena materialises only the 3-px frame the blur reads; the 19-px border copyMakeBorder(..., BORDER_REFLECT_101) gives
+    // mvImagePyramid (ORBextractor.cc:1105-1108) is synthesised here from the interior, which is the same pixels by definition
+    if (border > (which ? 0 : kEdge)) { g_lastError = which ? "blurred levels carry no border" : "border larger than EDGE_THRESHOLD (19)"; return RUMI_E_INVALID; }
+    const uint8_t *srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off;
+    uint8_t *inner = out + (size_t)border * out_stride + border;
+    HIP_TRY(hipMemcpy2D(inner, out_stride, srcp, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    auto refl = [](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p; return p; };
+    for (int y = 0; y < L.h; y++) {
+        uint8_t *row = inner + (size_t)y * out_stride;
+        for (int x = 1; x <= border; x++) { row[-x] = row[refl(-x, L.w)]; row[L.w - 1 + x] = row[refl(L.w - 1 + x, L.w)]; }
+    }
+    for (int y = 1; y <= border; y++) {
+        std::memcpy(inner + (long long)(-y) * out_stride - border, inner + (size_t)refl(-y, L.h) * out_stride - border, (size_t)L.w + 2 * border);
+        std::memcpy(inner + (size_t)(L.h - 1 + y) * out_stride - border, inner + (size_t)refl(L.h - 1 + y, L.h) * out_stride - border, (size_t)L.w + 2 * border);
+    }
     return RUMI_OK;
 }
 

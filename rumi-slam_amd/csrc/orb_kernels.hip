@@ -51,7 +51,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 //             rule, orb_geom.h); a lane produces 4 horizontally adjacent pixels of the FRAMED output (frame pixels
 //             recompute their mirror pixel) and stores one dword.  HBM-bound: 1.19 B written, ~1.44 B read per pixel.
 // ------------------------------------------------------------------------------------------------
-// k_pyr0 / k_resize write the pixel columns [0, w) of the rows [-kPadY, h + kPadY) (the frame rows above and below are
+// k_pyr0 / k_resize write the pixel columns [0, w) of the rows [-kFrameRows, h + kFrameRows) (the frame rows above and below are
 // computed like any other row, from the mirrored source row); k_frame_cols then mirrors the left / right frame columns of
 // every level of every frame in ONE launch (no level reads another level's frame columns).
 __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, ImgSrc src) {
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, I
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
     const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oy = by * 4 + (threadIdx.x >> 6) - kPadY;
-    if (ox >= D.w || oy >= D.h + kPadY) return;
+    const int oy = by * 4 + (threadIdx.x >> 6) - kFrameRows;
+    if (ox >= D.w || oy >= D.h + kFrameRows) return;
     const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch + ox;
     uint8_t *out = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
     uint32_t v;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
     const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows - kPadY;
-    if (ox >= D.w || oyBase >= D.h + kPadY) return;
+    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows - kFrameRows;
+    if (ox >= D.w || oyBase >= D.h + kFrameRows) return;
     const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
     uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) {
         const int oy = oyBase + r;
-        live[r] = oy < D.h + kPadY;
+        live[r] = oy < D.h + kFrameRows;
         const int dy = reflect101(live[r] ? oy : 0, D.h);
         const int sy = yofs[dy];
         b0[r] = ya[dy * 2]; b1[r] = ya[dy * 2 + 1];
@@ -161,20 +161,20 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     }
 }
 
-// left / right REFLECT_101 frame columns of all levels: thread = (frame, level, framed row, one of 17 aligned dword strips)
+// left / right REFLECT_101 frame columns of all levels: thread = (frame, level, framed row, one of 3 aligned dword strips)
 __global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict__ P, ImgSrc src) {
     const int level = blockIdx.y, frame = blockIdx.z;
     const DevLevel &D = P->lv[level];
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int strip = t % 17, row = t / 17 - kPadY;
-    if (row >= D.h + kPadY) return;
+    const int strip = t % 3, row = t / 3 - kFrameRows;
+    if (row >= D.h + kFrameRows) return;
     uint8_t *rp = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)row * D.pitch;
-    // strips 0..7: x = -32..-1; strips 8..16: x = (w & ~3) .. (w & ~3) + 35 (covers w .. w+31 and re-writes <= 3 interior pixels)
-    const int x0 = strip < 8 ? -kPadX + 4 * strip : (D.w & ~3) + 4 * (strip - 8);
+    // strip 0: x = -4..-1; strips 1, 2: x = (w & ~3) .. (w & ~3) + 7 (covers w .. w+3 and re-writes <= 3 interior pixels)
+    const int x0 = strip == 0 ? -kFrameCols : (D.w & ~3) + 4 * (strip - 1);
     uint32_t v = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) v |= (uint32_t)rp[reflect101(x0 + i, D.w)] << (8 * i);
-    if (x0 + 3 < D.w + kPadX + 4) *reinterpret_cast<uint32_t *>(rp + x0) = v;
+    *reinterpret_cast<uint32_t *>(rp + x0) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,16 +640,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
 
 // ---- launch wrappers (called from orb_host.hip) ----
 void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
-    dim3 g((hP.lv[0].w + 255) / 256, (hP.lv[0].h + 2 * kPadY + 3) / 4, nframes);
+    dim3 g((hP.lv[0].w + 255) / 256, (hP.lv[0].h + 2 * kFrameRows + 3) / 4, nframes);
     hipLaunchKernelGGL(k_pyr0, g, dim3(256), 0, st, dP, src);
 }
 void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
-    dim3 g(((hP.lv[0].h + 2 * kPadY) * 17 + 255) / 256, hP.nlevels, nframes);
+    dim3 g(((hP.lv[0].h + 2 * kFrameRows) * 3 + 255) / 256, hP.nlevels, nframes);
     hipLaunchKernelGGL(k_frame_cols, g, dim3(256), 0, st, dP, src);
 }
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
                    hipStream_t st) {
-    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kPadY + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kFrameRows + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
