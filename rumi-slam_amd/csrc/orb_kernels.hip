@@ -492,17 +492,19 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
         uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
         if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
         if (lane == 63) Rw = *reinterpret_cast<const uint32_t *>(row + min(xl + 4, (w + kPadX - 4) & ~3));
-        int b[10];
-        b[0] = (Lw >> 8) & 255; b[1] = (Lw >> 16) & 255; b[2] = Lw >> 24;
-        b[3] = C & 255; b[4] = (C >> 8) & 255; b[5] = (C >> 16) & 255; b[6] = C >> 24;
-        b[7] = Rw & 255; b[8] = (Rw >> 8) & 255; b[9] = (Rw >> 16) & 255;
 #pragma unroll
         for (int k = 0; k < 6; k++)
 #pragma unroll
             for (int i = 0; i < 4; i++) ring[k][i] = ring[k + 1][i];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            ring[6][i] = 18 * (b[i] + b[i + 6]) + 34 * (b[i + 1] + b[i + 5]) + 48 * (b[i + 2] + b[i + 4]) + 56 * b[i + 3];
+        // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
+        // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
+        constexpr uint32_t tA = 18u | (34u << 8) | (48u << 16) | (56u << 24), tB = 48u | (34u << 8) | (18u << 16);
+        const uint32_t A0 = __builtin_amdgcn_alignbyte(C, Lw, 1), A1 = __builtin_amdgcn_alignbyte(C, Lw, 2), A2 = __builtin_amdgcn_alignbyte(C, Lw, 3);
+        const uint32_t B0 = __builtin_amdgcn_alignbyte(Rw, C, 1), B1 = __builtin_amdgcn_alignbyte(Rw, C, 2), B2 = __builtin_amdgcn_alignbyte(Rw, C, 3);
+        ring[6][0] = (int)__builtin_amdgcn_udot4(B0, tB, __builtin_amdgcn_udot4(A0, tA, 0u, false), false);
+        ring[6][1] = (int)__builtin_amdgcn_udot4(B1, tB, __builtin_amdgcn_udot4(A1, tA, 0u, false), false);
+        ring[6][2] = (int)__builtin_amdgcn_udot4(B2, tB, __builtin_amdgcn_udot4(A2, tA, 0u, false), false);
+        ring[6][3] = (int)__builtin_amdgcn_udot4(Rw, tB, __builtin_amdgcn_udot4(C, tA, 0u, false), false);
         const int y = r - 3;                                     // the ring now holds rows y-3 .. y+3
         if (y >= y0 && xa < w) {
             uint32_t o[4];
