@@ -120,20 +120,26 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
             s0[r] = reinterpret_cast<const U64 *>(r0p[r] + sx0)->v;
             s1[r] = reinterpret_cast<const U64 *>(r1p[r] + sx0)->v;
         }
-        int sh[4], a0[4], a1[4];
+        // horizontal pass as a 2-element dot product: the two source bytes of an output are adjacent, v_perm_b32 spreads them into
+        // 16-bit halves and v_dot2_u32_u16 multiplies by the (non-negative, <= 2048) tap pair as it lies in the table
+        typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+        int sh[4];
+        uint32_t tap[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             sh[i] = 8 * ((int)(int16_t)(ofs >> (16 * i)) - sx0);
             const uint64_t tt = i < 2 ? ta : tb;
-            a0[i] = (int16_t)(tt >> (32 * (i & 1))); a1[i] = (int16_t)(tt >> (32 * (i & 1) + 16));
+            tap[i] = (uint32_t)(tt >> (32 * (i & 1)));
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int q0 = (int)((s0[r] >> sh[i]) & 255) * a0[i] + (int)((s0[r] >> (sh[i] + 8)) & 255) * a1[i];
-                const int q1 = (int)((s1[r] >> sh[i]) & 255) * a0[i] + (int)((s1[r] >> (sh[i] + 8)) & 255) * a1[i];
+                const uint32_t w0 = (uint32_t)(s0[r] >> sh[i]), w1 = (uint32_t)(s1[r] >> sh[i]);
+                const uint32_t p0 = __builtin_amdgcn_perm(0u, w0, 0x0c010c00u), p1 = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);   // [b0, 0, b1, 0]
+                const int q0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
+                const int q1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
                 packed |= (uint32_t)((((b0[r] * (q0 >> 4)) >> 16) + ((b1[r] * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
             }
             if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
