@@ -228,23 +228,30 @@ __device__ __forceinline__ int fast_score_polar(const uint8_t *t, const int TP, 
 }
 
 // Necessary condition for score >= thr - 1, per polarity: every arc of 9 contains 4 consecutive of the 8 EVEN circle positions,
-// so the best "4 consecutive even positions" contrast bounds that polarity's score from above.  Returns bit 0 = the darker-ring
-// polarity can reach thr, bit 1 = the brighter-ring polarity can.  Pixels with no bit set can never reach the threshold; the
-// others are compacted (one entry per polarity) and scored exactly for that polarity only.
-__device__ __forceinline__ int fast_quick_at(const uint8_t *t, const int TP, const int thr) {
-    const int v = t[0];
-    int e[8];
-    e[0] = v - t[3 * TP];  e[1] = v - t[2 * TP + 2];  e[2] = v - t[3];   e[3] = v - t[-2 * TP + 2];
-    e[4] = v - t[-3 * TP]; e[5] = v - t[-2 * TP - 2]; e[6] = v - t[-3];  e[7] = v - t[2 * TP - 2];
-    int lo2[8], hi2[8];
+// so the best "4 consecutive even positions" contrast bounds that polarity's score from above.  Evaluated for TWO horizontally
+// adjacent pixels per lane in packed 16-bit halves (v_pk_sub/min/max_i16: contrasts are in [-255, 255]).  Returns bit 0 / bit 1 =
+// the darker-ring polarity of pixel 0 / pixel 1 can reach thr, bit 2 / bit 3 = the brighter-ring polarity can.  Pixels with no
+// bit set can never reach the threshold; the others are compacted (one entry per polarity) and scored exactly for that polarity.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pair_at(const uint8_t *t, const int o) { return __builtin_bit_cast(v2s, (uint32_t)t[o] | ((uint32_t)t[o + 1] << 16)); }
+__device__ __forceinline__ int fast_quick_pair(const uint8_t *t, const int TP, const int thr) {
+    const v2s v = pair_at(t, 0);
+    v2s e[8];
+    e[0] = v - pair_at(t, 3 * TP);  e[1] = v - pair_at(t, 2 * TP + 2);  e[2] = v - pair_at(t, 3);   e[3] = v - pair_at(t, -2 * TP + 2);
+    e[4] = v - pair_at(t, -3 * TP); e[5] = v - pair_at(t, -2 * TP - 2); e[6] = v - pair_at(t, -3);  e[7] = v - pair_at(t, 2 * TP - 2);
+    v2s lo2[8], hi2[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { lo2[k] = min(e[k], e[(k + 1) & 7]); hi2[k] = max(e[k], e[(k + 1) & 7]); }
-    int lo4[8], hi4[8];
+    for (int k = 0; k < 8; k++) { lo2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 7]); hi2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 7]); }
+    v2s A = __builtin_elementwise_min(lo2[0], lo2[2]), Bn = __builtin_elementwise_max(hi2[0], hi2[2]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 7]); hi4[k] = max(hi2[k], hi2[(k + 2) & 7]); }
-    const int A = max3i(max3i(lo4[0], lo4[1], lo4[2]), max3i(lo4[3], lo4[4], lo4[5]), max(lo4[6], lo4[7]));
-    const int Bn = min3i(min3i(hi4[0], hi4[1], hi4[2]), min3i(hi4[3], hi4[4], hi4[5]), min(hi4[6], hi4[7]));
-    return (A >= thr ? 1 : 0) | (-Bn >= thr ? 2 : 0);
+    for (int k = 1; k < 8; k++) {
+        A = __builtin_elementwise_max(A, __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 7]));
+        Bn = __builtin_elementwise_min(Bn, __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 7]));
+    }
+    // A >= thr  <=>  sign(A - thr) clear;   -Bn >= thr  <=>  Bn + (thr - 1) < 0  <=>  sign set
+    const v2s th = {(short)thr, (short)thr}, th1 = {(short)(thr - 1), (short)(thr - 1)};
+    const uint32_t da = ~__builtin_bit_cast(uint32_t, A - th), db = __builtin_bit_cast(uint32_t, Bn + th1);
+    return (int)(((da >> 15) & 1u) | ((da >> 30) & 2u) | ((db >> 13) & 4u) | ((db >> 28) & 8u));
 }
 
 // exact scores of up to 64 ring entries (entry = pixel index | polarity << 15).  A pixel that passed both quick tests has two
@@ -264,35 +271,44 @@ __device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *s
     if (active && bright && s >= tlow && s > (int)*dst) *dst = (uint8_t)s;
 }
 
-// score map of one cell: quick test on every pixel, exact score on the compacted survivors (CTP != 0: compile-time tile pitch)
+// score map of one cell: quick test on every pixel (two per lane), exact score on the compacted survivors (CTP != 0: compile-time
+// tile pitch).  Ring entries = pixel index | polarity << 15; a pixel's darker entry always precedes its brighter one.
 template <int CTP>
-__device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, int tp, int SP, int shx, int dw, unsigned Mdw,
-                                                int npx, int tlow, int lane) {
+__device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, int tp, int SP, int shx, int dw, int dh, unsigned Mdw,
+                                                int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
+    const int pw = (dw + 1) >> 1, npairs = pw * dh;       // pixel pairs per row / per cell (the last pair of an odd row is half empty)
+    const unsigned Mpw = magic_of(pw);
     int pending = 0;                                   // entries waiting in cl[0..pending), pending < 64 between steps
-    for (int base = 0; base < npx; base += 64) {
-        const int idx = base + lane;
-        int pass = 0;
-        if (idx < npx) {
-            const int py = magic_div(idx, Mdw), px = idx - py * dw;
-            pass = fast_quick_at(&tile[(py + 3) * TP + px + 3 + shx], TP, tlow + 1);
+    for (int base = 0; base < npairs; base += 64) {
+        const int ip = base + lane;
+        int pass = 0, idx = 0;
+        if (ip < npairs) {
+            const int py = magic_div(ip, Mpw), px = (ip - py * pw) * 2;
+            idx = py * dw + px;
+            pass = fast_quick_pair(&tile[(py + 3) * TP + px + 3 + shx], TP, tlow + 1);
+            if (px + 1 >= dw) pass &= 5;                // second pixel of the pair lies outside the detection region
         }
-        // ring positions: entries of lower lanes first, darker before brighter within a lane
-        const unsigned long long bd = __ballot(pass & 1), bb = __ballot(pass & 2);
+        // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1)
+        const unsigned long long b0 = __ballot(pass & 1), b1 = __ballot(pass & 4), b2 = __ballot(pass & 2), b3 = __ballot(pass & 8);
         const unsigned long long below = (1ull << lane) - 1ull;
-        int pos = pending + __popcll(bd & below) + __popcll(bb & below);
+        int pos = pending + __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
         if (pass & 1) cl[pos++] = (uint16_t)idx;
-        if (pass & 2) cl[pos] = (uint16_t)(idx | 0x8000);
-        pending += __popcll(bd) + __popcll(bb);
+        if (pass & 4) cl[pos++] = (uint16_t)(idx | 0x8000);
+        if (pass & 2) cl[pos++] = (uint16_t)(idx + 1);
+        if (pass & 8) cl[pos] = (uint16_t)((idx + 1) | 0x8000);
+        pending += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         while (pending >= 64) {                        // a full wave of entries: score them exactly
             wave_lds_fence();
             const int e = cl[lane];
             const int rest = pending - 64;
-            const int mv0 = lane < rest ? cl[64 + lane] : 0, mv1 = lane + 64 < rest ? cl[128 + lane] : 0;
+            int mv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) mv[q] = lane + 64 * q < rest ? cl[64 * (q + 1) + lane] : 0;
             fast_score_batch<CTP>(tile, sc, e, true, tp, SP, shx, dw, Mdw, tlow);
             wave_lds_fence();
-            if (lane < rest) cl[lane] = (uint16_t)mv0;
-            if (lane + 64 < rest) cl[64 + lane] = (uint16_t)mv1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (lane + 64 * q < rest) cl[64 * q + lane] = (uint16_t)mv[q];
             pending = rest;
         }
     }
@@ -343,10 +359,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int npx = dw * dh;
     uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
     switch (TP) {                                                // compile-time pitches for the common geometries
-        case 48: fast_score_cell<48>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
-        case 52: fast_score_cell<52>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
-        case 56: fast_score_cell<56>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
-        default: fast_score_cell<0>(tile, sc, cl, TP, SP, shx, dw, Mdw, npx, tlow, lane); break;
+        case 48: fast_score_cell<48>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        case 52: fast_score_cell<52>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        case 56: fast_score_cell<56>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        default: fast_score_cell<0>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
     }
     wave_lds_fence();
     const int iters = (npx + 63) >> 6;
@@ -672,8 +688,8 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (192 x uint16)
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 192 * 2 + 15) & ~15;
+    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (320 x uint16: 63 waiting + up to 4 per lane and step)
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 320 * 2 + 15) & ~15;
     hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
