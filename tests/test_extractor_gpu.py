@@ -154,3 +154,21 @@ def test_workgroup_sort_replays_std_sort():
         assert H.rumi_hook_sort_device(capi.ptr(k2), capi.ptr(i2), n) == 0
         assert np.array_equal(k1, k2), f"keys not sorted alike, n={n}"
         assert np.array_equal(i1, i2), f"tie order differs from std::sort, n={n}: {np.count_nonzero(i1 != i2)} positions"
+
+
+def test_featureless_and_saturated_frames():
+    """No corner anywhere (constant image), corners only from clipping (saturated blobs), and a frame with fewer candidates than
+    wanted features on some levels: counts, order and descriptors still equal the oracle's; a constant image yields zero key-points."""
+    g, o = _pair()
+    flat = np.full((480, 640), 97, np.uint8)
+    mono, k, d = g(flat, None, (0, 1000))
+    om, ok, od = o.extract(flat, (0, 1000))
+    assert len(k) == 0 and len(ok) == 0 and mono == om
+    rng = np.random.default_rng(3)
+    sat = np.zeros((480, 640), np.uint8)
+    for _ in range(40):
+        x, y, r = int(rng.integers(30, 610)), int(rng.integers(30, 450)), int(rng.integers(3, 12))
+        sat[y - r:y + r, x - r:x + r] = 255
+    _assert_same(g(sat, None, (0, 1000)), o.extract(sat, (0, 1000)), "saturated blobs")
+    few = synth_frame(21, n_rect=6, noise=0)
+    _assert_same(g(few, None, (0, 1000)), o.extract(few, (0, 1000)), "few candidates")

@@ -308,3 +308,59 @@ def test_search_by_sim3(matcher, seed, th):
     n_gpu, got = SearchBySim3(matcher(), KF1, KF2, K_TUM3, log_sf, side1, side2, th)
     assert n_ref > 50 and n_ref == np.count_nonzero(ref >= 0)
     assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} differ"
+
+
+def _random_frame(rng, n, w=640, h=480, clustered=False):
+    """Random key-points (not from an image): uniform or piled into a few spots, random octaves / angles / descriptors."""
+    k = np.zeros(n, O.KP_DTYPE)
+    if clustered and n:
+        c = rng.uniform([40, 40], [w - 40, h - 40], (6, 2))
+        p = c[rng.integers(0, 6, n)] + rng.normal(0, 6, (n, 2))
+        k["x"], k["y"] = np.clip(p[:, 0], 0, w - 1), np.clip(p[:, 1], 0, h - 1)
+    else:
+        k["x"], k["y"] = rng.uniform(0, w, n), rng.uniform(0, h, n)
+    k["octave"] = rng.integers(0, 8, n)
+    k["angle"] = rng.uniform(0, 360, n)
+    k["size"] = 31; k["response"] = rng.integers(7, 255, n); k["class_id"] = -1
+    return k, rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("case", ["empty_frame", "no_queries", "all_invalid", "max_features_clustered", "list_arena_grows"])
+def test_matcher_edge_cases(case):
+    """Empty and degenerate inputs, the largest frame the grid sort takes (8192 key-points, piled up so that windows hold
+    hundreds of candidates and many queries fight for the same features), and the candidate-list arena growing mid-call."""
+    from rumi_slam_amd.matcher import FrameView, ORBmatcher
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    n_f = {"empty_frame": 0, "max_features_clustered": 8192}.get(case, 1500)
+    keys, desc = _random_frame(rng, n_f, clustered=case in ("max_features_clustered", "list_arena_grows"))
+    nq = 0 if case == "no_queries" else (3000 if case == "max_features_clustered" else 900)
+    mp = dict(track_in_view=(np.zeros(nq, np.uint8) if case == "all_invalid" else (rng.random(nq) < 0.9).astype(np.uint8)),
+              proj_x=rng.uniform(0, 640, nq).astype(np.float32), proj_y=rng.uniform(0, 480, nq).astype(np.float32),
+              scale_level=rng.integers(0, 8, nq).astype(np.int32), view_cos=rng.uniform(0.99, 1.0, nq).astype(np.float32),
+              track_depth=rng.uniform(1, 60, nq).astype(np.float32), is_bad=(rng.random(nq) < 0.05).astype(np.uint8),
+              desc=rng.integers(0, 256, (nq, 32), dtype=np.uint8), obs=rng.integers(0, 5, nq).astype(np.int32))
+    if n_f and nq:                                  # put queries where the key-points are and give them near-identical descriptors
+        pick = rng.integers(0, n_f, nq)
+        mp["proj_x"], mp["proj_y"] = (keys["x"][pick] + rng.normal(0, 2, nq)).astype(np.float32), (keys["y"][pick] + rng.normal(0, 2, nq)).astype(np.float32)
+        mp["scale_level"] = np.clip(keys["octave"][pick] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+        mp["desc"] = desc[pick].copy()
+        mp["desc"][:, 0] ^= rng.integers(0, 256, nq, dtype=np.uint8)
+    if case == "list_arena_grows":                  # one pile, one octave: every query lists ~all 1500 key-points (1.3 M entries > 300 k arena)
+        keys["x"], keys["y"] = 320 + rng.normal(0, 5, n_f), 240 + rng.normal(0, 5, n_f)
+        keys["octave"] = 3
+        mp["proj_x"], mp["proj_y"] = (320 + rng.normal(0, 3, nq)).astype(np.float32), (240 + rng.normal(0, 3, nq)).astype(np.float32)
+        mp["scale_level"][:] = 3
+    fm0 = np.where(rng.random(n_f) < 0.1, rng.integers(0, max(nq, 1), n_f), -1).astype(np.int32) if nq else np.full(n_f, -1, np.int32)
+    th = 12.0 if case in ("max_features_clustered", "list_arena_grows") else 3.0
+    small = case == "list_arena_grows"              # 64 + 65536/256 queries' worth of list entries: a dense call must outgrow it
+    m = ORBmatcher(0.8, True, max_features=8192, max_queries=1024 if small else 16384)
+    F = FrameView(keys, desc, 640, 480, sf)
+    n_ref, fm_ref = O.search_by_projection_mappoints(keys, desc, 640, 480, sf, mp, fm0, th, False, 0.0, 0.8)
+    for rep in range(2):                            # second call: the grown arena is reused
+        n_gpu, fm = m.SearchByProjection_MapPoints(F, mp, fm0, th)
+        assert n_gpu == n_ref and np.array_equal(fm, fm_ref), f"{case}: {np.count_nonzero(fm != fm_ref)} differ"
+    if case in ("max_features_clustered", "list_arena_grows"):
+        assert n_ref > 200
+    if case in ("empty_frame", "no_queries", "all_invalid"):
+        assert n_ref == 0
