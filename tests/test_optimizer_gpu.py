@@ -113,3 +113,27 @@ def test_merge_ba_stop_flag(opt):
     stop = np.ones(1, np.uint8)
     stats, kp, mp, er = opt.MergeBundleAdjustment(*a, stop_flag=stop)
     assert stats[0] == 0 and np.array_equal(kp, b["kf_pose"]) and np.array_equal(mp, b["mp_pos"])
+
+
+def test_local_ba_degenerate_graphs(opt):
+    """All key-frames fixed (structure-only adjustment: the reduced pose system is empty), a landmark with no edge, no edge at all."""
+    b = ba_problem(seed=11, n_opt=0, n_fixed=6, n_points=400)
+    a = [b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"]]
+    its_ref, kp_ref, mp_ref, er_ref = O.local_ba(*a)
+    stats, kp, mp, er = opt.LocalBundleAdjustment(*a)
+    assert stats[0] == its_ref and np.array_equal(kp, b["kf_pose"])
+    scale = np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-2)
+    assert (np.linalg.norm(mp - mp_ref, axis=1) <= RTOL * scale).all() and np.array_equal(er, er_ref)
+    # one more landmark that nobody observes: it must come back untouched
+    b2 = ba_problem(seed=12, n_opt=3, n_fixed=2, n_points=150)
+    mp_pos = np.concatenate([b2["mp_pos"], np.array([[1.0, 2.0, 3.0]], np.float32)])
+    a2 = [b2["kf_pose"], b2["kf_fixed"], mp_pos, b2["e_mp"], b2["e_kf"], b2["e_obs"], b2["e_w"], b2["K"]]
+    its_ref, kp_ref, mp_ref, er_ref = O.local_ba(*a2)
+    stats, kp, mp, er = opt.LocalBundleAdjustment(*a2)
+    assert stats[0] == its_ref and np.array_equal(mp[-1], mp_pos[-1]) and np.array_equal(er, er_ref)
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    # no edges
+    e0 = np.zeros(0, np.int32)
+    stats, kp, mp, er = opt.LocalBundleAdjustment(b2["kf_pose"], b2["kf_fixed"], b2["mp_pos"], e0, e0, np.zeros((0, 2), np.float32), np.zeros(0, np.float32), b2["K"])
+    assert np.array_equal(kp, b2["kf_pose"]) and np.array_equal(mp, b2["mp_pos"]) and len(er) == 0
