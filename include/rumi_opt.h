@@ -75,6 +75,18 @@ int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t 
  * [0] linearise+Hll/Hpl, [1] pose block J^T W J on f64 MFMA, [2] Schur complement, [3] reduced solve, [4] update+chi2, [5] total */
 int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);
 
+/* Sim3Solver::ComputeInliersNum(map1KFs, map2KFs, avpValidKPMatches, gSw1w2) — R/lib_src/Sim3Solver.cc:564-664, the alignment score of
+ * the rumination sub-map merge (CloudMerging.cc:611,748,809).  One entry per matched key-point pair, concatenated over the key-frame
+ * pairs (pair_start [n_pairs + 1]); per pair the two composed transforms gSc1w2 = gSc1w1 * gSw1w2 and gSc2w1 = gSc2w2 * gSw1w2^-1 as
+ * (qx qy qz qw tx ty tz s) doubles, formed by the caller with g2o::Sim3 itself (:620-621); per match the two map points' world
+ * positions, the two key-points (mvKeys), mvLevelSigma2 at their octaves and the points' isEdge flags.  pair_denominator[p] =
+ * vpValidKPMatches.size() (matches skipped for NULL map points still count, :644).  Outputs: inlier flag per match, ratio per pair,
+ * and the returned value: the sorted ratios' element [n/2]. */
+int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_t *pair_start, const int32_t *pair_denominator, const double *S_c1w2,
+                      const double *S_c2w1, const float *K4_1, const float *K4_2, const float *X1, const float *X2, const float *kp1,
+                      const float *kp2, const float *sigma2_1, const float *sigma2_2, const uint8_t *edge1, const uint8_t *edge2,
+                      uint8_t *inlier_out, float *ratio_out, float *median_out);
+
 #ifdef __cplusplus
 }
 #endif

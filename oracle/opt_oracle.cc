@@ -538,4 +538,36 @@ int orc_merge_ba(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float 
     return its;
 }
 
+
+// Sim3Solver::ComputeInliersNum (R/lib_src/Sim3Solver.cc:564-664) on flat arrays (layout: include/rumi_opt.h, rumi_sim3_inliers).
+float orc_sim3_inliers(int nPairs, const int32_t *pairStart, const int32_t *pairDenom, const double *Sc1w2, const double *Sc2w1, const float *K1,
+                       const float *K2, const float *X1, const float *X2, const float *kp1, const float *kp2, const float *sigma1,
+                       const float *sigma2, const uint8_t *edge1, const uint8_t *edge2, uint8_t *inlier, float *ratioOut) {
+    if (nPairs == 0) return 0.f;
+    std::vector<float> ratios;
+    auto reproj2 = [](const double *S, const float *K, const float *X, const float *kp) {
+        const Quat q{S[0], S[1], S[2], S[3]};
+        const V3 r = rotate(q, V3{(double)X[0], (double)X[1], (double)X[2]});                 // g2o::Sim3::map: s*(r*xyz) + t
+        const double s = S[7];
+        const double px = s * r.x + S[4], py = s * r.y + S[5], pz = s * r.z + S[6];
+        const float u = (float)(K[0] * px / pz + K[2]), v = (float)(K[1] * py / pz + K[3]);   // Pinhole::project(Vector3d).cast<float>()
+        const float dx = kp[0] - u, dy = kp[1] - v;
+        return dx * dx + dy * dy;                                                             // dist.dot(dist)
+    };
+    for (int p = 0; p < nPairs; p++) {
+        int nIn = 0;
+        for (int i = pairStart[p]; i < pairStart[p + 1]; i++) {
+            const float err1 = reproj2(Sc1w2 + (size_t)p * 8, K1, X2 + (size_t)i * 3, kp1 + (size_t)i * 2);
+            const float err2 = reproj2(Sc2w1 + (size_t)p * 8, K2, X1 + (size_t)i * 3, kp2 + (size_t)i * 2);
+            const bool in = (err1 < (2 * 9.210 * sigma1[i]) || edge2[i]) && (err2 < (2 * 9.210 * sigma2[i]) || edge1[i]);
+            inlier[i] = in;
+            nIn += in;
+        }
+        ratios.push_back(pairDenom[p] ? (float)nIn / (float)pairDenom[p] : 0.f);
+    }
+    if (ratioOut) std::memcpy(ratioOut, ratios.data(), ratios.size() * sizeof(float));
+    std::sort(ratios.begin(), ratios.end());
+    return ratios[ratios.size() / 2];
+}
+
 }  // extern "C"

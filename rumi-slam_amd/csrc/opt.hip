@@ -705,6 +705,31 @@ __global__ void k_ba_finalize(BADev B, const double *T, const double *X, int use
     erase[e] = (chi2 > 5.991 || !(pc.z > 0.0)) ? 1 : 0;       // Optimizer.cc:1292
 }
 
+// Sim3Solver::ComputeInliersNum (R/lib_src/Sim3Solver.cc:564-664): one lane per matched key-point pair.
+// g2o::Sim3::map = s * (r * xyz) + t in double (G/types/sim3.h:144-146), Pinhole::project(Vector3d) in double then .cast<float>()
+// (Pinhole.cpp:35-41), squared reprojection errors in float, tests against 2 * 9.210 * mvLevelSigma2 in double.
+__global__ void k_sim3_inliers(int total, const int32_t *pairOf, const double *Sc1w2, const double *Sc2w1, const float *K1, const float *K2,
+                               const float *X1, const float *X2, const float *kp1, const float *kp2, const float *sigma1, const float *sigma2,
+                               const uint8_t *edge1, const uint8_t *edge2, uint8_t *inlier) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pr = pairOf[i];
+    auto reproj2 = [](const double *S, const float *K, const float *X, const float *kp) -> float {
+        const DQuat q{S[0], S[1], S[2], S[3]};
+        const D3 r = quat_rotate(q, D3{(double)X[0], (double)X[1], (double)X[2]});
+        const double s = S[7];
+        const double px = s * r.x + S[4], py = s * r.y + S[5], pz = s * r.z + S[6];
+        const float u = (float)((double)K[0] * px / pz + (double)K[2]), v = (float)((double)K[1] * py / pz + (double)K[3]);
+        const float dx = kp[0] - u, dy = kp[1] - v;
+        return dx * dx + dy * dy;
+    };
+    const float err1 = reproj2(Sc1w2 + (size_t)pr * 8, K1, X2 + (size_t)i * 3, kp1 + (size_t)i * 2);   // map-2 point into key-frame 1
+    const float err2 = reproj2(Sc2w1 + (size_t)pr * 8, K2, X1 + (size_t)i * 3, kp2 + (size_t)i * 2);   // map-1 point into key-frame 2
+    const bool ok1 = (double)err1 < 2 * 9.210 * (double)sigma1[i] || edge2[i];
+    const bool ok2 = (double)err2 < 2 * 9.210 * (double)sigma2[i] || edge1[i];
+    inlier[i] = ok1 && ok2;
+}
+
 }  // namespace rumi
 
 using namespace rumi;
@@ -1067,4 +1092,52 @@ extern "C" int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
                              int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
                              const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
     return ba_run(o, 1, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats);
+}
+
+
+extern "C" int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_t *pair_start, const int32_t *pair_denominator,
+                                 const double *S_c1w2, const double *S_c2w1, const float *K4_1, const float *K4_2, const float *X1, const float *X2,
+                                 const float *kp1, const float *kp2, const float *sigma2_1, const float *sigma2_2, const uint8_t *edge1,
+                                 const uint8_t *edge2, uint8_t *inlier_out, float *ratio_out, float *median_out) {
+    if (!o || n_pairs < 0 || !pair_start || !pair_denominator || !K4_1 || !K4_2 || !median_out) return RUMI_E_INVALID;
+    *median_out = 0.f;
+    if (n_pairs == 0) return RUMI_OK;
+    const int total = pair_start[n_pairs];
+    if (total < 0 || (total > 0 && (!S_c1w2 || !S_c2w1 || !X1 || !X2 || !kp1 || !kp2 || !sigma2_1 || !sigma2_2 || !edge1 || !edge2 || !inlier_out)))
+        return RUMI_E_INVALID;
+    std::vector<float> ratio(n_pairs, 0.f);
+    if (total > 0) {
+        HIP_TRY(hipSetDevice(o->device));
+        // one pinned block up (read in place), one flag array back
+        auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        const size_t oP = 0, oA = al(oP + (size_t)total * 4), oB = al(oA + (size_t)n_pairs * 64), oK = al(oB + (size_t)n_pairs * 64), oX1 = al(oK + 32),
+                     oX2 = al(oX1 + (size_t)total * 12), oK1 = al(oX2 + (size_t)total * 12), oK2 = al(oK1 + (size_t)total * 8), oS1 = al(oK2 + (size_t)total * 8),
+                     oS2 = al(oS1 + (size_t)total * 4), oE1 = al(oS2 + (size_t)total * 4), oE2 = al(oE1 + (size_t)total), bytes = al(oE2 + (size_t)total);
+        if (bytes > o->baStageCap || (size_t)total > o->baStageCap) { g_lastError = "Sim3 inliers: more matches than the optimiser's arenas hold"; return RUMI_E_CAPACITY; }
+        uint8_t *h = o->hBa;
+        int32_t *pairOf = reinterpret_cast<int32_t *>(h + oP);
+        for (int p = 0; p < n_pairs; p++) for (int i = pair_start[p]; i < pair_start[p + 1]; i++) pairOf[i] = p;
+        std::memcpy(h + oA, S_c1w2, (size_t)n_pairs * 64); std::memcpy(h + oB, S_c2w1, (size_t)n_pairs * 64);
+        std::memcpy(h + oK, K4_1, 16); std::memcpy(h + oK + 16, K4_2, 16);
+        std::memcpy(h + oX1, X1, (size_t)total * 12); std::memcpy(h + oX2, X2, (size_t)total * 12);
+        std::memcpy(h + oK1, kp1, (size_t)total * 8); std::memcpy(h + oK2, kp2, (size_t)total * 8);
+        std::memcpy(h + oS1, sigma2_1, (size_t)total * 4); std::memcpy(h + oS2, sigma2_2, (size_t)total * 4);
+        std::memcpy(h + oE1, edge1, (size_t)total); std::memcpy(h + oE2, edge2, (size_t)total);
+        HIP_TRY(hipMemcpyAsync(o->dBa, h, bytes, hipMemcpyHostToDevice, nullptr));
+        uint8_t *d = o->dBa;
+        hipLaunchKernelGGL(k_sim3_inliers, dim3((total + 255) / 256), dim3(256), 0, nullptr, total, (const int32_t *)(d + oP), (const double *)(d + oA),
+                           (const double *)(d + oB), (const float *)(d + oK), (const float *)(d + oK + 16), (const float *)(d + oX1), (const float *)(d + oX2),
+                           (const float *)(d + oK1), (const float *)(d + oK2), (const float *)(d + oS1), (const float *)(d + oS2), d + oE1, d + oE2, o->dBaOut);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(inlier_out, o->dBaOut, (size_t)total, hipMemcpyDeviceToHost));
+    }
+    for (int p = 0; p < n_pairs; p++) {                                       // :643-646
+        int nIn = 0;
+        for (int i = pair_start[p]; i < pair_start[p + 1]; i++) nIn += inlier_out[i];
+        ratio[p] = pair_denominator[p] ? (float)nIn / (float)pair_denominator[p] : 0.f;
+    }
+    if (ratio_out) std::memcpy(ratio_out, ratio.data(), (size_t)n_pairs * sizeof(float));
+    std::sort(ratio.begin(), ratio.end());                                    // :654-662
+    *median_out = ratio[n_pairs / 2];
+    return RUMI_OK;
 }

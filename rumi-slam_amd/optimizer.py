@@ -6,7 +6,7 @@ import numpy as np
 
 from . import capi
 
-OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba",
+OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_sim3_inliers",
                "rumi_opt_stage_ms"]
 
 
@@ -21,6 +21,7 @@ def _lib():
     L.rumi_pose_optimization.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.rumi_pose_optimization_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_local_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
     L._opt_ready = True
@@ -80,6 +81,19 @@ class Optimizer:
     def MergeBundleAdjustment(self, *args, **kw):
         """Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag): the two-pass merge-window BA."""
         return self.LocalBundleAdjustment(*args, merge=True, **kw)
+
+    def ComputeInliersNum(self, pair_start, pair_denominator, S_c1w2, S_c2w1, K4_1, K4_2, X1, X2, kp1, kp2, sigma2_1, sigma2_2, edge1, edge2):
+        """Sim3Solver::ComputeInliersNum on flat arrays (include/rumi_opt.h).  Returns (median ratio, ratio per pair, inlier flags)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        ps = np.ascontiguousarray(pair_start, np.int32); pd = np.ascontiguousarray(pair_denominator, np.int32)
+        A = np.ascontiguousarray(S_c1w2, np.float64); B = np.ascontiguousarray(S_c2w1, np.float64)
+        arrs = [f32(K4_1), f32(K4_2), f32(X1), f32(X2), f32(kp1), f32(kp2), f32(sigma2_1), f32(sigma2_2), np.ascontiguousarray(edge1, np.uint8),
+                np.ascontiguousarray(edge2, np.uint8)]
+        n_pairs, total = len(ps) - 1, int(ps[-1])
+        inl = np.zeros(max(total, 1), np.uint8); ratio = np.zeros(max(n_pairs, 1), np.float32); med = C.c_float()
+        capi.check(self._lib.rumi_sim3_inliers(self._h, n_pairs, capi.ptr(ps), capi.ptr(pd), capi.ptr(A), capi.ptr(B), *[capi.ptr(a) for a in arrs],
+                                               capi.ptr(inl), capi.ptr(ratio), C.byref(med)))
+        return med.value, ratio[:n_pairs], inl[:total]
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)

@@ -18,6 +18,7 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
+#include "Sim3Scoring.h"
 
 struct Map { std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int changes = 0; void IncreaseChangeIndex() { changes++; } };
 struct KeyFrame;
@@ -28,7 +29,7 @@ struct Camera {
 };
 struct MapPoint {
     static std::mutex mGlobalMutex;
-    Eigen::Vector3f pos, normal{0, 0, 1}; cv::Mat desc; int nObs = 1; bool bad = false; Map *map = nullptr; long mnBALocalForKF = -1;
+    Eigen::Vector3f pos, normal{0, 0, 1}; cv::Mat desc; int nObs = 1; bool bad = false, isEdge = false; Map *map = nullptr; long mnBALocalForKF = -1;
     std::map<KeyFrame *, std::tuple<int, int>> obs;
     float minD = 0.5f, maxD = 60.f;
     Eigen::Vector3f GetWorldPos() { return pos; }
@@ -52,7 +53,8 @@ std::mutex MapPoint::mGlobalMutex;
 struct Frame {
     int N = 0;
     std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<MapPoint *> mvpMapPoints; std::vector<bool> mvbOutlier;
-    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2, mvLevelSigma2;
+    std::vector<cv::KeyPoint> mvKeys;
     float mnMinX = 0, mnMinY = 0, mnMaxX = 640, mnMaxY = 480, fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
     float mfLogScaleFactor = 0.1823216f; int mnScaleLevels = 8;
     Sophus::SE3f pose;
@@ -194,6 +196,32 @@ int main(int argc, char **argv) {
         CHECK(ng > 500, "PoseOptimization inliers");
         CHECK(std::fabs(T.translation()(0) - 0.02f) < 5e-3f && std::fabs(T.translation()(2) - 0.03f) < 5e-3f && std::fabs(T.unit_quaternion().x() - 0.004f) < 2e-3f,
               "PoseOptimization recovers the pose the points were built with");
+    }
+    // --- ComputeInliersNum: two key-frames observing the same points; world 2 = world 1 under a similarity -> all inliers ---
+    {
+        KeyFrame A = kf[0], B = kf[0];
+        A.mvKeys = A.mvKeysUn; B.mvKeys = B.mvKeysUn;
+        A.mvLevelSigma2.assign(8, 1.f); B.mvLevelSigma2.assign(8, 1.f);
+        for (int l = 1; l < 8; l++) { A.mvLevelSigma2[l] = A.mvScaleFactors[l] * A.mvScaleFactors[l]; B.mvLevelSigma2[l] = A.mvLevelSigma2[l]; }
+        const double sc = 2.0;
+        g2o::Sim3 Sw1w2(Eigen::Quaterniond{1, 0, 0, 0}, Eigen::Vector3d{{0.5, -0.25, 1.0}}, sc);     // Pw1 = sc * Pw2 + t
+        B.pose = Sophus::SE3f(Eigen::Quaternionf(1, 0, 0, 0), Eigen::Vector3f(0.25f, -0.125f, 0.5f));   // camera 2 = camera 1 seen from world 2: t / sc
+        std::vector<MapPoint> ma(A.N), mb(B.N);
+        std::vector<std::pair<int, int>> matches;
+        for (int i = 0; i < A.N; i++) {
+            const float z = 3.f + (i % 40) / 10.f;
+            const Eigen::Vector3f pcA((A.mvKeysUn[i].pt.x - 320.1f) / 535.4f * z, (A.mvKeysUn[i].pt.y - 247.6f) / 539.2f * z, z);
+            ma[i].pos = pcA;                                                                         // camera 1 at the origin of world 1
+            mb[i].pos = Eigen::Vector3f((pcA(0) - 0.5f) / 2.f, (pcA(1) + 0.25f) / 2.f, (pcA(2) - 1.0f) / 2.f);
+            if (i % 9 == 0) mb[i].pos = mb[i].pos + Eigen::Vector3f(0.3f, 0.f, 0.f);                   // a few gross outliers
+            A.mvpMapPoints[i] = &ma[i]; B.mvpMapPoints[i] = &mb[i];
+            matches.push_back({i, i});
+        }
+        std::vector<KeyFrame *> m1 = {&A, nullptr}, m2 = {&B, &B};
+        std::vector<std::vector<std::pair<int, int>>> all = {matches, matches};
+        const float ratio = rumi_facade::ComputeInliersNum(m1, m2, all, Sw1w2);
+        CHECK(ratio > 0.85f && ratio < 0.92f, "ComputeInliersNum: 8/9 of the matches are inliers");
+        std::printf("ComputeInliersNum ratio %.4f\n", ratio);
     }
     if (fails == 0) std::printf("facade (Sophus overloads): all checks passed\n");
     return fails ? 1 : 0;

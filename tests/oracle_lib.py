@@ -386,3 +386,18 @@ class OracleVocabulary:
         nw, nn = np.zeros(1, np.int32), np.zeros(1, np.int32)
         self._L.orc_voc_transform(self._h, _p(d), n, int(levelsup), _p(bi), _p(bv), _p(nw), _p(fn), _p(fo), _p(fi), _p(nn))
         return (bi[:nw[0]].copy(), bv[:nw[0]].copy()), (fn[:nn[0]].copy(), fo[:nn[0] + 1].copy(), fi[:fo[nn[0]]].copy())
+
+
+def sim3_inliers(pair_start, pair_denominator, S_c1w2, S_c2w1, K4_1, K4_2, X1, X2, kp1, kp2, sigma2_1, sigma2_2, edge1, edge2):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    ps = np.ascontiguousarray(pair_start, np.int32); pd = np.ascontiguousarray(pair_denominator, np.int32)
+    A = np.ascontiguousarray(S_c1w2, np.float64); B = np.ascontiguousarray(S_c2w1, np.float64)
+    arrs = [f32(K4_1), f32(K4_2), f32(X1), f32(X2), f32(kp1), f32(kp2), f32(sigma2_1), f32(sigma2_2), np.ascontiguousarray(edge1, np.uint8),
+            np.ascontiguousarray(edge2, np.uint8)]
+    n_pairs, total = len(ps) - 1, int(ps[-1])
+    inl = np.zeros(max(total, 1), np.uint8); ratio = np.zeros(max(n_pairs, 1), np.float32)
+    L = _olib()
+    L.orc_sim3_inliers.restype = C.c_float
+    L.orc_sim3_inliers.argtypes = [C.c_int32] + [C.c_void_p] * 16
+    med = L.orc_sim3_inliers(n_pairs, _p(ps), _p(pd), _p(A), _p(B), *[_p(a) for a in arrs], _p(inl), _p(ratio))
+    return med, ratio[:n_pairs], inl[:total]

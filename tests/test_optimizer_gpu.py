@@ -137,3 +137,53 @@ def test_local_ba_degenerate_graphs(opt):
     e0 = np.zeros(0, np.int32)
     stats, kp, mp, er = opt.LocalBundleAdjustment(b2["kf_pose"], b2["kf_fixed"], b2["mp_pos"], e0, e0, np.zeros((0, 2), np.float32), np.zeros(0, np.float32), b2["K"])
     assert np.array_equal(kp, b2["kf_pose"]) and np.array_equal(mp, b2["mp_pos"]) and len(er) == 0
+
+
+def test_sim3_inlier_scoring(opt):
+    """Sim3Solver::ComputeInliersNum: two maps related by a similarity, per key-frame pair the matched points re-projected both
+    ways; inlier flags identical, ratios and the returned median identical (the same float divisions)."""
+    from scene import quat_from_rotvec, quat_rotate
+    rng = np.random.default_rng(4)
+    K = K_TUM = np.array([535.4, 539.2, 320.1, 247.6], np.float32)
+    n_pairs = 9
+    s12 = 1.7
+    qS = quat_from_rotvec(np.array([0.05, -0.1, 0.2])); tS = np.array([0.4, -0.2, 1.0])
+    _, RS = quat_rotate(qS, np.zeros((1, 3)))
+    ps, den, A, B, X1, X2, k1, k2, s1, s2, e1, e2 = [0], [], [], [], [], [], [], [], [], [], [], []
+
+    def compose(qa, ta, sa, qb, tb, sb):            # (sa, Ra, ta) * (sb, Rb, tb)
+        _, Ra = quat_rotate(qa, np.zeros((1, 3)))
+        x, y, z, w = qa; x2, y2, z2, w2 = qb
+        q = np.array([w * x2 + x * w2 + y * z2 - z * y2, w * y2 + y * w2 + z * x2 - x * z2, w * z2 + z * w2 + x * y2 - y * x2, w * w2 - x * x2 - y * y2 - z * z2])
+        return q, sa * (Ra @ tb) + ta, sa * sb
+
+    for p in range(n_pairs):
+        m = int(rng.integers(0, 120)) if p != 3 else 0
+        qc = quat_from_rotvec(rng.normal(size=3) * 0.05); tc = rng.normal(size=3) * 0.1            # camera 1 from world 1
+        _, Rc = quat_rotate(qc, np.zeros((1, 3)))
+        Pc = np.stack([rng.uniform(-1, 1, m), rng.uniform(-0.8, 0.8, m), rng.uniform(2, 6, m)], 1)   # points in camera 1
+        Pw1 = (Pc - tc) @ Rc                                                                         # world 1
+        Pw2 = ((Pw1 - tS) @ RS) / s12                                                                # world 2: Pw1 = s R Pw2 + t
+        # gSw1w2 = (s12, RS, tS); camera 2 == camera 1 seen from world 2: Sc2w2 = Sc1w1 * Sw1w2 with unit scale kept by rescaling points
+        q12, t12, sc = compose(qc, tc, 1.0, qS, tS, s12)                                             # gSc1w2
+        A.append(np.concatenate([q12, t12, [sc]]))
+        # key-frame 2 pose in world 2 (scale 1): same rotation, translation scaled
+        q2, t2 = q12, t12 / s12
+        # gSc2w1 = gSc2w2 * gSw1w2^-1
+        _, RSi = RS.T, None
+        qSi = np.array([-qS[0], -qS[1], -qS[2], qS[3]]); tSi = -(RS.T @ tS) / s12
+        qb, tb, sb = compose(q2, t2, 1.0, qSi, tSi, 1.0 / s12)
+        B.append(np.concatenate([qb, tb, [sb]]))
+        u = K[0] * Pc[:, 0] / Pc[:, 2] + K[2]; v = K[1] * Pc[:, 1] / Pc[:, 2] + K[3]
+        noise = rng.normal(0, 1.5, (m, 2)); noise[rng.random(m) < 0.2] += 30
+        k1.append(np.stack([u, v], 1) + noise); k2.append(np.stack([u, v], 1) + rng.normal(0, 1.5, (m, 2)))
+        X1.append(Pw1); X2.append(Pw2)
+        s1.append(np.float32(1.2) ** (2 * rng.integers(0, 8, m))); s2.append(np.float32(1.2) ** (2 * rng.integers(0, 8, m)))
+        e1.append((rng.random(m) < 0.1)); e2.append((rng.random(m) < 0.1))
+        ps.append(ps[-1] + m); den.append(m + int(rng.integers(0, 3)))
+    cat = lambda l, w: np.concatenate(l).reshape(-1, w) if w else np.concatenate(l)
+    args = (ps, den, np.stack(A), np.stack(B), K, K, cat(X1, 3), cat(X2, 3), cat(k1, 2), cat(k2, 2), cat(s1, 0), cat(s2, 0), cat(e1, 0), cat(e2, 0))
+    med_ref, r_ref, in_ref = O.sim3_inliers(*args)
+    med, r, inl = opt.ComputeInliersNum(*args)
+    assert 0.3 < in_ref.mean() < 0.99 and len(in_ref) > 300
+    assert np.array_equal(inl, in_ref) and np.array_equal(r, r_ref) and med == med_ref
