@@ -75,6 +75,16 @@ int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t 
  * [0] linearise+Hll/Hpl, [1] pose block J^T W J on f64 MFMA, [2] Schur complement, [3] reduced solve, [4] update+chi2, [5] total */
 int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);
 
+/* Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) — R/lib_src/Optimizer.cc:54-351, monocular edges: the
+ * full BA behind GlobalBundleAdjustemnt (map initialisation, Tracking.cc CreateInitialMapMonocular: 2 key-frames, 20 iterations; loop /
+ * merge correction).  Same flattened graph as rumi_local_ba (kf_fixed[k] = the key-frame is the map's first one, :116); one
+ * optimize(n_iterations) with Huber(sqrt(5.99)) when robust.  Landmarks without an edge keep their position (:248-250).  As for the
+ * other BA entry points the reduced pose system is dense and limited to 42 optimised key-frames (RUMI_E_CAPACITY beyond).
+ * stats = {LM iterations, LM trials, optimised key-frames, 0}. */
+int rumi_bundle_adjustment(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3, int32_t nE,
+                           const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2, const float *K4,
+                           const volatile uint8_t *stop_flag, int32_t n_iterations, int32_t robust, int32_t *stats);
+
 /* Sim3Solver::ComputeInliersNum(map1KFs, map2KFs, avpValidKPMatches, gSw1w2) — R/lib_src/Sim3Solver.cc:564-664, the alignment score of
  * the rumination sub-map merge (CloudMerging.cc:611,748,809).  One entry per matched key-point pair, concatenated over the key-frame
  * pairs (pair_start [n_pairs + 1]); per pair the two composed transforms gSc1w2 = gSc1w1 * gSw1w2 and gSc2w1 = gSc2w2 * gSw1w2^-1 as

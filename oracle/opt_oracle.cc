@@ -539,6 +539,29 @@ int orc_merge_ba(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float 
 }
 
 
+// Optimizer::BundleAdjustment (R/lib_src/Optimizer.cc:54-351), monocular edges, on the flattened graph of orc_local_ba: one
+// optimize(nIterations), Huber(sqrt(5.99)) on every edge when bRobust.  Returns the LM iterations run.
+int orc_bundle_adjustment(int nKF, float *kfPose, const uint8_t *kfFixed, int nMP, float *mpPos, int nE, const int32_t *eMP, const int32_t *eKF,
+                          const float *eObs, const float *eInvSigma2, const float *K4, const volatile uint8_t *stop, int nIterations, int bRobust) {
+    BAProblem P;
+    P.nKF = nKF; P.nMP = nMP; P.nE = nE; P.fixedKF = kfFixed; P.eMP = eMP; P.eKF = eKF; P.stop = stop;
+    P.T.resize(nKF); P.X.resize(nMP);
+    for (int k = 0; k < nKF; k++) P.T[k] = se3_from_float7(kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) P.X[p] = {mpPos[3 * p], mpPos[3 * p + 1], mpPos[3 * p + 2]};
+    std::vector<double> o(2 * (size_t)nE), w(nE);
+    for (int e = 0; e < nE; e++) { o[2 * e] = eObs[2 * e]; o[2 * e + 1] = eObs[2 * e + 1]; w[e] = eInvSigma2[e]; }
+    P.obs = o.data(); P.info = w.data();
+    P.cam = {K4[0], K4[1], K4[2], K4[3]};
+    const float thHuber2D = (float)std::sqrt(5.99);                       // :122
+    P.delta = thHuber2D; P.dsqr = P.delta * P.delta;
+    P.init();
+    P.robust = bRobust != 0;
+    const int its = lm_optimize(P, nIterations);                          // :258-260
+    for (int k = 0; k < nKF; k++) if (!kfFixed[k]) se3_to_float7(P.T[k], kfPose + 7 * k);
+    for (int p = 0; p < nMP; p++) { mpPos[3 * p] = (float)P.X[p].x; mpPos[3 * p + 1] = (float)P.X[p].y; mpPos[3 * p + 2] = (float)P.X[p].z; }
+    return its;
+}
+
 // Sim3Solver::ComputeInliersNum (R/lib_src/Sim3Solver.cc:564-664) on flat arrays (layout: include/rumi_opt.h, rumi_sim3_inliers).
 float orc_sim3_inliers(int nPairs, const int32_t *pairStart, const int32_t *pairDenom, const double *Sc1w2, const double *Sc2w1, const float *K1,
                        const float *K2, const float *X1, const float *X2, const float *kp1, const float *kp2, const float *sigma1,

@@ -886,9 +886,11 @@ extern "C" int rumi_pose_optimization(RumiOptimizer *o, const float *Xw, const f
 // mode 1: Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vpAdjustKF, vpFixedKF, bool*) (merge window, Optimizer.cc:3768-4183) —
 //         optimize(5) with Huber(sqrt(5.99)); unless stopped: outlier edges to level 1, kernels off, initializeOptimization(0) +
 //         optimize(10); the erase test reads every edge's stored error (level-1 edges: the one they had when they left).
+// mode 2: Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) (Optimizer.cc:54-351, monocular edges) —
+//         one optimize(nIterations), Huber(sqrt(5.99)) only if bRobust.
 static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
                   int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
-                  const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
+                  const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats, int gbaIterations = 0, int gbaRobust = 1) {
     if (!o || nKF < 1 || nMP < 0 || nE < 0 || !kf_pose7 || !kf_fixed || !K4 || (nMP > 0 && !mp_pos3) ||
         (nE > 0 && (!e_mp || !e_kf || !e_obs || !e_inv_sigma2 || !erase_out)))
         return RUMI_E_INVALID;
@@ -897,7 +899,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     int nFixed = 0;
     for (int k = 0; k < nKF; k++) nFixed += kf_fixed[k] ? 1 : 0;
     if (nFixed == 0 && mode == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
-    if (stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                                     // :1274-1276
+    if (mode != 2 && stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                         // :1274-1276 / :3982-3984
     for (int e = 0; e < nE; e++)
         if (e_mp[e] < 0 || e_mp[e] >= nMP || e_kf[e] < 0 || e_kf[e] >= nKF) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(o->device));
@@ -950,7 +952,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     B.cam = DCam{K4[0], K4[1], K4[2], K4[3]};
     B.delta = mode == 0 ? (double)(float)std::sqrt(5.991) : (double)(float)std::sqrt(5.99);   // thHuberMono = sqrt(5.991) / thHuber2D = sqrt(5.99)
     B.dsqr = B.delta * B.delta;
-    B.off = o->dEOff; B.robust = 1;
+    B.off = o->dEOff; B.robust = mode == 2 ? (gbaRobust ? 1 : 0) : 1;
     if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, nullptr));
     B.Hll = o->dHll; B.bl = o->dBl; B.Hpl = o->dHpl; B.panel = o->dPanel; B.Hpp = o->dHpp; B.bp = o->dBp; B.Dinv = o->dDinv; B.S = o->dS;
     B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
@@ -1053,7 +1055,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     return RUMI_OK;
     };
     int itersFirst = 0;
-    if ((rc = lm(mode == 0 ? 10 : 5)) != RUMI_OK) return rc;
+    if ((rc = lm(mode == 0 ? 10 : mode == 1 ? 5 : gbaIterations)) != RUMI_OK) return rc;
     itersFirst = iters;
     if (mode == 1 && !(stop_flag && *stop_flag)) {          // bDoMore
         if (nE > 0 && ranChi2) hipLaunchKernelGGL(k_ba_mark, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], o->dEOff);
@@ -1078,7 +1080,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
     }
     for (size_t i = 0; i < (size_t)nMP * 3; i++) mp_pos3[i] = (float)X1[i];
-    if (stats) { stats[0] = mode == 0 ? iters : itersFirst; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 0 ? 0 : iters - itersFirst; }
+    if (stats) { stats[0] = mode == 1 ? itersFirst : iters; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 1 ? iters - itersFirst : 0; }
     return RUMI_OK;
 }
 
@@ -1086,6 +1088,14 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
                              int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
                              const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
     return ba_run(o, 0, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats);
+}
+
+extern "C" int rumi_bundle_adjustment(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,
+                                      int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
+                                      const float *K4, const volatile uint8_t *stop_flag, int32_t n_iterations, int32_t robust, int32_t *stats) {
+    if (n_iterations < 0) return RUMI_E_INVALID;
+    std::vector<uint8_t> erase((size_t)std::max(nE, 1));
+    return ba_run(o, 2, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase.data(), stats, n_iterations, robust);
 }
 
 extern "C" int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,

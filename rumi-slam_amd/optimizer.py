@@ -6,7 +6,7 @@ import numpy as np
 
 from . import capi
 
-OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_sim3_inliers",
+OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
                "rumi_opt_stage_ms"]
 
 
@@ -21,6 +21,7 @@ def _lib():
     L.rumi_pose_optimization.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.rumi_pose_optimization_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_local_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_bundle_adjustment.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
@@ -77,6 +78,18 @@ class Optimizer:
         capi.check(fn(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
                       capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
         return stats, kp, mp, erase[:len(em)]
+
+    def BundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, n_iterations=5, robust=True, stop_flag=None):
+        """Optimizer::BundleAdjustment (global BA): returns (stats[4], kf_pose, mp_pos)."""
+        kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
+        mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32)
+        ek = np.ascontiguousarray(e_kf, np.int32); eo = np.ascontiguousarray(e_obs, np.float32)
+        ew = np.ascontiguousarray(e_inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+        stats = np.zeros(4, np.int32)
+        sp = capi.ptr(stop_flag) if stop_flag is not None else None
+        capi.check(self._lib.rumi_bundle_adjustment(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
+                                                    capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, int(n_iterations), int(robust), capi.ptr(stats)))
+        return stats, kp, mp
 
     def MergeBundleAdjustment(self, *args, **kw):
         """Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag): the two-pass merge-window BA."""

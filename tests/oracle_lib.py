@@ -242,6 +242,17 @@ def local_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, sto
     return its, kp, mp, erase
 
 
+def bundle_adjustment(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, n_iterations, robust):
+    kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)
+    mp = np.ascontiguousarray(mp_pos, np.float32).copy(); em = np.ascontiguousarray(e_mp, np.int32); ek = np.ascontiguousarray(e_kf, np.int32)
+    eo = np.ascontiguousarray(e_obs, np.float32); ew = np.ascontiguousarray(e_inv_sigma2, np.float32); K4 = np.ascontiguousarray(K4, np.float32)
+    L = _olib()
+    L.orc_bundle_adjustment.restype = C.c_int32
+    L.orc_bundle_adjustment.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32]
+    its = L.orc_bundle_adjustment(len(kfix), _p(kp), _p(kfix), len(mp), _p(mp), len(em), _p(em), _p(ek), _p(eo), _p(ew), _p(K4), None, int(n_iterations), int(robust))
+    return its, kp, mp
+
+
 def merge_ba(kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop=None):
     """Returns (its of the two optimize() calls, kf_pose, mp_pos, erase)."""
     kp = np.ascontiguousarray(kf_pose, np.float32).copy(); kfix = np.ascontiguousarray(kf_fixed, np.uint8)

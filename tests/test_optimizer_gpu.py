@@ -187,3 +187,19 @@ def test_sim3_inlier_scoring(opt):
     med, r, inl = opt.ComputeInliersNum(*args)
     assert 0.3 < in_ref.mean() < 0.99 and len(in_ref) > 300
     assert np.array_equal(inl, in_ref) and np.array_equal(r, r_ref) and med == med_ref
+
+
+@pytest.mark.parametrize("cfg,its,robust", [(dict(seed=21, n_opt=1, n_fixed=1, n_points=300), 20, True), (dict(seed=22, n_opt=24, n_fixed=1, n_points=1200), 10, False),
+                                            (dict(seed=23, n_opt=9, n_fixed=1, n_points=700, outlier_frac=0.1), 5, True)])
+def test_global_bundle_adjustment(opt, cfg, its, robust):
+    """Optimizer::BundleAdjustment: the 2-key-frame, 20-iteration BA of the monocular map initialisation, and larger windows with
+    and without the robust kernel; one fixed key-frame (the map's first)."""
+    b = ba_problem(**cfg)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    its_ref, kp_ref, mp_ref = O.bundle_adjustment(*a, its, robust)
+    stats, kp, mp = opt.BundleAdjustment(*a, n_iterations=its, robust=robust)
+    assert stats[0] == its_ref and its_ref > 1
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    scale = np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-2)
+    assert (np.linalg.norm(mp - mp_ref, axis=1) <= RTOL * scale).all(), "landmarks"
