@@ -739,14 +739,10 @@ struct RumiOptimizer {
     int device = 0;
     int maxPoseEdges = 0, maxPoseBatch = 0, maxKF = 0, maxMP = 0, maxE = 0;
     // pose optimisation
-    int32_t *dStart = nullptr, *dNGood = nullptr;
-    float *dXw = nullptr, *dObs = nullptr, *dW = nullptr, *dK = nullptr, *dT7 = nullptr;
-    uint8_t *dOutlier = nullptr, *dActive = nullptr, *dEOff = nullptr;
+    uint8_t *dActive = nullptr, *dEOff = nullptr;       // pose inputs / outputs live in the transfer blocks below
     double *dLastChi2 = nullptr;
     // BA
-    int32_t *dEMP = nullptr, *dEKF = nullptr, *dPoseCol = nullptr, *dPtStart = nullptr, *dPtEdge = nullptr, *dRowSlot = nullptr,
-            *dKfRowStart = nullptr;
-    double *dObsD = nullptr, *dInfo = nullptr, *dT[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr};
+    double *dT[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr};   // graph arrays are read in place from the upload mirror (dBa)
     double *dHll = nullptr, *dBl = nullptr, *dHpl = nullptr, *dPanel = nullptr, *dHpp = nullptr, *dBp = nullptr, *dDinv = nullptr,
            *dS = nullptr, *dBs = nullptr, *dXv = nullptr, *dChi = nullptr, *dScal = nullptr, *dAglob = nullptr, *dYt = nullptr, *dG = nullptr, *dLp = nullptr;
     int npCap = 0;
@@ -767,8 +763,7 @@ template <class T> static int oalloc(T **p, size_t n) {
 extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     if (!o) return;
     (void)hipSetDevice(o->device);
-    void *p[] = {o->dStart, o->dNGood, o->dXw, o->dObs, o->dW, o->dK, o->dT7, o->dOutlier, o->dActive, o->dLastChi2, o->dEMP, o->dEKF,
-                 o->dPoseCol, o->dPtStart, o->dPtEdge, o->dRowSlot, o->dKfRowStart, o->dObsD, o->dInfo, o->dT[0], o->dT[1], o->dX[0],
+    void *p[] = {o->dActive, o->dLastChi2, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
                  o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp};
     for (void *q : p) if (q) (void)hipFree(q);
@@ -798,12 +793,7 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     const size_t PE = max_pose_edges, PB = max_pose_batch, K = max_kf, M = max_mp, E = max_edges, N = 6 * K;
     int rc;
 #define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_opt_destroy(o); return rc; }
-    TRYA(oalloc(&o->dStart, PB + 1)); TRYA(oalloc(&o->dNGood, PB)); TRYA(oalloc(&o->dXw, PE * 3)); TRYA(oalloc(&o->dObs, PE * 2));
-    TRYA(oalloc(&o->dW, PE)); TRYA(oalloc(&o->dK, 4)); TRYA(oalloc(&o->dT7, PB * 7)); TRYA(oalloc(&o->dOutlier, PE));
     TRYA(oalloc(&o->dActive, PE)); TRYA(oalloc(&o->dLastChi2, PE));
-    TRYA(oalloc(&o->dEMP, E)); TRYA(oalloc(&o->dEKF, E)); TRYA(oalloc(&o->dPoseCol, K)); TRYA(oalloc(&o->dPtStart, M + 1));
-    TRYA(oalloc(&o->dPtEdge, E)); TRYA(oalloc(&o->dRowSlot, E)); TRYA(oalloc(&o->dKfRowStart, K + 1));
-    TRYA(oalloc(&o->dObsD, E * 2)); TRYA(oalloc(&o->dInfo, E));
     for (int i = 0; i < 2; i++) { TRYA(oalloc(&o->dT[i], K * 8)); TRYA(oalloc(&o->dX[i], M * 3)); }
     TRYA(oalloc(&o->dHll, M * 9)); TRYA(oalloc(&o->dBl, M * 3)); TRYA(oalloc(&o->dHpl, E * 18)); TRYA(oalloc(&o->dPanel, E * 16 + 64));
     TRYA(oalloc(&o->dHpp, K * 36)); TRYA(oalloc(&o->dBp, N)); TRYA(oalloc(&o->dDinv, M * 9)); TRYA(oalloc(&o->dS, N * N));
