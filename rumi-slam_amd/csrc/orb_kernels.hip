@@ -184,13 +184,14 @@ __global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST 9/16 + per-cell NMS + threshold fallback, one 256-thread workgroup per (frame, cell).
+// FAST 9/16 + per-cell NMS + threshold fallback, one wave per (frame, cell).
 //
 // score(p) = max over the 16 arcs of 9 of min |v - I_k| on the bright or dark side, minus 1  (cv's
 // cornerScore with the start threshold folded out); p is a corner at T  <=>  score(p) >= T, so ONE
 // score tile serves both thresholds.  NMS neighbours outside the cell's detection region count as 0,
 // exactly as cv::FAST's zero-initialised score rows make them.
-// The sub-image (<= 96x96 B) is staged in LDS; scores never touch HBM.
+// The sub-image is staged in LDS; scores never touch HBM.  A cheap necessary test on every pixel selects the (pixel, polarity)
+// pairs that get the exact score (fast_quick_pair / fast_score_polar).
 // ------------------------------------------------------------------------------------------------
 #include <algorithm>
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }

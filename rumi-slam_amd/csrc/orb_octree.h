@@ -1,7 +1,8 @@
 // Quadtree ("OctTree") key-point distribution — array-based restatement of
 // ORBextractor::DistributeOctTree / ExtractorNode::DivideNode / compareNodes
-// (R/lib_src/ORBextractor.cc:471-724), written so the same serial step runs on the host and as the
-// single-lane control part of the HIP kernel (orb_octree_kernel.hip).
+// (R/lib_src/ORBextractor.cc:471-724): node / entry types, the serial replay of libstdc++'s std::sort and a serial host
+// driver of the algorithm (test hooks).  The HIP kernel (orb_octree_kernel.hip) shares the types and the helpers and runs the
+// list passes and the sort workgroup-parallel.
 //
 // Design (MI355X-first, not the reference's std::list<ExtractorNode> with per-node key vectors):
 //   * keys never move; every key carries the id of the node that currently owns it (owner[i]);
@@ -281,7 +282,7 @@ RUMI_HD int cand_x(uint32_t c) { return (int)(c & 0xFFFu); }
 RUMI_HD int cand_y(uint32_t c) { return (int)((c >> 12) & 0xFFFu); }
 RUMI_HD int cand_score(uint32_t c) { return (int)(c >> 24); }
 
-// Host driver of the same state machine (used by the v1 host quadtree stage and by CPU tests of the
+// Host driver of the same state machine (used by the CPU tests of the
 // replayed sort / list logic).  out receives indices into cand in the reference's result order.
 inline int octree_host(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
                        std::vector<int> &out) {

@@ -1,11 +1,11 @@
 // On-device quadtree key-point distribution + output slot assignment (gfx950).
 //
-//   k_octree    one 256-thread workgroup per (frame, level): DistributeOctTree, R/lib_src/ORBextractor.cc:538-724.
+//   k_octree    one 512-thread workgroup per (frame, level): DistributeOctTree, R/lib_src/ORBextractor.cc:538-724.
 //               Keys stay where the FAST kernel left them (cand[], HBM/L2); each key only carries a 16-bit owner
-//               id (owner[], HBM/L2).  The node pool, the list links, the open/sort arrays live in LDS.
-//               Lane-parallel sweeps relabel keys and count quadrant populations with LDS atomics; thread 0 runs
-//               the list choreography + the replayed std::sort (orb_octree.h) between barriers, so the result
-//               ORDER equals the reference's.
+//               id (owner[], HBM/L2).  The node pool, the list (an array in list order), the open/sort arrays live in LDS.
+//               Lane-parallel sweeps relabel keys and count quadrant populations with LDS atomics; the list passes
+//               (divide, push children to the front, erase parents) are workgroup prefix sums + scatters, std::sort is
+//               replayed by the whole workgroup (wg_sort_like_libstdcxx), so the result ORDER equals the reference's.
 //   k_assemble  one workgroup per frame: concatenates the levels and assigns the output slot of every key-point
 //               by the lapping-area rule of operator() (:1067-1088) with a block scan (the reference walks them
 //               serially with monoIndex++ / stereoIndex--).
