@@ -258,29 +258,40 @@ __device__ __forceinline__ int fast_quick_pair(const uint8_t *t, const int TP, c
 // exact scores of up to 64 ring entries (entry = pixel index | polarity << 15).  A pixel that passed both quick tests has two
 // entries, darker first; darker entries store their score, then brighter entries keep the maximum (their darker twin sits
 // earlier in the ring, i.e. in this batch or a previous one).
+// Every pixel whose score reaches tlow is also appended to the cell's SCORED LIST sl (pixel indices, ascending because the ring is
+// filled in pixel order; a pixel scored for both polarities appears twice in a row): NMS and emission then walk a few hundred
+// listed pixels instead of the whole score map.  nScored counts all appends; entries beyond kScoredCap are dropped and the caller
+// falls back to scanning the map.
+constexpr int kScoredCap = 512;
 template <int CTP>
-__device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *sc, int entry, bool active, int tp, int SP, int shx, int dw,
-                                                 unsigned Mdw, int tlow) {
+__device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *sc, uint16_t *sl, int &nScored, int entry, bool active, int tp, int SP,
+                                                 int shx, int dw, unsigned Mdw, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
     const int i2 = entry & 0x7FFF, bright = entry >> 15;
     const int py = magic_div(i2, Mdw), px = i2 - py * dw;
     int s = 0;
     if (active) s = fast_score_polar(&tile[(py + 3) * TP + px + 3 + shx], TP, bright ? -1 : 1);
     uint8_t *dst = &sc[(py + 1) * SP + px + 1];
-    if (active && !bright && s >= tlow) *dst = (uint8_t)s;
+    const bool hit = active && s >= tlow;
+    if (hit && !bright) *dst = (uint8_t)s;
+    const unsigned long long bh = __ballot(hit);
+    const int pos = nScored + __popcll(bh & ((1ull << lane) - 1ull));
+    if (hit && pos < kScoredCap) sl[pos] = (uint16_t)i2;
+    nScored += __popcll(bh);
     wave_lds_fence();
-    if (active && bright && s >= tlow && s > (int)*dst) *dst = (uint8_t)s;
+    if (hit && bright && s > (int)*dst) *dst = (uint8_t)s;
 }
 
 // score map of one cell: quick test on every pixel (two per lane), exact score on the compacted survivors (CTP != 0: compile-time
 // tile pitch).  Ring entries = pixel index | polarity << 15; a pixel's darker entry always precedes its brighter one.
 template <int CTP>
-__device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, int tp, int SP, int shx, int dw, int dh, unsigned Mdw,
-                                                int tlow, int lane) {
+__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int SP, int shx, int dw, int dh,
+                                               unsigned Mdw, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
     const int pw = (dw + 1) >> 1, npairs = pw * dh;       // pixel pairs per row / per cell (the last pair of an odd row is half empty)
     const unsigned Mpw = magic_of(pw);
     int pending = 0;                                   // entries waiting in cl[0..pending), pending < 64 between steps
+    int nScored = 0;
     for (int base = 0; base < npairs; base += 64) {
         const int ip = base + lane;
         int pass = 0, idx = 0;
@@ -306,7 +317,7 @@ __device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc
             int mv[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) mv[q] = lane + 64 * q < rest ? cl[64 * (q + 1) + lane] : 0;
-            fast_score_batch<CTP>(tile, sc, e, true, tp, SP, shx, dw, Mdw, tlow);
+            fast_score_batch<CTP>(tile, sc, sl, nScored, e, true, tp, SP, shx, dw, Mdw, tlow, lane);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < 4; q++) if (lane + 64 * q < rest) cl[64 * q + lane] = (uint16_t)mv[q];
@@ -314,7 +325,8 @@ __device__ __forceinline__ void fast_score_cell(const uint8_t *tile, uint8_t *sc
         }
     }
     wave_lds_fence();
-    fast_score_batch<CTP>(tile, sc, lane < pending ? cl[lane] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow);
+    fast_score_batch<CTP>(tile, sc, sl, nScored, lane < pending ? cl[lane] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow, lane);
+    return nScored;
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
@@ -359,25 +371,33 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
     uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
+    uint16_t *sl = cl + 320;
+    int nScored;
     switch (TP) {                                                // compile-time pitches for the common geometries
-        case 48: fast_score_cell<48>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        case 52: fast_score_cell<52>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        case 56: fast_score_cell<56>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        default: fast_score_cell<0>(tile, sc, cl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        case 48: nScored = fast_score_cell<48>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        case 52: nScored = fast_score_cell<52>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        case 56: nScored = fast_score_cell<56>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
+        default: nScored = fast_score_cell<0>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
     }
     wave_lds_fence();
-    const int iters = (npx + 63) >> 6;
+    // NMS + emission over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
+    // kScoredCap scored pixels scans its whole score map instead
+    const bool listed = nScored <= kScoredCap;
+    const int nItems = listed ? nScored : npx;
+    const int iters = (nItems + 63) >> 6;
     const int iniTh = P->iniTh, minTh = P->minTh;
     int ti = 0, tm = 0;
     for (int it = 0; it < iters; it++) {
-        const int idx = it * 64 + lane;
+        const int k = it * 64 + lane;
         bool isMax = false;
         int v = 0;
-        if (idx < npx) {
+        if (k < nItems) {
+            const int idx = listed ? (int)sl[k] : k;
+            const bool dup = listed && k > 0 && (int)sl[k - 1] == idx;        // second entry of a pixel scored for both polarities
             const int py = magic_div(idx, Mdw), px = idx - py * dw;
             const uint8_t *s = &sc[(py + 1) * SP + px + 1];
             v = s[0];
-            isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
+            isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
                     v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
         }
         const unsigned long long bi = __ballot(isMax && v >= iniTh);
@@ -393,7 +413,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     for (int it = 0; it < iters; it++) {
         const unsigned long long b = useMin ? balM[it] : balI[it];
         if ((b >> lane) & 1ull) {
-            const int idx = it * 64 + lane;
+            const int k = it * 64 + lane;
+            const int idx = listed ? (int)sl[k] : k;
             const int py = magic_div(idx, Mdw), px = idx - py * dw;
             const uint32_t x = (uint32_t)(px + 3 + ci_j * L.wCell), y = (uint32_t)(py + 3 + ci_i * L.hCell);
             out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[(py + 1) * SP + px + 1] << 24);
@@ -689,8 +710,9 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (320 x uint16: 63 waiting + up to 4 per lane and step)
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 320 * 2 + 15) & ~15;
+    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (320 x uint16: 63 waiting + up to 4 per lane and step) |
+    // list of scored pixels (kScoredCap x uint16)
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 320 * 2 + 512 * 2 + 15) & ~15;
     hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
