@@ -290,7 +290,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
     const int TP = CTP ? CTP : tp;
     const int pw = (dw + 1) >> 1, npairs = pw * dh;       // pixel pairs per row / per cell (the last pair of an odd row is half empty)
     const unsigned Mpw = magic_of(pw);
-    int pending = 0;                                   // entries waiting in cl[0..pending), pending < 64 between steps
+    int head = 0, pending = 0;                         // circular ring: entries wait in cl[(head + k) & 511], k < pending (< 64 between steps)
     int nScored = 0;
     for (int base = 0; base < npairs; base += 64) {
         const int ip = base + lane;
@@ -304,28 +304,22 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1)
         const unsigned long long b0 = __ballot(pass & 1), b1 = __ballot(pass & 4), b2 = __ballot(pass & 2), b3 = __ballot(pass & 8);
         const unsigned long long below = (1ull << lane) - 1ull;
-        int pos = pending + __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
-        if (pass & 1) cl[pos++] = (uint16_t)idx;
-        if (pass & 4) cl[pos++] = (uint16_t)(idx | 0x8000);
-        if (pass & 2) cl[pos++] = (uint16_t)(idx + 1);
-        if (pass & 8) cl[pos] = (uint16_t)((idx + 1) | 0x8000);
+        int pos = head + pending + __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
+        if (pass & 1) cl[pos++ & 511] = (uint16_t)idx;
+        if (pass & 4) cl[pos++ & 511] = (uint16_t)(idx | 0x8000);
+        if (pass & 2) cl[pos++ & 511] = (uint16_t)(idx + 1);
+        if (pass & 8) cl[pos & 511] = (uint16_t)((idx + 1) | 0x8000);
         pending += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         while (pending >= 64) {                        // a full wave of entries: score them exactly
             wave_lds_fence();
-            const int e = cl[lane];
-            const int rest = pending - 64;
-            int mv[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) mv[q] = lane + 64 * q < rest ? cl[64 * (q + 1) + lane] : 0;
+            const int e = cl[(head + lane) & 511];
             fast_score_batch<CTP>(tile, sc, sl, nScored, e, true, tp, SP, shx, dw, Mdw, tlow, lane);
-            wave_lds_fence();
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (lane + 64 * q < rest) cl[64 * q + lane] = (uint16_t)mv[q];
-            pending = rest;
+            head = (head + 64) & 511;
+            pending -= 64;
         }
     }
     wave_lds_fence();
-    fast_score_batch<CTP>(tile, sc, sl, nScored, lane < pending ? cl[lane] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow, lane);
+    fast_score_batch<CTP>(tile, sc, sl, nScored, lane < pending ? cl[(head + lane) & 511] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow, lane);
     return nScored;
 }
 
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
     uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
-    uint16_t *sl = cl + 320;
+    uint16_t *sl = cl + 512;
     int nScored;
     switch (TP) {                                                // compile-time pitches for the common geometries
         case 48: nScored = fast_score_cell<48>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
@@ -710,9 +704,9 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (320 x uint16: 63 waiting + up to 4 per lane and step) |
+    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (circular, 512 x uint16: 63 waiting + up to 4 per lane and step) |
     // list of scored pixels (kScoredCap x uint16)
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 320 * 2 + 512 * 2 + 15) & ~15;
+    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 512 * 2 + 512 * 2 + 15) & ~15;
     hipLaunchKernelGGL(k_fast_cells, dim3((hP.totalCells + 3) / 4, nframes), dim3(256), (size_t)4 * F.perWave, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
