@@ -625,21 +625,21 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
 
     // IC_Angle (ORBextractor.cc:73-97): two disc rows per step
     const uint8_t *dc = &sDisc[wave][kHalfPatch * kDiscP + (x - xd)];
+    // lane = (column u, row parity): the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a lane's rows are
+    // |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
     const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
-    int m10 = 0, m01 = 0;
-#pragma unroll 4
+    const int vmaxU = (lane & 31) < 31 ? P->umax[u < 0 ? -u : u] : -1;
+    int colSum = 0, m01 = 0;
+#pragma unroll
     for (int i = 0; i < 16; i++) {
         const int v = -kHalfPatch + 2 * i + half;
-        const int av = v < 0 ? -v : v;
-        if (v <= kHalfPatch && (lane & 31) < 31) {
-            const int d = P->umax[av];
-            if (u >= -d && u <= d) {
-                const int val = dc[v * kDiscP + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+        if (v <= vmaxU && -v <= vmaxU) {
+            const int val = dc[v * kDiscP + u];
+            colSum += val;
+            m01 += v * val;
         }
     }
+    int m10 = u * colSum;
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
