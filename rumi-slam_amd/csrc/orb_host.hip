@@ -100,6 +100,10 @@ struct RumiOrb {
     hipEvent_t ev[8] = {nullptr};
     // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
     hipStream_t sideStream = nullptr;
+    // a chunk's frames are split over the caller's stream and these, see Stage B
+    static constexpr int kMaxParts = 4;
+    hipStream_t partStream[kMaxParts - 1] = {nullptr};
+    hipEvent_t evPartFork = nullptr, evPartJoin[kMaxParts - 1] = {nullptr};
     hipEvent_t evFork = nullptr, evJoin = nullptr, evB0 = nullptr, evB1 = nullptr;
 };
 
@@ -185,6 +189,9 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (h->evB0) (void)hipEventDestroy(h->evB0);
     if (h->evB1) (void)hipEventDestroy(h->evB1);
     if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
+    for (auto &ps : h->partStream) if (ps) (void)hipStreamDestroy(ps);
+    for (auto &e : h->evPartJoin) if (e) (void)hipEventDestroy(e);
+    if (h->evPartFork) (void)hipEventDestroy(h->evPartFork);
     if (h->hIn) (void)hipHostFree(h->hIn);
     if (h->hOut1) (void)hipHostFree(h->hOut1);
     if (h->dOut1) (void)hipFree(h->dOut1);
@@ -264,6 +271,10 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
 #undef TRY_ALLOC
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
+    for (int i = 0; i < RumiOrb::kMaxParts - 1; ++i)
+        if (hipStreamCreateWithFlags(&h->partStream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evPartJoin[i], hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part stream"; return RUMI_E_NO_DEVICE; }
+    if (hipEventCreateWithFlags(&h->evPartFork, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part event"; return RUMI_E_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&h->evB0) != hipSuccess ||
@@ -329,20 +340,57 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         cs.pyr = src.pyr + (long long)base * P.arenaStride;
         cs.blur = src.blur + (long long)base * P.arenaStride;
         HIP_TRY(hipMemsetAsync(h->dOverflow, 0, nf * sizeof(int32_t), st));
-        if (prof) HIP_TRY(hipEventRecord(h->ev[3], st));
-        launch_fast(h->dP, P, cs, h->dCellBuf, h->dCellCnt, nf, st);
-        if (prof) HIP_TRY(hipEventRecord(h->ev[4], st));
-        launch_compact(h->dP, P, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart, h->dOverflow, nf, st);
-        if (prof) HIP_TRY(hipEventRecord(h->ev[5], st));
-        launch_octree(h->dP, P, h->dCand, h->dLevelStart, h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, h->dErr,
-                      nf, h->octLds, st);
-        launch_assemble(h->dP, h->dSelLevel, h->dSelLevelCnt, h->selLevelCap, lap0, lap1, h->dSelPacked, h->dSelMeta,
-                        h->dSelCount, h->capSel, (int32_t *)d_counts + 2 * base, h->dErr, nf, st);
-        if (prof) HIP_TRY(hipEventRecord(h->ev[6], st));
-        if (base == 0) HIP_TRY(hipStreamWaitEvent(st, h->evJoin, 0));               // join: rBRIEF reads the blurred levels
-        launch_orient_desc(h->dP, cs, h->dSelPacked, h->dSelMeta, h->dSelCount, h->capSel, h->capSel,
-                           (RumiKeyPoint *)d_kp + (size_t)base * cap, (uint8_t *)d_desc + (size_t)base * cap * 32, cap, nf, st);
-        if (prof) HIP_TRY(hipEventRecord(h->ev[7], st));
+        // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [f0, f0 + n) of this chunk on stream s: every
+        // scratch array is indexed by the frame's position in the chunk, so disjoint frame ranges can run on different streams
+        auto run_part = [&](int f0, int n, hipStream_t s, bool timed) -> int {
+            ImgSrc ps = cs;
+            ps.l0 = cs.l0 + (long long)f0 * frame_stride;
+            ps.pyr = cs.pyr + (long long)f0 * P.arenaStride;
+            ps.blur = cs.blur + (long long)f0 * P.arenaStride;
+            uint32_t *cellBuf = h->dCellBuf + (size_t)f0 * P.totalCells * P.maxCellCand;
+            int32_t *cellCnt = h->dCellCnt + (size_t)f0 * P.totalCells;
+            uint32_t *candp = h->dCand + (size_t)f0 * P.totalCand;
+            int32_t *lvStart = h->dLevelStart + (size_t)f0 * (kMaxLevels + 1);
+            uint32_t *selLevel = h->dSelLevel + (size_t)f0 * P.nlevels * h->selLevelCap;
+            int32_t *selLevelCnt = h->dSelLevelCnt + (size_t)f0 * P.nlevels;
+            uint32_t *selPacked = h->dSelPacked + (size_t)f0 * h->capSel, *selMeta = h->dSelMeta + (size_t)f0 * h->capSel;
+            if (timed) HIP_TRY(hipEventRecord(h->ev[3], s));
+            launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
+            if (timed) HIP_TRY(hipEventRecord(h->ev[4], s));
+            launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dOverflow + f0, n, s);
+            if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
+            launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)f0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
+            launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + f0, h->capSel,
+                            (int32_t *)d_counts + 2 * (size_t)(base + f0), h->dErr, n, s);
+            if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
+            HIP_TRY(hipStreamWaitEvent(s, h->evJoin, 0));                            // join: rBRIEF reads the blurred levels
+            launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + f0, h->capSel, h->capSel,
+                               (RumiKeyPoint *)d_kp + (size_t)(base + f0) * cap, (uint8_t *)d_desc + (size_t)(base + f0) * cap * 32, cap, n, s);
+            if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
+            return RUMI_OK;
+        };
+        // Two halves on two streams: the quadtree of one half (LDS-latency-bound, few waves) runs beside FAST / rBRIEF of the other
+        // (VALU-bound).  Profiling and RUMI_SERIAL keep one stream so that stage times stay per-kernel.
+        if (!prof && !serial && nf >= 32) {
+            static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 2;
+            const int parts = std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts);
+            HIP_TRY(hipEventRecord(h->evPartFork, st));
+            for (int p = 0, f0 = 0; p < parts; ++p) {
+                const int n = (nf - f0) / (parts - p);
+                hipStream_t s = p == 0 ? st : h->partStream[p - 1];
+                if (p) HIP_TRY(hipStreamWaitEvent(s, h->evPartFork, 0));
+                const int rcp = run_part(f0, n, s, false);
+                if (rcp != RUMI_OK) return rcp;
+                if (p) {
+                    HIP_TRY(hipEventRecord(h->evPartJoin[p - 1], s));
+                    HIP_TRY(hipStreamWaitEvent(st, h->evPartJoin[p - 1], 0));
+                }
+                f0 += n;
+            }
+        } else {
+            const int rcp = run_part(0, nf, st, prof);
+            if (rcp != RUMI_OK) return rcp;
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (prof || base + kChunk < nframes) {
