@@ -97,6 +97,27 @@ int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_t *pair_sta
                       const float *kp2, const float *sigma2_1, const float *sigma2_2, const uint8_t *edge1, const uint8_t *edge2,
                       uint8_t *inlier_out, float *ratio_out, float *median_out);
 
+/* Optimizer::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale, mAcumHessian, bAllPoints) — R/lib_src/Optimizer.cc:1920-2167
+ * (LoopClosing.cc:522,728, CloudMerging.cc:965,1169) and Optimizer::OptimizeCloudSim3(map1KFs, map2KFs, avpMatches, gSw1w2, th2, bFixScale,
+ * mAcumHessian, bAllPoints) — :2169-2471 (CloudMerging.cc:803): Levenberg-Marquardt over ONE Sim3 vertex with numeric Jacobians,
+ * optimize(5), removal of the correspondences whose edges exceed th2, optimize(10 or 5) without robust kernel, final inlier count.
+ * One entry per correspondence that reaches "nCorrespondences++" (:2035 / :2316; the caller applies the map-point / isBad / i2 /
+ * depth filters before): both points in their own camera frames (P3D1c, P3D2c as float, :1986-1998), the two observations (obs1 =
+ * mvKeysUn of key-frame 1; obs2 = mvKeysUn of key-frame 2 or the float-normalised projection of :2065-2071, :2354-2360), mvInvLevelSigma2 at the two
+ * octaves, skip12 / skip21 = the edge is not created (pMP2->isEdge / pMP1->isEdge, :2323,:2366; NULL = none).
+ * S_c1w == NULL selects EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ (OptimizeSim3: the vertex maps camera 2 into camera 1); otherwise
+ * the world edges of OptimizeCloudSim3 with per key-frame-pair g2o::Sim3(R, t, 1.0) of both key-frames (:2231-2232) as
+ * (qx qy qz qw tx ty tz s) doubles formed by the caller, and pair_of[i] = key-frame pair of correspondence i.
+ * robust_first_pass: Huber(sqrt(th2)) on the first optimize (OptimizeSim3 :2050-2052; OptimizeCloudSim3 passes none, :2335,:2378).
+ * S_io8: vertex estimate in / out (on the early return it holds the estimate after the first optimize, which OptimizeCloudSim3 has
+ * already published at :2397 and OptimizeSim3 discards).  status_out[i]: 0 inlier, 1 removed after the first optimize, 2 fails the final
+ * test, 3 kept but uncounted (one of its edges absent).  result3 = {nIn, nBad, 1 if "nCorrespondences - nBad < 10" returned early}.
+ * mAcumHessian is zeroed by the reference and never accumulated (:2144, :2446): the facade does the same. */
+int rumi_optimize_sim3(RumiOptimizer *o, int32_t n, const int32_t *pair_of, int32_t n_pairs, const double *S_c1w, const double *S_c2w,
+                       const float *P1c, const float *P2c, const float *obs1, const float *obs2, const float *inv_sigma2_1,
+                       const float *inv_sigma2_2, const uint8_t *skip12, const uint8_t *skip21, const float *K4_1, const float *K4_2, float th2,
+                       int32_t fix_scale, int32_t robust_first_pass, double *S_io8, uint8_t *status_out, int32_t *result3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -412,6 +412,153 @@ struct BAProblem : LMProblem {
 
 using namespace orcopt;
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// g2o::Sim3 (G/types/sim3.h) and the one-vertex Sim3 problems Optimizer::OptimizeSim3 (R/lib_src/Optimizer.cc:1920-2167) and
+// Optimizer::OptimizeCloudSim3 (:2169-2471) build: all points are fixed vertices, the edges have no analytic linearizeOplus
+// (commented out in OptimizableTypes.h:186,205,224,249,267,292), so g2o differentiates numerically
+// (G/core/base_binary_edge.hpp:131-203: central differences, delta 1e-9, through VertexSim3Expmap::oplusImpl).
+// ---------------------------------------------------------------------------------------------------------------
+struct Sim3 { Quat r; V3 t; double s; };
+static inline V3 sim3_map(const Sim3 &S, V3 p) { const V3 r = rotate(S.r, p); return {S.s * r.x + S.t.x, S.s * r.y + S.t.y, S.s * r.z + S.t.z}; }   // sim3.h:144-146
+static inline Sim3 sim3_mul(const Sim3 &a, const Sim3 &b) {                                             // sim3.h:266-272 (no re-normalisation)
+    Sim3 o;
+    o.r = qmul(a.r, b.r);
+    const V3 rt = rotate(a.r, b.t);
+    o.t = {a.s * rt.x + a.t.x, a.s * rt.y + a.t.y, a.s * rt.z + a.t.z};
+    o.s = a.s * b.s;
+    return o;
+}
+static inline Sim3 sim3_inverse(const Sim3 &a) {                                                         // sim3.h:233-236
+    const Quat c{-a.r.x, -a.r.y, -a.r.z, a.r.w};
+    const double k = -1. / a.s;
+    return Sim3{c, rotate(c, V3{k * a.t.x, k * a.t.y, k * a.t.z}), 1. / a.s};
+}
+static Sim3 sim3_exp(const double u[7]) {                                                                // sim3.h:70-142
+    const double wx = u[0], wy = u[1], wz = u[2], sigma = u[6];
+    const double theta = std::sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double O2[3][3], R[3][3], W[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { O2[i][j] = 0; for (int k = 0; k < 3; k++) O2[i][j] += O[i][k] * O[k][j]; }
+    const double s = std::exp(sigma), eps = 0.00001;
+    double A, B, C;
+    auto setR = [&](double a, double b) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = ((i == j) + a * O[i][j]) + b * O2[i][j]; };
+    if (std::fabs(sigma) < eps) {
+        C = 1;
+        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; setR(1, 1); }
+        else {
+            const double theta2 = theta * theta;
+            A = (1 - std::cos(theta)) / theta2; B = (theta - std::sin(theta)) / (theta2 * theta);
+            setR(std::sin(theta) / theta, (1 - std::cos(theta)) / (theta * theta));
+        }
+    } else {
+        C = (s - 1) / sigma;
+        if (theta < eps) {
+            const double sigma2 = sigma * sigma;
+            A = ((sigma - 1) * s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
+            setR(1, 1);
+        } else {
+            setR(std::sin(theta) / theta, (1 - std::cos(theta)) / (theta * theta));
+            const double a = s * std::sin(theta), b = s * std::cos(theta), theta2 = theta * theta, sigma2 = sigma * sigma, c = theta2 + sigma2;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W[i][j] = (A * O[i][j] + B * O2[i][j]) + C * (i == j);
+    Sim3 S;
+    S.r = quat_from_R(R);
+    S.t = {W[0][0] * u[3] + W[0][1] * u[4] + W[0][2] * u[5], W[1][0] * u[3] + W[1][1] * u[4] + W[1][2] * u[5],
+           W[2][0] * u[3] + W[2][1] * u[4] + W[2][2] * u[5]};
+    S.s = s;
+    return S;
+}
+
+struct Sim3Problem : LMProblem {
+    int n = 0;
+    const int32_t *pairOf = nullptr; const double *Sc1w = nullptr, *Sc2w = nullptr;   // null: EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ
+    const float *P1c, *P2c, *obs1, *obs2, *w1, *w2;
+    std::vector<uint8_t> on12, on21;          // edge present in the active graph
+    Cam cam1, cam2; bool fixScale = false, robust = false; double delta = 0, dsqr = 0;
+    Sim3 est, saved;
+    double H[49], b[7], x[7];
+    std::vector<double> chi12, chi21;         // chi2 as of the last computeActiveErrors()
+
+    // computeError of the edge pair of correspondence i under the vertex estimate S
+    void errors(int i, const Sim3 &S, bool do12, bool do21, double e12[2], double e21[2]) const {
+        const int p = pairOf ? pairOf[i] : 0;
+        if (do12) {
+            Sim3 T = S;
+            if (Sc1w) T = sim3_mul(sim3_mul(sim3_from(Sc1w + 8 * (size_t)p), S), sim3_inverse(sim3_from(Sc2w + 8 * (size_t)p)));   // gSc1w * est * gSc2w.inverse()
+            double u, v;
+            project(cam1, sim3_map(T, V3{P2c[3 * i], P2c[3 * i + 1], P2c[3 * i + 2]}), u, v);
+            e12[0] = (double)obs1[2 * i] - u; e12[1] = (double)obs1[2 * i + 1] - v;
+        }
+        if (do21) {
+            Sim3 T = sim3_inverse(S);
+            if (Sc1w) T = sim3_mul(sim3_mul(sim3_from(Sc2w + 8 * (size_t)p), sim3_inverse(S)), sim3_inverse(sim3_from(Sc1w + 8 * (size_t)p)));
+            double u, v;
+            project(cam2, sim3_map(T, V3{P1c[3 * i], P1c[3 * i + 1], P1c[3 * i + 2]}), u, v);
+            e21[0] = (double)obs2[2 * i] - u; e21[1] = (double)obs2[2 * i + 1] - v;
+        }
+    }
+    static Sim3 sim3_from(const double *S) { return Sim3{{S[0], S[1], S[2], S[3]}, {S[4], S[5], S[6]}, S[7]}; }
+    Sim3 oplus(const Sim3 &S, const double *upd) const {             // VertexSim3Expmap::oplusImpl (OptimizableTypes.h:156-164)
+        double u[7];
+        for (int k = 0; k < 7; k++) u[k] = upd[k];
+        if (fixScale) u[6] = 0;
+        return sim3_mul(sim3_exp(u), S);
+    }
+    static double chi2_of(const double e[2], double w) { return e[0] * w * e[0] + e[1] * w * e[1]; }
+    double robust_chi2() override {
+        double chi = 0;
+        for (int i = 0; i < n; i++) {
+            double e12[2], e21[2];
+            errors(i, est, on12[i], on21[i], e12, e21);
+            if (on12[i]) { const double c = chi2_of(e12, w1[i]); chi12[i] = c; double r[3] = {c, 1, 0}; if (robust) huber(c, delta, dsqr, r); chi += r[0]; }
+            if (on21[i]) { const double c = chi2_of(e21, w2[i]); chi21[i] = c; double r[3] = {c, 1, 0}; if (robust) huber(c, delta, dsqr, r); chi += r[0]; }
+        }
+        return chi;
+    }
+    void accumulate(const double e[2], const double J[2][7], double w) {
+        double c = chi2_of(e, w), r[3] = {c, 1, 0};
+        if (robust) huber(c, delta, dsqr, r);
+        for (int a = 0; a < 7; a++) {
+            b[a] -= r[1] * (J[0][a] * w * e[0] + J[1][a] * w * e[1]);
+            for (int c2 = 0; c2 < 7; c2++) H[a * 7 + c2] += (r[1] * w) * (J[0][a] * J[0][c2] + J[1][a] * J[1][c2]);
+        }
+    }
+    void build() override {
+        std::memset(H, 0, sizeof H); std::memset(b, 0, sizeof b);
+        const double dlt = 1e-9, scalar = 1.0 / (2 * dlt);
+        for (int i = 0; i < n; i++) {
+            if (!on12[i] && !on21[i]) continue;
+            double e12[2], e21[2], J12[2][7], J21[2][7];
+            for (int d = 0; d < 7; d++) {
+                double add[7] = {0, 0, 0, 0, 0, 0, 0}, p12[2], p21[2], m12[2], m21[2];
+                add[d] = dlt;
+                errors(i, oplus(est, add), on12[i], on21[i], p12, p21);
+                add[d] = -dlt;
+                errors(i, oplus(est, add), on12[i], on21[i], m12, m21);
+                for (int r = 0; r < 2; r++) { J12[r][d] = scalar * (p12[r] - m12[r]); J21[r][d] = scalar * (p21[r] - m21[r]); }
+            }
+            errors(i, est, on12[i], on21[i], e12, e21);
+            if (on12[i]) accumulate(e12, J12, w1[i]);
+            if (on21[i]) accumulate(e21, J21, w2[i]);
+        }
+    }
+    double max_diag() override { double m = 0; for (int j = 0; j < 7; j++) m = std::max(std::fabs(H[j * 8]), m); return m; }
+    bool solve(double lambda) override {
+        std::vector<double> A(H, H + 49);
+        for (int j = 0; j < 7; j++) A[j * 8] += lambda;
+        return chol_solve(A, 7, b, x);
+    }
+    double scale(double lambda) override { double s = 0; for (int j = 0; j < 7; j++) s += x[j] * (lambda * x[j] + b[j]); return s; }
+    void push() override { saved = est; }
+    void pop() override { est = saved; }
+    void update() override { est = oplus(est, x); }
+};
+
 extern "C" {
 
 // Optimizer::PoseOptimization on flat arrays (one entry per feature that holds a map point, in feature order).
@@ -591,6 +738,46 @@ float orc_sim3_inliers(int nPairs, const int32_t *pairStart, const int32_t *pair
     if (ratioOut) std::memcpy(ratioOut, ratios.data(), ratios.size() * sizeof(float));
     std::sort(ratios.begin(), ratios.end());
     return ratios[ratios.size() / 2];
+}
+
+// Optimizer::OptimizeSim3 / OptimizeCloudSim3 on flat arrays (layout: include/rumi_opt.h, rumi_optimize_sim3).  One entry per
+// correspondence that reaches "nCorrespondences++" (:2035 / :2316).  status: 0 inlier, 1 removed after the first optimize(5),
+// 2 fails the final test, 3 kept but uncounted (one of its two edges absent, :2450-2451).  res = {nIn, nBad, early return}.
+int orc_optimize_sim3(int n, const int32_t *pairOf, const double *Sc1w, const double *Sc2w, const float *P1c, const float *P2c,
+                      const float *obs1, const float *obs2, const float *w1, const float *w2, const uint8_t *skip12, const uint8_t *skip21,
+                      const float *K1, const float *K2, float th2, int fixScale, int robustFirst, double *S8, uint8_t *status, int32_t *res) {
+    Sim3Problem P;
+    P.n = n; P.pairOf = pairOf; P.Sc1w = Sc1w; P.Sc2w = Sc2w; P.P1c = P1c; P.P2c = P2c; P.obs1 = obs1; P.obs2 = obs2; P.w1 = w1; P.w2 = w2;
+    P.on12.resize(n); P.on21.resize(n); P.chi12.assign(n, 0.); P.chi21.assign(n, 0.);
+    for (int i = 0; i < n; i++) { P.on12[i] = !(skip12 && skip12[i]); P.on21[i] = !(skip21 && skip21[i]); status[i] = 0; }
+    P.cam1 = {K1[0], K1[1], K1[2], K1[3]}; P.cam2 = {K2[0], K2[1], K2[2], K2[3]};
+    P.fixScale = fixScale != 0; P.robust = robustFirst != 0;
+    const float deltaHuber = std::sqrt(th2);
+    P.delta = deltaHuber; P.dsqr = P.delta * P.delta;
+    P.est = Sim3Problem::sim3_from(S8);
+    lm_optimize(P, 5);
+    auto put = [&](const Sim3 &S) { S8[0] = S.r.x; S8[1] = S.r.y; S8[2] = S.r.z; S8[3] = S.r.w; S8[4] = S.t.x; S8[5] = S.t.y; S8[6] = S.t.z; S8[7] = S.s; };
+    put(P.est);                                                     // OptimizeCloudSim3 publishes the estimate here already (:2397)
+    int nBad = 0;
+    for (int i = 0; i < n; i++) {
+        // chi2() of the errors the last computeActiveErrors() left on the edges (:2407 / :2110)
+        if ((P.on12[i] && P.chi12[i] > (double)th2) || (P.on21[i] && P.chi21[i] > (double)th2)) { status[i] = 1; P.on12[i] = P.on21[i] = 0; nBad++; }
+    }
+    P.robust = false;
+    res[0] = 0; res[1] = nBad; res[2] = 1;
+    if (n - nBad < 10) return 0;
+    lm_optimize(P, nBad > 0 ? 10 : 5);
+    int nIn = 0;
+    for (int i = 0; i < n; i++) {
+        if (status[i] == 1) continue;
+        if (!P.on12[i] || !P.on21[i]) { status[i] = 3; continue; }
+        double e12[2], e21[2];
+        P.errors(i, P.est, true, true, e12, e21);
+        if (Sim3Problem::chi2_of(e12, w1[i]) > (double)th2 || Sim3Problem::chi2_of(e21, w2[i]) > (double)th2) status[i] = 2; else nIn++;
+    }
+    put(P.est);
+    res[0] = nIn; res[2] = 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -51,29 +51,30 @@ template <int NV> __device__ __forceinline__ void block_sum(double (&v)[NV], dou
     for (int k = 0; k < NV; k++) v[k] = (red[k] + red[NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
 }
 
-__device__ __forceinline__ bool chol6_solve(const double *H /*upper 21, row-major packed*/, double lambda, const double *b, double *x) {
-    double A[6][6];
+template <int N> __device__ __forceinline__ bool chol_solve_packed(const double *H /*upper N(N+1)/2, row-major packed*/, double lambda, const double *b, double *x) {
+    double A[N][N];
     int p = 0;
-    for (int i = 0; i < 6; i++)
-        for (int j = i; j < 6; j++) { A[i][j] = H[p]; A[j][i] = H[p]; p++; }
-    for (int i = 0; i < 6; i++) A[i][i] += lambda;
-    for (int j = 0; j < 6; j++) {
+    for (int i = 0; i < N; i++)
+        for (int j = i; j < N; j++) { A[i][j] = H[p]; A[j][i] = H[p]; p++; }
+    for (int i = 0; i < N; i++) A[i][i] += lambda;
+    for (int j = 0; j < N; j++) {
         double d = A[j][j];
         for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
         if (!(d > 0) || !isfinite(d)) return false;
         d = sqrt(d);
         A[j][j] = d;
-        for (int i = j + 1; i < 6; i++) {
+        for (int i = j + 1; i < N; i++) {
             double s = A[i][j];
             for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
             A[i][j] = s / d;
         }
     }
-    double y[6];
-    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s / A[i][i]; }
-    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= A[k][i] * x[k]; x[i] = s / A[i][i]; }
+    double y[N];
+    for (int i = 0; i < N; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s / A[i][i]; }
+    for (int i = N - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < N; k++) s -= A[k][i] * x[k]; x[i] = s / A[i][i]; }
     return true;
 }
+__device__ __forceinline__ bool chol6_solve(const double *H, double lambda, const double *b, double *x) { return chol_solve_packed<6>(H, lambda, b, x); }
 
 // ==================================================================================================================
 // PoseOptimization
@@ -730,6 +731,214 @@ __global__ void k_sim3_inliers(int total, const int32_t *pairOf, const double *S
     inlier[i] = ok1 && ok2;
 }
 
+
+// ==================================================================================================================
+// OptimizeSim3 / OptimizeCloudSim3 (R/lib_src/Optimizer.cc:1920-2167, :2169-2471): one Sim3 vertex, fixed points, two reprojection
+// edges per correspondence, numeric Jacobians (G/core/base_binary_edge.hpp:131-203, delta 1e-9, through VertexSim3Expmap::oplusImpl).
+// One 256-thread workgroup runs both optimize() calls.  The transform an edge applies depends only on its key-frame pair and on the
+// perturbation (gSc1w * est' * gSc2w^-1 and gSc2w * est'^-1 * gSc1w^-1, OptimizableTypes.h:242,285): the 15 (base, +-delta per
+// dimension) x 2 composites per pair are formed once per linearisation and every correspondence evaluates 30 map + project against them.
+// ==================================================================================================================
+struct Sim3Args {
+    int n, nPairs, world, fixScale, robustFirst;
+    float th2;
+    const int32_t *pairOf;
+    const double *Sc1w, *Sc2w, *Sin;
+    const float *P1c, *P2c, *obs1, *obs2, *w1, *w2;
+    const uint8_t *skip12, *skip21;
+    const float *K1, *K2;
+    double *Sout; int32_t *res; uint8_t *status;          // results
+    double *comp, *chi12, *chi21; uint8_t *on12, *on21;   // scratch
+};
+
+__global__ __launch_bounds__(256) void k_sim3_opt(Sim3Args A) {
+    __shared__ double red[4 * 36];
+    const int tid = threadIdx.x, n = A.n, np = A.world ? A.nPairs : 1;
+    const DCam cam1{A.K1[0], A.K1[1], A.K1[2], A.K1[3]}, cam2{A.K2[0], A.K2[1], A.K2[2], A.K2[3]};
+    const double delta = (double)sqrtf(A.th2), dsqr = delta * delta, th2 = (double)A.th2;
+    DSim3 est = sim3_from8(A.Sin);
+    bool robust = A.robustFirst != 0;
+    for (int i = tid; i < n; i += 256) { A.on12[i] = !(A.skip12 && A.skip12[i]); A.on21[i] = !(A.skip21 && A.skip21[i]); A.status[i] = 0; }
+
+    auto oplus = [&](const DSim3 &S, const double *upd) -> DSim3 {          // VertexSim3Expmap::oplusImpl
+        double u[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) u[k] = upd[k];
+        if (A.fixScale) u[6] = 0;
+        return sim3_mul(sim3_exp(u), S);
+    };
+    auto fill = [&](const DSim3 &S0, bool full) {                            // composites of every pair: slot 0 base, 1 + 2d / 2 + 2d = +-delta in dimension d
+        const int cnt = full ? 15 : 1;
+        for (int idx = tid; idx < np * cnt; idx += 256) {
+            const int p = idx / cnt, k = idx - p * cnt;
+            DSim3 S = S0;
+            if (k) {
+                double add[7] = {0, 0, 0, 0, 0, 0, 0};
+                const int d = (k - 1) >> 1;
+                const double v = (k & 1) ? 1e-9 : -1e-9;
+#pragma unroll
+                for (int q = 0; q < 7; q++) if (q == d) add[q] = v;
+                S = oplus(S0, add);
+            }
+            DSim3 F = S, I = sim3_inverse(S);
+            if (A.world) {
+                const DSim3 a = sim3_from8(A.Sc1w + (size_t)p * 8), b = sim3_from8(A.Sc2w + (size_t)p * 8);
+                F = sim3_mul(sim3_mul(a, S), sim3_inverse(b));
+                I = sim3_mul(sim3_mul(b, sim3_inverse(S)), sim3_inverse(a));
+            }
+            sim3_to8(F, A.comp + ((size_t)p * 30 + k) * 8);
+            sim3_to8(I, A.comp + ((size_t)p * 30 + 15 + k) * 8);
+        }
+        __threadfence_block();
+        __syncthreads();
+    };
+    auto err12 = [&](int i, int p, int k, double &e0, double &e1) {
+        const D3 pc = sim3_map(sim3_from8(A.comp + ((size_t)p * 30 + k) * 8), D3{(double)A.P2c[3 * i], (double)A.P2c[3 * i + 1], (double)A.P2c[3 * i + 2]});
+        double u, v;
+        cam_project(cam1, pc, u, v);
+        e0 = (double)A.obs1[2 * i] - u; e1 = (double)A.obs1[2 * i + 1] - v;
+    };
+    auto err21 = [&](int i, int p, int k, double &e0, double &e1) {
+        const D3 pc = sim3_map(sim3_from8(A.comp + ((size_t)p * 30 + 15 + k) * 8), D3{(double)A.P1c[3 * i], (double)A.P1c[3 * i + 1], (double)A.P1c[3 * i + 2]});
+        double u, v;
+        cam_project(cam2, pc, u, v);
+        e0 = (double)A.obs2[2 * i] - u; e1 = (double)A.obs2[2 * i + 1] - v;
+    };
+    auto robust_chi2 = [&](const DSim3 &S) -> double {                       // computeActiveErrors + activeRobustChi2
+        fill(S, false);
+        double acc[1] = {0};
+        for (int i = tid; i < n; i += 256) {
+            const int p = A.pairOf ? A.pairOf[i] : 0;
+            if (A.on12[i]) {
+                double e0, e1; err12(i, p, 0, e0, e1);
+                const double w = (double)A.w1[i], c = e0 * w * e0 + e1 * w * e1;
+                A.chi12[i] = c;
+                double r0 = c, r1 = 1;
+                if (robust) huber(c, delta, dsqr, r0, r1);
+                acc[0] += r0;
+            }
+            if (A.on21[i]) {
+                double e0, e1; err21(i, p, 0, e0, e1);
+                const double w = (double)A.w2[i], c = e0 * w * e0 + e1 * w * e1;
+                A.chi21[i] = c;
+                double r0 = c, r1 = 1;
+                if (robust) huber(c, delta, dsqr, r0, r1);
+                acc[0] += r0;
+            }
+        }
+        block_sum<1>(acc, red);
+        return acc[0];
+    };
+    auto lm = [&](int maxIt) {                                               // optimization_algorithm_levenberg.cpp:61-169
+        double lambda = -1, ni = 2;
+        int nBadIt = 0;
+        for (int itl = 0; itl < maxIt; itl++) {
+            double hb[36];                                                   // 28 upper entries of H, 7 of b, robust chi2
+#pragma unroll
+            for (int k = 0; k < 36; k++) hb[k] = 0;
+            fill(est, true);
+            for (int i = tid; i < n; i += 256) {
+                const int p = A.pairOf ? A.pairOf[i] : 0;
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    if (!(side ? A.on21[i] : A.on12[i])) continue;
+                    double e0, e1, J0[7], J1[7];
+                    if (side) err21(i, p, 0, e0, e1); else err12(i, p, 0, e0, e1);
+#pragma unroll
+                    for (int d = 0; d < 7; d++) {
+                        double p0, p1, m0, m1;
+                        if (side) { err21(i, p, 1 + 2 * d, p0, p1); err21(i, p, 2 + 2 * d, m0, m1); }
+                        else { err12(i, p, 1 + 2 * d, p0, p1); err12(i, p, 2 + 2 * d, m0, m1); }
+                        J0[d] = 5e8 * (p0 - m0); J1[d] = 5e8 * (p1 - m1);       // scalar = 1 / (2 delta)
+                    }
+                    const double w = (double)(side ? A.w2[i] : A.w1[i]), c = e0 * w * e0 + e1 * w * e1;
+                    if (side) A.chi21[i] = c; else A.chi12[i] = c;
+                    double r0 = c, r1 = 1;
+                    if (robust) huber(c, delta, dsqr, r0, r1);
+                    hb[35] += r0;
+                    const double rw = r1 * w;
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 7; a++) {
+#pragma unroll
+                        for (int c2 = a; c2 < 7; c2++) hb[q++] += rw * (J0[a] * J0[c2] + J1[a] * J1[c2]);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 7; a++) hb[28 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
+                }
+            }
+            block_sum<36>(hb, red);
+            double currentChi = hb[35];
+            const double iniChi = currentChi;
+            if (itl == 0) {
+                double m = 0;
+                int q = 0;
+                for (int a = 0; a < 7; a++) { m = fmax(fabs(hb[q]), m); q += 7 - a; }
+                lambda = 1e-5 * m; ni = 2; nBadIt = 0;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                const DSim3 saved = est;
+                double x[7];
+                const bool ok2 = chol_solve_packed<7>(hb, lambda, hb + 28, x);
+                if (ok2) est = oplus(est, x);
+                double tempChi = robust_chi2(est);
+                if (!ok2) tempChi = DBL_MAX;
+                rho = currentChi - tempChi;
+                double scale = 0;
+                if (ok2) for (int j = 0; j < 7; j++) scale += x[j] * (lambda * x[j] + hb[28 + j]);
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                    est = saved;
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBadIt++; else nBadIt = 0;
+            if (nBadIt >= 3) break;
+        }
+    };
+
+    __syncthreads();
+    if (n > 0) lm(5);                                                        // optimizer.optimize(5)
+    if (tid == 0) sim3_to8(est, A.Sout);                                     // OptimizeCloudSim3 publishes this estimate already (:2397)
+    double bad[1] = {0};
+    for (int i = tid; i < n; i += 256) {                                     // :2110 / :2407: chi2() of the errors the last computeActiveErrors() left
+        if ((A.on12[i] && A.chi12[i] > th2) || (A.on21[i] && A.chi21[i] > th2)) { A.status[i] = 1; A.on12[i] = 0; A.on21[i] = 0; bad[0] += 1; }
+    }
+    block_sum<1>(bad, red);
+    const int nBad = (int)bad[0];
+    robust = false;                                                          // setRobustKernel(0)
+    if (n - nBad < 10) {
+        if (tid == 0) { A.res[0] = 0; A.res[1] = nBad; A.res[2] = 1; }
+        return;
+    }
+    lm(nBad > 0 ? 10 : 5);
+    fill(est, false);
+    double in[1] = {0};
+    for (int i = tid; i < n; i += 256) {
+        if (A.status[i] == 1) continue;
+        if (!A.on12[i] || !A.on21[i]) { A.status[i] = 3; continue; }         // :2450-2451
+        const int p = A.pairOf ? A.pairOf[i] : 0;
+        double a0, a1, b0, b1;
+        err12(i, p, 0, a0, a1); err21(i, p, 0, b0, b1);
+        const double w1 = (double)A.w1[i], w2 = (double)A.w2[i];
+        if (a0 * w1 * a0 + a1 * w1 * a1 > th2 || b0 * w2 * b0 + b1 * w2 * b1 > th2) A.status[i] = 2; else in[0] += 1;
+    }
+    block_sum<1>(in, red);
+    if (tid == 0) { sim3_to8(est, A.Sout); A.res[0] = (int)in[0]; A.res[1] = nBad; A.res[2] = 0; }
+}
+
 }  // namespace rumi
 
 using namespace rumi;
@@ -1139,5 +1348,56 @@ extern "C" int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_
     if (ratio_out) std::memcpy(ratio_out, ratio.data(), (size_t)n_pairs * sizeof(float));
     std::sort(ratio.begin(), ratio.end());                                    // :654-662
     *median_out = ratio[n_pairs / 2];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_optimize_sim3(RumiOptimizer *o, int32_t n, const int32_t *pair_of, int32_t n_pairs, const double *S_c1w, const double *S_c2w,
+                                  const float *P1c, const float *P2c, const float *obs1, const float *obs2, const float *inv_sigma2_1,
+                                  const float *inv_sigma2_2, const uint8_t *skip12, const uint8_t *skip21, const float *K4_1, const float *K4_2,
+                                  float th2, int32_t fix_scale, int32_t robust_first_pass, double *S_io8, uint8_t *status_out, int32_t *result3) {
+    if (!o || n < 0 || !K4_1 || !K4_2 || !S_io8 || !result3) return RUMI_E_INVALID;
+    if (n > 0 && (!P1c || !P2c || !obs1 || !obs2 || !inv_sigma2_1 || !inv_sigma2_2 || !status_out)) return RUMI_E_INVALID;
+    const bool world = S_c1w != nullptr;
+    if (world && (!S_c2w || n_pairs < 1 || (n > 0 && !pair_of))) return RUMI_E_INVALID;
+    if (!world) n_pairs = 1;
+    if (world) for (int i = 0; i < n; i++) if (pair_of[i] < 0 || pair_of[i] >= n_pairs) { g_lastError = "rumi_optimize_sim3: pair index out of range"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(o->device));
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t N = (size_t)n, NP = (size_t)n_pairs;
+    const size_t oS = 0, oA = al(oS + 64), oB = al(oA + NP * 64), oK = al(oB + NP * 64), oP = al(oK + 32), oX1 = al(oP + N * 4), oX2 = al(oX1 + N * 12),
+                 oO1 = al(oX2 + N * 12), oO2 = al(oO1 + N * 8), oW1 = al(oO2 + N * 8), oW2 = al(oW1 + N * 4), oE1 = al(oW2 + N * 4), oE2 = al(oE1 + N),
+                 inBytes = al(oE2 + N);
+    // result block: estimate, counters, status; scratch behind it
+    const size_t rS = 0, rR = 64, rSt = 80, outBytes = al(rSt + N), sC = outBytes, sX1 = al(sC + NP * 30 * 64), sX2 = al(sX1 + N * 8), sO1 = al(sX2 + N * 8),
+                 sO2 = al(sO1 + N), scratchEnd = al(sO2 + N);
+    if (inBytes > o->baStageCap || scratchEnd > o->baStageCap) { g_lastError = "rumi_optimize_sim3: more correspondences than the optimiser's arenas hold"; return RUMI_E_CAPACITY; }
+    uint8_t *h = o->hBa;
+    std::memcpy(h + oS, S_io8, 64);
+    if (world) { std::memcpy(h + oA, S_c1w, NP * 64); std::memcpy(h + oB, S_c2w, NP * 64); if (n) std::memcpy(h + oP, pair_of, N * 4); }
+    std::memcpy(h + oK, K4_1, 16); std::memcpy(h + oK + 16, K4_2, 16);
+    if (n) {
+        std::memcpy(h + oX1, P1c, N * 12); std::memcpy(h + oX2, P2c, N * 12); std::memcpy(h + oO1, obs1, N * 8); std::memcpy(h + oO2, obs2, N * 8);
+        std::memcpy(h + oW1, inv_sigma2_1, N * 4); std::memcpy(h + oW2, inv_sigma2_2, N * 4);
+        if (skip12) std::memcpy(h + oE1, skip12, N); else std::memset(h + oE1, 0, N);
+        if (skip21) std::memcpy(h + oE2, skip21, N); else std::memset(h + oE2, 0, N);
+    }
+    HIP_TRY(hipMemcpyAsync(o->dBa, h, inBytes, hipMemcpyHostToDevice, nullptr));
+    uint8_t *d = o->dBa, *r = o->dBaOut;
+    Sim3Args A;
+    A.n = n; A.nPairs = n_pairs; A.world = world; A.fixScale = fix_scale != 0; A.robustFirst = robust_first_pass != 0; A.th2 = th2;
+    A.pairOf = world ? (const int32_t *)(d + oP) : nullptr;
+    A.Sc1w = (const double *)(d + oA); A.Sc2w = (const double *)(d + oB); A.Sin = (const double *)(d + oS);
+    A.P1c = (const float *)(d + oX1); A.P2c = (const float *)(d + oX2); A.obs1 = (const float *)(d + oO1); A.obs2 = (const float *)(d + oO2);
+    A.w1 = (const float *)(d + oW1); A.w2 = (const float *)(d + oW2); A.skip12 = d + oE1; A.skip21 = d + oE2;
+    A.K1 = (const float *)(d + oK); A.K2 = (const float *)(d + oK + 16);
+    A.Sout = (double *)(r + rS); A.res = (int32_t *)(r + rR); A.status = r + rSt;
+    A.comp = (double *)(r + sC); A.chi12 = (double *)(r + sX1); A.chi21 = (double *)(r + sX2); A.on12 = r + sO1; A.on21 = r + sO2;
+    hipLaunchKernelGGL(k_sim3_opt, dim3(1), dim3(256), 0, nullptr, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(o->hBa, r, outBytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(S_io8, o->hBa + rS, 64);
+    std::memcpy(result3, o->hBa + rR, 12);
+    if (n) std::memcpy(status_out, o->hBa + rSt, N);
     return RUMI_OK;
 }

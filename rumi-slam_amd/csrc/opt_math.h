@@ -138,4 +138,66 @@ RUMI_HD void jac_pose(const DCam &c, D3 p, double J0[6], double J1[6]) {
     J1[3] = 0;                       J1[4] = -j11;                      J1[5] = -j12;
 }
 
+// ---- g2o::Sim3 (G/types/sim3.h): rotation quaternion (never re-normalised), translation, scale ----
+struct DSim3 { DQuat r; D3 t; double s; };
+
+RUMI_HD DSim3 sim3_from8(const double *S) { return DSim3{{S[0], S[1], S[2], S[3]}, {S[4], S[5], S[6]}, S[7]}; }
+RUMI_HD void sim3_to8(const DSim3 &S, double *o) { o[0] = S.r.x; o[1] = S.r.y; o[2] = S.r.z; o[3] = S.r.w; o[4] = S.t.x; o[5] = S.t.y; o[6] = S.t.z; o[7] = S.s; }
+RUMI_HD D3 sim3_map(const DSim3 &S, D3 p) {                                    // sim3.h:144-146   s*(r*xyz) + t
+    const D3 r = quat_rotate(S.r, p);
+    return {S.s * r.x + S.t.x, S.s * r.y + S.t.y, S.s * r.z + S.t.z};
+}
+RUMI_HD DSim3 sim3_mul(const DSim3 &a, const DSim3 &b) {                       // sim3.h:266-272
+    DSim3 o;
+    o.r = quat_mul(a.r, b.r);
+    const D3 rt = quat_rotate(a.r, b.t);
+    o.t = {a.s * rt.x + a.t.x, a.s * rt.y + a.t.y, a.s * rt.z + a.t.z};
+    o.s = a.s * b.s;
+    return o;
+}
+RUMI_HD DSim3 sim3_inverse(const DSim3 &a) {                                   // sim3.h:233-236
+    const DQuat c{-a.r.x, -a.r.y, -a.r.z, a.r.w};
+    const double k = -1. / a.s;
+    return DSim3{c, quat_rotate(c, D3{k * a.t.x, k * a.t.y, k * a.t.z}), 1. / a.s};
+}
+// Sim3(const Vector7d& update): (omega, upsilon, sigma)                          sim3.h:70-142
+RUMI_HD DSim3 sim3_exp(const double u[7]) {
+    const double wx = u[0], wy = u[1], wz = u[2], sigma = u[6];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double O2[3][3], R[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+    const double s = exp(sigma), eps = 0.00001;
+    const bool smallT = theta < eps;
+    double A, B, C;
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (smallT) { A = 1. / 2.; B = 1. / 6.; }
+        else { const double theta2 = theta * theta; A = (1 - cos(theta)) / theta2; B = (theta - sin(theta)) / (theta2 * theta); }
+    } else {
+        C = (s - 1) / sigma;
+        if (smallT) { const double sigma2 = sigma * sigma; A = ((sigma - 1) * s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma); }
+        else {
+            const double a = s * sin(theta), b = s * cos(theta), theta2 = theta * theta, sigma2 = sigma * sigma, c = theta2 + sigma2;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    const double ra = smallT ? 1.0 : sin(theta) / theta, rb = smallT ? 1.0 : (1 - cos(theta)) / (theta * theta);
+    double W[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const double I = i == j ? 1.0 : 0.0;
+            R[i][j] = smallT ? (I + O[i][j]) + O2[i][j] : (I + ra * O[i][j]) + rb * O2[i][j];
+            W[i][j] = (A * O[i][j] + B * O2[i][j]) + C * I;
+        }
+    DSim3 S;
+    S.r = quat_from_matrix(R);
+    S.t = {W[0][0] * u[3] + W[0][1] * u[4] + W[0][2] * u[5], W[1][0] * u[3] + W[1][1] * u[4] + W[1][2] * u[5],
+           W[2][0] * u[3] + W[2][1] * u[4] + W[2][2] * u[5]};
+    S.s = s;
+    return S;
+}
+
 }  // namespace rumi

@@ -264,6 +264,116 @@ public:
         }
         pMap->IncreaseChangeIndex();
     }
+
+#ifdef RUMI_HAVE_SOPHUS
+    // Gathers one correspondence of OptimizeSim3 / OptimizeCloudSim3 (Optimizer.cc:1972-2100, :2246-2392); false when the reference skips it.
+    struct Sim3Gather {
+        std::vector<float> P1c, P2c, obs1, obs2, w1, w2;
+        std::vector<uint8_t> skip12, skip21;
+        std::vector<int32_t> pairOf;
+        std::vector<size_t> index;             // vnIndexEdge
+        int n() const { return (int)w1.size(); }
+    };
+    template <class KeyFrameT, class MapPointT>
+    static bool sim3_gather(Sim3Gather &g, KeyFrameT *pKF1, KeyFrameT *pKF2, MapPointT *pMP1, MapPointT *pMP2, size_t i, int pair, bool bAllPoints) {
+        if (!pMP1 || !pMP2) return false;                                              // "match without map point": vertices only, no edges (:2016-2031)
+        if (pMP1->isBad() || pMP2->isBad()) return false;                              // :2011-2014
+        const int i2 = std::get<0>(pMP2->GetIndexInKeyFrame(pKF2));
+        const auto P3D1c = pKF1->GetRotation() * pMP1->GetWorldPos() + pKF1->GetTranslation();   // :1990, :1997
+        const auto P3D2c = pKF2->GetRotation() * pMP2->GetWorldPos() + pKF2->GetTranslation();
+        if (i2 < 0 && !bAllPoints) return false;                                       // :2033-2036
+        if (P3D2c(2) < 0) return false;                                                // :2038-2041
+        const auto &kpUn1 = pKF1->mvKeysUn[i];
+        float ox, oy; int octave2;
+        if (i2 >= 0) { const auto &kpUn2 = pKF2->mvKeysUn[i2]; ox = kpUn2.pt.x; oy = kpUn2.pt.y; octave2 = kpUn2.octave; }
+        else { const float invz = 1 / P3D2c(2); ox = P3D2c(0) * invz; oy = P3D2c(1) * invz; octave2 = pMP2->mnTrackScaleLevel; }   // :2065-2071
+        for (int c = 0; c < 3; c++) { g.P1c.push_back(P3D1c(c)); g.P2c.push_back(P3D2c(c)); }
+        g.obs1.push_back(kpUn1.pt.x); g.obs1.push_back(kpUn1.pt.y); g.obs2.push_back(ox); g.obs2.push_back(oy);
+        g.w1.push_back(pKF1->mvInvLevelSigma2[kpUn1.octave]); g.w2.push_back(pKF2->mvInvLevelSigma2[octave2]);
+        g.skip12.push_back(pMP2->isEdge); g.skip21.push_back(pMP1->isEdge);
+        g.pairOf.push_back(pair); g.index.push_back(i);
+        return true;
+    }
+    template <class Sim3T> static void sim3_to8(const Sim3T &S, double *o) {
+        const auto q = S.rotation(); const auto t = S.translation();
+        o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); o[3] = q.w(); o[4] = t(0); o[5] = t(1); o[6] = t(2); o[7] = S.scale();
+    }
+    template <class Sim3T> static Sim3T sim3_from8(const double *S) {
+        return Sim3T(Eigen::Quaterniond(S[3], S[0], S[1], S[2]), Eigen::Vector3d(S[4], S[5], S[6]), S[7]);
+    }
+
+    // static int OptimizeSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches1, g2o::Sim3 &g2oS12, const float th2,
+    //                         const bool bFixScale, Eigen::Matrix<double, 7, 7> &mAcumHessian, const bool bAllPoints)      Optimizer.cc:1920-2167
+    template <class KeyFrameT, class MapPointT, class Sim3T, class HessianT>
+    static int OptimizeSim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches1, Sim3T &g2oS12, const float th2, const bool bFixScale,
+                            HessianT &mAcumHessian, const bool bAllPoints = false) {
+        const int N = (int)vpMatches1.size();
+        const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+        Sim3Gather g;
+        for (int i = 0; i < N; i++) {
+            if (!vpMatches1[i]) continue;
+            sim3_gather(g, pKF1, pKF2, vpMapPoints1[i], vpMatches1[i], (size_t)i, 0, bAllPoints);
+        }
+        // the isEdge tests belong to the cloud variant only: here both edges always exist
+        const float K1[4] = {pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy}, K2[4] = {pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy};
+        double S[8];
+        sim3_to8(g2oS12, S);
+        std::vector<uint8_t> status(g.n() + 1);
+        int32_t res[3] = {0, 0, 1};
+        if (rumi_optimize_sim3(arena(), g.n(), nullptr, 0, nullptr, nullptr, g.P1c.data(), g.P2c.data(), g.obs1.data(), g.obs2.data(), g.w1.data(), g.w2.data(),
+                               nullptr, nullptr, K1, K2, th2, bFixScale, 1, S, status.data(), res) != RUMI_OK) {
+            std::fprintf(stderr, "OptimizeSim3: %s\n", rumi_last_error());
+            return 0;
+        }
+        for (int k = 0; k < g.n(); k++)
+            if (status[k] == 1 || (!res[2] && status[k] == 2)) vpMatches1[g.index[k]] = static_cast<MapPointT *>(nullptr);   // :2112, :2156
+        if (res[2]) return 0;                                                          // :2135-2136: g2oS12 keeps its value
+        mAcumHessian.setZero();                                                        // :2144 (never accumulated upstream)
+        g2oS12 = sim3_from8<Sim3T>(S);                                                 // :2163-2164
+        return res[0];
+    }
+
+    // static float OptimizeCloudSim3(const vector<KeyFrame *> &map1KFs, const vector<KeyFrame *> &map2KFs, const vector<vector<MapPoint *>> &avpMatches,
+    //                                g2o::Sim3 &gSw1w2, const float th2, const bool bFixScale, Eigen::Matrix<double, 7, 7> &mAcumHessian,
+    //                                const bool bAllPoints)                                                              Optimizer.cc:2169-2471
+    template <class KeyFrameT, class MapPointT, class Sim3T, class HessianT>
+    static float OptimizeCloudSim3(const std::vector<KeyFrameT *> &map1KFs, const std::vector<KeyFrameT *> &map2KFs,
+                                   const std::vector<std::vector<MapPointT *>> &avpMatches, Sim3T &gSw1w2, const float th2, const bool bFixScale,
+                                   HessianT &mAcumHessian, const bool bAllPoints = false) {
+        Sim3Gather g;
+        std::vector<double> A, B;
+        for (size_t k = 0; k < map2KFs.size(); ++k) {
+            KeyFrameT *pKF1 = map1KFs[k], *pKF2 = map2KFs[k];
+            const Sim3T gSc1w(pKF1->GetRotation().template cast<double>(), pKF1->GetTranslation().template cast<double>(), 1.0);   // :2231-2232
+            const Sim3T gSc2w(pKF2->GetRotation().template cast<double>(), pKF2->GetTranslation().template cast<double>(), 1.0);
+            double a[8], b[8];
+            sim3_to8(gSc1w, a); sim3_to8(gSc2w, b);
+            A.insert(A.end(), a, a + 8); B.insert(B.end(), b, b + 8);
+            const auto &vpMatches1 = avpMatches[k];
+            const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+            for (size_t i = 0; i < vpMatches1.size(); i++) {
+                if (!vpMapPoints1[i] || !vpMatches1[i]) continue;                       // :2251-2252
+                sim3_gather(g, pKF1, pKF2, vpMapPoints1[i], vpMatches1[i], i, (int)k, bAllPoints);
+            }
+        }
+        if (map2KFs.empty()) return 0.f;
+        const float K1[4] = {map1KFs[0]->fx, map1KFs[0]->fy, map1KFs[0]->cx, map1KFs[0]->cy};   // vSim3->pCamera1 = map1KFs[0]->mpCamera (:2192-2193)
+        const float K2[4] = {map2KFs[0]->fx, map2KFs[0]->fy, map2KFs[0]->cx, map2KFs[0]->cy};
+        double S[8];
+        sim3_to8(gSw1w2, S);
+        std::vector<uint8_t> status(g.n() + 1);
+        int32_t res[3] = {0, 0, 1};
+        if (rumi_optimize_sim3(arena(), g.n(), g.pairOf.data(), (int32_t)map2KFs.size(), A.data(), B.data(), g.P1c.data(), g.P2c.data(), g.obs1.data(),
+                               g.obs2.data(), g.w1.data(), g.w2.data(), g.skip12.data(), g.skip21.data(), K1, K2, th2, bFixScale, 0, S, status.data(), res) != RUMI_OK) {
+            std::fprintf(stderr, "OptimizeCloudSim3: %s\n", rumi_last_error());
+            return 0.f;
+        }
+        gSw1w2 = sim3_from8<Sim3T>(S);                                                 // :2397 (before the early return) and :2466
+        if (res[2]) return 0;                                                          // :2437-2438
+        mAcumHessian.setZero();                                                        // :2446
+        return (float)res[0] / (float)g.n();                                           // :2468
+    }
+#endif
 };
 
 }  // namespace ORB_SLAM3

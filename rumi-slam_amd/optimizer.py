@@ -7,7 +7,7 @@ import numpy as np
 from . import capi
 
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
-               "rumi_opt_stage_ms"]
+               "rumi_optimize_sim3", "rumi_opt_stage_ms"]
 
 
 def _lib():
@@ -25,6 +25,7 @@ def _lib():
     L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
+    L.rumi_optimize_sim3.argtypes = [vp, i32, vp, i32] + [vp] * 12 + [C.c_float, i32, i32, vp, vp, vp]
     L._opt_ready = True
     return L
 
@@ -107,6 +108,27 @@ class Optimizer:
         capi.check(self._lib.rumi_sim3_inliers(self._h, n_pairs, capi.ptr(ps), capi.ptr(pd), capi.ptr(A), capi.ptr(B), *[capi.ptr(a) for a in arrs],
                                                capi.ptr(inl), capi.ptr(ratio), C.byref(med)))
         return med.value, ratio[:n_pairs], inl[:total]
+
+    def OptimizeSim3(self, S8, P1c, P2c, obs1, obs2, inv_sigma2_1, inv_sigma2_2, K4_1, K4_2, th2=10.0, fix_scale=False, robust_first_pass=True,
+                     pair_of=None, S_c1w=None, S_c2w=None, skip12=None, skip21=None):
+        """Optimizer::OptimizeSim3 (robust first pass, no key-frame transforms) and, with pair_of / S_c1w / S_c2w and
+        robust_first_pass=False, Optimizer::OptimizeCloudSim3, on flat arrays (include/rumi_opt.h).
+        Returns (nIn, nBad, early, S8, status[n])."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        P1c, P2c, obs1, obs2, w1, w2, K1, K2 = (f32(a) for a in (P1c, P2c, obs1, obs2, inv_sigma2_1, inv_sigma2_2, K4_1, K4_2))
+        n = len(w1)
+        S = np.ascontiguousarray(S8, np.float64).copy()
+        world = S_c1w is not None
+        po = np.ascontiguousarray(pair_of, np.int32) if world else None
+        A = np.ascontiguousarray(S_c1w, np.float64).reshape(-1, 8) if world else None
+        B = np.ascontiguousarray(S_c2w, np.float64).reshape(-1, 8) if world else None
+        s12, s21 = u8(skip12), u8(skip21)
+        status = np.zeros(max(n, 1), np.uint8); res = np.zeros(3, np.int32)
+        P = lambda a: None if a is None else capi.ptr(a)
+        capi.check(self._lib.rumi_optimize_sim3(self._h, n, P(po), len(A) if world else 0, P(A), P(B), P(P1c), P(P2c), P(obs1), P(obs2), P(w1), P(w2),
+                                                P(s12), P(s21), P(K1), P(K2), float(th2), int(fix_scale), int(robust_first_pass), P(S), P(status), P(res)))
+        return int(res[0]), int(res[1]), bool(res[2]), S, status[:n]
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)

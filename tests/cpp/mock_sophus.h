@@ -5,10 +5,17 @@
 #include <cmath>
 
 namespace Eigen {
-struct Vector3d { double v[3]; double operator()(int i) const { return v[i]; } };
+struct Vector3d {
+    double v[3];
+    Vector3d() : v{0, 0, 0} {}
+    Vector3d(double x, double y, double z) : v{x, y, z} {}
+    double operator()(int i) const { return v[i]; }
+};
 struct Matrix3d { double m[3][3]; double operator()(int r, int c) const { return m[r][c]; } };
 struct Quaterniond {
     double qw, qx, qy, qz;
+    Quaterniond() : qw(1), qx(0), qy(0), qz(0) {}
+    Quaterniond(double w, double x, double y, double z) : qw(w), qx(x), qy(y), qz(z) {}
     double x() const { return qx; } double y() const { return qy; } double z() const { return qz; } double w() const { return qw; }
 };
 struct Vector2f { float v[2]; float operator()(int i) const { return v[i]; } float &operator()(int i) { return v[i]; } };
@@ -22,7 +29,7 @@ struct Vector3f {
     Vector3f operator*(float s) const { return Vector3f(v[0] * s, v[1] * s, v[2] * s); }
     Vector3f operator+(const Vector3f &o) const { return Vector3f(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
     Vector3f operator-(const Vector3f &o) const { return Vector3f(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
-    template <class T> Vector3d cast() const { return Vector3d{{(double)v[0], (double)v[1], (double)v[2]}}; }
+    template <class T> Vector3d cast() const { return Vector3d((double)v[0], (double)v[1], (double)v[2]); }
 };
 struct Matrix3f {
     float m[3][3];
@@ -70,6 +77,8 @@ struct Quaternionf {
         return R;
     }
 };
+// stand-in for Eigen::Matrix<double, 7, 7> (OptimizeSim3's mAcumHessian)
+struct Matrix77d { double m[7][7]; void setZero() { for (auto &r : m) for (double &x : r) x = 0; } };
 }  // namespace Eigen
 
 namespace Sophus {
@@ -108,7 +117,7 @@ using Sim3f = Sim3<float>;
 // g2o::Sim3 stand-in (double): rotation as a quaternion, map = s * (r * p) + t, composition and inverse as in G/types/sim3.h
 namespace g2o {
 struct Sim3 {
-    Eigen::Quaterniond r{1, 0, 0, 0}; Eigen::Vector3d t{{0, 0, 0}}; double s = 1;
+    Eigen::Quaterniond r{1, 0, 0, 0}; Eigen::Vector3d t{0, 0, 0}; double s = 1;
     Sim3() {}
     Sim3(const Eigen::Quaterniond &r_, const Eigen::Vector3d &t_, double s_) : r(r_), t(t_), s(s_) {}
     Sim3(const Eigen::Matrix3d &R, const Eigen::Vector3d &t_, double s_) : t(t_), s(s_) {
@@ -122,18 +131,18 @@ struct Sim3 {
     double scale() const { return s; }
     static Eigen::Vector3d rot(const Eigen::Quaterniond &q, const Eigen::Vector3d &v) {
         const double ux = 2 * (q.qy * v.v[2] - q.qz * v.v[1]), uy = 2 * (q.qz * v.v[0] - q.qx * v.v[2]), uz = 2 * (q.qx * v.v[1] - q.qy * v.v[0]);
-        return Eigen::Vector3d{{v.v[0] + q.qw * ux + (q.qy * uz - q.qz * uy), v.v[1] + q.qw * uy + (q.qz * ux - q.qx * uz), v.v[2] + q.qw * uz + (q.qx * uy - q.qy * ux)}};
+        return Eigen::Vector3d{v.v[0] + q.qw * ux + (q.qy * uz - q.qz * uy), v.v[1] + q.qw * uy + (q.qz * ux - q.qx * uz), v.v[2] + q.qw * uz + (q.qx * uy - q.qy * ux)};
     }
     Sim3 inverse() const {
         const Eigen::Quaterniond c{r.qw, -r.qx, -r.qy, -r.qz};
         const Eigen::Vector3d rt = rot(c, t);
-        return Sim3(c, Eigen::Vector3d{{-rt.v[0] / s, -rt.v[1] / s, -rt.v[2] / s}}, 1.0 / s);
+        return Sim3(c, Eigen::Vector3d{-rt.v[0] / s, -rt.v[1] / s, -rt.v[2] / s}, 1.0 / s);
     }
     Sim3 operator*(const Sim3 &o) const {
         const Eigen::Quaterniond q{r.qw * o.r.qw - r.qx * o.r.qx - r.qy * o.r.qy - r.qz * o.r.qz, r.qw * o.r.qx + r.qx * o.r.qw + r.qy * o.r.qz - r.qz * o.r.qy,
                                    r.qw * o.r.qy + r.qy * o.r.qw + r.qz * o.r.qx - r.qx * o.r.qz, r.qw * o.r.qz + r.qz * o.r.qw + r.qx * o.r.qy - r.qy * o.r.qx};
         const Eigen::Vector3d rt = rot(r, o.t);
-        return Sim3(q, Eigen::Vector3d{{s * rt.v[0] + t.v[0], s * rt.v[1] + t.v[1], s * rt.v[2] + t.v[2]}}, s * o.s);
+        return Sim3(q, Eigen::Vector3d{s * rt.v[0] + t.v[0], s * rt.v[1] + t.v[1], s * rt.v[2] + t.v[2]}, s * o.s);
     }
 };
 }  // namespace g2o

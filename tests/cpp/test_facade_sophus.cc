@@ -31,7 +31,7 @@ struct MapPoint {
     static std::mutex mGlobalMutex;
     Eigen::Vector3f pos, normal{0, 0, 1}; cv::Mat desc; int nObs = 1; bool bad = false, isEdge = false; Map *map = nullptr; long mnBALocalForKF = -1;
     std::map<KeyFrame *, std::tuple<int, int>> obs;
-    float minD = 0.5f, maxD = 60.f;
+    float minD = 0.5f, maxD = 60.f; int mnTrackScaleLevel = 0;
     Eigen::Vector3f GetWorldPos() { return pos; }
     Eigen::Vector3f GetNormal() { return normal; }
     void SetWorldPos(const Eigen::Vector3f &p) { pos = p; }
@@ -75,6 +75,8 @@ struct KeyFrame : Frame {
     void AddMapPoint(MapPoint *p, size_t i) { mvpMapPoints[i] = p; }
     void EraseMapPointMatch(MapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
     Sophus::SE3f GetPoseInverse() const { return pose.inverse(); }
+    Eigen::Matrix3f GetRotation() const { return pose.rotationMatrix(); }
+    Eigen::Vector3f GetTranslation() const { return pose.translation(); }
     Eigen::Vector3f GetCameraCenter() const { return pose.inverse().translation(); }
     bool isBad() { return bad; }
     Map *GetMap() { return map; }
@@ -204,7 +206,7 @@ int main(int argc, char **argv) {
         A.mvLevelSigma2.assign(8, 1.f); B.mvLevelSigma2.assign(8, 1.f);
         for (int l = 1; l < 8; l++) { A.mvLevelSigma2[l] = A.mvScaleFactors[l] * A.mvScaleFactors[l]; B.mvLevelSigma2[l] = A.mvLevelSigma2[l]; }
         const double sc = 2.0;
-        g2o::Sim3 Sw1w2(Eigen::Quaterniond{1, 0, 0, 0}, Eigen::Vector3d{{0.5, -0.25, 1.0}}, sc);     // Pw1 = sc * Pw2 + t
+        g2o::Sim3 Sw1w2(Eigen::Quaterniond{1, 0, 0, 0}, Eigen::Vector3d{0.5, -0.25, 1.0}, sc);     // Pw1 = sc * Pw2 + t
         B.pose = Sophus::SE3f(Eigen::Quaternionf(1, 0, 0, 0), Eigen::Vector3f(0.25f, -0.125f, 0.5f));   // camera 2 = camera 1 seen from world 2: t / sc
         std::vector<MapPoint> ma(A.N), mb(B.N);
         std::vector<std::pair<int, int>> matches;
@@ -222,6 +224,49 @@ int main(int argc, char **argv) {
         const float ratio = rumi_facade::ComputeInliersNum(m1, m2, all, Sw1w2);
         CHECK(ratio > 0.85f && ratio < 0.92f, "ComputeInliersNum: 8/9 of the matches are inliers");
         std::printf("ComputeInliersNum ratio %.4f\n", ratio);
+    }
+    // --- OptimizeSim3 / OptimizeCloudSim3: key-frame B sees the points of key-frame A from a world that is a similarity away ---
+    {
+        KeyFrame A = kf[0], B = kf[0];
+        const double sc = 1.25;
+        // S12 maps camera-2 coordinates into camera-1 coordinates: P1c = sc * P2c + t (no rotation)
+        std::vector<MapPoint> ma(A.N), mb(B.N);
+        std::vector<MapPoint *> matches(A.N, nullptr);
+        A.pose = Sophus::SE3f(); B.pose = Sophus::SE3f();
+        for (int i = 0; i < A.N; i++) {
+            const float z = 3.f + (i % 40) / 10.f;
+            const Eigen::Vector3f pcA((A.mvKeysUn[i].pt.x - 320.1f) / 535.4f * z, (A.mvKeysUn[i].pt.y - 247.6f) / 539.2f * z, z);
+            ma[i].pos = pcA;
+            mb[i].pos = Eigen::Vector3f((pcA(0) - 0.1f) / (float)sc, (pcA(1) + 0.05f) / (float)sc, (pcA(2) - 0.2f) / (float)sc);
+            A.mvpMapPoints[i] = &ma[i];
+            // key-frame 2 observes its point where it projects (feature i of B), except for a few gross outliers
+            const Eigen::Vector2f uv = B.cam.project(mb[i].pos);
+            B.mvKeysUn[i].pt.x = uv(0) + (i % 11 == 0 ? 40.f : 0.f); B.mvKeysUn[i].pt.y = uv(1);
+            mb[i].obs[&B] = std::make_tuple(i, -1);
+            if (i % 3) matches[i] = &mb[i];
+        }
+        g2o::Sim3 S12(Eigen::Quaterniond{1, 0, 0, 0}, Eigen::Vector3d{0.12, -0.04, 0.22}, 1.22);       // perturbed start
+        Eigen::Matrix77d H;
+        std::vector<MapPoint *> m1 = matches;
+        int nGiven = 0, nOut = 0;
+        for (int i = 0; i < A.N; i++) if (matches[i]) { nGiven++; nOut += (i % 11 == 0); }
+        const int nIn = ORB_SLAM3::Optimizer::OptimizeSim3(&A, &B, m1, S12, 10.f, false, H, true);
+        int nNulled = 0, outNulled = 0;
+        for (int i = 0; i < A.N; i++) if (matches[i] && !m1[i]) { nNulled++; outNulled += (i % 11 == 0); }
+        std::printf("OptimizeSim3: %d given, %d inliers, %d removed (%d of %d outliers), s %.5f t %.4f %.4f %.4f\n", nGiven, nIn, nNulled, outNulled, nOut, S12.scale(),
+                    S12.translation()(0), S12.translation()(1), S12.translation()(2));
+        CHECK(nIn == nGiven - nNulled && outNulled == nOut && nNulled <= nOut + nGiven / 50, "OptimizeSim3 removes exactly the gross outliers");
+        CHECK(std::fabs(S12.scale() - sc) < 2e-3 && std::fabs(S12.translation()(0) - 0.1) < 3e-3 && std::fabs(S12.translation()(2) - 0.2) < 6e-3, "OptimizeSim3 recovers the similarity");
+        CHECK(H.m[3][3] == 0.0, "mAcumHessian zeroed");
+        // the cloud variant over two key-frame pairs (the same pair twice), fixed scale: the vertex is gSw1w2 and both key-frames sit at their worlds' origins
+        g2o::Sim3 Sw(Eigen::Quaterniond{1, 0, 0, 0}, Eigen::Vector3d{0.11, -0.05, 0.21}, sc);
+        std::vector<KeyFrame *> k1 = {&A, &A}, k2 = {&B, &B};
+        std::vector<std::vector<MapPoint *>> av = {matches, matches};
+        ma[5].isEdge = true;
+        const float ratio = ORB_SLAM3::Optimizer::OptimizeCloudSim3(k1, k2, av, Sw, 10.f, true, H, true);
+        std::printf("OptimizeCloudSim3: ratio %.4f, t %.4f %.4f %.4f s %.4f\n", ratio, Sw.translation()(0), Sw.translation()(1), Sw.translation()(2), Sw.scale());
+        CHECK(ratio > 0.85f && ratio < 0.93f, "OptimizeCloudSim3 inlier ratio (1/11 of the matches are outliers)");
+        CHECK(Sw.scale() == sc && std::fabs(Sw.translation()(0) - 0.1) < 3e-3 && std::fabs(Sw.translation()(2) - 0.2) < 6e-3, "OptimizeCloudSim3 recovers the translation, keeps the scale");
     }
     if (fails == 0) std::printf("facade (Sophus overloads): all checks passed\n");
     return fails ? 1 : 0;

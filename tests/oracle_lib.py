@@ -412,3 +412,25 @@ def sim3_inliers(pair_start, pair_denominator, S_c1w2, S_c2w1, K4_1, K4_2, X1, X
     L.orc_sim3_inliers.argtypes = [C.c_int32] + [C.c_void_p] * 16
     med = L.orc_sim3_inliers(n_pairs, _p(ps), _p(pd), _p(A), _p(B), *[_p(a) for a in arrs], _p(inl), _p(ratio))
     return med, ratio[:n_pairs], inl[:total]
+
+
+def optimize_sim3(S8, P1c, P2c, obs1, obs2, w1, w2, K4_1, K4_2, th2=10.0, fix_scale=False, robust_first_pass=True, pair_of=None, S_c1w=None,
+                  S_c2w=None, skip12=None, skip21=None):
+    """orc_optimize_sim3: Optimizer::OptimizeSim3 / OptimizeCloudSim3.  Returns (nIn, nBad, early, S8, status)."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    P1c, P2c, obs1, obs2, w1, w2, K1, K2 = (f32(a) for a in (P1c, P2c, obs1, obs2, w1, w2, K4_1, K4_2))
+    n = len(w1)
+    S = np.ascontiguousarray(S8, np.float64).copy()
+    world = S_c1w is not None
+    po = np.ascontiguousarray(pair_of, np.int32) if world else None
+    A = np.ascontiguousarray(S_c1w, np.float64) if world else None
+    B = np.ascontiguousarray(S_c2w, np.float64) if world else None
+    s12 = None if skip12 is None else np.ascontiguousarray(skip12, np.uint8)
+    s21 = None if skip21 is None else np.ascontiguousarray(skip21, np.uint8)
+    status = np.zeros(max(n, 1), np.uint8); res = np.zeros(3, np.int32)
+    L = _olib()
+    L.orc_optimize_sim3.argtypes = [C.c_int32] + [C.c_void_p] * 13 + [C.c_float, C.c_int32, C.c_int32] + [C.c_void_p] * 3
+    P = lambda a: None if a is None else _p(a)
+    L.orc_optimize_sim3(n, P(po), P(A), P(B), P(P1c), P(P2c), P(obs1), P(obs2), P(w1), P(w2), P(s12), P(s21), P(K1), P(K2), float(th2), int(fix_scale),
+                        int(robust_first_pass), P(S), P(status), P(res))
+    return int(res[0]), int(res[1]), bool(res[2]), S, status[:n]

@@ -64,3 +64,27 @@ def test_local_ba_stop_flag_aborts_before_optimising():
     stop = np.ones(1, np.uint8)
     its, kp, mp, erase = O.local_ba(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"], stop)
     assert its == -1 and np.array_equal(kp, b["kf_pose"]) and np.array_equal(mp, b["mp_pos"])
+
+
+def test_optimize_sim3_oracle_recovers_similarity_and_rejects_outliers():
+    """OptimizeSim3 restatement (numeric Jacobians through the Sim3 exponential): converges to the true similarity, removes the
+    gross outliers after the first pass, keeps the scale when it is fixed."""
+    from sim3_scene import sim3_pair_problem
+    b = sim3_pair_problem(seed=1, n=500, outlier_frac=0.1)
+    a = (b["S0"], b["P1c"], b["P2c"], b["obs1"], b["obs2"], b["w1"], b["w2"], b["K"], b["K"])
+    nin, nbad, early, S, st = O.optimize_sim3(*a, 10.0, False, True)
+    assert not early and nin + nbad + (st == 2).sum() == 500
+    assert (st[b["bad"]] == 1).mean() > 0.95 and (st[~b["bad"]] == 0).mean() > 0.9
+    assert np.abs(S[:4] - b["S_true"][:4]).max() < 2e-3 and np.abs(S[4:7] - b["S_true"][4:7]).max() < 2e-2 and abs(S[7] - 1.3) < 1e-2
+    nin, nbad, early, S, st = O.optimize_sim3(*a, 10.0, True, True)
+    assert S[7] == b["S0"][7]                                 # update[6] = 0: exp(0) * s is exact
+
+
+def test_optimize_cloud_sim3_oracle_world_edges():
+    """OptimizeCloudSim3 restatement: the vertex lives between the two worlds, every key-frame pair wraps it in its own poses."""
+    from sim3_scene import sim3_cloud_problem
+    c = sim3_cloud_problem(seed=2, outlier_frac=0.03)
+    nin, nbad, early, S, st = O.optimize_sim3(c["S0"], c["P1c"], c["P2c"], c["obs1"], c["obs2"], c["w1"], c["w2"], c["K"], c["K"], 10.0, True, False,
+                                              c["pair_of"], c["S_c1w"], c["S_c2w"], c["skip12"], c["skip21"])
+    assert not early and nin > 0.6 * len(st) and (st == 3).sum() > 0
+    assert np.abs(S[:4] - c["S_true"][:4]).max() < 2e-3 and np.abs(S[4:7] - c["S_true"][4:7]).max() < 2e-2 and S[7] == 1.0

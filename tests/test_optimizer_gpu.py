@@ -203,3 +203,62 @@ def test_global_bundle_adjustment(opt, cfg, its, robust):
         _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
     scale = np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-2)
     assert (np.linalg.norm(mp - mp_ref, axis=1) <= RTOL * scale).all(), "landmarks"
+
+
+def _sim3_close(a, b, what):
+    """Sim3 as (qx qy qz qw tx ty tz s): 1e-4 relative on the rotation as a whole, the translation as a whole and the scale."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert np.linalg.norm(a[:4] - b[:4]) <= 1e-4, f"{what}: rotation {a[:4]} vs {b[:4]}"
+    assert np.linalg.norm(a[4:7] - b[4:7]) <= 1e-4 * max(np.linalg.norm(b[4:7]), 1.0), f"{what}: translation {a[4:7]} vs {b[4:7]}"
+    assert abs(a[7] - b[7]) <= 1e-4 * abs(b[7]), f"{what}: scale {a[7]} vs {b[7]}"
+
+
+@pytest.mark.parametrize("cfg,fix", [(dict(seed=1), False), (dict(seed=2, n=900, outlier_frac=0.2), False), (dict(seed=3, n=120, scale=1.0), True),
+                                     (dict(seed=4, n=60, outlier_frac=0.0, init_err=0.2), False)])
+def test_optimize_sim3_pair(opt, cfg, fix):
+    """Optimizer::OptimizeSim3 (loop / merge candidate verification): Huber first pass, numeric Jacobians, outlier removal, second
+    pass.  Same inlier set and counts as the oracle, Sim3 within 1e-4."""
+    from sim3_scene import sim3_pair_problem
+    b = sim3_pair_problem(**cfg)
+    a = (b["S0"], b["P1c"], b["P2c"], b["obs1"], b["obs2"], b["w1"], b["w2"], b["K"], b["K"], 10.0, fix, True)
+    nin_r, nbad_r, early_r, S_r, st_r = O.optimize_sim3(*a)
+    nin, nbad, early, S, st = opt.OptimizeSim3(*a)
+    assert nin_r > 0.5 * len(st_r) and not early_r
+    assert (nin, nbad, early) == (nin_r, nbad_r, early_r) and np.array_equal(st, st_r)
+    _sim3_close(S, S_r, "S12")
+    if fix:
+        assert S[7] == b["S0"][7]
+
+
+@pytest.mark.parametrize("seed,fix", [(11, True), (12, False)])
+def test_optimize_cloud_sim3(opt, seed, fix):
+    """Optimizer::OptimizeCloudSim3 (rumination sub-map alignment): world edges over several key-frame pairs, no robust kernel,
+    absent edges for isEdge points, one nearly empty pair."""
+    from sim3_scene import sim3_cloud_problem
+    c = sim3_cloud_problem(seed=seed)
+    a = (c["S0"], c["P1c"], c["P2c"], c["obs1"], c["obs2"], c["w1"], c["w2"], c["K"], c["K"], 10.0, fix, False, c["pair_of"], c["S_c1w"], c["S_c2w"],
+         c["skip12"], c["skip21"])
+    nin_r, nbad_r, early_r, S_r, st_r = O.optimize_sim3(*a)
+    nin, nbad, early, S, st = opt.OptimizeSim3(*a)
+    assert nin_r > 0.4 * len(st_r) and (st_r == 3).any() and not early_r
+    assert (nin, nbad, early) == (nin_r, nbad_r, early_r) and np.array_equal(st, st_r)
+    _sim3_close(S, S_r, "gSw1w2")
+
+
+def test_optimize_sim3_early_returns(opt):
+    """Fewer than 10 surviving correspondences: returns 0 after the first optimize (Optimizer.cc:2135-2136, :2437-2438); no
+    correspondences at all: the estimate comes back unchanged."""
+    from sim3_scene import sim3_pair_problem
+    b = sim3_pair_problem(seed=7, n=9)
+    a = (b["S0"], b["P1c"], b["P2c"], b["obs1"], b["obs2"], b["w1"], b["w2"], b["K"], b["K"], 10.0, False, True)
+    r_ref, r = O.optimize_sim3(*a), opt.OptimizeSim3(*a)
+    assert r_ref[2] and r_ref[0] == 0 and r[:3] == r_ref[:3] and np.array_equal(r[4], r_ref[4])
+    _sim3_close(r[3], r_ref[3], "after the first pass")
+    # all observations of key-frame 1 are wrong: everything is removed after the first pass
+    b = sim3_pair_problem(seed=8, n=200, outlier_frac=1.0)
+    a = (b["S0"], b["P1c"], b["P2c"], b["obs1"], b["obs2"], b["w1"], b["w2"], b["K"], b["K"], 10.0, False, True)
+    r_ref, r = O.optimize_sim3(*a), opt.OptimizeSim3(*a)
+    assert r_ref[2] and r[:3] == r_ref[:3] and np.array_equal(r[4], r_ref[4])
+    e = np.zeros((0, 3), np.float32); e2 = np.zeros((0, 2), np.float32); e1 = np.zeros(0, np.float32)
+    nin, nbad, early, S, st = opt.OptimizeSim3(b["S0"], e, e, e2, e2, e1, e1, b["K"], b["K"])
+    assert (nin, nbad, early) == (0, 0, True) and np.array_equal(S, b["S0"]) and len(st) == 0
