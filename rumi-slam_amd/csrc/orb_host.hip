@@ -91,7 +91,7 @@ struct RumiOrb {
     bool tapValid = false;
     // last-call bookkeeping for the stage taps
     ImgSrc lastSrc{};
-    int lastFrames = 0, lastChunkBase = 0, lastChunkFrames = 0;
+    int lastFrames = 0, lastChunkBase = 0, lastChunkFrames = 0, lastChunkSlot = 0;   // frames / scratch slot the stage taps can read
     RumiKeyPoint *lastKp = nullptr;  // device pointer the last call wrote key-points to
     int32_t *lastCounts = nullptr;
     int lastOutCap = 0;
@@ -101,9 +101,9 @@ struct RumiOrb {
     // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
     hipStream_t sideStream = nullptr;
     // a chunk's frames are split over the caller's stream and these, see Stage B
-    static constexpr int kMaxParts = 4;
-    hipStream_t partStream[kMaxParts - 1] = {nullptr};
-    hipEvent_t evPartFork = nullptr, evPartJoin[kMaxParts - 1] = {nullptr};
+    static constexpr int kMaxParts = 8;
+    hipStream_t partStream[kMaxParts - 1] = {nullptr}, partSide[kMaxParts - 1] = {nullptr};   // partSide: the part's blur when the pyramid is split too
+    hipEvent_t evPartFork = nullptr, evPartJoin[kMaxParts - 1] = {nullptr}, evSideFork[kMaxParts - 1] = {nullptr}, evSideJoin[kMaxParts - 1] = {nullptr};
     hipEvent_t evFork = nullptr, evJoin = nullptr, evB0 = nullptr, evB1 = nullptr;
 };
 
@@ -190,7 +190,10 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (h->evB1) (void)hipEventDestroy(h->evB1);
     if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
     for (auto &ps : h->partStream) if (ps) (void)hipStreamDestroy(ps);
+    for (auto &ps : h->partSide) if (ps) (void)hipStreamDestroy(ps);
     for (auto &e : h->evPartJoin) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->evSideFork) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->evSideJoin) if (e) (void)hipEventDestroy(e);
     if (h->evPartFork) (void)hipEventDestroy(h->evPartFork);
     if (h->hIn) (void)hipHostFree(h->hIn);
     if (h->hOut1) (void)hipHostFree(h->hOut1);
@@ -247,7 +250,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dCellCnt, C * h->capCells));
     TRY_ALLOC(dev_alloc(&h->dCand, C * h->capCand));
     TRY_ALLOC(dev_alloc(&h->dLevelStart, C * (kMaxLevels + 1)));
-    TRY_ALLOC(dev_alloc(&h->dOverflow, C));
+    TRY_ALLOC(dev_alloc(&h->dOverflow, B));
     TRY_ALLOC(dev_alloc(&h->dSelPacked, C * h->capSel));
     TRY_ALLOC(dev_alloc(&h->dSelMeta, C * h->capSel));
     TRY_ALLOC(dev_alloc(&h->dSelCount, C));
@@ -266,13 +269,14 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dSelLevel, C * cfg->nlevels * h->selLevelCap));
     TRY_ALLOC(dev_alloc(&h->dSelLevelCnt, C * cfg->nlevels));
     TRY_ALLOC(dev_alloc(&h->dErr, 1));
-    TRY_ALLOC(pin_alloc(&h->hOverflow, C));
+    TRY_ALLOC(pin_alloc(&h->hOverflow, B));
     TRY_ALLOC(pin_alloc(&h->hErr, 1));
 #undef TRY_ALLOC
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
     for (int i = 0; i < RumiOrb::kMaxParts - 1; ++i)
-        if (hipStreamCreateWithFlags(&h->partStream[i], hipStreamNonBlocking) != hipSuccess ||
+        if (hipStreamCreateWithFlags(&h->partStream[i], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->partSide[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evSideFork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evSideJoin[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->evPartJoin[i], hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part stream"; return RUMI_E_NO_DEVICE; }
     if (hipEventCreateWithFlags(&h->evPartFork, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part event"; return RUMI_E_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess ||
@@ -313,102 +317,104 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     float acc[8] = {0};
     h->tapValid = false;
 
-    // Stage A (all frames): pyramid + blur.  Levels depend on each other, frames do not.
-    HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
-    if (prof) HIP_TRY(hipEventRecord(h->ev[0], st));
-    launch_pyr0(h->dP, P, src, nframes, st);
-    for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, src, h->dCoef, l, nframes, st);
-    launch_frame_cols(h->dP, P, src, nframes, st);
-    if (prof) HIP_TRY(hipEventRecord(h->ev[1], st));
-    // fork: blur on the side stream, next to FAST / quadtree (stage times are taken with the same overlap the timed path has)
-    // RUMI_SERIAL=1 (profiling aid): blur on the main stream, so that every kernel's duration is its stand-alone duration
+    // Stage A: pyramid + blur.  Levels depend on each other, frames do not.  The blur runs on a side stream next to FAST / quadtree and
+    // joins before rBRIEF (stage times are taken with the same overlap the timed path has).
+    // RUMI_SERIAL=1 (profiling aid): everything on the caller's stream, so that every kernel's duration is its stand-alone duration.
     static const bool serial = std::getenv("RUMI_SERIAL") != nullptr;
-    hipStream_t bs = serial ? st : h->sideStream;
-    HIP_TRY(hipEventRecord(h->evFork, st));
-    HIP_TRY(hipStreamWaitEvent(bs, h->evFork, 0));
-    if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
-    launch_blur(h->dP, P, src, nframes, bs);
-    if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
-    HIP_TRY(hipEventRecord(h->evJoin, bs));
-    HIP_TRY(hipGetLastError());
+    // Batches of 64 frames and more are pipelined: sub-chunks of frames run pyramid -> FAST -> ... -> rBRIEF on up to 4 streams (sub-chunk j
+    // on stream j % parts, in scratch slot j % parts), so the narrow launches of one sub-chunk (upper pyramid levels, compaction, quadtree:
+    // latency-bound, few waves) sit beside the wide VALU-bound ones of the others.  Profiling and RUMI_SERIAL keep one stream.
+    static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 4;
+    const int parts = (!prof && !serial) ? std::min(std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts), std::max(nframes / 32, 1)) : 1;
+    HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
+    auto stage_a = [&](const ImgSrc &ps, int n, hipStream_t s, int side) -> int {
+        if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
+        launch_pyr0(h->dP, P, ps, n, s);
+        for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, l, n, s);
+        launch_frame_cols(h->dP, P, ps, n, s);
+        if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
+        hipStream_t bs = serial ? s : (side ? h->partSide[side - 1] : h->sideStream);
+        hipEvent_t fork = side ? h->evSideFork[side - 1] : h->evFork, join = side ? h->evSideJoin[side - 1] : h->evJoin;
+        HIP_TRY(hipEventRecord(fork, s));
+        HIP_TRY(hipStreamWaitEvent(bs, fork, 0));
+        if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
+        launch_blur(h->dP, P, ps, n, bs);
+        if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
+        HIP_TRY(hipEventRecord(join, bs));
+        HIP_TRY(hipGetLastError());
+        return RUMI_OK;
+    };
+    HIP_TRY(hipMemsetAsync(h->dOverflow, 0, nframes * sizeof(int32_t), st));
+    if (parts == 1) { rc = stage_a(src, nframes, st, 0); if (rc != RUMI_OK) return rc; }
 
-    // Stage B (chunks of kChunk frames share the candidate / quadtree scratch; no host round trip in between)
-    for (int base = 0; base < nframes; base += kChunk) {
-        const int nf = std::min(kChunk, nframes - base);
-        ImgSrc cs = src;
-        cs.l0 = src.l0 + (long long)base * frame_stride;
-        cs.pyr = src.pyr + (long long)base * P.arenaStride;
-        cs.blur = src.blur + (long long)base * P.arenaStride;
-        HIP_TRY(hipMemsetAsync(h->dOverflow, 0, nf * sizeof(int32_t), st));
-        // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [f0, f0 + n) of this chunk on stream s: every
-        // scratch array is indexed by the frame's position in the chunk, so disjoint frame ranges can run on different streams
-        auto run_part = [&](int f0, int n, hipStream_t s, bool timed) -> int {
-            ImgSrc ps = cs;
-            ps.l0 = cs.l0 + (long long)f0 * frame_stride;
-            ps.pyr = cs.pyr + (long long)f0 * P.arenaStride;
-            ps.blur = cs.blur + (long long)f0 * P.arenaStride;
-            uint32_t *cellBuf = h->dCellBuf + (size_t)f0 * P.totalCells * P.maxCellCand;
-            int32_t *cellCnt = h->dCellCnt + (size_t)f0 * P.totalCells;
-            uint32_t *candp = h->dCand + (size_t)f0 * P.totalCand;
-            int32_t *lvStart = h->dLevelStart + (size_t)f0 * (kMaxLevels + 1);
-            uint32_t *selLevel = h->dSelLevel + (size_t)f0 * P.nlevels * h->selLevelCap;
-            int32_t *selLevelCnt = h->dSelLevelCnt + (size_t)f0 * P.nlevels;
-            uint32_t *selPacked = h->dSelPacked + (size_t)f0 * h->capSel, *selMeta = h->dSelMeta + (size_t)f0 * h->capSel;
-            if (timed) HIP_TRY(hipEventRecord(h->ev[3], s));
-            launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
-            if (timed) HIP_TRY(hipEventRecord(h->ev[4], s));
-            launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dOverflow + f0, n, s);
-            if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
-            launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)f0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
-            launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + f0, h->capSel,
-                            (int32_t *)d_counts + 2 * (size_t)(base + f0), h->dErr, n, s);
-            if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
-            HIP_TRY(hipStreamWaitEvent(s, h->evJoin, 0));                            // join: rBRIEF reads the blurred levels
-            launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + f0, h->capSel, h->capSel,
-                               (RumiKeyPoint *)d_kp + (size_t)(base + f0) * cap, (uint8_t *)d_desc + (size_t)(base + f0) * cap * 32, cap, n, s);
-            if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
-            return RUMI_OK;
-        };
-        // Two halves on two streams: the quadtree of one half (LDS-latency-bound, few waves) runs beside FAST / rBRIEF of the other
-        // (VALU-bound).  Profiling and RUMI_SERIAL keep one stream so that stage times stay per-kernel.
-        if (!prof && !serial && nf >= 32) {
-            static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 2;
-            const int parts = std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts);
-            HIP_TRY(hipEventRecord(h->evPartFork, st));
-            for (int p = 0, f0 = 0; p < parts; ++p) {
-                const int n = (nf - f0) / (parts - p);
-                hipStream_t s = p == 0 ? st : h->partStream[p - 1];
-                if (p) HIP_TRY(hipStreamWaitEvent(s, h->evPartFork, 0));
-                const int rcp = run_part(f0, n, s, false);
-                if (rcp != RUMI_OK) return rcp;
-                if (p) {
-                    HIP_TRY(hipEventRecord(h->evPartJoin[p - 1], s));
-                    HIP_TRY(hipStreamWaitEvent(st, h->evPartJoin[p - 1], 0));
-                }
-                f0 += n;
-            }
-        } else {
-            const int rcp = run_part(0, nf, st, prof);
-            if (rcp != RUMI_OK) return rcp;
+    // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [frame0, frame0 + n) of the batch on stream s, in the scratch
+    // arenas from frame slot scr0 on (every scratch array is indexed by frame slot, so disjoint slot ranges can run on different streams)
+    auto run_part = [&](int frame0, int n, int scr0, hipStream_t s, bool timed, int side, bool withStageA) -> int {
+        ImgSrc ps = src;
+        ps.l0 = src.l0 + (long long)frame0 * frame_stride;
+        ps.pyr = src.pyr + (long long)frame0 * P.arenaStride;
+        ps.blur = src.blur + (long long)frame0 * P.arenaStride;
+        if (withStageA) { const int ra = stage_a(ps, n, s, side); if (ra != RUMI_OK) return ra; }
+        uint32_t *cellBuf = h->dCellBuf + (size_t)scr0 * P.totalCells * P.maxCellCand;
+        int32_t *cellCnt = h->dCellCnt + (size_t)scr0 * P.totalCells;
+        uint32_t *candp = h->dCand + (size_t)scr0 * P.totalCand;
+        int32_t *lvStart = h->dLevelStart + (size_t)scr0 * (kMaxLevels + 1);
+        uint32_t *selLevel = h->dSelLevel + (size_t)scr0 * P.nlevels * h->selLevelCap;
+        int32_t *selLevelCnt = h->dSelLevelCnt + (size_t)scr0 * P.nlevels;
+        uint32_t *selPacked = h->dSelPacked + (size_t)scr0 * h->capSel, *selMeta = h->dSelMeta + (size_t)scr0 * h->capSel;
+        if (timed) HIP_TRY(hipEventRecord(h->ev[3], s));
+        launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[4], s));
+        launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dOverflow + frame0, n, s);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
+        launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)scr0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
+        launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
+                        (int32_t *)d_counts + 2 * (size_t)frame0, h->dErr, n, s);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
+        HIP_TRY(hipStreamWaitEvent(s, side ? h->evSideJoin[side - 1] : h->evJoin, 0));   // join: rBRIEF reads the blurred levels
+        launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
+                           (RumiKeyPoint *)d_kp + (size_t)frame0 * cap, (uint8_t *)d_desc + (size_t)frame0 * cap * 32, cap, n, s);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
+        return RUMI_OK;
+    };
+    if (parts > 1) {
+        const int slotFrames = std::min<int>(kChunk, h->cfg.max_batch) / parts, sub = std::min(slotFrames, (nframes + parts - 1) / parts);
+        HIP_TRY(hipEventRecord(h->evPartFork, st));
+        int used = 0;
+        for (int j = 0, base = 0; base < nframes; j++, base += sub) {
+            const int n = std::min(sub, nframes - base), slot = j % parts;
+            hipStream_t s = slot ? h->partStream[slot - 1] : st;
+            if (j < parts && slot) HIP_TRY(hipStreamWaitEvent(s, h->evPartFork, 0));
+            rc = run_part(base, n, slot * slotFrames, s, false, slot, true);
+            if (rc != RUMI_OK) return rc;
+            used = std::max(used, slot + 1);
+            h->lastChunkBase = base; h->lastChunkFrames = n; h->lastChunkSlot = slot * slotFrames;
+        }
+        for (int p = 1; p < used; p++) {
+            HIP_TRY(hipEventRecord(h->evPartJoin[p - 1], h->partStream[p - 1]));
+            HIP_TRY(hipStreamWaitEvent(st, h->evPartJoin[p - 1], 0));
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (prof || base + kChunk < nframes) {
-            // scratch arenas are reused by the next chunk; the overflow words are read below
-            HIP_TRY(hipStreamSynchronize(st));
-            for (int f = 0; f < nf; f++)
-                if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
+    } else {
+        // one stream: chunks of kChunk frames reuse the scratch arenas in stream order
+        for (int base = 0; base < nframes; base += kChunk) {
+            const int nf = std::min(kChunk, nframes - base);
+            rc = run_part(base, nf, 0, st, prof, 0, false);
+            if (rc != RUMI_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            if (prof) {
+                float ms;
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); acc[1] += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); acc[2] += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, h->ev[5], h->ev[6])); acc[4] += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); acc[5] += ms;
+            }
+            h->lastChunkBase = base; h->lastChunkFrames = nf; h->lastChunkSlot = 0;
         }
-        if (prof) {
-            float ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); acc[1] += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); acc[2] += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev[5], h->ev[6])); acc[4] += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); acc[5] += ms;
-        }
-        h->lastChunkBase = base; h->lastChunkFrames = nf;
     }
-    // One synchronisation per call: the error word and the overflow words of the last chunk (and, for the single-frame host
+    HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // One synchronisation per call: the error word and the frames' overflow words (and, for the single-frame host
     // API, its result block).
     if (h->out1Bytes) HIP_TRY(hipMemcpyAsync(h->hOut1, h->dOut1, h->out1Bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -423,7 +429,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     h->lastSrc = src; h->lastFrames = nframes;
     h->lastKp = (RumiKeyPoint *)d_kp; h->lastOutCap = cap;
     h->lastCounts = (int32_t *)d_counts;
-    for (int f = 0; f < h->lastChunkFrames; f++)
+    for (int f = 0; f < nframes; f++)
         if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
     const int err = *h->hErr;
     if (err & 1) { g_lastError = "aspect ratio gives 0 or more than 16 quadtree roots"; return RUMI_E_INVALID; }
@@ -500,11 +506,12 @@ static int fetch_taps(RumiOrb *h) {
     h->tapCand.resize(nf * h->capCand);
     h->tapSelPacked.resize(nf * h->capSel);
     h->tapSelMeta.resize(nf * h->capSel);
-    HIP_TRY(hipMemcpy(h->tapLevelStart.data(), h->dLevelStart, h->tapLevelStart.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h->tapSelCount.data(), h->dSelCount, nf * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h->tapCand.data(), h->dCand, h->tapCand.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h->tapSelPacked.data(), h->dSelPacked, h->tapSelPacked.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h->tapSelMeta.data(), h->dSelMeta, h->tapSelMeta.size() * 4, hipMemcpyDeviceToHost));
+    const size_t s0 = (size_t)h->lastChunkSlot;
+    HIP_TRY(hipMemcpy(h->tapLevelStart.data(), h->dLevelStart + s0 * (kMaxLevels + 1), h->tapLevelStart.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelCount.data(), h->dSelCount + s0, nf * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapCand.data(), h->dCand + s0 * h->capCand, h->tapCand.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelPacked.data(), h->dSelPacked + s0 * h->capSel, h->tapSelPacked.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->tapSelMeta.data(), h->dSelMeta + s0 * h->capSel, h->tapSelMeta.size() * 4, hipMemcpyDeviceToHost));
     h->tapValid = true;
     return RUMI_OK;
 }
@@ -513,7 +520,7 @@ extern "C" int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level
                                         int32_t cap, int32_t *n_out) {
     if (!h || !n_out || h->lastFrames == 0 || level < 0 || level >= h->hP.nlevels) return RUMI_E_INVALID;
     const int f = frame - h->lastChunkBase;
-    if (f < 0 || f >= h->lastChunkFrames) { g_lastError = "stage taps cover the last 256-frame chunk only"; return RUMI_E_INVALID; }
+    if (f < 0 || f >= h->lastChunkFrames) { g_lastError = "stage taps cover the frames of the last sub-chunk only"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(h->device));
     int rc = fetch_taps(h);
     if (rc != RUMI_OK) return rc;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag r01) and prints a summary.
-Expects gpurun_out/{prof_b256,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r01.json, bench_matrix.json, stage_serial.log."""
+Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r01.json, bench_matrix.json, stage_serial.log."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -10,7 +10,8 @@ def newest(pattern):
     return max(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
 
 
-shutil.copy(newest("prof_b256/*/*kernel_stats.csv"), os.path.join(P, "r01_extract_match_b256_kernel_stats.csv"))
+shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, "r01_extract_match_kernel_stats.csv"))
+shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, "r01_extract_match_serial_kernel_stats.csv"))
 shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, "r01_lba_20kf_3000mp_kernel_stats.csv"))
 for d, tmp in (("pmc_fetch", "/tmp/_pf"), ("pmc_write", "/tmp/_pw")):
     shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/x")
@@ -31,7 +32,7 @@ json.dump(out, open(os.path.join(P, "r01_pmc_sq_counters.json"), "w"), indent=1)
 shutil.copy(os.path.join(G, "bench_r01.json"), os.path.join(P, "r01_bench_line.json"))
 shutil.copy(os.path.join(G, "bench_matrix.json"), os.path.join(P, "r01_bench_matrix.json"))
 shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, "r01_stage_ms_standalone.txt"))
-for f in ("r01_extract_match_b256_kernel_stats.csv", "r01_lba_20kf_3000mp_kernel_stats.csv"):
+for f in ("r01_extract_match_kernel_stats.csv", "r01_extract_match_serial_kernel_stats.csv", "r01_lba_20kf_3000mp_kernel_stats.csv"):
     print(f)
     for r in list(csv.DictReader(open(os.path.join(P, f))))[:12]:
         print("   ", r["Name"][:42].ljust(44), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us", r["Percentage"])
