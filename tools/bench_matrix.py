@@ -173,6 +173,21 @@ def main():
                                       "gpu_ms": round(tg * 1e3, 3), "cpu_oracle_ms": round(tc * 1e3, 2), "gpu_fps": round(1 / tg, 1), "cpu_fps": round(1 / tc, 1),
                                       "note": "one 640x480 frame, host arrays in and out at every call (PCIe included), python wrapper overhead included on both sides"}
 
+    # ---- OptimizeSim3 (loop / merge verification) and OptimizeCloudSim3 (sub-map alignment) through the host ABI vs the oracle ----
+    from sim3_scene import sim3_pair_problem, sim3_cloud_problem
+    b = sim3_pair_problem(seed=1, n=400)
+    ap_ = (b["S0"], b["P1c"], b["P2c"], b["obs1"], b["obs2"], b["w1"], b["w2"], b["K"], b["K"], 10.0, False, True)
+    c = sim3_cloud_problem(seed=11)
+    ac_ = (c["S0"], c["P1c"], c["P2c"], c["obs1"], c["obs2"], c["w1"], c["w2"], c["K"], c["K"], 10.0, True, False, c["pair_of"], c["S_c1w"], c["S_c2w"],
+           c["skip12"], c["skip21"])
+    doc["optimize_sim3_host_api"] = {
+        "note": "median latency of one call, host arrays in/out; one 256-thread workgroup runs both optimize() calls with g2o's numeric Jacobians",
+        "OptimizeSim3": {"correspondences": 400, "gpu_us": round(median_call(lambda: opt.OptimizeSim3(*ap_), 20) * 1e6, 1),
+                         "cpu_oracle_us": round(median_call(lambda: O.optimize_sim3(*ap_), 5) * 1e6, 1)},
+        "OptimizeCloudSim3": {"correspondences": int(len(c["pair_of"])), "key_frame_pairs": int(len(c["S_c1w"])),
+                              "gpu_us": round(median_call(lambda: opt.OptimizeSim3(*ac_), 20) * 1e6, 1),
+                              "cpu_oracle_us": round(median_call(lambda: O.optimize_sim3(*ac_), 5) * 1e6, 1)}}
+
     # ---- CPU oracle, all cores (config 5: one frame per thread) ----
     T = args.cpu_threads
     orcs = [O.OracleExtractor(1000, 1.2, 8, 20, 7) for _ in range(T)]

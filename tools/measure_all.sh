@@ -10,10 +10,10 @@ rm -rf $O/prof_default $O/prof_serial $O/pmc_fetch $O/pmc_write $O/prof_lba $O/p
 # the bench command as timed (sub-chunks of 64 frames pipelined over 4 streams), and with every kernel alone on one stream in 256-frame launches
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/prof_default.log 2>&1
 RUMI_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/prof_serial.log 2>&1
-RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_fetch.log 2>&1
-RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_write.log 2>&1
-RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_a.log 2>&1
-RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_b -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_b.log 2>&1
+RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --batch 256 --no-cpu > $O/pmc_fetch.log 2>&1
+RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --batch 256 --no-cpu > $O/pmc_write.log 2>&1
+RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_a -- python3 $R/bench.py --steps 2 --warmup 1 --batch 256 --no-cpu > $O/pmc_a.log 2>&1
+RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_b -- python3 $R/bench.py --steps 2 --warmup 1 --batch 256 --no-cpu > $O/pmc_b.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lba -- python3 $R/tools/prof_lba.py > $O/prof_lba.log 2>&1
 cd $R
 RUMI_SERIAL=1 python tools/stage_probe.py 1000 2000 5000 > $O/stage_serial.log 2>&1
