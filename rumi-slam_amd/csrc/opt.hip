@@ -637,6 +637,202 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
     }
 }
 
+
+// ==================================================================================================================
+// Reduced system of a LARGE window (more than 42 optimised key-frames: global bundle adjustment after a loop closure or a map merge,
+// Optimizer.cc:48-351).  The dense panel Y of the small-window path would be 3 P x 6 K; here the Schur complement is accumulated block-sparsely
+// (a landmark seen by k key-frames touches k (k + 1) / 2 blocks of 6 x 6) into the dense lower triangle of the augmented matrix
+// [H_pp + lambda I - sum W W^T ; (b_p - sum W z)^T], which a multi-workgroup blocked Cholesky (panel 64) then factors in place: per panel
+// one wave factors the diagonal block in registers (row per lane, pivots and columns by v_readlane), one lane per row solves the rows
+// below, and 64 x 64 tiles take the trailing update; the right-hand side rides along as the extra row, a blocked backward substitution
+// finishes.  No host round trip inside a trial.
+// ==================================================================================================================
+constexpr int kNB = 64;
+
+__global__ void k_big_init(BADev B, double lambda, double *A, int ld) {
+    const int n = B.n;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)(n + 1) * n) return;
+    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+    double v = 0;
+    if (i == n) v = B.bp[j];
+    else if (i / 6 == j / 6) { v = B.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 6 + (j % 6)]; if (i == j) v += lambda; }
+    A[(size_t)i * ld + j] = v;
+    if (idx == 0) B.scal[3] = 1.0;
+}
+
+// W_e = H_pl(e) L_p (6 x 3), L_p L_p^T = (H_ll + lambda I)^-1
+__global__ void k_big_w(BADev B, const double *Lp, double *W) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B.nE) return;
+    if (B.poseCol[B.eKF[e]] < 0) return;
+    const double *L = Lp + (size_t)B.eMP[e] * 6, *h = B.Hpl + (size_t)e * 18;
+    const double l00 = L[0], l10 = L[1], l20 = L[2], l11 = L[3], l21 = L[4], l22 = L[5];
+    double *w = W + (size_t)e * 18;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double h0 = h[a * 3], h1 = h[a * 3 + 1], h2 = h[a * 3 + 2];
+        w[a * 3] = h0 * l00 + h1 * l10 + h2 * l20; w[a * 3 + 1] = h1 * l11 + h2 * l21; w[a * 3 + 2] = h2 * l22;
+    }
+}
+
+// one wave per landmark: A[blocks (ca, cb), cb <= ca] -= W_a W_b^T, A[n][ca] -= W_a z
+__global__ __launch_bounds__(256) void k_big_schur(BADev B, const double *W, const double *z, double *A, int ld) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= B.nMP) return;
+    const int s = B.ptStart[p], k = B.ptStart[p + 1] - s, n = B.n;
+    const double z0 = z[3 * (size_t)p], z1 = z[3 * (size_t)p + 1], z2 = z[3 * (size_t)p + 2];
+    for (int ai = 0; ai < k; ai++) {
+        const int ea = B.ptEdge[s + ai], ca = B.poseCol[B.eKF[ea]];
+        if (ca < 0) continue;
+        const double *wa = W + (size_t)ea * 18;
+        if (lane < 6) atomicAdd(&A[(size_t)n * ld + 6 * ca + lane], -(wa[lane * 3] * z0 + wa[lane * 3 + 1] * z1 + wa[lane * 3 + 2] * z2));
+        for (int idx = lane; idx < k * 36; idx += 64) {
+            const int bi = idx / 36, ent = idx - bi * 36, r = ent / 6, c = ent - r * 6;
+            const int eb = B.ptEdge[s + bi], cb = B.poseCol[B.eKF[eb]];
+            if (cb < 0 || cb > ca || (cb == ca && bi != ai)) continue;
+            const double *wb = W + (size_t)eb * 18;
+            const double v = wa[r * 3] * wb[c * 3] + wa[r * 3 + 1] * wb[c * 3 + 1] + wa[r * 3 + 2] * wb[c * 3 + 2];
+            atomicAdd(&A[(size_t)(6 * ca + r) * ld + 6 * cb + c], -v);
+        }
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// diagonal block [j0, j0 + w): lane i holds row i; column j is scaled by 1 / sqrt(pivot), the pivot and the column entries of the other rows
+// come through readlane (uniform).  Lanes / columns past w carry an identity so that the unrolled code needs no bounds.
+__global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int n, int j0, double *rdg, double *scal) {
+    const int lane = threadIdx.x, w = min(kNB, n - j0);
+    double a[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; c++) a[c] = (lane < w && c <= lane) ? A[(size_t)(j0 + lane) * ld + j0 + min(c, w - 1)] : (c == lane ? 1.0 : 0.0);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < kNB; j++) {
+        const double d = readlane_f64(a[j], j);
+        if (!(d > 0) || !isfinite(d)) bad = true;
+        const double rs = fast_rsqrt(d);
+        a[j] *= rs;                                   // row j: d * rs = sqrt(d); rows below: L[i][j]; rows above hold 0
+        if (lane == j && j < w) rdg[j0 + j] = rs;
+#pragma unroll
+        for (int k = j + 1; k < kNB; k++) a[k] -= a[j] * readlane_f64(a[j], k);
+    }
+#pragma unroll
+    for (int c = 0; c < kNB; c++) if (lane < w && c <= lane) A[(size_t)(j0 + lane) * ld + j0 + c] = a[c];
+    if (bad && lane == 0) scal[3] = 0.0;
+}
+
+// rows below the block (the right-hand side row n included): L[r][j0..] = A[r][j0..] Ld^-T, one lane per row; the lane's row lives in LDS
+// column-major (conflict-free), the block's factor is read as LDS broadcasts with the reciprocal pivots on its diagonal
+__global__ __launch_bounds__(64) void k_chol_trsm(double *A, int ld, int n, int j0, const double *rdg) {
+    __shared__ double sL[kNB * kNB], sX[kNB * 64];
+    const int lane = threadIdx.x, w = min(kNB, n - j0), t0 = j0 + w;
+    for (int idx = lane; idx < kNB * kNB; idx += 64) {
+        const int b = idx / kNB, k = idx - b * kNB;
+        sL[idx] = (b < w && k < b) ? A[(size_t)(j0 + b) * ld + j0 + k] : (b < w && k == b) ? rdg[j0 + b] : 0.0;
+    }
+    const int r0 = t0 + blockIdx.x * 64, r = r0 + lane;
+    // coalesced: the 64 rows of this workgroup, 64 columns each
+    for (int idx = lane; idx < 64 * kNB; idx += 64) {
+        const int rr = idx / kNB, c = idx - rr * kNB;
+        sX[c * 64 + rr] = (r0 + rr <= n && c < w) ? A[(size_t)(r0 + rr) * ld + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (r <= n) {
+        for (int b = 0; b < w; b++) {
+            double t0a = sX[b * 64 + lane], t1a = 0;
+            int k = 0;
+            for (; k + 1 < b; k += 2) { t0a -= sX[k * 64 + lane] * sL[b * kNB + k]; t1a -= sX[(k + 1) * 64 + lane] * sL[b * kNB + k + 1]; }
+            if (k < b) t0a -= sX[k * 64 + lane] * sL[b * kNB + k];
+            sX[b * 64 + lane] = (t0a + t1a) * sL[b * kNB + b];
+        }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 64 * kNB; idx += 64) {
+        const int rr = idx / kNB, c = idx - rr * kNB;
+        if (r0 + rr <= n && c < w) A[(size_t)(r0 + rr) * ld + j0 + c] = sX[c * 64 + rr];
+    }
+}
+
+// trailing update A[i][k] -= sum_q L[i][j0 + q] L[k][j0 + q] for t0 <= k <= i <= n, k < n: one 64 x 64 tile per workgroup, 4 x 4 per thread
+__global__ __launch_bounds__(256) void k_chol_syrk(double *A, int ld, int n, int j0) {
+    const int w = min(kNB, n - j0), t0 = j0 + w;
+    const int ti = blockIdx.y, tk = blockIdx.x;
+    if (tk > ti) return;
+    const int i0 = t0 + ti * 64, k0 = t0 + tk * 64;
+    if (k0 >= n) return;
+    __shared__ double sI[64][33], sK[64][33];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0;
+    for (int q0 = 0; q0 < w; q0 += 32) {
+        for (int idx = tid; idx < 64 * 32; idx += 256) {
+            const int r = idx >> 5, q = idx & 31;
+            const bool qv = q0 + q < w;
+            sI[r][q] = (qv && i0 + r <= n) ? A[(size_t)(i0 + r) * ld + j0 + q0 + q] : 0.0;
+            sK[r][q] = (qv && k0 + r < n) ? A[(size_t)(k0 + r) * ld + j0 + q0 + q] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 32; q++) {
+            double li[4], lk[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) { li[a] = sI[ty + 16 * a][q]; lk[a] = sK[tx + 16 * a][q]; }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] += li[a] * lk[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = i0 + ty + 16 * a, k = k0 + tx + 16 * b;
+            if (i <= n && k < n && k <= i) A[(size_t)i * ld + k] -= acc[a][b];
+        }
+}
+
+// L^T x = y (y = the factor's row n), blocks of 64 from the back: wave 0 solves the block, all threads update the unknowns before it
+__global__ __launch_bounds__(1024) void k_chol_backsub(const double *A, int ld, int n, const double *rdg, double *x, const double *scal) {
+    extern __shared__ double ysm[];
+    volatile double *ys = ysm;
+    const int tid = threadIdx.x;
+    if (scal[3] == 0.0) {                               // not positive definite: g2o's solve() fails, the LM step is rejected
+        for (int i = tid; i < n; i += 1024) x[i] = 0;
+        return;
+    }
+    for (int i = tid; i < n; i += 1024) ys[i] = A[(size_t)n * ld + i];
+    __syncthreads();
+    for (int jb = (n + kNB - 1) / kNB - 1; jb >= 0; jb--) {
+        const int j0 = jb * kNB, w = min(kNB, n - j0);
+        if (tid < 64) {
+            for (int j = j0 + w - 1; j >= j0; j--) {
+                const double xj = ys[j] * rdg[j];
+                const int i = j0 + tid;
+                if (i < j) ys[i] -= A[(size_t)j * ld + i] * xj;
+                if (i == j) ys[j] = xj;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += 1024) {
+            double acc = 0;
+            for (int q = 0; q < w; q++) acc += A[(size_t)(j0 + q) * ld + i] * ys[j0 + q];
+            ys[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) x[i] = ys[i];
+}
+
 // x_l = D^-1 (b_l - H_pl^T x_p); trial state = oplus(current, x); scale += x^T (lambda x + b)
 // Landmark back-substitution x_l = D^-1 (b_l - H_pl^T x_p) (block_solver.hpp:468-481), oplus of points and poses, and the
 // gain-ratio denominator.  Eight lanes share a landmark (its ~15 edges are two rounds instead of fifteen dependent ones); the
@@ -956,6 +1152,7 @@ struct RumiOptimizer {
            *dS = nullptr, *dBs = nullptr, *dXv = nullptr, *dChi = nullptr, *dScal = nullptr, *dAglob = nullptr, *dYt = nullptr, *dG = nullptr, *dLp = nullptr;
     int npCap = 0;
     uint8_t *dErase = nullptr;
+    double *dW = nullptr;            // H_pl L per edge, allocated by the first large-window call
     double *hScal = nullptr;
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
@@ -974,7 +1171,7 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     (void)hipSetDevice(o->device);
     void *p[] = {o->dActive, o->dLastChi2, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
-                 o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp};
+                 o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hPose) (void)hipHostFree(o->hPose);
@@ -1157,11 +1354,19 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
 
     const int gE = std::max(1, (nE + 255) / 256);
-    if (n > 255) { g_lastError = "local BA: more than 42 optimised key-frames is not supported (reduced system limited to 255 unknowns)"; return RUMI_E_CAPACITY; }
-    const int NP = (n + 1 + 15) / 16 * 16, NT = NP / 16, K3 = 3 * nMP;
-    if (NP > o->npCap) { g_lastError = "local BA: reduced system larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    // up to 42 optimised key-frames (255 unknowns): dense Schur panel on the matrix cores + one-workgroup solve; beyond: block-sparse Schur
+    // accumulation + multi-workgroup blocked Cholesky (the "big" kernels above)
+    const bool big = n > 255;
+    const int NP = big ? 16 : (n + 1 + 15) / 16 * 16, NT = NP / 16, K3 = 3 * nMP;
+    if (!big && NP > o->npCap) { g_lastError = "local BA: reduced system larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    if (big) {
+        if ((size_t)n * 8 > 150 * 1024) { g_lastError = "bundle adjustment: more than 3200 optimised key-frames"; return RUMI_E_CAPACITY; }
+        if (!o->dW) { const int rcw = oalloc(&o->dW, (size_t)o->maxE * 18); if (rcw != RUMI_OK) return rcw; }
+        if ((size_t)n * 8 > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, n * 8));
+    }
     const size_t ldsSolve = ((size_t)(n + 1) * (n + 1) + (size_t)n) * sizeof(double);
-    const int useLds = ldsSolve <= 158 * 1024;
+    const int useLds = !big && ldsSolve <= 158 * 1024;
     // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses
     if (useLds && ldsSolve > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
@@ -1175,7 +1380,35 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         *out = o->hScal[0];
         return RUMI_OK;
     };
-    if (nMP > 0) HIP_TRY(hipMemsetAsync(o->dYt, 0, (size_t)K3 * NP * sizeof(double), st));   // pattern of Y is fixed: zero once, live entries are rewritten per trial
+    if (nMP > 0 && !big) HIP_TRY(hipMemsetAsync(o->dYt, 0, (size_t)K3 * NP * sizeof(double), st));   // pattern of Y is fixed: zero once, live entries are rewritten per trial
+    // reduced system of one LM trial -> B.x, B.scal[3]
+    auto solve_big = [&](double lambda) -> int {
+        double *A = o->dAglob, *rdg = A + (size_t)(n + 1) * n;
+        const int ld = n;
+        const size_t tot = (size_t)(n + 1) * n;
+        hipLaunchKernelGGL(k_big_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, lambda, A, ld);
+        if (nMP > 0) {
+            BADev Bz = B;
+            Bz.n = 0;                                                      // z = L^T b_l lands in dYt[3 p .. 3 p + 2]
+            hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, Bz, lambda, o->dYt, 1, o->dLp);
+            if (nE > 0) {
+                hipLaunchKernelGGL(k_big_w, dim3(gE), dim3(256), 0, st, B, o->dLp, o->dW);
+                hipLaunchKernelGGL(k_big_schur, dim3((nMP + 3) / 4), dim3(256), 0, st, B, o->dW, o->dYt, A, ld);
+            }
+        }
+        for (int j0 = 0; j0 < n; j0 += kNB) {
+            const int w = std::min(kNB, n - j0), rows = n + 1 - (j0 + w);
+            hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, st, A, ld, n, j0, rdg, o->dScal);
+            if (rows > 0) {
+                hipLaunchKernelGGL(k_chol_trsm, dim3((rows + 63) / 64), dim3(64), 0, st, A, ld, n, j0, rdg);
+                const int T = (rows + 63) / 64;
+                if (j0 + w < n) hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, A, ld, n, j0);
+            }
+        }
+        hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), (size_t)n * sizeof(double), st, A, ld, n, rdg, o->dXv, o->dScal);
+        HIP_TRY(hipGetLastError());
+        return RUMI_OK;
+    };
     HIP_TRY(hipEventRecord(o->ev[0], st));
     int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
     bool ranChi2 = false;
@@ -1210,9 +1443,11 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         do {
             const int trial = cur ^ 1;
             {
-                const ZeroList Z{{o->dG, o->dScal, nullptr, nullptr}, {NP * NP, 2, 0, 0}};
-                hipLaunchKernelGGL(k_ba_zero, dim3((NP * NP + 255) / 256), dim3(256), 0, st, Z);
+                const ZeroList Z{{o->dG, o->dScal, nullptr, nullptr}, {big ? 0 : NP * NP, 2, 0, 0}};
+                hipLaunchKernelGGL(k_ba_zero, dim3(((big ? 2 : NP * NP) + 255) / 256), dim3(256), 0, st, Z);
             }
+            if (big) { if ((rc = solve_big(lambda)) != RUMI_OK) return rc; }
+            else {
             if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
             if (nE > 0) hipLaunchKernelGGL(k_ba_yfill, dim3(gE), dim3(256), 0, st, B, o->dYt, NP, o->dLp);
             if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
@@ -1221,6 +1456,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
                 else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(1024), 0, st, B, lambda, o->dG, NP, o->dAglob);
             }
             else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
+            }
             hipLaunchKernelGGL(k_ba_update, dim3(((nMP + nKF) * kLmLanes + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
             hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
             HIP_TRY(hipGetLastError());

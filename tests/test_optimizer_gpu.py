@@ -262,3 +262,41 @@ def test_optimize_sim3_early_returns(opt):
     e = np.zeros((0, 3), np.float32); e2 = np.zeros((0, 2), np.float32); e1 = np.zeros(0, np.float32)
     nin, nbad, early, S, st = opt.OptimizeSim3(b["S0"], e, e, e2, e2, e1, e1, b["K"], b["K"])
     assert (nin, nbad, early) == (0, 0, True) and np.array_equal(S, b["S0"]) and len(st) == 0
+
+
+@pytest.fixture(scope="module")
+def opt_big():
+    from rumi_slam_amd.optimizer import Optimizer
+    return Optimizer(max_kf=192, max_mp=8192, max_edges=1 << 18)
+
+
+@pytest.mark.parametrize("cfg,its,robust", [(dict(seed=31, n_opt=60, n_fixed=2, n_points=1500), 10, False),
+                                            (dict(seed=32, n_opt=130, n_fixed=1, n_points=2500, outlier_frac=0.08), 6, True)])
+def test_large_window_bundle_adjustment(opt_big, cfg, its, robust):
+    """Optimizer::BundleAdjustment over more than 42 optimised key-frames (global BA after a loop closure / merge): block-sparse
+    Schur accumulation and the multi-workgroup blocked Cholesky instead of the dense-panel path; same iteration count, poses and
+    landmarks within 1e-4 of the oracle's dense solve."""
+    b = ba_problem(**cfg)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    its_ref, kp_ref, mp_ref = O.bundle_adjustment(*a, its, robust)
+    stats, kp, mp = opt_big.BundleAdjustment(*a, n_iterations=its, robust=robust)
+    assert stats[2] == cfg["n_opt"] and 6 * cfg["n_opt"] > 255
+    assert stats[0] == its_ref, f"LM iterations {stats[0]} vs {its_ref}"
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    rel = np.linalg.norm(mp - mp_ref, axis=1) / np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-3)
+    assert rel.max() <= RTOL, f"landmark rel diff {rel.max()}"
+    assert np.abs(kp[~b["kf_fixed"].astype(bool)] - b["kf_pose"][~b["kf_fixed"].astype(bool)]).max() > 1e-3      # the poses did move
+
+
+def test_large_window_local_ba(opt_big):
+    """LocalBundleAdjustment with 50 optimised key-frames (a dense local map) goes down the same large-window path."""
+    b = ba_problem(seed=33, n_opt=50, n_fixed=4, n_points=1200)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    its_ref, kp_ref, mp_ref, er_ref = O.local_ba(*a)
+    stats, kp, mp, er = opt_big.LocalBundleAdjustment(*a)
+    assert stats[0] == its_ref and np.array_equal(er, er_ref)
+    for k in range(len(kp)):
+        _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
+    rel = np.linalg.norm(mp - mp_ref, axis=1) / np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-3)
+    assert rel.max() <= RTOL
