@@ -662,10 +662,12 @@ __global__ void k_big_init(BADev B, double lambda, double *A, int ld) {
 }
 
 // W_e = H_pl(e) L_p (6 x 3), L_p L_p^T = (H_ll + lambda I)^-1
-__global__ void k_big_w(BADev B, const double *Lp, double *W) {
+__global__ void k_big_w(BADev B, const double *Lp, double *W, int32_t *colOf) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B.nE) return;
-    if (B.poseCol[B.eKF[e]] < 0) return;
+    const int col = B.poseCol[B.eKF[e]];
+    colOf[e] = col;
+    if (col < 0) return;
     const double *L = Lp + (size_t)B.eMP[e] * 6, *h = B.Hpl + (size_t)e * 18;
     const double l00 = L[0], l10 = L[1], l20 = L[2], l11 = L[3], l21 = L[4], l22 = L[5];
     double *w = W + (size_t)e * 18;
@@ -676,26 +678,41 @@ __global__ void k_big_w(BADev B, const double *Lp, double *W) {
     }
 }
 
-// one wave per landmark: A[blocks (ca, cb), cb <= ca] -= W_a W_b^T, A[n][ca] -= W_a z
-__global__ __launch_bounds__(256) void k_big_schur(BADev B, const double *W, const double *z, double *A, int ld) {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (p >= B.nMP) return;
-    const int s = B.ptStart[p], k = B.ptStart[p + 1] - s, n = B.n;
-    const double z0 = z[3 * (size_t)p], z1 = z[3 * (size_t)p + 1], z2 = z[3 * (size_t)p + 2];
-    for (int ai = 0; ai < k; ai++) {
-        const int ea = B.ptEdge[s + ai], ca = B.poseCol[B.eKF[ea]];
-        if (ca < 0) continue;
-        const double *wa = W + (size_t)ea * 18;
-        if (lane < 6) atomicAdd(&A[(size_t)n * ld + 6 * ca + lane], -(wa[lane * 3] * z0 + wa[lane * 3 + 1] * z1 + wa[lane * 3 + 2] * z2));
-        for (int idx = lane; idx < k * 36; idx += 64) {
-            const int bi = idx / 36, ent = idx - bi * 36, r = ent / 6, c = ent - r * 6;
-            const int eb = B.ptEdge[s + bi], cb = B.poseCol[B.eKF[eb]];
-            if (cb < 0 || cb > ca || (cb == ca && bi != ai)) continue;
-            const double *wb = W + (size_t)eb * 18;
-            const double v = wa[r * 3] * wb[c * 3] + wa[r * 3 + 1] * wb[c * 3 + 1] + wa[r * 3 + 2] * wb[c * 3 + 2];
-            atomicAdd(&A[(size_t)(6 * ca + r) * ld + 6 * cb + c], -v);
+// One wave per non-empty 6 x 6 block (ca, cb <= ca) of the Schur complement: the host groups the observation pairs (a, b) of all landmarks by
+// block once per call (the structure is the same for every trial), lane (r, c) accumulates sum_pairs W_a[r] . W_b[c] in a register and
+// subtracts it from the matrix with a plain store; lanes 36..41 of the diagonal blocks do the same for W_a z.  No atomics: device-scope f64
+// atomics are served past the per-XCD L2s (the per-landmark atomic formulation measured 0.69 ms at 130 key-frames, LDS f64 atomics on a
+// row strip per key-frame 0.9 - 1.6 ms, this one 0.05 ms).
+constexpr int kSchurSeg = 32;   // pairs per wave: long blocks (the diagonal ones: every observation of the key-frame) are cut into segments
+__global__ __launch_bounds__(256) void k_big_schur(BADev B, const int32_t *blk, int nb, const int32_t *pairs, const double *W, const double *z, double *A, int ld) {
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= nb) return;
+    const int ca = blk[4 * wv], cbm = blk[4 * wv + 1], s = blk[4 * wv + 2], len = blk[4 * wv + 3] - s;
+    const int cb = cbm & 0x3fffffff;
+    const bool multi = (cbm >> 30) != 0;                  // the block has more segments: combine with atomics
+    // the segment's pairs, one per lane (coalesced), broadcast below: no dependent index loads inside the loop
+    int myA = 0, myB = 0;
+    if (lane < len) { myA = pairs[2 * (size_t)(s + lane)]; myB = pairs[2 * (size_t)(s + lane) + 1]; }
+    const bool ent = lane < 36, rhs = lane >= 36 && lane < 42 && ca == cb;
+    const int r = ent ? lane / 6 : rhs ? lane - 36 : 0, c = ent ? lane - (lane / 6) * 6 : 0;
+    double acc = 0;
+#pragma unroll 1
+    for (int t = 0; t < len; t++) {
+        const int ea = __builtin_amdgcn_readlane(myA, t), eb = __builtin_amdgcn_readlane(myB, t);
+        const double *wa = W + (size_t)ea * 18 + r * 3, *wb = W + (size_t)eb * 18 + c * 3;
+        acc += wa[0] * wb[0] + wa[1] * wb[1] + wa[2] * wb[2];
+    }
+    if (rhs) {                                            // diagonal block: pairs are (a, a); - W_a z on lanes 36..41
+        acc = 0;
+        for (int t = 0; t < len; t++) {
+            const int ea = __builtin_amdgcn_readlane(myA, t);
+            const double *wa = W + (size_t)ea * 18 + r * 3, *zp = z + 3 * (size_t)B.eMP[ea];
+            acc += wa[0] * zp[0] + wa[1] * zp[1] + wa[2] * zp[2];
         }
     }
+    if (!ent && !rhs) return;
+    double *dst = ent ? &A[(size_t)(6 * ca + r) * ld + 6 * cb + c] : &A[(size_t)B.n * ld + 6 * ca + r];
+    if (multi) atomicAdd(dst, -acc); else *dst -= acc;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -703,58 +720,140 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// diagonal block [j0, j0 + w): lane i holds row i; column j is scaled by 1 / sqrt(pivot), the pivot and the column entries of the other rows
-// come through readlane (uniform).  Lanes / columns past w carry an identity so that the unrolled code needs no bounds.
-__global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int n, int j0, double *rdg, double *scal) {
-    const int lane = threadIdx.x, w = min(kNB, n - j0);
-    double a[kNB];
-#pragma unroll
-    for (int c = 0; c < kNB; c++) a[c] = (lane < w && c <= lane) ? A[(size_t)(j0 + lane) * ld + j0 + min(c, w - 1)] : (c == lane ? 1.0 : 0.0);
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < kNB; j++) {
-        const double d = readlane_f64(a[j], j);
-        if (!(d > 0) || !isfinite(d)) bad = true;
-        const double rs = fast_rsqrt(d);
-        a[j] *= rs;                                   // row j: d * rs = sqrt(d); rows below: L[i][j]; rows above hold 0
-        if (lane == j && j < w) rdg[j0 + j] = rs;
-#pragma unroll
-        for (int k = j + 1; k < kNB; k++) a[k] -= a[j] * readlane_f64(a[j], k);
+// diagonal block [j0, j0 + w) in LDS, sub-panels of 8 columns: wave 0 factors the 8 x 8 sub-diagonal in registers (every lane the same
+// values: a chain of 36 dependent steps instead of 8 LDS round trips), lane i solves row i against it and publishes the row's eight entries;
+// then four waves (lane = row, 16 columns each) take the trailing update with 8-term dot products.  Rows past w carry an identity; the
+// update also runs over the unused upper triangle, which keeps the loops uniform.
+__global__ __launch_bounds__(256) void k_chol_diag(double *A, int ld, int n, int j0, double *rdg, double *scal) {
+    constexpr int kS = kNB + 1, kP = 8;
+    __shared__ double S[kNB * kS];
+    __shared__ double P[kNB * kP];                         // the current sub-panel, row-major: P[i][q] = L[i][c0 + q]
+    const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6, w = min(kNB, n - j0);
+    for (int idx = tid; idx < kNB * kNB; idx += 256) {
+        const int r = idx / kNB, c = idx - r * kNB;
+        S[r * kS + c] = (r < w && c <= r) ? A[(size_t)(j0 + r) * ld + j0 + c] : (r == c ? 1.0 : 0.0);
     }
+    __syncthreads();
+    bool bad = false;
+    double myRs = 1.0;
+    double *__restrict__ row = S + lane * kS;
+    for (int c0 = 0; c0 < kNB; c0 += kP) {
+        if (part == 0) {
+            double Ld[kP][kP], rd[kP];
 #pragma unroll
-    for (int c = 0; c < kNB; c++) if (lane < w && c <= lane) A[(size_t)(j0 + lane) * ld + j0 + c] = a[c];
-    if (bad && lane == 0) scal[3] = 0.0;
+            for (int a = 0; a < kP; a++)
+#pragma unroll
+                for (int b = 0; b < kP; b++) Ld[a][b] = b <= a ? S[(c0 + a) * kS + c0 + b] : 0.0;
+#pragma unroll
+            for (int j = 0; j < kP; j++) {
+                double d = Ld[j][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) d -= Ld[j][k] * Ld[j][k];
+                if (!(d > 0) || !isfinite(d)) bad = true;
+                const double rs = fast_rsqrt(d);
+                rd[j] = rs;
+                Ld[j][j] = d * rs;
+#pragma unroll
+                for (int i = j + 1; i < kP; i++) {
+                    double t = Ld[i][j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) t -= Ld[i][k] * Ld[j][k];
+                    Ld[i][j] = t * rs;
+                }
+            }
+            // own row: rows of the sub-diagonal take their factor row, rows below solve x Ld^T = a, rows above keep zeros
+            double x[kP];
+#pragma unroll
+            for (int b = 0; b < kP; b++) x[b] = row[c0 + b];
+            const int a = lane - c0;
+#pragma unroll
+            for (int b = 0; b < kP; b++) {
+                double t = x[b];
+#pragma unroll
+                for (int k = 0; k < b; k++) t -= x[k] * Ld[b][k];
+                x[b] = t * rd[b];
+            }
+#pragma unroll
+            for (int q = 0; q < kP; q++) {
+#pragma unroll
+                for (int b = 0; b < kP; b++) if (a == q) { x[b] = b <= q ? Ld[q][b] : 0.0; if (b == q) myRs = rd[q]; }
+            }
+            if (a < 0) {
+#pragma unroll
+                for (int b = 0; b < kP; b++) x[b] = 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < kP; b++) { if (a >= 0) row[c0 + b] = x[b]; P[lane * kP + b] = x[b]; }
+        }
+        __syncthreads();
+        if (part * 16 + 15 >= c0 + kP) {                  // this wave's 16 columns of the trailing block
+            double li[kP];
+#pragma unroll
+            for (int q = 0; q < kP; q++) li[q] = P[lane * kP + q];
+#pragma unroll 4
+            for (int u = 0; u < 16; u++) {
+                const int k = part * 16 + u;
+                double acc = 0;
+#pragma unroll
+                for (int q = 0; q < kP; q++) acc += li[q] * P[k * kP + q];
+                if (k >= c0 + kP) row[k] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < kNB * kNB; idx += 256) {
+        const int r = idx / kNB, c = idx - r * kNB;
+        if (r < w && c <= r) A[(size_t)(j0 + r) * ld + j0 + c] = S[r * kS + c];
+    }
+    if (part == 0 && lane < w) rdg[j0 + lane] = myRs;
+    if (bad && tid == 0) scal[3] = 0.0;
 }
 
-// rows below the block (the right-hand side row n included): L[r][j0..] = A[r][j0..] Ld^-T, one lane per row; the lane's row lives in LDS
-// column-major (conflict-free), the block's factor is read as LDS broadcasts with the reciprocal pivots on its diagonal
-__global__ __launch_bounds__(64) void k_chol_trsm(double *A, int ld, int n, int j0, const double *rdg) {
-    __shared__ double sL[kNB * kNB], sX[kNB * 64];
-    const int lane = threadIdx.x, w = min(kNB, n - j0), t0 = j0 + w;
-    for (int idx = lane; idx < kNB * kNB; idx += 64) {
-        const int b = idx / kNB, k = idx - b * kNB;
-        sL[idx] = (b < w && k < b) ? A[(size_t)(j0 + b) * ld + j0 + k] : (b < w && k == b) ? rdg[j0 + b] : 0.0;
+// rows below the block (the right-hand side row n included): L[r][j0..] = A[r][j0..] Ld^-T, one lane per row.  Eight columns at a time live
+// in registers; the columns already solved are read back from LDS (column-major: conflict-free), the block's factor as LDS broadcasts
+// (stored transposed, so the eight factors of one step are contiguous), the reciprocal pivots on its diagonal.
+__global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int n, int j0, const double *rdg) {
+    __shared__ double sLt[kNB * kNB], sX[kNB * 64];          // sLt[k][b] = L[b][k]
+    const int tid = threadIdx.x, lane = tid & 63, w = min(kNB, n - j0), t0 = j0 + w;
+    for (int k = tid >> 6; k < kNB; k += 4) {                 // lanes over b: conflict-free LDS rows (the 64 x 64 block is re-read from L1 / L2)
+        const int b = lane;
+        sLt[k * kNB + b] = (b < w && k < b) ? A[(size_t)(j0 + b) * ld + j0 + k] : (k == b) ? (b < w ? rdg[j0 + b] : 1.0) : 0.0;
     }
-    const int r0 = t0 + blockIdx.x * 64, r = r0 + lane;
-    // coalesced: the 64 rows of this workgroup, 64 columns each
-    for (int idx = lane; idx < 64 * kNB; idx += 64) {
+    const int r0 = t0 + blockIdx.x * 64;
+    // the 64 rows of this workgroup, coalesced; element (row rr, column c) sits at sX[c][rr ^ c]: the fill (lanes over c) and the solve
+    // (lanes over rr) are both conflict-free
+    for (int idx = tid; idx < 64 * kNB; idx += 256) {
         const int rr = idx / kNB, c = idx - rr * kNB;
-        sX[c * 64 + rr] = (r0 + rr <= n && c < w) ? A[(size_t)(r0 + rr) * ld + j0 + c] : 0.0;
+        sX[c * 64 + (rr ^ c)] = (r0 + rr <= n && c < w) ? A[(size_t)(r0 + rr) * ld + j0 + c] : 0.0;
     }
     __syncthreads();
-    if (r <= n) {
-        for (int b = 0; b < w; b++) {
-            double t0a = sX[b * 64 + lane], t1a = 0;
-            int k = 0;
-            for (; k + 1 < b; k += 2) { t0a -= sX[k * 64 + lane] * sL[b * kNB + k]; t1a -= sX[(k + 1) * 64 + lane] * sL[b * kNB + k + 1]; }
-            if (k < b) t0a -= sX[k * 64 + lane] * sL[b * kNB + k];
-            sX[b * 64 + lane] = (t0a + t1a) * sL[b * kNB + b];
+    if (tid < 64)
+    for (int sp = 0; sp < kNB / 8; sp++) {
+        const int c0 = sp * 8;
+        double x[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) x[b] = sX[(c0 + b) * 64 + (lane ^ (c0 + b))];
+#pragma unroll 4
+        for (int k = 0; k < c0; k++) {
+            const double xk = sX[k * 64 + (lane ^ k)];
+            const double *l = sLt + k * kNB + c0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) x[b] -= xk * l[b];
         }
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            double t = x[b];
+#pragma unroll
+            for (int k = 0; k < b; k++) t -= x[k] * sLt[(c0 + k) * kNB + c0 + b];
+            x[b] = t * sLt[(c0 + b) * kNB + c0 + b];
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) sX[(c0 + b) * 64 + (lane ^ (c0 + b))] = x[b];
     }
     __syncthreads();
-    for (int idx = lane; idx < 64 * kNB; idx += 64) {
+    for (int idx = tid; idx < 64 * kNB; idx += 256) {
         const int rr = idx / kNB, c = idx - rr * kNB;
-        if (r0 + rr <= n && c < w) A[(size_t)(r0 + rr) * ld + j0 + c] = sX[c * 64 + rr];
+        if (r0 + rr <= n && c < w) A[(size_t)(r0 + rr) * ld + j0 + c] = sX[c * 64 + (rr ^ c)];
     }
 }
 
@@ -803,8 +902,8 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double *A, int ld, int n, int
 
 // L^T x = y (y = the factor's row n), blocks of 64 from the back: wave 0 solves the block, all threads update the unknowns before it
 __global__ __launch_bounds__(1024) void k_chol_backsub(const double *A, int ld, int n, const double *rdg, double *x, const double *scal) {
-    extern __shared__ double ysm[];
-    volatile double *ys = ysm;
+    extern __shared__ double ys[];
+    __shared__ double sD[kNB * kNB];
     const int tid = threadIdx.x;
     if (scal[3] == 0.0) {                               // not positive definite: g2o's solve() fails, the LM step is rejected
         for (int i = tid; i < n; i += 1024) x[i] = 0;
@@ -814,19 +913,36 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *A, int ld, 
     __syncthreads();
     for (int jb = (n + kNB - 1) / kNB - 1; jb >= 0; jb--) {
         const int j0 = jb * kNB, w = min(kNB, n - j0);
-        if (tid < 64) {
-            for (int j = j0 + w - 1; j >= j0; j--) {
-                const double xj = ys[j] * rdg[j];
-                const int i = j0 + tid;
-                if (i < j) ys[i] -= A[(size_t)j * ld + i] * xj;
-                if (i == j) ys[j] = xj;
+        for (int idx = tid; idx < kNB * kNB; idx += 1024) {   // the diagonal block, coalesced, for the sequential solve below
+            const int r = idx / kNB, c = idx - r * kNB;
+            sD[idx] = (r < w && c < r) ? A[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {                                       // lane t carries unknown j0 + t; the solved one is broadcast by readlane
+            double y = tid < w ? ys[j0 + tid] : 0.0;
+            const double rd = tid < w ? rdg[j0 + tid] : 0.0;
+            for (int jj = w - 1; jj >= 0; jj--) {
+                const double l = sD[jj * kNB + tid];          // row jj of the block (zero from the diagonal on)
+                const double xj = readlane_f64(y, jj) * readlane_f64(rd, jj);
+                y = tid == jj ? xj : y - l * xj;
             }
+            if (tid < w) ys[j0 + tid] = y;
         }
         __syncthreads();
         for (int i = tid; i < j0; i += 1024) {
-            double acc = 0;
-            for (int q = 0; q < w; q++) acc += A[(size_t)(j0 + q) * ld + i] * ys[j0 + q];
-            ys[i] -= acc;
+            double acc0 = 0, acc1 = 0;
+            const double *col = A + (size_t)j0 * ld + i;
+            int q = 0;
+#pragma unroll 1
+            for (; q + 16 <= w; q += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = col[(size_t)(q + u) * ld];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { acc0 += v[u] * ys[j0 + q + u]; acc1 += v[u + 1] * ys[j0 + q + u + 1]; }
+            }
+            for (; q < w; q++) acc0 += col[(size_t)q * ld] * ys[j0 + q];
+            ys[i] -= acc0 + acc1;
         }
         __syncthreads();
     }
@@ -1153,6 +1269,8 @@ struct RumiOptimizer {
     int npCap = 0;
     uint8_t *dErase = nullptr;
     double *dW = nullptr;            // H_pl L per edge, allocated by the first large-window call
+    int32_t *dColOf = nullptr;       // column block of every edge's key-frame (-1 fixed), same
+    int32_t *dPairs = nullptr; size_t pairCap = 0, pairOff = 0;   // Schur block descriptors + observation pairs of the large-window path
     double *hScal = nullptr;
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
@@ -1171,8 +1289,9 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     (void)hipSetDevice(o->device);
     void *p[] = {o->dActive, o->dLastChi2, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
-                 o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW};
+                 o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW, o->dColOf};
     for (void *q : p) if (q) (void)hipFree(q);
+    if (o->dPairs) (void)hipFree(o->dPairs);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hPose) (void)hipHostFree(o->hPose);
     if (o->hBa) (void)hipHostFree(o->hBa);
@@ -1311,20 +1430,22 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     std::vector<int32_t> kfRowStart(nOpt + 1, 0);
     for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) kfRowStart[c + 1] += 2; }
     for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
-    { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; fill[c] += 2; } } }
+    std::vector<int32_t> kfEdge((size_t)std::max(nE, 1), 0);      // edges grouped by optimised key-frame: kfEdge[rowSlot / 2]
+    { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; kfEdge[fill[c] >> 1] = e; fill[c] += 2; } } }
     // one pinned block up: the kernels read the graph arrays straight from its device mirror; the initial state is copied on the
     // device into the first of the two state buffers
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t oPC = 0, oPS = al(oPC + (size_t)nKF * 4), oKR = al(oPS + (size_t)(nMP + 1) * 4), oPE = al(oKR + (size_t)(nOpt + 1) * 4),
                  oRS = al(oPE + (size_t)nE * 4), oEM = al(oRS + (size_t)nE * 4), oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4),
-                 oIn = al(oOb + (size_t)nE * 16), oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), upBytes = al(oX + (size_t)nMP * 24);
+                 oIn = al(oOb + (size_t)nE * 16), oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), oKE = al(oX + (size_t)nMP * 24),
+                 upBytes = al(oKE + (size_t)nE * 4);
     if (upBytes > o->baStageCap) { g_lastError = "local BA: upload block larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
     uint8_t *hs = o->hBa;
     std::memcpy(hs + oPC, poseCol.data(), (size_t)nKF * 4); std::memcpy(hs + oPS, ptStart.data(), (size_t)(nMP + 1) * 4);
     std::memcpy(hs + oKR, kfRowStart.data(), (size_t)(nOpt + 1) * 4);
     if (nE > 0) {
         std::memcpy(hs + oPE, ptEdge.data(), (size_t)nE * 4); std::memcpy(hs + oRS, rowSlot.data(), (size_t)nE * 4);
-        std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4);
+        std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4); std::memcpy(hs + oKE, kfEdge.data(), (size_t)nE * 4);
         double *ob = reinterpret_cast<double *>(hs + oOb), *inf = reinterpret_cast<double *>(hs + oIn);
         for (int e = 0; e < nE; e++) { ob[2 * e] = e_obs[2 * e]; ob[2 * e + 1] = e_obs[2 * e + 1]; inf[e] = e_inv_sigma2[e]; }
     }
@@ -1359,10 +1480,50 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     const bool big = n > 255;
     const int NP = big ? 16 : (n + 1 + 15) / 16 * 16, NT = NP / 16, K3 = 3 * nMP;
     if (!big && NP > o->npCap) { g_lastError = "local BA: reduced system larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    int nBlocks = 0;
     if (big) {
-        if ((size_t)n * 8 > 150 * 1024) { g_lastError = "bundle adjustment: more than 3200 optimised key-frames"; return RUMI_E_CAPACITY; }
-        if (!o->dW) { const int rcw = oalloc(&o->dW, (size_t)o->maxE * 18); if (rcw != RUMI_OK) return rcw; }
-        if ((size_t)n * 8 > 48 * 1024)
+        if ((size_t)n * 8 > 120 * 1024) { g_lastError = "bundle adjustment: more than 2560 optimised key-frames"; return RUMI_E_CAPACITY; }
+        // observation pairs of every landmark grouped by Schur block (ca, cb <= ca): counting sort over the blocks
+        std::vector<int64_t> cnt((size_t)nOpt * nOpt + 1, 0);
+        auto for_pairs = [&](auto &&f) {
+            for (int p = 0; p < nMP; p++)
+                for (int ia = ptStart[p]; ia < ptStart[p + 1]; ia++) {
+                    const int ea = ptEdge[ia], ca = poseCol[e_kf[ea]];
+                    if (ca < 0) continue;
+                    for (int ib = ptStart[p]; ib < ptStart[p + 1]; ib++) {
+                        const int eb = ptEdge[ib], cb = poseCol[e_kf[eb]];
+                        if (cb < 0 || cb > ca || (cb == ca && eb != ea)) continue;
+                        f((size_t)ca * nOpt + cb, ea, eb);
+                    }
+                }
+        };
+        for_pairs([&](size_t key, int, int) { cnt[key + 1]++; });
+        std::vector<int32_t> blk;
+        for (size_t key = 0; key < (size_t)nOpt * nOpt; key++) {
+            const int64_t c0 = cnt[key], c1 = cnt[key] + cnt[key + 1];
+            for (int64_t a0 = c0; a0 < c1; a0 += kSchurSeg) {
+                blk.push_back((int32_t)(key / nOpt)); blk.push_back((int32_t)(key % nOpt) | (c1 - c0 > kSchurSeg ? 1 << 30 : 0));
+                blk.push_back((int32_t)a0); blk.push_back((int32_t)std::min<int64_t>(a0 + kSchurSeg, c1));
+            }
+            cnt[key + 1] += cnt[key];
+        }
+        const int64_t nPairs = cnt[(size_t)nOpt * nOpt];
+        if (nPairs > (int64_t)1 << 30) { g_lastError = "bundle adjustment: more than 2^30 co-observation pairs"; return RUMI_E_CAPACITY; }
+        std::vector<int32_t> pairs((size_t)std::max<int64_t>(nPairs, 1) * 2);
+        for_pairs([&](size_t key, int ea, int eb) { const int64_t at = cnt[key]++; pairs[2 * at] = ea; pairs[2 * at + 1] = eb; });
+        nBlocks = (int)(blk.size() / 4);
+        const size_t need = (blk.size() + pairs.size()) * sizeof(int32_t);
+        if (need > o->pairCap) {
+            if (o->dPairs) (void)hipFree(o->dPairs);
+            o->dPairs = nullptr; o->pairCap = 0;
+            HIP_TRY(hipMalloc((void **)&o->dPairs, need + need / 4));
+            o->pairCap = need + need / 4;
+        }
+        o->pairOff = blk.size();
+        if (!blk.empty()) HIP_TRY(hipMemcpy(o->dPairs, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(o->dPairs + blk.size(), pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!o->dW) { int rcw = oalloc(&o->dW, (size_t)o->maxE * 18); if (rcw == RUMI_OK) rcw = oalloc(&o->dColOf, (size_t)o->maxE); if (rcw != RUMI_OK) return rcw; }
+        if ((size_t)n * 8 > 16 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, n * 8));
     }
     const size_t ldsSolve = ((size_t)(n + 1) * (n + 1) + (size_t)n) * sizeof(double);
@@ -1392,15 +1553,15 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             Bz.n = 0;                                                      // z = L^T b_l lands in dYt[3 p .. 3 p + 2]
             hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, Bz, lambda, o->dYt, 1, o->dLp);
             if (nE > 0) {
-                hipLaunchKernelGGL(k_big_w, dim3(gE), dim3(256), 0, st, B, o->dLp, o->dW);
-                hipLaunchKernelGGL(k_big_schur, dim3((nMP + 3) / 4), dim3(256), 0, st, B, o->dW, o->dYt, A, ld);
+                hipLaunchKernelGGL(k_big_w, dim3(gE), dim3(256), 0, st, B, o->dLp, o->dW, o->dColOf);
+                if (nBlocks > 0) hipLaunchKernelGGL(k_big_schur, dim3((nBlocks + 3) / 4), dim3(256), 0, st, B, o->dPairs, nBlocks, o->dPairs + o->pairOff, o->dW, o->dYt, A, ld);
             }
         }
         for (int j0 = 0; j0 < n; j0 += kNB) {
             const int w = std::min(kNB, n - j0), rows = n + 1 - (j0 + w);
-            hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, st, A, ld, n, j0, rdg, o->dScal);
+            hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, A, ld, n, j0, rdg, o->dScal);
             if (rows > 0) {
-                hipLaunchKernelGGL(k_chol_trsm, dim3((rows + 63) / 64), dim3(64), 0, st, A, ld, n, j0, rdg);
+                hipLaunchKernelGGL(k_chol_trsm, dim3((rows + 63) / 64), dim3(256), 0, st, A, ld, n, j0, rdg);
                 const int T = (rows + 63) / 64;
                 if (j0 + w < n) hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, A, ld, n, j0);
             }
