@@ -79,7 +79,8 @@ int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);
  * full BA behind GlobalBundleAdjustemnt (map initialisation, Tracking.cc CreateInitialMapMonocular: 2 key-frames, 20 iterations; loop /
  * merge correction).  Same flattened graph as rumi_local_ba (kf_fixed[k] = the key-frame is the map's first one, :116); one
  * optimize(n_iterations) with Huber(sqrt(5.99)) when robust.  Landmarks without an edge keep their position (:248-250).  As for the
- * other BA entry points the reduced pose system is dense and limited to 42 optimised key-frames (RUMI_E_CAPACITY beyond).
+ * other BA entry points, up to 42 optimised key-frames take the dense-panel path; larger windows (up to 2560 optimised key-frames, within
+ * the handle's max_kf) accumulate the Schur complement block-sparsely and factor it with a multi-workgroup blocked Cholesky.
  * stats = {LM iterations, LM trials, optimised key-frames, 0}. */
 int rumi_bundle_adjustment(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3, int32_t nE,
                            const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2, const float *K4,

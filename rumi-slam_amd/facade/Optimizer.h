@@ -14,13 +14,24 @@
 
 #include "rumi_opt.h"
 
+// capacity of the per-thread optimiser arenas (key-frames incl. fixed ones, map points, observations of one call)
+#ifndef RUMI_OPT_MAX_KF
+#define RUMI_OPT_MAX_KF 512
+#endif
+#ifndef RUMI_OPT_MAX_MP
+#define RUMI_OPT_MAX_MP (1 << 17)
+#endif
+#ifndef RUMI_OPT_MAX_EDGES
+#define RUMI_OPT_MAX_EDGES (1 << 20)
+#endif
+
 namespace ORB_SLAM3 {
 
 class Optimizer {
 public:
     static RumiOptimizer *arena() {
         thread_local RumiOptimizer *o = nullptr;
-        if (!o && rumi_opt_create(1 << 16, 64, 256, 1 << 16, 1 << 20, -1, &o) != RUMI_OK) return nullptr;
+        if (!o && rumi_opt_create(1 << 16, 64, RUMI_OPT_MAX_KF, RUMI_OPT_MAX_MP, RUMI_OPT_MAX_EDGES, -1, &o) != RUMI_OK) return nullptr;
         return o;
     }
 
@@ -264,6 +275,83 @@ public:
         }
         pMap->IncreaseChangeIndex();
     }
+
+#ifdef RUMI_HAVE_SOPHUS
+    // void static BundleAdjustment(const vector<KeyFrame *> &vpKFs, const vector<MapPoint *> &vpMP, int nIterations = 5, bool *pbStopFlag = NULL,
+    //                              const unsigned long nLoopKF = 0, const bool bRobust = true)                Optimizer.cc:54-351 (monocular edges)
+    template <class KeyFrameT, class MapPointT>
+    static void BundleAdjustment(const std::vector<KeyFrameT *> &vpKFs, const std::vector<MapPointT *> &vpMP, int nIterations = 5, bool *pbStopFlag = nullptr,
+                                 const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        std::vector<bool> vbNotIncludedMP(vpMP.size(), false);
+        auto *pMap = vpKFs[0]->GetMap();
+        std::vector<KeyFrameT *> kfs;
+        std::unordered_map<KeyFrameT *, int> kfId;
+        std::vector<float> kfPose;
+        std::vector<uint8_t> kfFixed;
+        unsigned long maxKFid = 0;
+        for (KeyFrameT *pKF : vpKFs) {                                                        // :103-115
+            if (pKF->isBad()) continue;
+            kfId[pKF] = (int)kfs.size(); kfs.push_back(pKF);
+            const auto T = pKF->GetPose(); const auto q = T.unit_quaternion(); const auto t = T.translation();
+            const float p7[7] = {q.x(), q.y(), q.z(), q.w(), t(0), t(1), t(2)};
+            kfPose.insert(kfPose.end(), p7, p7 + 7);
+            kfFixed.push_back(pKF->mnId == pMap->GetInitKFid());
+            if ((unsigned long)pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+        }
+        std::vector<MapPointT *> mps;
+        std::vector<size_t> mpIndex;
+        std::vector<float> mpPos, eObs, eW;
+        std::vector<int32_t> eMp, eKf;
+        for (size_t i = 0; i < vpMP.size(); i++) {                                            // :123-253
+            MapPointT *pMP = vpMP[i];
+            if (pMP->isBad()) continue;
+            const auto P = pMP->GetWorldPos();
+            int nEdges = 0;
+            for (const auto &ob : pMP->GetObservations()) {
+                KeyFrameT *pKF = ob.first;
+                if (pKF->isBad() || (unsigned long)pKF->mnId > maxKFid) continue;
+                auto it = kfId.find(pKF);
+                if (it == kfId.end()) continue;                                               // optimizer.vertex(pKF->mnId) == NULL
+                nEdges++;
+                const int leftIndex = std::get<0>(ob.second);
+                if (leftIndex == -1 || !(pKF->mvuRight[leftIndex] < 0)) continue;             // monocular observations only
+                const auto &kpUn = pKF->mvKeysUn[leftIndex];
+                eMp.push_back((int32_t)mps.size()); eKf.push_back(it->second);
+                eObs.push_back(kpUn.pt.x); eObs.push_back(kpUn.pt.y);
+                eW.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+            }
+            if (nEdges == 0) { vbNotIncludedMP[i] = true; continue; }                         // :251-254: the vertex is removed again
+            mps.push_back(pMP); mpIndex.push_back(i);
+            mpPos.push_back(P(0)); mpPos.push_back(P(1)); mpPos.push_back(P(2));
+        }
+        if (kfs.empty()) return;
+        const float K4[4] = {kfs[0]->fx, kfs[0]->fy, kfs[0]->cx, kfs[0]->cy};
+        int32_t stats[4];
+        if (rumi_bundle_adjustment(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(), eKf.data(),
+                                   eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), nIterations, bRobust, stats) != RUMI_OK) {
+            std::fprintf(stderr, "BundleAdjustment: %s\n", rumi_last_error());
+            return;
+        }
+        const bool direct = nLoopKF == (unsigned long)pMap->GetOriginKF()->mnId;
+        for (size_t k = 0; k < kfs.size(); k++) {                                             // :264-327
+            const float *T7 = &kfPose[k * 7];
+            const Sophus::SE3f T(Eigen::Quaternionf(T7[3], T7[0], T7[1], T7[2]), Eigen::Vector3f(T7[4], T7[5], T7[6]));
+            if (direct) kfs[k]->SetPose(T);
+            else { kfs[k]->mTcwGBA = T; kfs[k]->mnBAGlobalForKF = nLoopKF; }
+        }
+        for (size_t p = 0; p < mps.size(); p++) {                                             // :330-349
+            const Eigen::Vector3f X(mpPos[3 * p], mpPos[3 * p + 1], mpPos[3 * p + 2]);
+            if (direct) { mps[p]->SetWorldPos(X); mps[p]->UpdateNormalAndDepth(); }
+            else { mps[p]->mPosGBA = X; mps[p]->mnBAGlobalForKF = nLoopKF; }
+        }
+    }
+
+    // void static GlobalBundleAdjustemnt(Map *pMap, int nIterations = 5, bool *pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true)   :48-52
+    template <class MapT>
+    static void GlobalBundleAdjustemnt(MapT *pMap, int nIterations = 5, bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    }
+#endif
 
 #ifdef RUMI_HAVE_SOPHUS
     // Gathers one correspondence of OptimizeSim3 / OptimizeCloudSim3 (Optimizer.cc:1972-2100, :2246-2392); false when the reference skips it.

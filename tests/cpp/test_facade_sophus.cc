@@ -20,8 +20,15 @@
 #include "Optimizer.h"
 #include "Sim3Scoring.h"
 
-struct Map { std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int changes = 0; void IncreaseChangeIndex() { changes++; } };
 struct KeyFrame;
+struct MapPoint;
+struct Map {
+    std::mutex mMutexMapUpdate; long GetInitKFid() { return 0; } int changes = 0; void IncreaseChangeIndex() { changes++; }
+    std::vector<KeyFrame *> allKFs; std::vector<MapPoint *> allMPs;
+    KeyFrame *GetOriginKF() { return allKFs[0]; }
+    std::vector<KeyFrame *> GetAllKeyFrames() { return allKFs; }
+    std::vector<MapPoint *> GetAllMapPoints() { return allMPs; }
+};
 struct Camera {
     float fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
     Eigen::Vector2f project(const Eigen::Vector3f &p) const { return Eigen::Vector2f{{fx * p(0) / p(2) + cx, fy * p(1) / p(2) + cy}}; }
@@ -31,7 +38,7 @@ struct MapPoint {
     static std::mutex mGlobalMutex;
     Eigen::Vector3f pos, normal{0, 0, 1}; cv::Mat desc; int nObs = 1; bool bad = false, isEdge = false; Map *map = nullptr; long mnBALocalForKF = -1;
     std::map<KeyFrame *, std::tuple<int, int>> obs;
-    float minD = 0.5f, maxD = 60.f; int mnTrackScaleLevel = 0;
+    float minD = 0.5f, maxD = 60.f; int mnTrackScaleLevel = 0; Eigen::Vector3f mPosGBA; unsigned long mnBAGlobalForKF = 0;
     Eigen::Vector3f GetWorldPos() { return pos; }
     Eigen::Vector3f GetNormal() { return normal; }
     void SetWorldPos(const Eigen::Vector3f &p) { pos = p; }
@@ -65,6 +72,7 @@ struct Frame {
 };
 struct KeyFrame : Frame {
     long mnId = 0, mnBALocalForKF = -1, mnBAFixedForKF = -1; Map *map = nullptr; bool bad = false;
+    std::vector<float> mvuRight; Sophus::SE3f mTcwGBA; unsigned long mnBAGlobalForKF = 0;
     std::vector<KeyFrame *> covis;
     KeyFrame() {}
     KeyFrame(const KeyFrame &o) : Frame(o), mnId(o.mnId), map(o.map) { mpCamera = &cam; }
@@ -267,6 +275,59 @@ int main(int argc, char **argv) {
         std::printf("OptimizeCloudSim3: ratio %.4f, t %.4f %.4f %.4f s %.4f\n", ratio, Sw.translation()(0), Sw.translation()(1), Sw.translation()(2), Sw.scale());
         CHECK(ratio > 0.85f && ratio < 0.93f, "OptimizeCloudSim3 inlier ratio (1/11 of the matches are outliers)");
         CHECK(Sw.scale() == sc && std::fabs(Sw.translation()(0) - 0.1) < 3e-3 && std::fabs(Sw.translation()(2) - 0.2) < 6e-3, "OptimizeCloudSim3 recovers the translation, keeps the scale");
+    }
+    // --- GlobalBundleAdjustemnt / BundleAdjustment: six key-frames around the points of kf[0], perturbed poses and points ---
+    {
+        Map M;
+        const int NK = 6, NP = std::min(kf[0].N, 600);
+        std::vector<KeyFrame> ks(NK);
+        std::vector<MapPoint> ps(NP);
+        std::vector<Sophus::SE3f> truth(NK);
+        for (int k = 0; k < NK; k++) {
+            ks[k].mnId = k; ks[k].map = &M; ks[k].mvInvLevelSigma2 = kf[0].mvInvLevelSigma2;
+            truth[k] = Sophus::SE3f(Eigen::Quaternionf(1.f, 0.f, 0.004f * k, 0.f), Eigen::Vector3f(-0.05f * k, 0.01f * k, 0.02f * k));
+            M.allKFs.push_back(&ks[k]);
+        }
+        for (int i = 0; i < NP; i++) {
+            const float z = 2.f + (i % 50) / 10.f;
+            const Eigen::Vector3f X((kf[0].mvKeysUn[i].pt.x - 320.1f) / 535.4f * z, (kf[0].mvKeysUn[i].pt.y - 247.6f) / 539.2f * z, z);
+            ps[i].pos = X + Eigen::Vector3f(0.01f * ((i * 7) % 5 - 2), 0.01f * ((i * 3) % 5 - 2), 0.02f * ((i * 11) % 5 - 2));   // perturbed map point
+            ps[i].map = &M;
+            for (int k = 0; k < NK; k++) {
+                const Eigen::Vector2f uv = ks[k].cam.project(truth[k] * X);
+                if (uv(0) < 0 || uv(0) >= 640 || uv(1) < 0 || uv(1) >= 480) continue;
+                cv::KeyPoint kp = kf[0].mvKeysUn[i];
+                kp.pt.x = uv(0); kp.pt.y = uv(1);
+                ps[i].obs[&ks[k]] = std::make_tuple((int)ks[k].mvKeysUn.size(), -1);
+                ks[k].mvKeysUn.push_back(kp); ks[k].mvuRight.push_back(-1.f); ks[k].mvpMapPoints.push_back(&ps[i]);
+            }
+            M.allMPs.push_back(&ps[i]);
+        }
+        for (int k = 0; k < NK; k++) {
+            ks[k].N = (int)ks[k].mvKeysUn.size();
+            ks[k].pose = k == 0 ? truth[0] : Sophus::SE3f(truth[k].unit_quaternion(), truth[k].translation() + Eigen::Vector3f(0.01f, -0.008f, 0.012f));
+        }
+        auto reproj = [&](bool gba) {
+            double sum = 0; int cnt = 0;
+            for (int i = 0; i < NP; i++)
+                for (auto &ob : ps[i].obs) {
+                    KeyFrame *k = ob.first;
+                    const Eigen::Vector2f uv = k->cam.project((gba ? k->mTcwGBA : k->pose) * (gba ? ps[i].mPosGBA : ps[i].pos));
+                    const auto &kp = k->mvKeysUn[std::get<0>(ob.second)];
+                    sum += std::hypot(uv(0) - kp.pt.x, uv(1) - kp.pt.y); cnt++;
+                }
+            return sum / cnt;
+        };
+        const double e0 = reproj(false);
+        const Sophus::SE3f pose1 = ks[1].pose;
+        ORB_SLAM3::Optimizer::GlobalBundleAdjustemnt(&M, 10, nullptr, 7, false);            // nLoopKF != origin: results parked in mTcwGBA / mPosGBA
+        const double eG = reproj(true);
+        CHECK(ks[1].pose.translation()(0) == pose1.translation()(0) && ks[1].mnBAGlobalForKF == 7 && ps[3].mnBAGlobalForKF == 7, "GlobalBundleAdjustemnt parks its result when nLoopKF is not the origin");
+        ORB_SLAM3::Optimizer::GlobalBundleAdjustemnt(&M, 10, nullptr, 0, false);            // nLoopKF == origin: SetPose / SetWorldPos
+        const double e1 = reproj(false);
+        std::printf("GlobalBundleAdjustemnt: mean reprojection error %.3f px -> %.4f px (parked result %.4f px)\n", e0, e1, eG);
+        CHECK(e0 > 1.0 && e1 < 0.05 * e0 && std::fabs(eG - e1) < 1e-3, "GlobalBundleAdjustemnt reduces the reprojection error");
+        CHECK(ks[0].pose.translation()(0) == truth[0].translation()(0), "the map's first key-frame stays fixed");
     }
     if (fails == 0) std::printf("facade (Sophus overloads): all checks passed\n");
     return fails ? 1 : 0;
