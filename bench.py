@@ -123,18 +123,31 @@ def main():
     ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
     cap = args.nfeatures + 4 * 8 + 64
 
+    pending = [None]
+
     def step():
         kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap)
         # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
         match = bruteforce_batch(desc, counts, torch.roll(desc, -1, 0), torch.roll(counts, -1, 0))
         if world > 1:
-            # the path's one exchange step: every GPU ends up with all key-points / descriptors
-            gc, gk, gd = rumination.all_gather_records(counts, kp, desc, B * world)
-            return gk, gd, gc, match
+            # the path's one exchange step: every GPU ends up with all key-points / descriptors.  It is launched
+            # here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of step i
+            # overlaps the extraction of step i + 1; drain() joins the last one inside the timed region.
+            prev, pending[0] = pending[0], rumination.all_gather_records_async(counts, kp, desc, B * world)
+            if prev is not None:
+                prev.wait()
         return kp, desc, counts, match
+
+    def drain():
+        if pending[0] is not None:
+            gc, gk, gd = pending[0].wait()
+            pending[0] = None
+            return gk, gd, gc
+        return None
 
     for _ in range(args.warmup):
         out = step()
+    drain()
     torch.cuda.synchronize()
     n_kp = float(out[2].reshape(-1, 2)[:, 0].float().mean().item())
 
@@ -144,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -35,6 +35,13 @@ def _worker(rank, world, port, n_frames, out_dir):
     lo, hi = rumination.shard_bounds(n_frames, rank, world)
     frames = [synth_frame(300 + i, w=320, h=240) for i in range(lo, hi)]
     counts, kp, desc = rumination.extract_queue(_records, frames, n_frames)
+    # the pipelined form bench.py uses: two exchanges in flight order, joined later, must give the same queue
+    k2, d2, c2 = _records(frames)
+    h1 = rumination.all_gather_records_async(c2, k2, d2, n_frames)
+    h2 = rumination.all_gather_records_async(c2, k2, d2, n_frames)
+    for h in (h1, h2):
+        gc, gk, gd = h.wait()
+        assert torch.equal(gc, counts) and gk.numpy().tobytes() == kp.numpy().tobytes() and torch.equal(gd, desc)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), counts=counts.numpy(), kp=kp.numpy(), desc=desc.numpy())
     dist.barrier()
     dist.destroy_process_group()
