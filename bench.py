@@ -197,6 +197,18 @@ def main():
                 traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        # VALU issue accounting of the same kernel: wave-instructions per launch from the committed SQ_INSTS_VALU pass
+        # (profiles/r01_pmc_sq_counters.json) over the chip's measured integer issue rate (tools/valu_rate.hip: 4.2 cycles per wave64
+        # instruction and SIMD = 585 G wave-instructions/s) and this run's launch duration
+        valu = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.json")))["kernels"]
+            insts = sq[{"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]]["SQ_INSTS_VALU"]
+            if per_launch == 256 and kern_ms[dom] > 0:
+                valu = {"wave_insts_per_launch": int(insts), "issue_rate_G_per_s": 585.0,
+                        "issue_frac": round(insts / 585e9 / (kern_ms[dom] / n_launch * 1e-3), 4)}
+        except Exception:
+            valu = None
         line = {
             "metric": "frames/sec ORB extract+match", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -209,7 +221,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(kern_bytes[dom] * per_launch), "frames_per_launch": per_launch,
                          "launch_ms": round(kern_ms[dom] / n_launch, 4),
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
-                         "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5)},
+                         "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
             "stage_ms_note": "one extra profiled step, every kernel alone on one stream (no overlap), summed over the step's launches",
         }

@@ -174,6 +174,20 @@ int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const float *tcw
                              const float *mp_max_dist, uint8_t *track_in_view, float *proj_x, float *proj_y, int32_t *scale_level,
                              float *view_cos, float *track_depth);
 
+/* Tracking::SearchLocalPoints, second half (R/lib_src/Tracking.cc:3012-3054): Frame::isInFrustum(pMP, 0.5) for every local map point and
+ * ORBmatcher(0.8).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, bFarPoints, thFarPoints) in ONE call — the frustum test's
+ * per-point fields stay on the device and feed the search directly (no host round trip between the two).
+ * skip[i] != 0: the point is not evaluated (mnLastFrameSeen == frame id, or isBad(); :3018-3021).  Pose and intrinsics as for
+ * rumi_frame_is_in_frustum (image bounds from F), map-point fields as for rumi_frame_is_in_frustum + GetDescriptor() / Observations().
+ * Outputs: the six tracking fields per point (the facade writes them on the non-skipped points and calls IncreaseVisible on those in
+ * view), *n_to_match_out (nToMatch), frame_mp in/out and *nmatches_out as for rumi_search_by_projection_mappoints. */
+int rumi_search_local_points(RumiMatcher *m, const RumiFrameFeatures *F, const float *Rcw9, const float *tcw3, const float *Ow3,
+                             const float *K4, float log_scale_factor, int32_t nlevels, float viewing_cos_limit, int32_t nmp, const uint8_t *skip,
+                             const float *mp_pos, const float *mp_normal, const float *mp_min_dist, const float *mp_max_dist,
+                             const uint8_t *mp_desc, const int32_t *mp_obs, float th, int32_t far_points, float th_far_points, float nnratio,
+                             uint8_t *track_in_view, float *proj_x, float *proj_y, int32_t *scale_level, float *view_cos, float *track_depth,
+                             int32_t *n_to_match_out, int32_t *frame_mp, int32_t *nmatches_out);
+
 /* Brute-force all-pairs 256-bit Hamming (the GPU formulation of BASELINE.json config 3), device pointers:
  * for each of B frame pairs, every query descriptor against every train descriptor; best index (first train index
  * wins ties, as in every loop of the reference), best and second-best distance.

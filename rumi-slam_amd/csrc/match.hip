@@ -323,9 +323,13 @@ __global__ void k_queries_init(int n1, const RumiKeyPoint *keys1, const float *p
 __global__ void k_is_in_frustum(int nmp, const float *pose /*Rcw9 tcw3 Ow3 K4*/, float minX, float minY, float maxX, float maxY,
                                 float logScaleFactor, int nLevels, float viewingCosLimit, const float *mpPos, const float *mpNormal,
                                 const float *mpMinDist, const float *mpMaxDist, uint8_t *inView, float *projX, float *projY,
-                                int32_t *scaleLevel, float *viewCosOut, float *trackDepth) {
+                                int32_t *scaleLevel, float *viewCosOut, float *trackDepth, const uint8_t *skip = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nmp) return;
+    if (skip && skip[i]) {                                // SearchLocalPoints does not evaluate these (already matched in this frame / bad)
+        inView[i] = 0; projX[i] = -1; projY[i] = -1; scaleLevel[i] = 0; viewCosOut[i] = 0; trackDepth[i] = 0;
+        return;
+    }
     const float *R = pose, *t = pose + 9, *Ow = pose + 12, *K = pose + 15;
     const float *P = mpPos + (size_t)i * 3;
     uint8_t in = 0;
@@ -1447,6 +1451,58 @@ extern "C" int rumi_frame_is_in_frustum(RumiMatcher *m, const float *Rcw9, const
     std::memcpy(proj_x, h + n16, (size_t)nmp * 4); std::memcpy(proj_y, h + n16 * 5, (size_t)nmp * 4);
     std::memcpy(view_cos, h + n16 * 9, (size_t)nmp * 4); std::memcpy(track_depth, h + n16 * 13, (size_t)nmp * 4);
     std::memcpy(scale_level, h + n16 * 17, (size_t)nmp * 4);
+    return RUMI_OK;
+}
+
+extern "C" int rumi_search_local_points(RumiMatcher *m, const RumiFrameFeatures *F, const float *Rcw9, const float *tcw3, const float *Ow3,
+                                        const float *K4, float log_scale_factor, int32_t nlevels, float viewing_cos_limit, int32_t nmp,
+                                        const uint8_t *skip, const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                                        const float *mp_max_dist, const uint8_t *mp_desc, const int32_t *mp_obs, float th, int32_t far_points,
+                                        float th_far_points, float nnratio, uint8_t *track_in_view, float *proj_x, float *proj_y,
+                                        int32_t *scale_level, float *view_cos, float *track_depth, int32_t *n_to_match_out, int32_t *frame_mp,
+                                        int32_t *nmatches_out) {
+    if (!m || !F || !Rcw9 || !tcw3 || !Ow3 || !K4 || !nmatches_out || !n_to_match_out || !frame_mp || nmp < 0) return RUMI_E_INVALID;
+    *nmatches_out = 0; *n_to_match_out = 0;
+    if (nmp > m->maxQ) { g_lastError = "more map points than max_queries"; return RUMI_E_CAPACITY; }
+    if (nmp == 0) return RUMI_OK;                          // nToMatch == 0: the reference does not search (Tracking.cc:3032)
+    if (!skip || !mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !mp_desc || !mp_obs || !track_in_view || !proj_x || !proj_y || !scale_level ||
+        !view_cos || !track_depth)
+        return RUMI_E_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    FrameDev fd;
+    int rc = upload_frame(m, F, &fd);
+    if (rc != RUMI_OK) return rc;
+    if (F->n > 0) H2D(m->dFeatMp, frame_mp, F->n);
+    float pose[19];
+    std::memcpy(pose, Rcw9, 36); std::memcpy(pose + 9, tcw3, 12); std::memcpy(pose + 12, Ow3, 12); std::memcpy(pose + 15, K4, 16);
+    H2D(m->dPose, pose, 19);
+    H2D(m->dF[0], mp_pos, (size_t)nmp * 3); H2D(m->dF[1], mp_normal, (size_t)nmp * 3); H2D(m->dF[2], mp_min_dist, nmp); H2D(m->dF[3], mp_max_dist, nmp);
+    H2D(m->dU8b, skip, nmp); H2D(m->dI[1], mp_obs, nmp); H2D(m->dQDesc, mp_desc, (size_t)nmp * 32);
+    // the frustum test writes the six per-point fields into the (by then scattered) upload mirror; the query kernel reads them there and the
+    // same block travels back to the host for the facade's write-back: no host round trip between isInFrustum and SearchByProjection
+    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+    if (n16 * 21 > m->stageCap) { g_lastError = "SearchLocalPoints: result block exceeds the staging block"; return RUMI_E_CAPACITY; }
+    uint8_t *dIn = m->dStage;
+    float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
+    int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
+    FLUSH(m);
+    hipLaunchKernelGGL(k_is_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, m->dPose, fd.minX, fd.minY, fd.maxX, fd.maxY, log_scale_factor,
+                       nlevels, viewing_cos_limit, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dIn, dX, dY, dL, dC, dD, m->dU8b);
+    HIP_TRY(hipMemcpyAsync(m->hStage, m->dStage, n16 * 21, hipMemcpyDeviceToHost, nullptr));
+    // is_bad of SearchByProjection = skip: a skipped point is never in view, so the flag is only read for points that are not bad
+    hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dIn, dX, dY, dL, dC, dD, m->dU8b, m->dI[1], m->dScale, th,
+                       far_points, th_far_points, m->dQ);
+    rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], nnratio, 0, frame_mp, nmatches_out);
+    if (rc != RUMI_OK) return rc;
+    const uint8_t *h = m->hStage;                           // complete: run_search synchronised the stream
+    std::memcpy(track_in_view, h, (size_t)nmp);
+    std::memcpy(proj_x, h + n16, (size_t)nmp * 4); std::memcpy(proj_y, h + n16 * 5, (size_t)nmp * 4);
+    std::memcpy(view_cos, h + n16 * 9, (size_t)nmp * 4); std::memcpy(track_depth, h + n16 * 13, (size_t)nmp * 4);
+    std::memcpy(scale_level, h + n16 * 17, (size_t)nmp * 4);
+    int nTo = 0;
+    for (int i = 0; i < nmp; i++) nTo += track_in_view[i];
+    *n_to_match_out = nTo;
+    if (nTo == 0) *nmatches_out = 0;                       // (nothing in view: no query was live, the search found nothing)
     return RUMI_OK;
 }
 

@@ -11,6 +11,8 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "ORBmatcher.h"
@@ -53,6 +55,77 @@ std::vector<uint8_t> IsInFrustum(FrameT &F, const std::vector<MapPointT *> &vpMP
         if (inView[i]) { p->mnTrackScaleLevel = lvl[i]; p->mTrackViewCos = vc[i]; p->mTrackDepth = depth[i]; }
     }
     return inView;
+}
+
+// Tracking::SearchLocalPoints from "int nToMatch = 0" on (R/lib_src/Tracking.cc:3012-3054): the frustum test of every local map point and
+// ORBmatcher(0.8).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, bFarPoints, thFarPoints) in one GPU call
+// (rumi_search_local_points): the per-point tracking fields feed the search on the device and come back once, for the write-back here.
+// Returns the match count (0 when nothing is in view: the reference does not search then).  Reference-side use:
+//     // ... first loop of SearchLocalPoints over mCurrentFrame.mvpMapPoints unchanged (:2998-3010) ...
+//     rumi_facade::SearchLocalPoints(mCurrentFrame, mvpLocalMapPoints, th, mpLocalMapper->mbFarPoints, mpLocalMapper->mThFarPoints);
+template <class FrameT, class MapPointT>
+int SearchLocalPoints(FrameT &F, const std::vector<MapPointT *> &vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float nnratio = 0.8f,
+                      int *pnToMatch = nullptr) {
+    const int n = (int)vpLocalMapPoints.size();
+    if (pnToMatch) *pnToMatch = 0;
+    if (n == 0) return 0;
+    std::vector<uint8_t> skip(n), desc((size_t)n * 32), inView(n);
+    std::vector<float> pos((size_t)n * 3), nrm((size_t)n * 3), mn(n), mx(n), px(n), py(n), vc(n), depth(n);
+    std::vector<int32_t> lvl(n), obs(n);
+    std::unordered_map<const MapPointT *, int> idOf;
+    std::vector<MapPointT *> byId(vpLocalMapPoints);
+    for (int i = 0; i < n; i++) {
+        MapPointT *p = vpLocalMapPoints[i];
+        idOf.emplace(p, i);
+        skip[i] = p->mnLastFrameSeen == F.mnId || p->isBad();                              // :3018-3021
+        const auto P = p->GetWorldPos(), N = p->GetNormal();
+        for (int c = 0; c < 3; c++) { pos[3 * i + c] = P(c); nrm[3 * i + c] = N(c); }
+        mn[i] = p->GetMinDistance(); mx[i] = p->GetMaxDistance(); obs[i] = p->Observations();
+        const cv::Mat d = p->GetDescriptor();
+        std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+    }
+    // features that already hold a map point: ids beyond n for points that are not in the local list (skipped, only Observations() is read)
+    std::vector<int32_t> frameMp(F.N, -1);
+    for (int f = 0; f < F.N; f++) {
+        MapPointT *p = F.mvpMapPoints[f];
+        if (!p) continue;
+        auto it = idOf.find(p);
+        if (it != idOf.end()) frameMp[f] = it->second;
+        else { frameMp[f] = (int)byId.size(); idOf.emplace(p, (int)byId.size()); byId.push_back(p); obs.push_back(p->Observations()); }
+    }
+    const int nid = (int)byId.size();
+    skip.resize(nid, 1); pos.resize((size_t)nid * 3, 0.f); nrm.resize((size_t)nid * 3, 0.f); mn.resize(nid, 0.f); mx.resize(nid, 0.f);
+    desc.resize((size_t)nid * 32, 0); inView.resize(nid); px.resize(nid); py.resize(nid); vc.resize(nid); depth.resize(nid); lvl.resize(nid);
+    float R[9], t[3], Ow[3];
+#ifdef RUMI_HAVE_SOPHUS
+    {
+        const Eigen::Matrix3f Rm = F.GetPose().rotationMatrix();
+        const Eigen::Vector3f tv = F.GetPose().translation(), ov = F.GetCameraCenter();
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = Rm(r, c); t[r] = tv(r); Ow[r] = ov(r); }
+    }
+#else
+    F.PoseMatrices(R, t, Ow);
+#endif
+    const float K4[4] = {F.fx, F.fy, F.cx, F.cy};
+    RumiFrameFeatures fv = ORB_SLAM3::ORBmatcher::view(F);
+    int32_t nToMatch = 0, nmatches = 0;
+    if (rumi_search_local_points(ORB_SLAM3::ORBmatcher::arena(), &fv, R, t, Ow, K4, F.mfLogScaleFactor, F.mnScaleLevels, 0.5f, nid, skip.data(), pos.data(),
+                                 nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), th, bFarPoints, thFarPoints, nnratio, inView.data(), px.data(),
+                                 py.data(), lvl.data(), vc.data(), depth.data(), &nToMatch, frameMp.data(), &nmatches) != RUMI_OK) {
+        std::fprintf(stderr, "SearchLocalPoints: %s\n", rumi_last_error());
+        std::abort();                                       // no CPU fallback
+    }
+    for (int i = 0; i < n; i++) {
+        if (skip[i]) continue;
+        MapPointT *p = vpLocalMapPoints[i];
+        p->mbTrackInView = inView[i] != 0;                                                  // Frame::isInFrustum's writes (Frame.cc:559-617)
+        p->mTrackProjX = px[i]; p->mTrackProjY = py[i];
+        if (inView[i]) { p->mnTrackScaleLevel = lvl[i]; p->mTrackViewCos = vc[i]; p->mTrackDepth = depth[i]; p->IncreaseVisible(); }   // :3023-3026
+    }
+    if (pnToMatch) *pnToMatch = nToMatch;
+    if (nToMatch == 0) return 0;
+    for (int f = 0; f < F.N; f++) F.mvpMapPoints[f] = frameMp[f] >= 0 ? byId[frameMp[f]] : nullptr;
+    return nmatches;
 }
 
 }  // namespace rumi_facade

@@ -475,6 +475,7 @@ protected:
         c.v = RumiFeatureVector{(int32_t)c.nodes.size(), c.nodes.data(), c.off.data(), c.idx.data()};
         return c;
     }
+public:   // also used by the free functions of FrameFrustum.h
     template <class FrameT> static RumiFrameFeatures view(const FrameT &F) {
         RumiFrameFeatures v;
         v.n = F.N;
@@ -486,6 +487,7 @@ protected:
         return v;
     }
 
+protected:
     float mfNNratio;
     bool mbCheckOrientation;
 };

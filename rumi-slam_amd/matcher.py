@@ -48,6 +48,7 @@ def _lib():
     L.rumi_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.rumi_fuse_candidates.argtypes = [vp, vp, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp]
     L.rumi_search_by_sim3.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
+    L.rumi_search_local_points.argtypes = [vp, C.POINTER(RumiFrameFeatures), vp, vp, vp, vp, f32, i32, f32, i32] + [vp] * 7 + [f32, i32, f32, f32] + [vp] * 6 + [C.POINTER(i32), vp, C.POINTER(i32)]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
@@ -119,6 +120,26 @@ class ORBmatcher:
             capi.ptr(a["view_cos"]), capi.ptr(a["track_depth"]), capi.ptr(a["is_bad"]), capi.ptr(a["desc"]), capi.ptr(a["obs"]),
             float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, capi.ptr(frame_mp), C.byref(nm)))
         return nm.value, frame_mp
+
+    def SearchLocalPoints(self, F, Rcw9, tcw3, Ow3, K4, log_sf, nlevels, pts, frame_mp, th=1.0, bFarPoints=False, thFarPoints=50.0, cos_limit=0.5):
+        """Tracking::SearchLocalPoints' frustum test + SearchByProjection(F, local points) in one call (rumi_search_local_points).
+        pts: dict pos, normal [n,3], min_dist, max_dist [n], desc [n,32], obs [n], skip [n] (mnLastFrameSeen == frame id or isBad()).
+        Returns (nToMatch, nmatches, frame_mp, fields) with fields = the six per-point arrays isInFrustum writes."""
+        n = len(pts["max_dist"])
+        R, t, O, K = _f32(Rcw9), _f32(tcw3), _f32(Ow3), _f32(K4)
+        a = dict(pos=_f32(pts["pos"]), normal=_f32(pts["normal"]), mn=_f32(pts["min_dist"]), mx=_f32(pts["max_dist"]),
+                 desc=np.ascontiguousarray(pts["desc"], np.uint8), obs=np.ascontiguousarray(pts["obs"], np.int32),
+                 skip=np.ascontiguousarray(pts["skip"], np.uint8))
+        out = dict(track_in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32),
+                   scale_level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32), track_depth=np.zeros(n, np.float32))
+        frame_mp = np.ascontiguousarray(frame_mp, np.int32).copy()
+        nto, nm = C.c_int32(), C.c_int32()
+        capi.check(self._lib.rumi_search_local_points(
+            self._h, C.byref(F.c), capi.ptr(R), capi.ptr(t), capi.ptr(O), capi.ptr(K), float(log_sf), int(nlevels), float(cos_limit), n, capi.ptr(a["skip"]),
+            capi.ptr(a["pos"]), capi.ptr(a["normal"]), capi.ptr(a["mn"]), capi.ptr(a["mx"]), capi.ptr(a["desc"]), capi.ptr(a["obs"]), float(th),
+            int(bFarPoints), float(thFarPoints), self.mfNNratio, capi.ptr(out["track_in_view"]), capi.ptr(out["proj_x"]), capi.ptr(out["proj_y"]),
+            capi.ptr(out["scale_level"]), capi.ptr(out["view_cos"]), capi.ptr(out["track_depth"]), C.byref(nto), capi.ptr(frame_mp), C.byref(nm)))
+        return nto.value, nm.value, frame_mp, out
 
     def SearchByProjection_Frame(self, Cur, Tcw7, K4, last_keys, last_mp, last_outlier, mp_pos, mp_desc, mp_obs, cur_mp, th):
         Tcw7 = np.ascontiguousarray(Tcw7, np.float32); K4 = np.ascontiguousarray(K4, np.float32)

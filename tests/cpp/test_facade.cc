@@ -56,10 +56,12 @@ struct MapPoint {
     void AddObservation(KeyFrame *k, int idx) { if (!obs.count(k)) nObs++; obs[k] = std::make_tuple(idx, -1); }
     void Replace(MapPoint *other);                     // defined after KeyFrame
     bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
+    long mnLastFrameSeen = -1; int nVisible = 0;
+    void IncreaseVisible() { nVisible++; }
 };
 std::mutex MapPoint::mGlobalMutex;
 struct Frame {
-    int N = 0;
+    int N = 0; long mnId = 7;
     std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<MapPoint *> mvpMapPoints; std::vector<bool> mvbOutlier;
     std::vector<float> mvScaleFactors, mvInvLevelSigma2; std::vector<float> mvuRight;
     float mnMinX = 0, mnMinY = 0, mnMaxX = 640, mnMaxY = 480, fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
@@ -236,6 +238,26 @@ int main(int argc, char **argv) {
             CHECK(nin > 300 && consistent, "IsInFrustum fills the tracking fields");
             const int nl = matcher.SearchByProjection(cur2, local, 3.f, false, 50.f);
             CHECK(nl > 100, "SearchByProjection(F, local points) after the batched isInFrustum");
+            // the fused call must leave the same fields on the points and the same matches in the frame
+            std::vector<float> px0, lv0;
+            for (auto *p : local) { px0.push_back(p->mbTrackInView ? p->mTrackProjX : -2.f); lv0.push_back((float)p->mnTrackScaleLevel); p->mbTrackInView = false; p->mTrackProjX = -3.f; p->nVisible = 0; }
+            Frame cur3 = fr[1];
+            cur3.mvpMapPoints.assign(cur3.N, nullptr);
+            int nTo = 0;
+            const int nf2 = rumi_facade::SearchLocalPoints(cur3, local, 3.f, false, 50.f, 0.9f, &nTo);   // the ratio of `matcher` above
+            bool same = nf2 == nl && nTo == nin;
+            for (size_t i = 0; i < local.size(); i++) {
+                if ((px0[i] != -2.f) != local[i]->mbTrackInView) same = false;
+                if (local[i]->mbTrackInView && (local[i]->mTrackProjX != px0[i] || (float)local[i]->mnTrackScaleLevel != lv0[i] || local[i]->nVisible != 1)) same = false;
+            }
+            for (int f = 0; f < cur3.N; f++) if (cur3.mvpMapPoints[f] != cur2.mvpMapPoints[f]) same = false;
+            if (!same) {
+                int dv = 0, dx = 0, dm = 0;
+                for (size_t i = 0; i < local.size(); i++) { if ((px0[i] != -2.f) != local[i]->mbTrackInView) dv++; else if (local[i]->mbTrackInView && (local[i]->mTrackProjX != px0[i] || (float)local[i]->mnTrackScaleLevel != lv0[i] || local[i]->nVisible != 1)) dx++; }
+                for (int f = 0; f < cur3.N; f++) if (cur3.mvpMapPoints[f] != cur2.mvpMapPoints[f]) dm++;
+                std::printf("SearchLocalPoints: matches %d vs %d, nToMatch %d vs %d, in-view flags differ %d, fields differ %d, frame entries differ %d\n", nf2, nl, nTo, nin, dv, dx, dm);
+            }
+            CHECK(same, "SearchLocalPoints (fused frustum + projection search) == IsInFrustum then SearchByProjection");
         }
         std::vector<cv::Point2f> prev(fr[0].mvKeysUn.size());
         for (size_t i = 0; i < prev.size(); i++) prev[i] = fr[0].mvKeysUn[i].pt;

@@ -209,6 +209,42 @@ def test_is_in_frustum_then_search_local_points(matcher, seed):
     assert n_gpu == n_ref and n_ref > 100 and np.array_equal(fm, fm_ref)
 
 
+@pytest.mark.parametrize("seed,th", [(0, 3.0), (2, 1.0), (4, 15.0)])
+def test_search_local_points_fused(matcher, seed, th):
+    """rumi_search_local_points: frustum test and projection search in one call, the per-point fields never leaving the device in
+    between.  Against the oracle's two steps: same fields (skipped points untouched = not in view), same nToMatch, same matches; some
+    points are skipped (already matched in this frame / bad) and some frame features already hold a map point."""
+    from rumi_slam_amd.matcher import FrameView
+    from scene import quat_rotate
+    s = TrackingScene(seed)
+    g = s.point_geometry()
+    _, R = quat_rotate(s.Tcw7[:4].astype(np.float64), np.zeros((1, 3)))
+    R32 = R.astype(np.float32)
+    rng = np.random.default_rng(seed)
+    n = len(s.mp_obs)
+    skip = (rng.random(n) < 0.15).astype(np.uint8)
+    pts = dict(pos=s.mp_pos, normal=g["normal"], min_dist=g["min_dist"], max_dist=g["max_dist"], desc=s.mp_desc, obs=s.mp_obs, skip=skip)
+    log_sf = float(np.log(np.float32(1.2)))
+    ref = O.is_in_frustum(R32.ravel(), s.Tcw7[4:], g["Ow"], K_TUM3, s.w, s.h, log_sf, 8, 0.5, pts)
+    for k in ref:                                           # the reference never calls isInFrustum on the skipped points
+        ref[k] = np.where(skip != 0, np.array(-1 if k in ("proj_x", "proj_y") else 0, ref[k].dtype), ref[k])
+    F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    frame_mp = np.full(F.n, -1, np.int32)
+    frame_mp[rng.choice(F.n, 40, replace=False)] = rng.integers(0, n, 40)      # features that already hold a (matched) map point
+    mp = dict(ref, is_bad=skip, desc=s.mp_desc, obs=s.mp_obs)
+    n_ref, fm_ref = O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, mp, frame_mp, th, False, 0.0, 0.8)
+    m = matcher(0.8)
+    nto, n_gpu, fm, got = m.SearchLocalPoints(F, R32.ravel(), s.Tcw7[4:], g["Ow"], K_TUM3, log_sf, 8, pts, frame_mp, th)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert nto == int(ref["track_in_view"].sum()) and nto > 200
+    assert n_gpu == n_ref and n_ref > 50 and np.array_equal(fm, fm_ref)
+    # nothing in view (all skipped): no search, the frame's vector untouched
+    pts0 = dict(pts, skip=np.ones(n, np.uint8))
+    nto, n_gpu, fm, got = m.SearchLocalPoints(F, R32.ravel(), s.Tcw7[4:], g["Ow"], K_TUM3, log_sf, 8, pts0, frame_mp, th)
+    assert nto == 0 and n_gpu == 0 and np.array_equal(fm, frame_mp) and not got["track_in_view"].any()
+
+
 @pytest.mark.parametrize("seed,ratio,ori,window", [(0, 0.9, True, 100), (1, 0.9, False, 100), (2, 0.7, True, 40), (3, 1.5, True, 200)])
 def test_search_for_initialization(matcher, seed, ratio, ori, window):
     """Monocular initialisation matcher: sequential steal rule (vMatchedDistance) replayed exactly; second call reuses vbPrevMatched."""

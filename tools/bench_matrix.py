@@ -129,6 +129,29 @@ def main():
     g3 = median_call(lambda: m.SearchByBoW(KF, A, s.last_mp, bad, F, Bv))
     c3 = cpu_time(lambda: O.search_by_bow(s.last_keys, s.last_desc, s.last_mp, bad, (A.node_ids, A.offsets, A.indices), s.cur_keys, s.cur_desc,
                                           (Bv.node_ids, Bv.offsets, Bv.indices), 0.8, True))
+    # fused Tracking::SearchLocalPoints (frustum test + M1 in one call) against the two calls it replaces
+    from rumi_slam_amd.matcher import isInFrustum
+    from scene import quat_rotate
+    gpts = s.point_geometry()
+    _, Rm = quat_rotate(s.Tcw7[:4].astype(np.float64), np.zeros((1, 3)))
+    R32 = Rm.astype(np.float32).ravel()
+    log_sf = float(np.log(np.float32(1.2)))
+    pts = dict(pos=s.mp_pos, normal=gpts["normal"], min_dist=gpts["min_dist"], max_dist=gpts["max_dist"], desc=s.mp_desc, obs=s.mp_obs,
+               skip=np.zeros(len(s.mp_obs), np.uint8))
+
+    def two_calls():
+        f = isInFrustum(m, R32, s.Tcw7[4:], gpts["Ow"], K_TUM3, s.w, s.h, log_sf, 8, 0.5, pts)
+        return m.SearchByProjection_MapPoints(F, dict(f, is_bad=pts["skip"], desc=s.mp_desc, obs=s.mp_obs), fm0, 3.0)
+
+    def two_calls_cpu():
+        f = O.is_in_frustum(R32, s.Tcw7[4:], gpts["Ow"], K_TUM3, s.w, s.h, log_sf, 8, 0.5, pts)
+        return O.search_by_projection_mappoints(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, dict(f, is_bad=pts["skip"], desc=s.mp_desc, obs=s.mp_obs), fm0, 3.0, False, 0.0, 0.8)
+    g_two = median_call(two_calls)
+    g_fused = median_call(lambda: m.SearchLocalPoints(F, R32, s.Tcw7[4:], gpts["Ow"], K_TUM3, log_sf, 8, pts, fm0, 3.0))
+    c_two = cpu_time(two_calls_cpu)
+    doc["search_local_points_host_api"] = {"map_points": int(len(s.mp_obs)), "gpu_us_fused": round(g_fused * 1e6, 1), "gpu_us_two_calls": round(g_two * 1e6, 1),
+                                           "cpu_oracle_us": round(c_two * 1e6, 1),
+                                           "note": "Tracking::SearchLocalPoints: Frame::isInFrustum for every local point + SearchByProjection(F, points); fused = rumi_search_local_points"}
     doc["windowed_matchers_host_api"] = {
         "note": "median latency of one call per frame pair, host arrays in/out (one pinned upload, kernels, one read-back); oracle = scalar CPU restatement",
         "M1_SearchByProjection_mappoints": {"queries": int(len(mp["obs"])), "gpu_us": round(g1 * 1e6, 1), "cpu_oracle_us": round(c1 * 1e6, 1)},
