@@ -462,12 +462,14 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
         if (c < nc) { sStart[c] = run; run += cnt[c]; }
     }
     __syncthreads();
+    // few frames per launch: gridDim.y workgroups share a frame's outputs (each repeats the cheap scan), which cuts the latency of a
+    // single-frame call; slice 0 publishes the level starts
     int32_t *ls = levelStart + (long long)frame * (kMaxLevels + 1);
-    if (tid <= P->nlevels) {
+    if (blockIdx.y == 0 && tid <= P->nlevels) {
         const int c = tid < P->nlevels ? P->lv[tid].cellBase : nc;
         ls[tid] = sStart[c];
     }
-    if (tid < P->nlevels) {
+    if (blockIdx.y == 0 && tid < P->nlevels) {
         const int c0 = P->lv[tid].cellBase, c1 = c0 + P->lv[tid].nCells;
         if (sStart[c1] - sStart[c0] > P->lv[tid].candCap) atomicOr(&overflow[frame], 1 << tid);
     }
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
     // lane has an independent load in flight instead of a wave walking its cells one round trip at a time
     const int nOut = min(sStart[nc], P->totalCand);
     const uint32_t *inBase = cellBuf + (long long)frame * nc * P->maxCellCand;
-    for (int j = tid; j < nOut; j += kCompactThreads) {
+    for (int j = blockIdx.y * kCompactThreads + tid; j < nOut; j += kCompactThreads * gridDim.y) {
         int lo = 0, hi = nc;                       // invariant: sStart[lo] <= j < sStart[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -711,7 +713,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
+    hipLaunchKernelGGL(k_compact, dim3(nframes, nframes < 32 ? 8 : 1), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
                        cand, levelStart, overflow);
 }
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Latency of the single-frame host API (rumi_orb_extract): image in host memory -> key-points + descriptors in host memory."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from rumi_slam_amd.extractor import ORBextractor
+from rumi_slam_amd.synth import synth_frame
+from tools.bench_matrix import median_call
+ext = ORBextractor(1000, 1.2, 8, 20, 7)
+imgs = [synth_frame(9000 + i) for i in range(4)]
+r0 = [ext(im) for im in imgs]
+r1 = [ext(im) for im in imgs]
+assert all(a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) for a, b in zip(r0, r1))
+k = [0]
+def one():
+    k[0] += 1
+    return ext(imgs[k[0] & 3])
+print("single frame median %.1f us" % (median_call(one, 200) * 1e6))
