@@ -107,6 +107,31 @@ def test_batch_device_matches_single():
         _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"batch frame {f}")
 
 
+@pytest.mark.parametrize("B,max_batch", [(70, 70), (130, 256), (300, 300)])
+def test_pipelined_batches_match_single_frames(B, max_batch):
+    """Batches of 64 frames and more run as sub-chunks pipelined over four streams with scratch slots reused in stream order (70 = 2 x 35,
+    130 = 4 x 33 and change, 300 = 5 sub-chunks of 64 over 4 slots): every frame must come out exactly as it does alone, and as the oracle
+    has it."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    g, o = _pair(batch=max_batch)
+    g1, _ = _pair(batch=1)
+    frames = synth_batch(B, seed0=800)
+    for rep in range(2):                                    # twice: the second call reuses every scratch slot
+        kp, desc, counts = g.extract_batch(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+    kp = kp.cpu().numpy(); desc = desc.cpu().numpy(); counts = counts.cpu().numpy()
+    for f in range(B):
+        mono, k1, d1 = g1(frames[f])
+        n = counts[f, 0]
+        gk = kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
+        _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (mono, k1, d1), f"batch of {B}, frame {f}")
+    for f in (0, B // 2, B - 1):
+        om, ok, od = o.extract(frames[f], (0, 1000))
+        n = counts[f, 0]
+        _assert_same((int(counts[f, 1]), kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1), desc[f, :n]), (om, ok, od), f"batch of {B}, frame {f} vs oracle")
+
+
 def test_golden_fixtures_on_gpu():
     import glob, os
     from rumi_slam_amd.extractor import ORBextractor
