@@ -23,7 +23,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        so = os.environ.get("RUMI_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")   # override: a sanitizer build of the same sources
         if not os.path.exists(so):
             build()
         _lib = C.CDLL(so)
