@@ -300,3 +300,27 @@ def test_large_window_local_ba(opt_big):
         _pose_close(kp[k], kp_ref[k], f"key-frame {k}")
     rel = np.linalg.norm(mp - mp_ref, axis=1) / np.maximum(np.linalg.norm(mp_ref, axis=1), 1e-3)
     assert rel.max() <= RTOL
+
+
+def test_error_conventions_of_the_new_entry_points(opt):
+    """Status codes instead of exceptions across the ABI: a key-frame-pair index outside the given pairs is RUMI_E_INVALID, a window larger
+    than the handle's arenas is RUMI_E_CAPACITY, and neither leaves the handle unusable."""
+    from rumi_slam_amd import capi
+    from rumi_slam_amd.optimizer import Optimizer
+    from sim3_scene import sim3_cloud_problem, sim3_pair_problem
+    c = sim3_cloud_problem(seed=5, n_pairs=3, per_pair=40)
+    bad = c["pair_of"].copy(); bad[7] = 3
+    with pytest.raises(capi.RumiError) as e:
+        opt.OptimizeSim3(c["S0"], c["P1c"], c["P2c"], c["obs1"], c["obs2"], c["w1"], c["w2"], c["K"], c["K"], 10.0, True, False, bad, c["S_c1w"], c["S_c2w"])
+    assert e.value.code == capi.RUMI_E_INVALID
+    small = Optimizer(max_kf=8, max_mp=256, max_edges=4096)
+    b = ba_problem(seed=9, n_opt=10, n_fixed=1, n_points=100)
+    with pytest.raises(capi.RumiError) as e:
+        small.BundleAdjustment(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"], n_iterations=3, robust=True)
+    assert e.value.code == capi.RUMI_E_CAPACITY
+    s = sim3_pair_problem(seed=6, n=60)                      # the handles still work
+    r = opt.OptimizeSim3(s["S0"], s["P1c"], s["P2c"], s["obs1"], s["obs2"], s["w1"], s["w2"], s["K"], s["K"])
+    assert r[0] > 30
+    b2 = ba_problem(seed=9, n_opt=4, n_fixed=1, n_points=100)
+    stats, _, _ = small.BundleAdjustment(b2["kf_pose"], b2["kf_fixed"], b2["mp_pos"], b2["e_mp"], b2["e_kf"], b2["e_obs"], b2["e_w"], b2["K"], n_iterations=3, robust=True)
+    assert stats[2] == 4
