@@ -385,16 +385,26 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
         }
         __syncthreads();
         { uint16_t *t = A; A = B; B = t; }
-        for (int i = tid; i < n; i += NT) {        // relabel keys of divided nodes, count inside the new owners
-            int id = own[i];
-            if (!nodes[id].split) continue;
-            const int x = cand_x(c[i]), y = cand_y(c[i]);
-            id = nodes[id].child[oct_quadrant(nodes[id], x, y)];
-            own[i] = (uint16_t)id;
-            OctNode &nd = nodes[id];
-            if (!nd.noMore) {
-                const int q = oct_quadrant(nd, x, y);
-                atomicAdd(reinterpret_cast<unsigned int *>(&nd.cnt[q & 2]), 1u << (16 * (q & 1)));
+        // relabel keys of divided nodes, count inside the new owners; four keys per trip so that their owner / key loads are in flight
+        // together (in the fine rounds few nodes are divided and the pass is one global round trip per key otherwise)
+        for (int i0 = tid; i0 < n; i0 += 4 * NT) {
+            int ids[4];
+            uint32_t ck[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * NT; ids[u] = i < n ? own[i] : -1; ck[u] = i < n ? c[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int id = ids[u];
+                if (id < 0 || !nodes[id].split) continue;
+                const int i = i0 + u * NT;
+                const int x = cand_x(ck[u]), y = cand_y(ck[u]);
+                id = nodes[id].child[oct_quadrant(nodes[id], x, y)];
+                own[i] = (uint16_t)id;
+                OctNode &nd = nodes[id];
+                if (!nd.noMore) {
+                    const int q = oct_quadrant(nd, x, y);
+                    atomicAdd(reinterpret_cast<unsigned int *>(&nd.cnt[q & 2]), 1u << (16 * (q & 1)));
+                }
             }
         }
         __syncthreads();
