@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
                 const uint32_t p0 = __builtin_amdgcn_perm(0u, w0, 0x0c010c00u), p1 = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);   // [b0, 0, b1, 0]
                 const int q0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
                 const int q1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                packed |= (uint32_t)((((b0[r] * (q0 >> 4)) >> 16) + ((b1[r] * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+                packed |= (uint32_t)(((__mul24(b0[r], q0 >> 4) >> 16) + (__mul24(b1[r], q1 >> 4) >> 16) + 2) >> 2) << (8 * i);   // taps <= 2048, q >> 4 <= 32 640
             }
             if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
@@ -268,10 +268,10 @@ __device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *s
                                                  int shx, int dw, unsigned Mdw, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
     const int i2 = entry & 0x7FFF, bright = entry >> 15;
-    const int py = magic_div(i2, Mdw), px = i2 - py * dw;
+    const int py = magic_div(i2, Mdw), px = i2 - mul24(py, dw);
     int s = 0;
-    if (active) s = fast_score_polar(&tile[(py + 3) * TP + px + 3 + shx], TP, bright ? -1 : 1);
-    uint8_t *dst = &sc[(py + 1) * SP + px + 1];
+    if (active) s = fast_score_polar(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, bright ? -1 : 1);
+    uint8_t *dst = &sc[mul24(py + 1, SP) + px + 1];
     const bool hit = active && s >= tlow;
     if (hit && !bright) *dst = (uint8_t)s;
     const unsigned long long bh = __ballot(hit);
@@ -296,9 +296,9 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         const int ip = base + lane;
         int pass = 0, idx = 0;
         if (ip < npairs) {
-            const int py = magic_div(ip, Mpw), px = (ip - py * pw) * 2;
-            idx = py * dw + px;
-            pass = fast_quick_pair(&tile[(py + 3) * TP + px + 3 + shx], TP, tlow + 1);
+            const int py = magic_div(ip, Mpw), px = (ip - mul24(py, pw)) * 2;
+            idx = mul24(py, dw) + px;
+            pass = fast_quick_pair(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, tlow + 1);
             if (px + 1 >= dw) pass &= 5;                // second pixel of the pair lies outside the detection region
         }
         // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1)
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int nd = (shx + cols + 3) >> 2;
     const unsigned Mnd = magic_of(nd);
     for (int idx = lane; idx < rows * nd; idx += 64) {
-        const int r = magic_div(idx, Mnd), c = idx - r * nd;
-        *reinterpret_cast<uint32_t *>(&tile[r * TP + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + (long long)r * pitch + 4 * c);
+        const int r = magic_div(idx, Mnd), c = idx - mul24(r, nd);
+        *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + mul24(r, pitch) + 4 * c);
     }
     const int dw = cols - 6, dh = rows - 6;
     const unsigned Mdw = magic_of(dw);
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
         if (k < nItems) {
             const int idx = listed ? (int)sl[k] : k;
             const bool dup = listed && k > 0 && (int)sl[k - 1] == idx;        // second entry of a pixel scored for both polarities
-            const int py = magic_div(idx, Mdw), px = idx - py * dw;
-            const uint8_t *s = &sc[(py + 1) * SP + px + 1];
+            const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
+            const uint8_t *s = &sc[mul24(py + 1, SP) + px + 1];
             v = s[0];
             isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
                     v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
@@ -409,9 +409,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
         if ((b >> lane) & 1ull) {
             const int k = it * 64 + lane;
             const int idx = listed ? (int)sl[k] : k;
-            const int py = magic_div(idx, Mdw), px = idx - py * dw;
+            const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
             const uint32_t x = (uint32_t)(px + 3 + ci_j * L.wCell), y = (uint32_t)(py + 3 + ci_i * L.hCell);
-            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[(py + 1) * SP + px + 1] << 24);
+            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[mul24(py + 1, SP) + px + 1] << 24);
         }
         run += __popcll(b);
     }
@@ -520,42 +520,51 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
     const int w = L.w, h = L.h;
     // strips that start beyond the row still feed their neighbours' halos; clamp their address inside the framed row
     const int xl = min(xa, ((w + kPadX - 4) & ~3));
-    int ring[7][4];
+    int ring[7][4];                                              // row results of the last seven source rows; slot = source row mod 7 of this walk
 #pragma unroll
     for (int k = 0; k < 7; k++)
 #pragma unroll
         for (int i = 0; i < 4; i++) ring[k][i] = 0;
-    const int yEnd = min(y0 + kBlurRows, h);
-    for (int r = y0 - 3; r < yEnd + 3; r++) {
-        const uint8_t *row = img + (long long)r * pitch;         // rows -3..-1 and h..h+2 are frame rows
-        const uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
-        uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
-        if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
-        if (lane == 63) Rw = *reinterpret_cast<const uint32_t *>(row + min(xl + 4, (w + kPadX - 4) & ~3));
+    const int yEnd = min(y0 + kBlurRows, h), rEnd = yEnd + 3;
+    // the walk is unrolled by seven so that the ring never moves: source row r0 + j lands in slot j, and the taps of the output row it
+    // completes sit at compile-time slots (a runtime ring costs 24 register moves per row)
+    for (int r0 = y0 - 3; r0 < rEnd; r0 += 7) {
 #pragma unroll
-        for (int k = 0; k < 6; k++)
+        for (int j = 0; j < 7; j++) {
+            const int r = r0 + j;
+            if (r >= rEnd) break;                                // wave-uniform
+            const uint8_t *row = img + (long long)r * pitch;     // rows -3..-1 and h..h+2 are frame rows
+            const uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
+            uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
+            if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
+            if (lane == 63) Rw = *reinterpret_cast<const uint32_t *>(row + min(xl + 4, (w + kPadX - 4) & ~3));
+            // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
+            // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
+            constexpr uint32_t tA = 18u | (34u << 8) | (48u << 16) | (56u << 24), tB = 48u | (34u << 8) | (18u << 16);
+            const uint32_t A0 = __builtin_amdgcn_alignbyte(C, Lw, 1), A1 = __builtin_amdgcn_alignbyte(C, Lw, 2), A2 = __builtin_amdgcn_alignbyte(C, Lw, 3);
+            const uint32_t B0 = __builtin_amdgcn_alignbyte(Rw, C, 1), B1 = __builtin_amdgcn_alignbyte(Rw, C, 2), B2 = __builtin_amdgcn_alignbyte(Rw, C, 3);
+            ring[j][0] = (int)__builtin_amdgcn_udot4(B0, tB, __builtin_amdgcn_udot4(A0, tA, 0u, false), false);
+            ring[j][1] = (int)__builtin_amdgcn_udot4(B1, tB, __builtin_amdgcn_udot4(A1, tA, 0u, false), false);
+            ring[j][2] = (int)__builtin_amdgcn_udot4(B2, tB, __builtin_amdgcn_udot4(A2, tA, 0u, false), false);
+            ring[j][3] = (int)__builtin_amdgcn_udot4(Rw, tB, __builtin_amdgcn_udot4(C, tA, 0u, false), false);
+            const int y = r - 3;                                 // slots (j+1)%7 .. j now hold rows y-3 .. y+3
+            if (y >= y0 && xa < w) {
+                uint32_t o[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) ring[k][i] = ring[k + 1][i];
-        // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
-        // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
-        constexpr uint32_t tA = 18u | (34u << 8) | (48u << 16) | (56u << 24), tB = 48u | (34u << 8) | (18u << 16);
-        const uint32_t A0 = __builtin_amdgcn_alignbyte(C, Lw, 1), A1 = __builtin_amdgcn_alignbyte(C, Lw, 2), A2 = __builtin_amdgcn_alignbyte(C, Lw, 3);
-        const uint32_t B0 = __builtin_amdgcn_alignbyte(Rw, C, 1), B1 = __builtin_amdgcn_alignbyte(Rw, C, 2), B2 = __builtin_amdgcn_alignbyte(Rw, C, 3);
-        ring[6][0] = (int)__builtin_amdgcn_udot4(B0, tB, __builtin_amdgcn_udot4(A0, tA, 0u, false), false);
-        ring[6][1] = (int)__builtin_amdgcn_udot4(B1, tB, __builtin_amdgcn_udot4(A1, tA, 0u, false), false);
-        ring[6][2] = (int)__builtin_amdgcn_udot4(B2, tB, __builtin_amdgcn_udot4(A2, tA, 0u, false), false);
-        ring[6][3] = (int)__builtin_amdgcn_udot4(Rw, tB, __builtin_amdgcn_udot4(C, tA, 0u, false), false);
-        const int y = r - 3;                                     // the ring now holds rows y-3 .. y+3
-        if (y >= y0 && xa < w) {
-            uint32_t o[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t acc = 18u * (uint32_t)(ring[0][i] + ring[6][i]) + 34u * (uint32_t)(ring[1][i] + ring[5][i]) +
-                                     48u * (uint32_t)(ring[2][i] + ring[4][i]) + 56u * (uint32_t)ring[3][i];
-                o[i] = (acc + 32768u) >> 16;
+                for (int i = 0; i < 4; i++) {
+                    // rounding constant folded into the first multiply-add; the result's byte 2 is the output pixel (sum <= 255 * 65536 + 32768)
+                    // row sums are <= 65 280 and their pairs <= 130 560: 24-bit multiply-adds (v_mad_u32_u24: tap and accumulation in one instruction)
+                    uint32_t acc = __umul24(56u, (uint32_t)ring[(j + 4) % 7][i]) + 32768u;
+                    acc += __umul24(48u, (uint32_t)(ring[(j + 3) % 7][i] + ring[(j + 5) % 7][i]));
+                    acc += __umul24(34u, (uint32_t)(ring[(j + 2) % 7][i] + ring[(j + 6) % 7][i]));
+                    acc += __umul24(18u, (uint32_t)(ring[(j + 1) % 7][i] + ring[j][i]));
+                    o[i] = acc;
+                }
+                // byte 2 of the four sums -> one dword (v_perm_b32: selectors 0-3 take from the second operand, 4-7 from the first, 0x0c = zero);
+                // the blurred arena has the same framed geometry, so a whole dword always fits in the row
+                const uint32_t p01 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
+                *reinterpret_cast<uint32_t *>(out + (long long)y * L.pitch + xa) = p01 | p23;
             }
-            // the blurred arena has the same framed geometry, so a whole dword always fits in the row
-            *reinterpret_cast<uint32_t *>(out + (long long)y * L.pitch + xa) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
         }
     }
 }
