@@ -123,24 +123,28 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         // horizontal pass as a 2-element dot product: the two source bytes of an output are adjacent, v_perm_b32 spreads them into
         // 16-bit halves and v_dot2_u32_u16 multiplies by the (non-negative, <= 2048) tap pair as it lies in the table
         typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
-        int sh[4];
-        uint32_t tap[4];
+        // output i reads the source bytes k_i, k_i + 1 of the 8-byte window: ONE v_perm_b32 over the window's two dwords puts them into the
+        // 16-bit halves [b0, 0, b1, 0] (selector built once per column, used for 2 source rows x kResizeRows outputs)
+        uint32_t sel[4], tap[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            sh[i] = 8 * ((int)(int16_t)(ofs >> (16 * i)) - sx0);
+            const uint32_t k = (uint32_t)((int)(int16_t)(ofs >> (16 * i)) - sx0);          // 0 .. 6
+            sel[i] = k | 0x0c000c00u | ((k + 1u) << 16);
             const uint64_t tt = i < 2 ? ta : tb;
             tap[i] = (uint32_t)(tt >> (32 * (i & 1)));
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
+            // vertical taps pre-shifted: (b * x) >> 16 == mulhi(b << 16, x) for the non-negative operands here (b <= 2048, x <= 32 640)
+            const uint32_t bh0 = (uint32_t)b0[r] << 16, bh1 = (uint32_t)b1[r] << 16;
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t w0 = (uint32_t)(s0[r] >> sh[i]), w1 = (uint32_t)(s1[r] >> sh[i]);
-                const uint32_t p0 = __builtin_amdgcn_perm(0u, w0, 0x0c010c00u), p1 = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);   // [b0, 0, b1, 0]
-                const int q0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                const int q1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                packed |= (uint32_t)(((__mul24(b0[r], q0 >> 4) >> 16) + (__mul24(b1[r], q1 >> 4) >> 16) + 2) >> 2) << (8 * i);   // taps <= 2048, q >> 4 <= 32 640
+                const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(s0[r] >> 32), (uint32_t)s0[r], sel[i]);
+                const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(s1[r] >> 32), (uint32_t)s1[r], sel[i]);
+                const uint32_t q0 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
+                const uint32_t q1 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
+                packed |= ((__umulhi(bh0, q0 >> 4) + __umulhi(bh1, q1 >> 4) + 2u) >> 2) << (8 * i);
             }
             if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
