@@ -856,6 +856,18 @@ __global__ __launch_bounds__(256) void k_tri_filter(int nq, const uint32_t *idx1
 // ---- brute force ----------------------------------------------------------------------------------------------------
 // grid (ceil(cap/256), B); 256 queries per workgroup in registers; train descriptors staged 256 at a time in LDS and
 // read as broadcasts (every lane reads the same address: conflict-free).
+// popcount(x) + acc in one instruction (the compiler re-associates a sum of popcounts into popcounts + 3-input adds)
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ qd, const int32_t *__restrict__ nqArr,
                                                     const uint8_t *__restrict__ td, const int32_t *__restrict__ ntArr,
                                                     int countStride, int cap, int32_t *__restrict__ bestIdx,
@@ -871,7 +883,9 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
         const uint4 a = src[0], c = src[1];
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = c.x; q[5] = c.y; q[6] = c.z; q[7] = c.w;
     }
-    int b1 = 256, b2 = 256, bi = -1;
+    // best and second best as packed keys (distance << 16 | train index): "first minimum wins, a tie goes to the second place" is then
+    // best = min(best, key), second = med3(best, second, key) — three instructions per pair next to the 8 xor + 8 popcount-accumulate
+    uint32_t best = 256u << 16, second = (256u << 16) | 0xFFFFu;
     for (int t0 = 0; t0 < nt; t0 += 256) {
         const int m = min(256, nt - t0);
         __syncthreads();
@@ -881,17 +895,24 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
             tile[tid * 2 + 1] = src[1];
         }
         __syncthreads();
-        for (int j = 0; j < m; j++) {
+        auto step = [&](int j) {
             const uint4 a = tile[j * 2], c = tile[j * 2 + 1];
-            const int d = __popc(q[0] ^ a.x) + __popc(q[1] ^ a.y) + __popc(q[2] ^ a.z) + __popc(q[3] ^ a.w) +
-                          __popc(q[4] ^ c.x) + __popc(q[5] ^ c.y) + __popc(q[6] ^ c.z) + __popc(q[7] ^ c.w);
-            if (d < b1) { b2 = b1; b1 = d; bi = t0 + j; }
-            else if (d < b2) b2 = d;
-        }
+            uint32_t d = popc_acc(q[0] ^ a.x, 0u);
+            d = popc_acc(q[1] ^ a.y, d); d = popc_acc(q[2] ^ a.z, d); d = popc_acc(q[3] ^ a.w, d);
+            d = popc_acc(q[4] ^ c.x, d); d = popc_acc(q[5] ^ c.y, d); d = popc_acc(q[6] ^ c.z, d); d = popc_acc(q[7] ^ c.w, d);
+            const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
+            second = umed3(best, second, key);
+            best = min(best, key);
+        };
+        int j = 0;
+        for (; j + 4 <= m; j += 4) { step(j); step(j + 1); step(j + 2); step(j + 3); }   // four independent popcount chains in flight
+        for (; j < m; j++) step(j);
     }
     if (qi < nq) {
         const size_t o = (size_t)b * cap + qi;
-        bestIdx[o] = bi; bestDist[o] = b1; secondDist[o] = b2;
+        const int b1 = (int)(best >> 16);
+        bestIdx[o] = b1 < 256 ? (int)(best & 0xFFFFu) : -1;     // a distance of 256 never beats the initial 256 (the reference's strict <)
+        bestDist[o] = b1; secondDist[o] = (int)(second >> 16);
     }
 }
 
@@ -1509,8 +1530,8 @@ extern "C" int rumi_search_local_points(RumiMatcher *m, const RumiFrameFeatures 
 extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
                                                   int32_t count_stride, int32_t cap, int32_t nbatch, void *d_best_idx,
                                                   void *d_best_dist, void *d_second_dist, void *hip_stream) {
-    if (!d_query || !d_nq || !d_train || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || nbatch < 1 || count_stride < 1)
-        return RUMI_E_INVALID;
+    if (!d_query || !d_nq || !d_train || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || cap > 65535 || nbatch < 1 || count_stride < 1)
+        return RUMI_E_INVALID;                                 // the kernel packs the train index into 16 bits next to the distance
     hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nbatch), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_query,
                        (const int32_t *)d_nq, (const uint8_t *)d_train, (const int32_t *)d_nt, count_stride, cap, (int32_t *)d_best_idx,
                        (int32_t *)d_best_dist, (int32_t *)d_second_dist);

@@ -125,6 +125,15 @@ def test_bruteforce_batch():
         assert np.array_equal(bi[b, :n].cpu().numpy(), rbi) and np.array_equal(bd[b, :n].cpu().numpy(), rbd)
         assert np.array_equal(sd[b, :n].cpu().numpy(), rsd)
     assert bi[1, 0].item() == 5 and bd[1, 0].item() == 0 and sd[1, 0].item() == 0
+    # no train descriptors, and a train set that holds only the query's bitwise complement (distance 256 never wins: strict <)
+    q2 = rng.integers(0, 256, (2, 8, 32), dtype=np.uint8)
+    t2 = np.zeros((2, 8, 32), np.uint8); t2[1, 0] = ~q2[1, 0]
+    bi, bd, sd = bruteforce_batch(torch.from_numpy(q2).cuda(), torch.from_numpy(np.array([[3, 0], [1, 0]], np.int32)).cuda(), torch.from_numpy(t2).cuda(),
+                                  torch.from_numpy(np.array([[0, 0], [1, 0]], np.int32)).cuda())
+    torch.cuda.synchronize()
+    assert bi[0, :3].tolist() == [-1, -1, -1] and bd[0, :3].tolist() == [256] * 3 and sd[0, :3].tolist() == [256] * 3
+    rbi, rbd, rsd = O.bruteforce_match(q2[1, :1], t2[1, :1])
+    assert [bi[1, 0].item(), bd[1, 0].item(), sd[1, 0].item()] == [int(rbi[0]), int(rbd[0]), int(rsd[0])] == [-1, 256, 256]
 
 
 @pytest.mark.parametrize("seed,nn", [(0, 0.75), (2, 0.9)])
