@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag r01) and prints a summary.
 Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r01.json, bench_matrix.json, stage_serial.log."""
-import collections, csv, glob, json, os, shutil, subprocess, sys
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
@@ -23,7 +23,7 @@ out = {"command": "RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc <4 counters> -- 
 for d in ("pmc_a", "pmc_b"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(newest(d + "/*/*counter_collection.csv"))):
-        n = r["Kernel_Name"].split("(")[0]
+        n = re.sub(r"<.*?>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()   # template arguments / return type dropped
         if n.startswith("rumi::"):
             agg[n.replace("rumi::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for n, c in agg.items():

@@ -5,14 +5,14 @@
 The factor 2 on the read side is the gfx950 correction of the guide, re-calibrated here with tools/pmc_calib.hip for BOTH
 16 B/lane and 4 B/lane coalesced streaming reads of 1 GiB (FETCH_SIZE * 1024 = 0.5000 x bytes read in both cases).
 usage: pmc_summary.py <dir-with-FETCH_SIZE-run> <dir-with-WRITE_SIZE-run> <out.json> [frames_per_launch]"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
 
 
 def per_kernel(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = re.sub(r"<.*?>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()   # template arguments / return type dropped
         if name.startswith("rumi::") and r["Counter_Name"] == counter:
             agg[name.replace("rumi::", "")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
