@@ -98,3 +98,43 @@ def test_closed_loop_tracking_matches_oracle_and_ground_truth():
     print(f"closed loop: {N_FRAMES - 1} frames, inliers {min(tracked)}..{max(tracked)}, translation RMSE {rmse_t * 1e3:.2f} mm, "
           f"max rotation error {max(errs_r):.4f} deg")
     assert rmse_t < 0.02 and max(errs_r) < 0.3, (errs_t, errs_r)
+
+
+def test_two_threads_two_handles():
+    """The reference runs one extractor in the Tracking thread and another inside KFDSample, matchers and optimisers on several threads
+    (SURVEY §8b): handles are per thread, the library keeps no shared mutable state.  Two Python threads (ctypes releases the GIL) hammer
+    their own extractor / matcher / optimiser concurrently; every result must equal the single-threaded one."""
+    import threading
+    from ba_scene import pose_problem
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.matcher import FrameView, ORBmatcher
+    from rumi_slam_amd.optimizer import Optimizer
+    from rumi_slam_amd.synth import synth_frame
+    from scene import TrackingScene
+    imgs = [synth_frame(4000 + i) for i in range(4)]
+    s = TrackingScene(1)
+    p = pose_problem(9, 250, 0.1)
+    mpv = s.mappoint_view()                                  # draws from the scene's RNG: once, shared by every call
+
+    def work(out, reps):
+        ext, m, opt = ORBextractor(1000, 1.2, 8, 20, 7), ORBmatcher(0.8, True), Optimizer()
+        F = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+        res = []
+        for r in range(reps):
+            mono, k, d = ext(imgs[r % 4])
+            n1, fm = m.SearchByProjection_MapPoints(F, mpv, np.full(F.n, -1, np.int32), 3.0)
+            ng, T, o = opt.PoseOptimization(p["Xw"], p["obs"], p["inv_sigma2"], p["K"], p["T0"])
+            res.append((mono, k.tobytes(), d.tobytes(), n1, fm.tobytes(), ng, T.tobytes(), o.tobytes()))
+        out.append(res)
+    ref = []
+    work(ref, 4)
+    outs = [[], []]
+    th = [threading.Thread(target=work, args=(outs[i], 12)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for o in outs:
+        assert len(o) == 1 and len(o[0]) == 12
+        for r, got in enumerate(o[0]):
+            names = ("mono", "key-points", "descriptors", "matches", "frame_mp", "pose inliers", "pose", "outlier flags")
+            bad = [names[i] for i in range(8) if got[i] != ref[0][r % 4][i]]
+            assert not bad, f"thread result {r} differs from the single-threaded one in {bad}"
