@@ -1196,8 +1196,9 @@ extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, c
     if (nqe > 0) H2D(m->dIdxA, kf_fv->indices, nqe);
     if (f_fv->n_nodes > 0) { H2D(m->dNodesB, f_fv->node_ids, f_fv->n_nodes); H2D(m->dOffB, f_fv->offsets, f_fv->n_nodes + 1); }
     if (nfe > 0) H2D(m->dFvIdx, f_fv->indices, nfe);
+    m->gridPending = false;                                 // candidates come from the FeatureVectors: the spatial grid is not read
+    FLUSH(m);
     if (kf_fv->n_nodes > 0)
-        FLUSH(m);
         hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
@@ -1227,8 +1228,9 @@ extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF
     if (nqe > 0) H2D(m->dIdxA, fv1->indices, nqe);
     if (fv2->n_nodes > 0) { H2D(m->dNodesB, fv2->node_ids, fv2->n_nodes); H2D(m->dOffB, fv2->offsets, fv2->n_nodes + 1); }
     if (nfe > 0) H2D(m->dFvIdx, fv2->indices, nfe);
+    m->gridPending = false;
+    FLUSH(m);
     if (fv1->n_nodes > 0)
-        FLUSH(m);
         hipLaunchKernelGGL(k_queries_bow, dim3((fv1->n_nodes + 255) / 256), dim3(256), 0, nullptr, fv1->n_nodes, m->dNodesA, m->dOffA, m->dIdxA,
                            m->dI[0], m->dU8a, m->dQKeys, fv2->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     std::vector<int32_t> assign(std::max(nqe, 1), -1);
