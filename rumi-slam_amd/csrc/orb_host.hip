@@ -37,6 +37,7 @@ extern "C" int rumi_device_count(void) {
 
 namespace {
 constexpr int kChunk = 256;  // frames per pass through the candidate / quadtree scratch arenas
+static int scratch_frames(int maxBatch) { return (std::min(kChunk, maxBatch) + 11) / 12 * 12; }
 
 template <class T> int dev_alloc(T **p, size_t n) {
     *p = nullptr;
@@ -238,7 +239,8 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     h->capCand = candSum + 64;
     h->capCoef = coefN + 64 * cfg->nlevels;
     h->capSel = cfg->nfeatures + 4 * cfg->nlevels + 64;   // the quadtree may return a few more than N per level
-    const size_t B = (size_t)cfg->max_batch, C = (size_t)std::min<int>(kChunk, cfg->max_batch);
+    // scratch arenas: frames of one pass, rounded up to a multiple of 12 so that 2, 3 or 4 equal slots hold ceil(frames / parts) each
+    const size_t B = (size_t)cfg->max_batch, C = (size_t)scratch_frames(cfg->max_batch);
     int rc = RUMI_OK;
 #define TRY_ALLOC(x) if ((rc = (x)) != RUMI_OK) { rumi_orb_destroy(h); return rc; }
     TRY_ALLOC(dev_alloc(&h->dP, 1));
@@ -378,7 +380,9 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         return RUMI_OK;
     };
     if (parts > 1) {
-        const int slotFrames = std::min<int>(kChunk, h->cfg.max_batch) / parts, sub = std::min(slotFrames, (nframes + parts - 1) / parts);
+        // equal sub-chunks: rounds of `parts` sub-chunks, as few rounds as the slots allow, no short tail
+        const int slotFrames = scratch_frames(h->cfg.max_batch) / parts;
+        const int rounds = (nframes + parts * slotFrames - 1) / (parts * slotFrames), sub = (nframes + parts * rounds - 1) / (parts * rounds);
         HIP_TRY(hipEventRecord(h->evPartFork, st));
         int used = 0;
         for (int j = 0, base = 0; base < nframes; j++, base += sub) {
