@@ -577,11 +577,18 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
 }
 
 // ------------------------------------------------------------------------------------------------
-// Orientation + descriptor + output assembly: one wave per selected key-point.
-//   IC_Angle: integer moments over the radius-15 disc of the UN-blurred level, two disc rows per step;
-//   rBRIEF:   lane l evaluates test pairs l, l+64, l+128, l+192; __ballot packs 64 bits at a time, which
+// Orientation + descriptor + output assembly: one HALF wave (32 lanes) per selected key-point, eight key-points per workgroup.
+//   The arithmetic that is the same for every lane of a key-point (fastAtan2, the libm sinf / cosf restatement in double precision, the
+//   record) is a third of the kernel: with two key-points per wave an instruction serves both.
+//   IC_Angle: integer moments over the radius-15 disc of the UN-blurred level, lane = disc column;
+//   rBRIEF:   lane l evaluates test pairs l, l+32, ... l+224; __ballot packs 32 bits per key-point at a time, which
 //             is exactly the descriptor's little-endian bit order (bit k of byte i = pair 8i+k).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int half_wave_sum(int v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -589,6 +596,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 constexpr int kDiscP = 36, kPatchP = 40;       // LDS row pitches: 31 (+3 alignment slack) and 37 (+3) bytes as whole dwords
+constexpr int kKpPerWg = 8;
 
 __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
@@ -596,13 +604,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
                                                      const int32_t *__restrict__ selCount, int selCap,
                                                      RumiKeyPoint *__restrict__ kpOut, uint8_t *__restrict__ descOut,
                                                      int outCap) {
-    // per wave: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged
+    // per key-point: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged
     // with aligned dword loads that are all in flight together (one memory latency instead of 24 dependent byte gathers)
-    __shared__ __attribute__((aligned(16))) uint8_t sDisc[4][31 * kDiscP];
-    __shared__ __attribute__((aligned(16))) uint8_t sPatch[4][37 * kPatchP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t sDisc[kKpPerWg][31 * kDiscP];
+    __shared__ __attribute__((aligned(16))) uint8_t sPatch[kKpPerWg][37 * kPatchP];
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;             // lane within the half wave, half-wave index 0..7
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // a frame's key-points share one L2
-    const int k = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
+    const int k = (wg % gridDim.x) * kKpPerWg + hw, frame = wg / gridDim.x;
     const bool live = k < selCount[frame];
     int level = 0, slot = 0, x = kEdge, y = kEdge, score = 0;
     if (live) {
@@ -616,41 +624,40 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
         int pitch;
         const uint8_t *c = level_base(src, P, level, frame, &pitch) + (long long)(y - kHalfPatch) * pitch + xd;
         const uint8_t *b = src.blur + (long long)frame * P->arenaStride + L.off + (long long)(y - 18) * L.pitch + xp;
-        uint32_t vd[5], vp[6];
+        uint32_t vd[9], vp[12];
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
-            const int idx = lane + 64 * q, r = idx / 9, cc = idx - r * 9;
+        for (int q = 0; q < 9; q++) {
+            const int idx = lane + 32 * q, r = idx / 9, cc = idx - r * 9;
             vd[q] = idx < 31 * 9 ? *reinterpret_cast<const uint32_t *>(c + (long long)r * pitch + 4 * cc) : 0;
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int idx = lane + 64 * q, r = idx / 10, cc = idx - r * 10;
+        for (int q = 0; q < 12; q++) {
+            const int idx = lane + 32 * q, r = idx / 10, cc = idx - r * 10;
             vp[q] = idx < 37 * 10 ? *reinterpret_cast<const uint32_t *>(b + (long long)r * L.pitch + 4 * cc) : 0;
         }
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
-            const int idx = lane + 64 * q, r = idx / 9, cc = idx - r * 9;
-            if (idx < 31 * 9) *reinterpret_cast<uint32_t *>(&sDisc[wave][r * kDiscP + 4 * cc]) = vd[q];
+        for (int q = 0; q < 9; q++) {
+            const int idx = lane + 32 * q, r = idx / 9, cc = idx - r * 9;
+            if (idx < 31 * 9) *reinterpret_cast<uint32_t *>(&sDisc[hw][r * kDiscP + 4 * cc]) = vd[q];
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int idx = lane + 64 * q, r = idx / 10, cc = idx - r * 10;
-            if (idx < 37 * 10) *reinterpret_cast<uint32_t *>(&sPatch[wave][r * kPatchP + 4 * cc]) = vp[q];
+        for (int q = 0; q < 12; q++) {
+            const int idx = lane + 32 * q, r = idx / 10, cc = idx - r * 10;
+            if (idx < 37 * 10) *reinterpret_cast<uint32_t *>(&sPatch[hw][r * kPatchP + 4 * cc]) = vp[q];
         }
     }
     __syncthreads();
     if (!live) return;
 
-    // IC_Angle (ORBextractor.cc:73-97): two disc rows per step
-    const uint8_t *dc = &sDisc[wave][kHalfPatch * kDiscP + (x - xd)];
-    // lane = (column u, row parity): the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a lane's rows are
-    // |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
-    const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
-    const int vmaxU = (lane & 31) < 31 ? P->umax[u < 0 ? -u : u] : -1;
+    // IC_Angle (ORBextractor.cc:73-97): lane = column u of the disc; the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a
+    // lane's rows are |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
+    const uint8_t *dc = &sDisc[hw][kHalfPatch * kDiscP + (x - xd)];
+    const int u = lane - kHalfPatch;
+    const int vmaxU = lane < 31 ? P->umax[u < 0 ? -u : u] : -1;
     int colSum = 0, m01 = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int v = -kHalfPatch + 2 * i + half;
+    for (int i = 0; i < 31; i++) {
+        const int v = -kHalfPatch + i;
         if (v <= vmaxU && -v <= vmaxU) {
             const int val = dc[v * kDiscP + u];
             colSum += val;
@@ -658,29 +665,32 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
         }
     }
     int m10 = u * colSum;
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    m10 = half_wave_sum(m10);
+    m01 = half_wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // computeOrbDescriptor (ORBextractor.cc:99-143) on the blurred level
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = angle * factorPI;
     const float a = cosf_glibc(ang), b = sinf_glibc(ang);
-    const uint8_t *bc = &sPatch[wave][18 * kPatchP + (x - xp)];
-    unsigned long long bits[4];
+    const uint8_t *bc = &sPatch[hw][18 * kPatchP + (x - xp)];
+    uint32_t bits[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int8_t *pt = &c_pattern[(j * 64 + lane) * 4];
+    for (int j = 0; j < 8; j++) {
+        const int8_t *pt = &c_pattern[(j * 32 + lane) * 4];
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
         const int r0 = cv_round_f(x0 * b + y0 * a), c0 = cv_round_f(x0 * a - y0 * b);
         const int r1 = cv_round_f(x1 * b + y1 * a), c1 = cv_round_f(x1 * a - y1 * b);
         const int t0 = bc[r0 * kPatchP + c0], t1 = bc[r1 * kPatchP + c1];
-        bits[j] = __ballot(t0 < t1);
+        const unsigned long long bal = __ballot(t0 < t1);                 // both key-points of the wave; mine is my half
+        bits[j] = (uint32_t)(bal >> (32 * (hw & 1)));
     }
     if (slot < outCap) {
-        if (lane < 4) {
-            unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-            reinterpret_cast<unsigned long long *>(descOut + ((long long)frame * outCap + slot) * 32)[lane] = w;
+        if (lane < 8) {
+            uint32_t w = bits[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) if (lane == j) w = bits[j];
+            reinterpret_cast<uint32_t *>(descOut + ((long long)frame * outCap + slot) * 32)[lane] = w;
         }
         if (lane == 0) {
             RumiKeyPoint kp;
@@ -754,7 +764,7 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
                         int outCap, int nframes, hipStream_t st) {
     if (maxSel <= 0) return;
-    hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + 3) / 4, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
+    hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + kKpPerWg - 1) / kKpPerWg, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
                        selCount, selCap, kpOut, descOut, outCap);
 }
 
