@@ -20,6 +20,7 @@ struct DevLevel {
     float patchSize;               // (float)(int)(31 * scale)  (ORBextractor.cc:816)
     int candCap;
     int coefX, coefY, xmax;        // resize tables (int16 units into the coefficient buffer)
+    int rowTab;                    // first entry of the level's output-row table (RowTap units, row -kFrameRows first)
 };
 
 struct DevParams {
@@ -42,7 +43,8 @@ struct ImgSrc {
 
 void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
 void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
-void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
+struct RowTap { int32_t off0, off1; uint32_t bh0, bh1; };   // byte offsets of the two source rows, vertical taps << 16
+void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st);

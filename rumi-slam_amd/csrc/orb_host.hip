@@ -64,6 +64,7 @@ struct RumiOrb {
     DevParams hP{};
     DevParams *dP = nullptr;
     int16_t *dCoef = nullptr;
+    RowTap *dRowTab = nullptr; int capRowTab = 0;   // per level and output row: source rows and vertical taps of the resize
     // HBM arenas (sized for max_batch frames unless noted)
     uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame)
     uint8_t *hIn = nullptr, *hOut1 = nullptr, *dOut1 = nullptr;   // pinned image / pinned + device [counts | kp | desc] block of that API
@@ -128,6 +129,7 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
     P.arenaStride = h->capArena;
     for (int i = 0; i < 16; i++) P.umax[i] = h->tab.umax[i];
     std::vector<int16_t> coef;
+    std::vector<RowTap> rowTab;
     for (int l = 0; l < P.nlevels; l++) {
         DevLevel &D = P.lv[l];
         const LevelGeom &G = g[l];
@@ -137,7 +139,7 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
         D.nfeat = G.nfeat; D.scale = G.scale;
         D.patchSize = (float)(int)(kPatchSize * G.scale);
         D.candCap = std::min(G.candCap, 65535);
-        D.coefX = D.coefY = 0; D.xmax = G.w;
+        D.coefX = D.coefY = 0; D.xmax = G.w; D.rowTab = 0;
         if (l > 0) {
             std::vector<int16_t> ofs, taps;
             int dmax;
@@ -149,11 +151,23 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
             D.coefY = (int)coef.size();
             coef.insert(coef.end(), ofs.begin(), ofs.end());
             coef.insert(coef.end(), taps.begin(), taps.end());
+            // output rows -kFrameRows .. h + kFrameRows - 1 (the frame rows resample the mirrored row): clamped source rows as byte offsets
+            // into the previous level, taps << 16
+            D.rowTab = (int)rowTab.size();
+            const int sh = g[l - 1].h, sp = g[l - 1].pitch;
+            auto reflect = [](int i, int n) { while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; };   // BORDER_REFLECT_101, as the kernels' reflect101
+            for (int oy = -kFrameRows; oy < G.h + kFrameRows; oy++) {
+                const int dy = reflect(oy, G.h), sy = ofs[dy];
+                const int sy0 = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0, sy1r = sy + 1, sy1 = sy1r >= 0 ? (sy1r < sh ? sy1r : sh - 1) : 0;
+                rowTab.push_back(RowTap{sy0 * sp, sy1 * sp, (uint32_t)taps[dy * 2] << 16, (uint32_t)taps[dy * 2 + 1] << 16});
+            }
         }
     }
     if ((int)coef.size() > h->capCoef) { g_lastError = "resize table capacity"; return RUMI_E_CAPACITY; }
     HIP_TRY(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
+    if ((int)rowTab.size() > h->capRowTab) { g_lastError = "resize row table capacity"; return RUMI_E_CAPACITY; }
     if (!coef.empty()) HIP_TRY(hipMemcpy(h->dCoef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (!rowTab.empty()) HIP_TRY(hipMemcpy(h->dRowTab, rowTab.data(), rowTab.size() * sizeof(RowTap), hipMemcpyHostToDevice));
     h->octLds = octree_lds_for(P);
     if (h->octLds > 160 * 1024) { g_lastError = "nfeatures too large for the LDS-resident quadtree node pool"; return RUMI_E_INVALID; }
     h->gw = w; h->gh = hgt;
@@ -178,7 +192,7 @@ extern "C" int rumi_orb_tables(const RumiOrbConfig *cfg, float *scale, float *in
 extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *dev[] = {h->dP, h->dCoef, h->dIn, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
+    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dIn, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
                    h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
                    h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -238,6 +252,8 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     for (int l = 0; l < cfg->nlevels; l++) candSum += std::min(g[l].candCap, 65535);
     h->capCand = candSum + 64;
     h->capCoef = coefN + 64 * cfg->nlevels;
+    h->capRowTab = 0;
+    for (int l = 1; l < cfg->nlevels; l++) h->capRowTab += g[l].h + 2 * kFrameRows + 8;
     h->capSel = cfg->nfeatures + 4 * cfg->nlevels + 64;   // the quadtree may return a few more than N per level
     // scratch arenas: frames of one pass, rounded up to a multiple of 12 so that 2, 3 or 4 equal slots hold ceil(frames / parts) each
     const size_t B = (size_t)cfg->max_batch, C = (size_t)scratch_frames(cfg->max_batch);
@@ -245,6 +261,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
 #define TRY_ALLOC(x) if ((rc = (x)) != RUMI_OK) { rumi_orb_destroy(h); return rc; }
     TRY_ALLOC(dev_alloc(&h->dP, 1));
     TRY_ALLOC(dev_alloc(&h->dCoef, (size_t)h->capCoef));
+    TRY_ALLOC(dev_alloc(&h->dRowTab, (size_t)std::max(h->capRowTab, 1)));
     TRY_ALLOC(dev_alloc(&h->dIn, (size_t)cfg->max_width * cfg->max_height));
     TRY_ALLOC(dev_alloc(&h->dPyr, (size_t)h->capArena * B));
     TRY_ALLOC(dev_alloc(&h->dBlur, (size_t)h->capArena * B));
@@ -332,7 +349,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     auto stage_a = [&](const ImgSrc &ps, int n, hipStream_t s, int side) -> int {
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         launch_pyr0(h->dP, P, ps, n, s);
-        for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, l, n, s);
+        for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
         launch_frame_cols(h->dP, P, ps, n, s);
         if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
         hipStream_t bs = serial ? s : (side ? h->partSide[side - 1] : h->sideStream);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, I
 // (the kernel is latency-bound: two dependent table -> pixel round trips per wave).
 constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
-                                                const int16_t *__restrict__ coef, int level) {
+                                                const int16_t *__restrict__ coef, const RowTap *__restrict__ rowTab, int level) {
     const DevLevel &D = P->lv[level];
     const DevLevel &S = P->lv[level - 1];
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
@@ -90,21 +90,18 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
     uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
-    const int16_t *yofs = coef + D.coefY, *ya = yofs + D.h;
+    // per output row (frame rows included): the two source rows and the vertical taps come ready from a host-built table (the mirrored
+    // row, the clamps and the row pitch products are the same for every lane of every frame)
     const uint8_t *r0p[kResizeRows], *r1p[kResizeRows];
-    int b0[kResizeRows], b1[kResizeRows];
+    uint32_t bh0[kResizeRows], bh1[kResizeRows];
     bool live[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) {
         const int oy = oyBase + r;
         live[r] = oy < D.h + kFrameRows;
-        const int dy = reflect101(live[r] ? oy : 0, D.h);
-        const int sy = yofs[dy];
-        b0[r] = ya[dy * 2]; b1[r] = ya[dy * 2 + 1];
-        const int sy0 = sy >= 0 ? (sy < S.h ? sy : S.h - 1) : 0;
-        const int sy1r = sy + 1;
-        const int sy1 = sy1r >= 0 ? (sy1r < S.h ? sy1r : S.h - 1) : 0;
-        r0p[r] = sb + (long long)sy0 * S.pitch; r1p[r] = sb + (long long)sy1 * S.pitch;
+        const RowTap t = rowTab[D.rowTab + (live[r] ? oy : 0) + kFrameRows];
+        r0p[r] = sb + t.off0; r1p[r] = sb + t.off1;
+        bh0[r] = t.bh0; bh1[r] = t.bh1;
     }
     const bool whole = ox + 3 < D.w;
     const int sx0 = xofs[ox];
@@ -135,8 +132,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
-            // vertical taps pre-shifted: (b * x) >> 16 == mulhi(b << 16, x) for the non-negative operands here (b <= 2048, x <= 32 640)
-            const uint32_t bh0 = (uint32_t)b0[r] << 16, bh1 = (uint32_t)b1[r] << 16;
+            // vertical taps come pre-shifted: (b * x) >> 16 == mulhi(b << 16, x) for the non-negative operands here (b <= 2048, x <= 32 640)
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -144,7 +140,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
                 const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(s1[r] >> 32), (uint32_t)s1[r], sel[i]);
                 const uint32_t q0 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
                 const uint32_t q1 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                packed |= ((__umulhi(bh0, q0 >> 4) + __umulhi(bh1, q1 >> 4) + 2u) >> 2) << (8 * i);
+                packed |= ((__umulhi(bh0[r], q0 >> 4) + __umulhi(bh1[r], q1 >> 4) + 2u) >> 2) << (8 * i);
             }
             if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
@@ -164,7 +160,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
                     q0 = r0p[r][sx] * 2048;
                     q1 = r1p[r][sx] * 2048;
                 }
-                packed |= (uint32_t)((((b0[r] * (q0 >> 4)) >> 16) + ((b1[r] * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+                packed |= (uint32_t)(((((int)(bh0[r] >> 16) * (q0 >> 4)) >> 16) + (((int)(bh1[r] >> 16) * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
             }
             *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
@@ -715,10 +711,10 @@ void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int
     dim3 g(((hP.lv[0].h + 2 * kFrameRows) * 3 + 255) / 256, hP.nlevels, nframes);
     hipLaunchKernelGGL(k_frame_cols, g, dim3(256), 0, st, dP, src);
 }
-void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, int level, int nframes,
+void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st) {
     dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kFrameRows + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
-    hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, level);
+    hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st) {
