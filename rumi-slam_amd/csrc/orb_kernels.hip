@@ -301,15 +301,20 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
             pass = fast_quick_pair(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, tlow + 1);
             if (px + 1 >= dw) pass &= 5;                // second pixel of the pair lies outside the detection region
         }
-        // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1)
-        const unsigned long long b0 = __ballot(pass & 1), b1 = __ballot(pass & 4), b2 = __ballot(pass & 2), b3 = __ballot(pass & 8);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        int pos = head + pending + __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
+        // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1).  A lane adds
+        // 0..4 entries: the exclusive prefix of that count over the lanes comes from three bit-plane ballots (v_mbcnt) instead of four
+        // per-flag ballots with a masked popcount each
+        const int cnt = __popc(pass);
+        const unsigned long long c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
+        const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c0, 0u));
+        const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c1, 0u));
+        const int p2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c2, 0u));
+        int pos = head + pending + p0 + 2 * p1 + 4 * p2;
         if (pass & 1) cl[pos++ & 511] = (uint16_t)idx;
         if (pass & 4) cl[pos++ & 511] = (uint16_t)(idx | 0x8000);
         if (pass & 2) cl[pos++ & 511] = (uint16_t)(idx + 1);
         if (pass & 8) cl[pos & 511] = (uint16_t)((idx + 1) | 0x8000);
-        pending += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        pending += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
         while (pending >= 64) {                        // a full wave of entries: score them exactly
             wave_lds_fence();
             const int e = cl[(head + lane) & 511];
