@@ -509,6 +509,12 @@ constexpr int kBlurRows = 16;
 
 // all levels in one launch: workgroup `lin` of a frame belongs to the level whose [base, base + gx * gy) range holds it
 struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; };
+// a * b + c on 24-bit operands as ONE v_mad_u32_u24 (the compiler splits the C expression into a multiply and a 3-input add)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -562,10 +568,10 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
                 for (int i = 0; i < 4; i++) {
                     // rounding constant folded into the first multiply-add; the result's byte 2 is the output pixel (sum <= 255 * 65536 + 32768)
                     // row sums are <= 65 280 and their pairs <= 130 560: 24-bit multiply-adds (v_mad_u32_u24: tap and accumulation in one instruction)
-                    uint32_t acc = __umul24(56u, (uint32_t)ring[(j + 4) % 7][i]) + 32768u;
-                    acc += __umul24(48u, (uint32_t)(ring[(j + 3) % 7][i] + ring[(j + 5) % 7][i]));
-                    acc += __umul24(34u, (uint32_t)(ring[(j + 2) % 7][i] + ring[(j + 6) % 7][i]));
-                    acc += __umul24(18u, (uint32_t)(ring[(j + 1) % 7][i] + ring[j][i]));
+                    uint32_t acc = mad_u24(56u, (uint32_t)ring[(j + 4) % 7][i], 32768u);
+                    acc = mad_u24(48u, (uint32_t)(ring[(j + 3) % 7][i] + ring[(j + 5) % 7][i]), acc);
+                    acc = mad_u24(34u, (uint32_t)(ring[(j + 2) % 7][i] + ring[(j + 6) % 7][i]), acc);
+                    acc = mad_u24(18u, (uint32_t)(ring[(j + 1) % 7][i] + ring[j][i]), acc);
                     o[i] = acc;
                 }
                 // byte 2 of the four sums -> one dword (v_perm_b32: selectors 0-3 take from the second operand, 4-7 from the first, 0x0c = zero);
