@@ -542,12 +542,14 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
     const int yEnd = min(y0 + kBlurRows, h), rEnd = yEnd + 3;
     // the walk is unrolled by seven so that the ring never moves: source row r0 + j lands in slot j, and the taps of the output row it
     // completes sit at compile-time slots (a runtime ring costs 24 register moves per row)
+    const uint8_t *row = img + (long long)(y0 - 3) * pitch - pitch;   // running pointers: one add per row instead of a 64-bit multiply-add
+    uint8_t *orow = out + (long long)(y0 - 6) * L.pitch + xa - L.pitch;
     for (int r0 = y0 - 3; r0 < rEnd; r0 += 7) {
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int r = r0 + j;
             if (r >= rEnd) break;                                // wave-uniform
-            const uint8_t *row = img + (long long)r * pitch;     // rows -3..-1 and h..h+2 are frame rows
+            row += pitch; orow += L.pitch;                       // rows -3..-1 and h..h+2 are frame rows
             const uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
             uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
             if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
                 // byte 2 of the four sums -> one dword (v_perm_b32: selectors 0-3 take from the second operand, 4-7 from the first, 0x0c = zero);
                 // the blurred arena has the same framed geometry, so a whole dword always fits in the row
                 const uint32_t p01 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
-                *reinterpret_cast<uint32_t *>(out + (long long)y * L.pitch + xa) = p01 | p23;
+                *reinterpret_cast<uint32_t *>(orow) = p01 | p23;         // orow = out + y * pitch + xa
             }
         }
     }
