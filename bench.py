@@ -128,7 +128,9 @@ def main():
     def step():
         kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap)
         # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
-        match = bruteforce_batch(desc, counts, torch.roll(desc, -1, 0), torch.roll(counts, -1, 0))
+        # (views of the extractor's output: the successor of frame i is the same buffer one record further, no copy; the last pair wraps)
+        match = (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
+                 bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
         if world > 1:
             # the path's one exchange step: every GPU ends up with all key-points / descriptors.  It is launched
             # here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of step i
