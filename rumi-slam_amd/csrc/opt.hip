@@ -51,6 +51,36 @@ template <int NV> __device__ __forceinline__ void block_sum(double (&v)[NV], dou
     for (int k = 0; k < NV; k++) v[k] = (red[k] + red[NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
 }
 
+// The same for up to 64 values per thread by a butterfly that halves the values a lane carries at every step (a lane ends with ONE
+// value summed over its wave): PAD - 1 shuffles instead of 6 per value, then one LDS round for the four waves.  PAD = 32 or 64 slots
+// (NV rounded up); red: 5 * PAD doubles.
+template <int NV> __device__ __forceinline__ void block_sum_butterfly(double (&v)[NV], double *red) {
+    static_assert(NV <= 64, "at most 64 values");
+    constexpr int PAD = NV <= 32 ? 32 : 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double w[PAD];
+#pragma unroll
+    for (int k = 0; k < PAD; k++) w[k] = k < NV ? v[k] : 0.0;
+#pragma unroll
+    for (int d = 32, n = PAD / 2; n >= 1; d >>= 1, n >>= 1) {   // lanes with bit d keep the upper n values, the others the lower n
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double send = up ? w[i] : w[i + n], keep = up ? w[i + n] : w[i];
+            w[i] = keep + __shfl_xor(send, d);
+        }
+    }
+    int idx = lane;
+    if (PAD == 32) { w[0] += __shfl_xor(w[0], 1); idx = lane >> 1; }      // 32 slots: lane pairs hold the same slot
+    __syncthreads();
+    if (PAD == 64 || (lane & 1) == 0) red[wave * PAD + idx] = w[0];
+    __syncthreads();
+    if (threadIdx.x < PAD) red[4 * PAD + threadIdx.x] = (red[threadIdx.x] + red[PAD + threadIdx.x]) + (red[2 * PAD + threadIdx.x] + red[3 * PAD + threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = red[4 * PAD + k];
+}
+
 template <int N> __device__ __forceinline__ bool chol_solve_packed(const double *H /*upper N(N+1)/2, row-major packed*/, double lambda, const double *b, double *x) {
     double A[N][N];
     int p = 0;
@@ -96,7 +126,7 @@ struct PoseArgs {
 constexpr int kPoseLdsEdges = 1024;
 template <bool LDS>
 __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
-    __shared__ double red[4 * 28];
+    __shared__ double red[160];
     __shared__ float sXw[LDS ? 3 * kPoseLdsEdges : 1], sObs[LDS ? 2 * kPoseLdsEdges : 1], sW[LDS ? kPoseLdsEdges : 1];
     __shared__ double sChi[LDS ? kPoseLdsEdges : 1];
     __shared__ uint8_t sAct[LDS ? kPoseLdsEdges : 1];
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                     for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
                 }
-                block_sum<28>(hb, red);
+                block_sum_butterfly<28>(hb, red);
                 double currentChi = hb[27];
                 const double iniChi = currentChi;
                 if (itl == 0) {                                            // computeLambdaInit: tau * max |H_jj|
@@ -1064,7 +1094,7 @@ struct Sim3Args {
 };
 
 __global__ __launch_bounds__(256) void k_sim3_opt(Sim3Args A) {
-    __shared__ double red[4 * 36];
+    __shared__ double red[5 * 64];
     const int tid = threadIdx.x, n = A.n, np = A.world ? A.nPairs : 1;
     const DCam cam1{A.K1[0], A.K1[1], A.K1[2], A.K1[3]}, cam2{A.K2[0], A.K2[1], A.K2[2], A.K2[3]};
     const double delta = (double)sqrtf(A.th2), dsqr = delta * delta, th2 = (double)A.th2;
@@ -1179,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_sim3_opt(Sim3Args A) {
                     for (int a = 0; a < 7; a++) hb[28 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
                 }
             }
-            block_sum<36>(hb, red);
+            block_sum_butterfly<36>(hb, red);
             double currentChi = hb[35];
             const double iniChi = currentChi;
             if (itl == 0) {
