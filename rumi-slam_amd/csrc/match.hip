@@ -1063,6 +1063,8 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
     }
     if (F->n > 0) { H2D(m->dKeys, F->keys_un, F->n); H2D(m->dDesc, F->desc, (size_t)F->n * 32); }
     H2D(m->dScale, F->scale_factors, F->nlevels);
+    static const int32_t kZeroHeader[4] = {0, 0, 0, 0};     // result header [nmatches | list overflow | - | -]: cleared by the same scatter
+    H2D(m->dOut, kZeroHeader, 4);
     fd->n = F->n; fd->keys = m->dKeys; fd->desc = m->dDesc;
     fd->minX = F->min_x; fd->minY = F->min_y; fd->maxX = F->max_x; fd->maxY = F->max_y;
     fd->wInv = (float)kGridCols / (float)(F->max_x - F->min_x);     // Frame.cc:322-323
@@ -1074,9 +1076,9 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
 
 // count pass, scan, fill pass.  The fill pass refuses to write past the list arena and raises the overflow word instead; the
 // caller sees it in the result block, grows the arena and repeats the call (run_search) — no mid-pipeline read-back.
-static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc) {
+static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, bool retry) {
     FLUSH(m);
-    HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));
+    if (retry) HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));   // the first attempt's header was cleared with the frame upload
     if (nq > 0) {
         hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists, 0, m->dOverflow);
@@ -1106,7 +1108,7 @@ static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, cons
                       float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
                       float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
     for (int attempt = 0; attempt < 2; attempt++) {
-        const int rcl = build_lists(m, mode, nq, fd, dQueryDesc);
+        const int rcl = build_lists(m, mode, nq, fd, dQueryDesc, attempt > 0);
         if (rcl != RUMI_OK) return rcl;
         ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
                       nnratio, checkOri, dBlocked0, thrF, thrI, m->dOverflow};
@@ -1423,7 +1425,7 @@ extern "C" int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFea
     FLUSH(m);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, nullptr, n1, m->dQKeys, m->dF[0], (float)window_size, m->dQ);
     for (int attempt = 0; attempt < 2; attempt++) {
-        rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc);
+        rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc, attempt > 0);
         if (rc != RUMI_OK) return rc;
         InitArgs A{n1, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dAssign, m->dF[0], m->dNmatches, nnratio, check_orientation,
                    m->dOverflow};
