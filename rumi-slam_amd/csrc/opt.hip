@@ -575,6 +575,11 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 constexpr int kPW = 8;
 // USE_LDS is a template parameter so that every access keeps a static address space (a runtime select would make A a
 // generic pointer and turn each LDS access into a flat_load / flat_store).
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const double *G, int NP, double *Aglob) {
     extern __shared__ double sa[];
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
             for (int q = 0; q < 4; q++) { const int i = tid + 64 * q; row[q] = i < j ? A[(size_t)j * ld + i] : 0.0; }
             const double rdj = rdg[j];
             const double ysel = jq == 0 ? y[0] : jq == 1 ? y[1] : jq == 2 ? y[2] : y[3];
-            const double xj = __shfl(ysel, jl) * rdj;
+            const double xj = readlane_f64(ysel, jl) * rdj;        // jl is wave-uniform: a readlane, not an LDS-routed shuffle
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 y[q] -= row[q] * xj;
@@ -793,10 +798,6 @@ __global__ __launch_bounds__(256) void k_big_schur(BADev B, const int32_t *blk, 
     if (multi) atomicAdd(dst, -acc); else *dst -= acc;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
 
 // diagonal block [j0, j0 + w) in LDS, sub-panels of 8 columns: wave 0 factors the 8 x 8 sub-diagonal in registers (every lane the same
 // values: a chain of 36 dependent steps instead of 8 LDS round trips), lane i solves row i against it and publishes the row's eight entries;
