@@ -1564,18 +1564,23 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     if (big) {
         if ((size_t)n * 8 > 120 * 1024) { g_lastError = "bundle adjustment: more than 2560 optimised key-frames"; return RUMI_E_CAPACITY; }
         // observation pairs of every landmark grouped by Schur block (ca, cb <= ca): counting sort over the blocks
+        std::vector<int32_t> colAt((size_t)std::max(nE, 1));             // column block of the t-th entry of ptEdge (-1 fixed)
+        for (int t = 0; t < nE; t++) colAt[t] = poseCol[e_kf[ptEdge[t]]];
         std::vector<int64_t> cnt((size_t)nOpt * nOpt + 1, 0);
         auto for_pairs = [&](auto &&f) {
-            for (int p = 0; p < nMP; p++)
-                for (int ia = ptStart[p]; ia < ptStart[p + 1]; ia++) {
-                    const int ea = ptEdge[ia], ca = poseCol[e_kf[ea]];
+            for (int p = 0; p < nMP; p++) {
+                const int t0 = ptStart[p], t1 = ptStart[p + 1];
+                for (int ia = t0; ia < t1; ia++) {
+                    const int ca = colAt[ia];
                     if (ca < 0) continue;
-                    for (int ib = ptStart[p]; ib < ptStart[p + 1]; ib++) {
-                        const int eb = ptEdge[ib], cb = poseCol[e_kf[eb]];
-                        if (cb < 0 || cb > ca || (cb == ca && eb != ea)) continue;
-                        f((size_t)ca * nOpt + cb, ea, eb);
+                    const size_t rowKey = (size_t)ca * nOpt;
+                    for (int ib = t0; ib < t1; ib++) {
+                        const int cb = colAt[ib];
+                        if (cb < 0 || cb > ca || (cb == ca && ib != ia)) continue;
+                        f(rowKey + cb, ia, ib);
                     }
                 }
+            }
         };
         for_pairs([&](size_t key, int, int) { cnt[key + 1]++; });
         std::vector<int32_t> blk;
@@ -1590,7 +1595,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         const int64_t nPairs = cnt[(size_t)nOpt * nOpt];
         if (nPairs > (int64_t)1 << 30) { g_lastError = "bundle adjustment: more than 2^30 co-observation pairs"; return RUMI_E_CAPACITY; }
         std::vector<int32_t> pairs((size_t)std::max<int64_t>(nPairs, 1) * 2);
-        for_pairs([&](size_t key, int ea, int eb) { const int64_t at = cnt[key]++; pairs[2 * at] = ea; pairs[2 * at + 1] = eb; });
+        for_pairs([&](size_t key, int ia, int ib) { const int64_t at = cnt[key]++; pairs[2 * at] = ptEdge[ia]; pairs[2 * at + 1] = ptEdge[ib]; });
         nBlocks = (int)(blk.size() / 4);
         const size_t need = (blk.size() + pairs.size()) * sizeof(int32_t);
         if (need > o->pairCap) {
