@@ -199,6 +199,22 @@ __device__ __forceinline__ int quadrants_open(const OctNode &nd) { return (nd.cn
 // nodes and pushes their children to the front then becomes: children (in reverse creation order) ++ surviving old nodes (in
 // their old order) — two prefix sums and a scatter, done by the whole workgroup.  Only the std::sort replay of the fine
 // rounds stays on one lane (its tie order is libstdc++'s introsort, orb_octree.h).
+// One LDS atomic per DISTINCT key of the wave instead of one per lane: the key-points of a level arrive in cell order, so the 64 of a wave
+// fall into a handful of nodes / quadrants, and in the first rounds ALL of them hit the same two or three counters (64 serialised
+// updates per instruction; the passes over the keys took 10 us each at level 0 of a 640 x 480 frame, 3 us now).
+// key < 0: the lane has nothing to add; lanes with equal keys must pass the same word and the same increment.
+__device__ __forceinline__ void wave_agg_add(int key, unsigned int *word, unsigned int one) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long mk = __ballot(key == k0);
+        if (lane == leader) atomicAdd(word, one * (unsigned int)__popcll(mk));
+        todo &= ~mk;
+    }
+}
+
 __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
                                                         const int32_t *__restrict__ levelStart, uint16_t *__restrict__ owner,
                                                         uint32_t *__restrict__ selLevel, int32_t *__restrict__ selLevelCnt,
@@ -261,10 +277,11 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
     if (tid == 0) { sNFree = cap - nIni; sNSplit = 0; sOverflow = 0; sPhase = 0; sNOpen = 0; }
     __syncthreads();
     // :564-567  keys -> roots
-    for (int i = tid; i < n; i += NT) {
-        const int r = (int)((float)cand_x(c[i]) / hX);
-        own[i] = (uint16_t)r;
-        atomicAdd(&sRootN[r], 1u);
+    for (int i0 = 0; i0 < n; i0 += NT) {               // uniform trip count: the aggregation below uses wave-wide ballots
+        const int i = i0 + tid;
+        int r = -1;
+        if (i < n) { r = (int)((float)cand_x(c[i]) / hX); own[i] = (uint16_t)r; }
+        wave_agg_add(r, &sRootN[r < 0 ? 0 : r], 1u);
     }
     __syncthreads();
     if (tid == 0) {                                // :570-578: empty roots leave the list (their ids are simply not reused)
@@ -279,12 +296,15 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
     }
     __syncthreads();
     // quadrant populations of the roots
-    for (int i = tid; i < n; i += NT) {
-        OctNode &nd = nodes[own[i]];
-        if (!nd.noMore) {
-            const int q = oct_quadrant(nd, cand_x(c[i]), cand_y(c[i]));
-            atomicAdd(reinterpret_cast<unsigned int *>(&nd.cnt[q & 2]), 1u << (16 * (q & 1)));
+    for (int i0 = 0; i0 < n; i0 += NT) {
+        const int i = i0 + tid;
+        int key = -1, q = 0, id = 0;
+        if (i < n) {
+            id = own[i];
+            const OctNode &nd = nodes[id];
+            if (!nd.noMore) { q = oct_quadrant(nd, cand_x(c[i]), cand_y(c[i])); key = id * 4 + q; }
         }
+        wave_agg_add(key, reinterpret_cast<unsigned int *>(&nodes[id].cnt[q & 2]), 1u << (16 * (q & 1)));
     }
     __syncthreads();
 
@@ -385,27 +405,22 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
         }
         __syncthreads();
         { uint16_t *t = A; A = B; B = t; }
-        // relabel keys of divided nodes, count inside the new owners; four keys per trip so that their owner / key loads are in flight
-        // together (in the fine rounds few nodes are divided and the pass is one global round trip per key otherwise)
-        for (int i0 = tid; i0 < n; i0 += 4 * NT) {
-            int ids[4];
-            uint32_t ck[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * NT; ids[u] = i < n ? own[i] : -1; ck[u] = i < n ? c[i] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int id = ids[u];
-                if (id < 0 || !nodes[id].split) continue;
-                const int i = i0 + u * NT;
-                const int x = cand_x(ck[u]), y = cand_y(ck[u]);
-                id = nodes[id].child[oct_quadrant(nodes[id], x, y)];
-                own[i] = (uint16_t)id;
-                OctNode &nd = nodes[id];
-                if (!nd.noMore) {
-                    const int q = oct_quadrant(nd, x, y);
-                    atomicAdd(reinterpret_cast<unsigned int *>(&nd.cnt[q & 2]), 1u << (16 * (q & 1)));
+        // relabel keys of divided nodes, count inside the new owners (one LDS atomic per distinct (node, quadrant) of the wave)
+        for (int i0 = 0; i0 < n; i0 += NT) {
+            const int i = i0 + tid;
+            int key = -1, q = 0, id = 0;
+            if (i < n) {
+                id = own[i];
+                if (nodes[id].split) {
+                    const uint32_t ck = c[i];
+                    const int x = cand_x(ck), y = cand_y(ck);
+                    id = nodes[id].child[oct_quadrant(nodes[id], x, y)];
+                    own[i] = (uint16_t)id;
+                    const OctNode &nd = nodes[id];
+                    if (!nd.noMore) { q = oct_quadrant(nd, x, y); key = id * 4 + q; }
                 }
             }
+            wave_agg_add(key, reinterpret_cast<unsigned int *>(&nodes[id].cnt[q & 2]), 1u << (16 * (q & 1)));
         }
         __syncthreads();
         {                                           // divided nodes return to the free stack
