@@ -201,7 +201,7 @@ __device__ __forceinline__ int quadrants_open(const OctNode &nd) { return (nd.cn
 // rounds stays on one lane (its tie order is libstdc++'s introsort, orb_octree.h).
 // One LDS atomic per DISTINCT key of the wave instead of one per lane: the key-points of a level arrive in cell order, so the 64 of a wave
 // fall into a handful of nodes / quadrants, and in the first rounds ALL of them hit the same two or three counters (64 serialised
-// updates per instruction; the passes over the keys took 10 us each at level 0 of a 640 x 480 frame, 3 us now).
+// updates per instruction otherwise).
 // key < 0: the lane has nothing to add; lanes with equal keys must pass the same word and the same increment.
 __device__ __forceinline__ void wave_agg_add(int key, unsigned int *word, unsigned int one) {
     const int lane = threadIdx.x & 63;
@@ -215,12 +215,60 @@ __device__ __forceinline__ void wave_agg_add(int key, unsigned int *word, unsign
     }
 }
 
-__global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
-                                                        const int32_t *__restrict__ levelStart, uint16_t *__restrict__ owner,
-                                                        uint32_t *__restrict__ selLevel, int32_t *__restrict__ selLevelCnt,
-                                                        int selLevelCap, int32_t *__restrict__ errFlag) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int sPhase, sM, sNOpen, sNFree, sNSplit, sOverflow, sRootId[kMaxRoots];
+constexpr int kKeysPerLane = 24;   // levels with at most kKeysPerLane * kOctThreads (12288) keys keep keys and owners in registers
+
+// The keys of one level, walked by the whole workgroup with a UNIFORM trip count (wave_agg_add ballots inside the visitor).
+// REG: every lane holds keys i = k * NT + tid and their owners in registers — the level is read from HBM/L2 once, with all loads
+// in flight together, and the passes of the rounds below cost LDS + VALU only (a pass over keys in memory paid one dependent L2
+// round trip per 512 keys: 6-10 us per pass at level 0 of a 640 x 480 frame, seven passes).  !REG: keys stay in memory, owners in owner[].
+template <bool REG>
+struct OctKeys {
+    uint32_t ck[REG ? kKeysPerLane : 1];
+    uint32_t ow[REG ? kKeysPerLane : 1];
+    const uint32_t *c;
+    uint16_t *own;
+    int n;
+    __device__ __forceinline__ void load() {
+        if constexpr (REG) {
+#pragma unroll
+            for (int k = 0; k < kKeysPerLane; k++) {
+                const int i = k * kOctThreads + (int)threadIdx.x;
+                ck[k] = i < n ? c[i] : 0u;
+                ow[k] = 0;
+            }
+        }
+    }
+    // f(i, valid, key, owner&): owner may be rewritten
+    template <class F>
+    __device__ __forceinline__ void for_each(F f) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int k = 0; k < kKeysPerLane; k++) {
+                if (k * kOctThreads >= n) break;
+                const int i = k * kOctThreads + (int)threadIdx.x;
+                int o = (int)ow[k];
+                f(i, i < n, ck[k], o);
+                ow[k] = (uint32_t)o;
+            }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += kOctThreads) {
+                const int i = i0 + (int)threadIdx.x;
+                const bool valid = i < n;
+                const int o0 = valid ? (int)own[i] : 0;
+                int o = o0;
+                f(i, valid, valid ? c[i] : 0u, o);
+                if (valid && o != o0) own[i] = (uint16_t)o;
+            }
+        }
+    }
+};
+
+template <bool REG>
+__device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
+                                             const int32_t *__restrict__ levelStart, uint16_t *__restrict__ owner,
+                                             uint32_t *__restrict__ selLevel, int32_t *__restrict__ selLevelCnt,
+                                             int selLevelCap, int32_t *__restrict__ errFlag, unsigned char *lds) {
+    __shared__ int sPhase, sM, sNOpen, sNFree, sNSplit, sOverflow;
     __shared__ unsigned int sRootN[kMaxRoots];
     __shared__ unsigned long long sWave[kOctThreads / 64];
     __shared__ int sSortCount[2];
@@ -229,9 +277,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
     const int tid = threadIdx.x, level = blockIdx.x, frame = blockIdx.y;
     const DevLevel &L = P->lv[level];
     const int32_t *ls = levelStart + (long long)frame * (kMaxLevels + 1);
-    const int n = ls[level + 1] - ls[level];
-    const uint32_t *c = cand + (long long)frame * P->totalCand + ls[level];
-    uint16_t *own = owner + (long long)frame * P->totalCand + ls[level];
+    OctKeys<REG> keys;
+    keys.n = ls[level + 1] - ls[level];
+    keys.c = cand + (long long)frame * P->totalCand + ls[level];
+    keys.own = owner + (long long)frame * P->totalCand + ls[level];
+    const int n = keys.n;
+    const uint32_t *c = keys.c;
     uint32_t *out = selLevel + ((long long)frame * P->nlevels + level) * selLevelCap;
     int32_t *outCnt = selLevelCnt + (long long)frame * P->nlevels + level;
     if (n <= 0) {
@@ -245,6 +296,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
         if (tid == 0) { *outCnt = 0; atomicOr(errFlag, 1); }
         return;
     }
+    keys.load();
     const float hX = (float)W / nIni;
     const int cap = octree_pool_cap(N, nIni);
 
@@ -272,17 +324,23 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
         r.n = 0; r.noMore = 0; r.split = 0;
         r.cnt[0] = r.cnt[1] = r.cnt[2] = r.cnt[3] = 0;
         r.child[0] = r.child[1] = r.child[2] = r.child[3] = kNil;
-        sRootId[tid] = tid;
     }
     if (tid == 0) { sNFree = cap - nIni; sNSplit = 0; sOverflow = 0; sPhase = 0; sNOpen = 0; }
     __syncthreads();
-    // :564-567  keys -> roots
-    for (int i0 = 0; i0 < n; i0 += NT) {               // uniform trip count: the aggregation below uses wave-wide ballots
-        const int i = i0 + tid;
-        int r = -1;
-        if (i < n) { r = (int)((float)cand_x(c[i]) / hX); own[i] = (uint16_t)r; }
-        wave_agg_add(r, &sRootN[r < 0 ? 0 : r], 1u);
-    }
+    // :564-567  keys -> roots, and in the same pass the quadrant populations of the roots (a root that turns out to hold one key
+    // is never divided, its counts are not read)
+    keys.for_each([&](int, bool valid, uint32_t ck, int &o) {
+        int r = -1, q = 0;
+        if (valid) {
+            const int x = cand_x(ck);
+            r = (int)((float)x / hX);
+            o = r;
+            q = oct_quadrant(nodes[r], x, cand_y(ck));
+        }
+        const int rr = r < 0 ? 0 : r;
+        wave_agg_add(r, &sRootN[rr], 1u);
+        wave_agg_add(r < 0 ? -1 : r * 4 + q, reinterpret_cast<unsigned int *>(&nodes[rr].cnt[q & 2]), 1u << (16 * (q & 1)));
+    });
     __syncthreads();
     if (tid == 0) {                                // :570-578: empty roots leave the list (their ids are simply not reused)
         int m = 0;
@@ -293,18 +351,6 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
             if (r.n != 0) A[m++] = (uint16_t)i;
         }
         sM = m;
-    }
-    __syncthreads();
-    // quadrant populations of the roots
-    for (int i0 = 0; i0 < n; i0 += NT) {
-        const int i = i0 + tid;
-        int key = -1, q = 0, id = 0;
-        if (i < n) {
-            id = own[i];
-            const OctNode &nd = nodes[id];
-            if (!nd.noMore) { q = oct_quadrant(nd, cand_x(c[i]), cand_y(c[i])); key = id * 4 + q; }
-        }
-        wave_agg_add(key, reinterpret_cast<unsigned int *>(&nodes[id].cnt[q & 2]), 1u << (16 * (q & 1)));
     }
     __syncthreads();
 
@@ -405,23 +451,19 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
         }
         __syncthreads();
         { uint16_t *t = A; A = B; B = t; }
+        if (sPhase == 2) break;                     // the last relabelling is folded into the selection pass below
         // relabel keys of divided nodes, count inside the new owners (one LDS atomic per distinct (node, quadrant) of the wave)
-        for (int i0 = 0; i0 < n; i0 += NT) {
-            const int i = i0 + tid;
+        keys.for_each([&](int, bool valid, uint32_t ck, int &o) {
             int key = -1, q = 0, id = 0;
-            if (i < n) {
-                id = own[i];
-                if (nodes[id].split) {
-                    const uint32_t ck = c[i];
-                    const int x = cand_x(ck), y = cand_y(ck);
-                    id = nodes[id].child[oct_quadrant(nodes[id], x, y)];
-                    own[i] = (uint16_t)id;
-                    const OctNode &nd = nodes[id];
-                    if (!nd.noMore) { q = oct_quadrant(nd, x, y); key = id * 4 + q; }
-                }
+            if (valid && nodes[o].split) {
+                const int x = cand_x(ck), y = cand_y(ck);
+                id = nodes[o].child[oct_quadrant(nodes[o], x, y)];
+                o = id;
+                const OctNode &nd = nodes[id];
+                if (!nd.noMore) { q = oct_quadrant(nd, x, y); key = id * 4 + q; }
             }
             wave_agg_add(key, reinterpret_cast<unsigned int *>(&nodes[id].cnt[q & 2]), 1u << (16 * (q & 1)));
-        }
+        });
         __syncthreads();
         {                                           // divided nodes return to the free stack
             const int ns = sNSplit, nf = sNFree;
@@ -430,15 +472,19 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
             if (tid == 0) { sNFree = nf + ns; sNSplit = 0; }
         }
         __syncthreads();
-        if (sPhase == 2) break;
     }
-    // :705-721  best key of every node, nodes in list order
+    // :705-721  best key of every node, nodes in list order; the keys of the nodes divided in the last round move to their
+    // children on the way (best shares its word with the quadrant counts of the surviving nodes, hence the clearing first)
     const int m = sM;
     if (tid == 0 && sOverflow) atomicOr(errFlag, 2);
     for (int r = tid; r < m; r += NT) nodes[A[r]].best = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT)
-        atomicMax(&nodes[own[i]].best, ((uint32_t)cand_score(c[i]) << 16) | (uint32_t)(0xFFFF - i));
+    keys.for_each([&](int i, bool valid, uint32_t ck, int &o) {
+        if (valid) {
+            if (nodes[o].split) o = nodes[o].child[oct_quadrant(nodes[o], cand_x(ck), cand_y(ck))];
+            atomicMax(&nodes[o].best, ((uint32_t)cand_score(ck) << 16) | (uint32_t)(0xFFFF - i));
+        }
+    });
     __syncthreads();
     if (m > selLevelCap) {
         if (tid == 0) { *outCnt = 0; atomicOr(errFlag, 4); }
@@ -446,6 +492,25 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
     }
     for (int r = tid; r < m; r += NT) out[r] = c[0xFFFF - (int)(nodes[A[r]].best & 0xFFFF)];
     if (tid == 0) *outCnt = m;
+}
+
+// REGS: levels of up to kKeysPerLane * kOctThreads keys run with their keys in registers (166 VGPRs: one workgroup per CU, the
+// latency of one (frame, level) is what counts — small batches); !REGS: 69 VGPRs, three workgroups per CU hide each other's L2
+// round trips (large batches).  launch_octree picks by the number of workgroups.
+template <bool REGS>
+__global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
+                                                        const int32_t *__restrict__ levelStart, uint16_t *__restrict__ owner,
+                                                        uint32_t *__restrict__ selLevel, int32_t *__restrict__ selLevelCnt,
+                                                        int selLevelCap, int32_t *__restrict__ errFlag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if constexpr (REGS) {
+        const int32_t *ls = levelStart + (long long)blockIdx.y * (kMaxLevels + 1);
+        if (ls[blockIdx.x + 1] - ls[blockIdx.x] <= kKeysPerLane * kOctThreads) {
+            octree_level<true>(P, cand, levelStart, owner, selLevel, selLevelCnt, selLevelCap, errFlag, lds);
+            return;
+        }
+    }
+    octree_level<false>(P, cand, levelStart, owner, selLevel, selLevelCnt, selLevelCap, errFlag, lds);
 }
 
 // Concatenate levels, assign slots: in (level, list) order, key-points with lap0 <= x*scale <= lap1 fill the
@@ -543,10 +608,13 @@ void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *can
                    int nframes, size_t ldsBytes, hipStream_t st) {
     static size_t attrSet = 0;
     if (ldsBytes > attrSet) {   // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         attrSet = ldsBytes;
     }
-    hipLaunchKernelGGL(k_octree, dim3(hP.nlevels, nframes), dim3(kOctThreads), ldsBytes, st, dP, cand, levelStart, owner, selLevel,
+    static const int forced = [] { const char *e = getenv("RUMI_OCT_REGS"); return e ? atoi(e) : -1; }();
+    const bool regs = forced >= 0 ? forced != 0 : hP.nlevels * nframes <= 256;   // at most one workgroup per CU
+    hipLaunchKernelGGL(regs ? k_octree<true> : k_octree<false>, dim3(hP.nlevels, nframes), dim3(kOctThreads), ldsBytes, st, dP, cand, levelStart, owner, selLevel,
                        selLevelCnt, selLevelCap, errFlag);
 }
 void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,

@@ -197,3 +197,18 @@ def test_featureless_and_saturated_frames():
     _assert_same(g(sat, None, (0, 1000)), o.extract(sat, (0, 1000)), "saturated blobs")
     few = synth_frame(21, n_rect=6, noise=0)
     _assert_same(g(few, None, (0, 1000)), o.extract(few, (0, 1000)), "few candidates")
+
+
+def test_level_with_more_keys_than_the_register_path_holds():
+    """One 800 x 600 frame of white noise: level 0 alone has more than 24 x 512 FAST keys, so the quadtree workgroup of a single-frame
+    call (register-resident keys, orb_octree_kernel.hip) takes its keys-in-memory route for that level and the register route
+    for the upper ones; both must reproduce the oracle's selection and order."""
+    g, o = _pair(nf=2000, w=800, h=600)
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (600, 800), dtype=np.uint8)
+    gout, oout = g(img, None, (0, 1000)), o.extract(img, (0, 1000))
+    assert len(g.stage_keypoints(0, 0)) > 24 * 512
+    assert 0 < len(g.stage_keypoints(3, 0)) <= 24 * 512
+    _assert_same(gout, oout, "noise 800x600")
+    for l in range(8):
+        assert g.stage_keypoints(l, 1).tobytes() == o.keypoints(l, True).tobytes(), f"selected key-points level {l}"
