@@ -251,13 +251,23 @@ struct OctKeys {
                 ow[k] = (uint32_t)o;
             }
         } else {
-            for (int i0 = 0; i0 < n; i0 += kOctThreads) {
-                const int i = i0 + (int)threadIdx.x;
-                const bool valid = i < n;
-                const int o0 = valid ? (int)own[i] : 0;
-                int o = o0;
-                f(i, valid, valid ? c[i] : 0u, o);
-                if (valid && o != o0) own[i] = (uint16_t)o;
+            for (int i0 = 0; i0 < n; i0 += 4 * kOctThreads) {            // four trips' loads in flight together
+                uint32_t k4[4];
+                int o4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * kOctThreads + (int)threadIdx.x;
+                    k4[u] = i < n ? c[i] : 0u;
+                    o4[u] = i < n ? (int)own[i] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i0 + u * kOctThreads >= n) break;
+                    const int i = i0 + u * kOctThreads + (int)threadIdx.x;
+                    int o = o4[u];
+                    f(i, i < n, k4[u], o);
+                    if (i < n && o != o4[u]) own[i] = (uint16_t)o;
+                }
             }
         }
     }
