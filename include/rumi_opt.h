@@ -98,6 +98,35 @@ int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_t *pair_sta
                       const float *kp2, const float *sigma2_1, const float *sigma2_2, const uint8_t *edge1, const uint8_t *edge2,
                       uint8_t *inlier_out, float *ratio_out, float *median_out);
 
+/* The alignment-score data of Sim3Solver::ComputeInliersNum (see rumi_sim3_inliers) for the hypotheses of rumi_sim3_ransac: instead of the
+ * composed transforms the caller passes g2o::Sim3(R, t, 1.0) of the two key-frames of every pair (Sim3Solver.cc:596-597) and of the solver's
+ * own key-frames mpKF1 / mpKF2 (:342-343), as (qx qy qz qw tx ty tz s) doubles; the composition with every hypothesis happens on the device. */
+typedef struct RumiSim3ScoreSet {
+    int32_t n_pairs;
+    const int32_t *pair_start, *pair_denominator;
+    const double *S_c1w1, *S_c2w2;
+    const double *S_kf1w, *S_kf2w;
+    const float *K4_1, *K4_2, *X1, *X2, *kp1, *kp2, *sigma2_1, *sigma2_2;
+    const uint8_t *edge1, *edge2;
+} RumiSim3ScoreSet;
+
+/* Sim3Solver::iterate — R/lib_src/Sim3Solver.cc:159-220, :222-290 and the rumination overload :292-404 (CloudMerging.cc:717): the hypotheses of one
+ * block of RANSAC iterations evaluated together, one workgroup each.  The n correspondences are those the constructor keeps (:78-126): both points in
+ * their own camera frames (mvX3Dc1 / mvX3Dc2) and mvLevelSigma2 at the two key-points' octaves (mvnMaxError = 9.210 * sigma2, truncated to
+ * size_t as upstream's vector<size_t> does; mvP1im1 / mvP2im2 are re-projected on the device, :128-129).  triples[3h..3h+2] = the minimal set of
+ * hypothesis h, drawn by the caller exactly as :181-191 (DUtils::Random::RandomInt over the shrinking vAvailableIndices) — the draws do not depend on
+ * earlier results, so a block of iterations is data-parallel and the caller replays the sequential "best so far / converged" logic of :198-214,
+ * :277-283 or :349-373 over the per-hypothesis outputs (rumi_slam_amd.sim3solver.Sim3Solver, facade/Sim3Solver.h).
+ * Per hypothesis: ComputeSim3 (:437-540, Horn 1987) and CheckInliers (:542-562); with score != NULL also ComputeInliersNum (:564-664) under
+ * gSw1w2 = gSc1w^-1 * gSc1c2 * gSc2w (:338-347).  T12_out[h] = {mR12i row-major (9), mt12i (3), ms12i, valid, 0, 0}: valid = 0 marks the
+ * degenerate set on which upstream returns early and keeps the previous iteration's transform (:493-494); n_inliers_out[h] = mnInliersi;
+ * inlier_out [n_hyp][n] (may be NULL) = mvbInliersi; ratio_out [n_hyp][n_pairs] (may be NULL), median_out [n_hyp] = the returned ratio.
+ * Upstream solves the 4x4 eigen-problem with Eigen::EigenSolver<Matrix4f> (not in the tree); here: Jacobi rotations in double on the same
+ * float matrix — the transforms agree to float rounding, not bit for bit ("parity unpinned"). */
+int rumi_sim3_ransac(RumiOptimizer *o, int32_t n, const float *X3Dc1, const float *X3Dc2, const float *sigma2_1, const float *sigma2_2,
+                     const float *K4_1, const float *K4_2, int32_t fix_scale, int32_t n_hyp, const int32_t *triples, const RumiSim3ScoreSet *score,
+                     float *T12_out, int32_t *n_inliers_out, uint8_t *inlier_out, float *ratio_out, float *median_out);
+
 /* Optimizer::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale, mAcumHessian, bAllPoints) — R/lib_src/Optimizer.cc:1920-2167
  * (LoopClosing.cc:522,728, CloudMerging.cc:965,1169) and Optimizer::OptimizeCloudSim3(map1KFs, map2KFs, avpMatches, gSw1w2, th2, bFixScale,
  * mAcumHessian, bAllPoints) — :2169-2471 (CloudMerging.cc:803): Levenberg-Marquardt over ONE Sim3 vertex with numeric Jacobians,

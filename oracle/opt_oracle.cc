@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -738,6 +739,145 @@ float orc_sim3_inliers(int nPairs, const int32_t *pairStart, const int32_t *pair
     if (ratioOut) std::memcpy(ratioOut, ratios.data(), ratios.size() * sizeof(float));
     std::sort(ratios.begin(), ratios.end());
     return ratios[ratios.size() / 2];
+}
+
+// ---- Sim3Solver::iterate, one hypothesis at a time (R/lib_src/Sim3Solver.cc:159-404; layout: include/rumi_opt.h, rumi_sim3_ransac) ----------
+// The minimal sets: nHyp x 3 indices drawn as :176-191 does, with DUtils::Random::RandomInt (Thirdparty/DBoW2/DUtils/Random.cpp:47-50) on this
+// process's glibc rand() (the caller seeds it, as DUtils::Random::SeedRandOnce(0) does upstream).
+void orc_sim3_draw_triples(int n, int nHyp, int32_t *triples) {
+    std::vector<int32_t> all(n), avail;
+    for (int i = 0; i < n; i++) all[i] = i;                                  // mvAllIndices
+    for (int h = 0; h < nHyp; h++) {
+        avail = all;
+        for (int i = 0; i < 3; i++) {
+            const int d = (int)avail.size();                                 // RandomInt(0, size - 1)
+            const int randi = int(((double)rand() / ((double)RAND_MAX + 1.0)) * d);
+            triples[h * 3 + i] = avail[randi];
+            avail[randi] = avail.back();
+            avail.pop_back();
+        }
+    }
+}
+
+// dominant eigenvector of a symmetric 4x4 matrix (Horn 1987 step 4); classical Jacobi: annihilate the largest off-diagonal entry until none is left.
+// Upstream: Eigen::EigenSolver<Matrix4f> (:477-481) — a third-party routine that is not in the tree; its result is the same vector up to sign and float
+// rounding, the rotation built from it does not depend on the sign.
+static void dominant_eigvec4(double a[4][4], double out[4]) {
+    double v[4][4] = {};
+    for (int i = 0; i < 4; i++) v[i][i] = 1;
+    for (int it = 0; it < 200; it++) {
+        int p = 0, q = 1;
+        double big = 0;
+        for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (std::fabs(a[i][j]) > big) { big = std::fabs(a[i][j]); p = i; q = j; }
+        if (big < 1e-290) break;
+        const double phi = 0.5 * std::atan2(2 * a[p][q], a[q][q] - a[p][p]);
+        const double c = std::cos(phi), sn = std::sin(phi);
+        for (int k = 0; k < 4; k++) { const double x = a[k][p], y = a[k][q]; a[k][p] = c * x - sn * y; a[k][q] = sn * x + c * y; }
+        for (int k = 0; k < 4; k++) { const double x = a[p][k], y = a[q][k]; a[p][k] = c * x - sn * y; a[q][k] = sn * x + c * y; }
+        for (int k = 0; k < 4; k++) { const double x = v[k][p], y = v[k][q]; v[k][p] = c * x - sn * y; v[k][q] = sn * x + c * y; }
+        if (big < 1e-18 * (std::fabs(a[0][0]) + std::fabs(a[1][1]) + std::fabs(a[2][2]) + std::fabs(a[3][3]))) break;
+    }
+    int best = 0;
+    for (int i = 1; i < 4; i++) if (a[i][i] > a[best][best]) best = i;
+    for (int k = 0; k < 4; k++) out[k] = v[k][best];
+}
+
+void orc_sim3_ransac(int n, const float *X1, const float *X2, const float *sigma2_1, const float *sigma2_2, const float *K1, const float *K2, int fixScale,
+                     int nHyp, const int32_t *triples,
+                     int nPairs, const int32_t *pairStart, const int32_t *pairDenom, const double *Sc1w1, const double *Sc2w2, const double *Skf1w,
+                     const double *Skf2w, const float *sK1, const float *sK2, const float *sX1, const float *sX2, const float *kp1, const float *kp2,
+                     const float *sg1, const float *sg2, const uint8_t *e1, const uint8_t *e2,
+                     float *T12out, int32_t *nInOut, uint8_t *inlierOut, float *ratioOut, float *medianOut) {
+    for (int h = 0; h < nHyp; h++) {
+        // ComputeSim3 :437-540 (float members, double where upstream declares doubles)
+        float P1[3][3], P2[3][3], O1[3], O2[3], Pr1[3][3], Pr2[3][3];
+        for (int i = 0; i < 3; i++) for (int r = 0; r < 3; r++) { P1[r][i] = X1[triples[h * 3 + i] * 3 + r]; P2[r][i] = X2[triples[h * 3 + i] * 3 + r]; }
+        for (int r = 0; r < 3; r++) {
+            O1[r] = (P1[r][0] + P1[r][1] + P1[r][2]) / 3.f; O2[r] = (P2[r][0] + P2[r][1] + P2[r][2]) / 3.f;
+            for (int i = 0; i < 3; i++) { Pr1[r][i] = P1[r][i] - O1[r]; Pr2[r][i] = P2[r][i] - O2[r]; }
+        }
+        float M[3][3];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { float acc = 0; for (int k = 0; k < 3; k++) acc += Pr2[r][k] * Pr1[c][k]; M[r][c] = acc; }
+        const double N11 = M[0][0] + M[1][1] + M[2][2], N12 = M[1][2] - M[2][1], N13 = M[2][0] - M[0][2], N14 = M[0][1] - M[1][0];
+        const double N22 = M[0][0] - M[1][1] - M[2][2], N23 = M[0][1] + M[1][0], N24 = M[2][0] + M[0][2];
+        const double N33 = -M[0][0] + M[1][1] - M[2][2], N34 = M[1][2] + M[2][1], N44 = -M[0][0] - M[1][1] + M[2][2];
+        const float Nf[4][4] = {{(float)N11, (float)N12, (float)N13, (float)N14}, {(float)N12, (float)N22, (float)N23, (float)N24},
+                                {(float)N13, (float)N23, (float)N33, (float)N34}, {(float)N14, (float)N24, (float)N34, (float)N44}};
+        double Nd[4][4], ev[4];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Nd[i][j] = Nf[i][j];
+        dominant_eigvec4(Nd, ev);
+        float vec[3] = {(float)ev[1], (float)ev[2], (float)ev[3]};
+        const float e0 = (float)ev[0];
+        const float nrm = std::sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+        const bool valid = !(vec[0] == 0 && vec[1] == 0 && vec[2] == 0);
+        float R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, s12 = 1.f, t12[3] = {0, 0, 0};
+        if (valid) {
+            const double ang = std::atan2((double)nrm, (double)e0);
+            const float f = (float)(2 * ang);
+            for (int k = 0; k < 3; k++) vec[k] = vec[k] * f / nrm;
+            const float thSq = vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2];           // Sophus::SO3f::exp
+            float im, re;
+            if (thSq < 1e-5f * 1e-5f) { const float th4 = thSq * thSq; im = 0.5f - (1.f / 48.f) * thSq + (1.f / 3840.f) * th4; re = 1.f - (1.f / 8.f) * thSq + (1.f / 384.f) * th4; }
+            else { const float th = std::sqrt(thSq); im = std::sin(0.5f * th) / th; re = std::cos(0.5f * th); }
+            const float q[4] = {im * vec[0], im * vec[1], im * vec[2], re};                 // x y z w
+            const float tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+            R[0][0] = 1 - (ty * q[1] + tz * q[2]); R[0][1] = ty * q[0] - tz * q[3]; R[0][2] = tz * q[0] + ty * q[3];
+            R[1][0] = ty * q[0] + tz * q[3]; R[1][1] = 1 - (tx * q[0] + tz * q[2]); R[1][2] = tz * q[1] - tx * q[3];
+            R[2][0] = tz * q[0] - ty * q[3]; R[2][1] = tz * q[1] + tx * q[3]; R[2][2] = 1 - (tx * q[0] + ty * q[1]);
+            if (!fixScale) {
+                float nom = 0, den = 0;
+                for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) {
+                    float p3 = 0;
+                    for (int k = 0; k < 3; k++) p3 += R[r][k] * Pr2[k][c];
+                    nom += Pr1[r][c] * p3; den += p3 * p3;
+                }
+                s12 = (float)((double)nom / (double)den);
+            }
+            for (int r = 0; r < 3; r++) { float acc = 0; for (int k = 0; k < 3; k++) acc += (s12 * R[r][k]) * O2[k]; t12[r] = O1[r] - acc; }
+        }
+        float T12[3][4], T21[3][4];
+        const float sinv = (float)(1.0 / s12);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { T12[r][c] = s12 * R[r][c]; T21[r][c] = sinv * R[c][r]; } T12[r][3] = t12[r]; }
+        for (int r = 0; r < 3; r++) { float acc = 0; for (int k = 0; k < 3; k++) acc += T21[r][k] * t12[k]; T21[r][3] = -acc; }
+        float *To = T12out + (size_t)h * 16;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) To[r * 3 + c] = R[r][c];
+        To[9] = t12[0]; To[10] = t12[1]; To[11] = t12[2]; To[12] = s12; To[13] = valid ? 1.f : 0.f; To[14] = To[15] = 0.f;
+        // CheckInliers :542-562
+        int nIn = 0;
+        for (int i = 0; i < n; i++) {
+            const float *a = X1 + (size_t)i * 3, *b = X2 + (size_t)i * 3;
+            auto proj = [](const float *K, const float *p, float &u, float &v) { u = K[0] * p[0] / p[2] + K[2]; v = K[1] * p[1] / p[2] + K[3]; };   // Pinhole.cpp:43-49
+            float u1, v1, u2, v2, pu, pv, ru, rv, p[3], r[3];
+            proj(K1, a, u1, v1); proj(K2, b, u2, v2);
+            for (int k = 0; k < 3; k++) {
+                p[k] = T12[k][0] * b[0] + T12[k][1] * b[1] + T12[k][2] * b[2] + T12[k][3];
+                r[k] = T21[k][0] * a[0] + T21[k][1] * a[1] + T21[k][2] * a[2] + T21[k][3];
+            }
+            proj(K1, p, pu, pv); proj(K2, r, ru, rv);
+            const float err1 = (u1 - pu) * (u1 - pu) + (v1 - pv) * (v1 - pv), err2 = (ru - u2) * (ru - u2) + (rv - v2) * (rv - v2);
+            const size_t m1 = (size_t)(9.210 * sigma2_1[i]), m2 = (size_t)(9.210 * sigma2_2[i]);      // Sim3Solver.h:77-78 vector<size_t>
+            const bool in = err1 < m1 && err2 < m2;
+            if (inlierOut) inlierOut[(size_t)h * n + i] = in;
+            nIn += in;
+        }
+        nInOut[h] = nIn;
+        if (nPairs > 0) {                                                                          // :338-348
+            double Rd[3][3];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rd[r][c] = R[r][c];
+            const Sim3 Sc1c2{quat_from_R(Rd), {(double)t12[0], (double)t12[1], (double)t12[2]}, (double)s12};
+            auto from8 = [](const double *S) { return Sim3{{S[0], S[1], S[2], S[3]}, {S[4], S[5], S[6]}, S[7]}; };
+            const Sim3 Sw1w2 = sim3_mul(sim3_mul(sim3_inverse(from8(Skf1w)), Sc1c2), from8(Skf2w));
+            std::vector<double> A((size_t)nPairs * 8), B((size_t)nPairs * 8);
+            auto to8 = [](const Sim3 &S, double *o) { o[0] = S.r.x; o[1] = S.r.y; o[2] = S.r.z; o[3] = S.r.w; o[4] = S.t.x; o[5] = S.t.y; o[6] = S.t.z; o[7] = S.s; };
+            for (int p = 0; p < nPairs; p++) {
+                to8(sim3_mul(from8(Sc1w1 + (size_t)p * 8), Sw1w2), &A[(size_t)p * 8]);              // gSc1w2 :621
+                to8(sim3_mul(from8(Sc2w2 + (size_t)p * 8), sim3_inverse(Sw1w2)), &B[(size_t)p * 8]); // gSc2w1 :620
+            }
+            std::vector<uint8_t> inl((size_t)std::max(pairStart[nPairs], 1));
+            medianOut[h] = orc_sim3_inliers(nPairs, pairStart, pairDenom, A.data(), B.data(), sK1, sK2, sX1, sX2, kp1, kp2, sg1, sg2, e1, e2, inl.data(),
+                                            ratioOut ? ratioOut + (size_t)h * nPairs : nullptr);
+        }
+    }
 }
 
 // Optimizer::OptimizeSim3 / OptimizeCloudSim3 on flat arrays (layout: include/rumi_opt.h, rumi_optimize_sim3).  One entry per

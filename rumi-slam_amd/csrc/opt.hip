@@ -1124,6 +1124,180 @@ __global__ void k_sim3_inliers(int total, const int32_t *pairOf, const double *S
 
 
 // ==================================================================================================================
+// Sim3Solver::iterate (R/lib_src/Sim3Solver.cc:159-404): the hypotheses of one block of RANSAC iterations, one workgroup each.
+// Lane 0 forms the hypothesis from its three correspondences (ComputeSim3 :437-540: Horn's closed form; float arithmetic as upstream
+// up to the 4x4 matrix N, whose dominant eigenvector comes from a cyclic Jacobi iteration in double — upstream calls Eigen's general
+// EigenSolver<Matrix4f>, which is not in the tree: "parity unpinned"), then the workgroup runs CheckInliers (:542-562)
+// over all correspondences and, for the rumination overload (:292-404), ComputeInliersNum (:564-664) under
+// gSw1w2 = gSc1w^-1 * gSc1c2 * gSc2w (:344-347) over every matched key-point pair of every key-frame pair.
+// ==================================================================================================================
+struct RansacArgs {
+    int n, nHyp, fixScale;
+    const float *X1, *X2, *thr1, *thr2, *K1, *K2;
+    const int32_t *tri;
+    float *T12; int32_t *nIn; uint8_t *inl;
+    int nPairs, total;                                            // score set (total == 0: none)
+    const int32_t *pairOf; const double *Sc1w1, *Sc2w2, *Skf;
+    const float *sK1, *sK2, *sX1, *sX2, *kp1, *kp2, *sg1, *sg2; const uint8_t *e1, *e2;
+    int32_t *pairCnt; double *comp;
+};
+
+// dominant eigenvector (largest eigenvalue) of a symmetric 4x4 matrix: cyclic Jacobi rotations
+__device__ inline void sym4_dominant_eigenvector(double a[4][4], double q[4]) {
+    double v[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; p++)
+            for (int r = p + 1; r < 4; r++) {
+                if (a[p][r] == 0) continue;
+                const double theta = (a[r][r] - a[p][p]) / (2 * a[p][r]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < 4; k++) { const double x = a[k][p], y = a[k][r]; a[k][p] = c * x - sn * y; a[k][r] = sn * x + c * y; }
+                for (int k = 0; k < 4; k++) { const double x = a[p][k], y = a[r][k]; a[p][k] = c * x - sn * y; a[r][k] = sn * x + c * y; }
+                for (int k = 0; k < 4; k++) { const double x = v[k][p], y = v[k][r]; v[k][p] = c * x - sn * y; v[k][r] = sn * x + c * y; }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; i++) if (a[i][i] > a[best][best]) best = i;
+    for (int k = 0; k < 4; k++) q[k] = v[k][best];
+}
+
+__global__ __launch_bounds__(256) void k_sim3_ransac(RansacArgs A) {
+    __shared__ float sT12[12], sT21[12];      // rows of [sR | t]
+    __shared__ int sCnt;
+    __shared__ DSim3 sSw1w2;
+    const int h = blockIdx.x, tid = threadIdx.x;
+    float *Tout = A.T12 + (size_t)h * 16;
+    if (tid == 0) {
+        sCnt = 0;
+        float P1[3][3], P2[3][3];                                  // column i = correspondence i (:185-188)
+        for (int i = 0; i < 3; i++) {
+            const int idx = A.tri[h * 3 + i];
+            for (int r = 0; r < 3; r++) { P1[r][i] = A.X1[idx * 3 + r]; P2[r][i] = A.X2[idx * 3 + r]; }
+        }
+        float O1[3], O2[3], Pr1[3][3], Pr2[3][3];                  // ComputeCentroid :430-435
+        for (int r = 0; r < 3; r++) {
+            O1[r] = ((P1[r][0] + P1[r][1]) + P1[r][2]) / 3.f;
+            O2[r] = ((P2[r][0] + P2[r][1]) + P2[r][2]) / 3.f;
+            for (int i = 0; i < 3; i++) { Pr1[r][i] = P1[r][i] - O1[r]; Pr2[r][i] = P2[r][i] - O2[r]; }
+        }
+        float M[3][3];                                             // Pr2 * Pr1^T :453
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r][c] = (Pr2[r][0] * Pr1[c][0] + Pr2[r][1] * Pr1[c][1]) + Pr2[r][2] * Pr1[c][2];
+        const double N11 = M[0][0] + M[1][1] + M[2][2], N12 = M[1][2] - M[2][1], N13 = M[2][0] - M[0][2], N14 = M[0][1] - M[1][0],
+                     N22 = M[0][0] - M[1][1] - M[2][2], N23 = M[0][1] + M[1][0], N24 = M[2][0] + M[0][2], N33 = -M[0][0] + M[1][1] - M[2][2],
+                     N34 = M[1][2] + M[2][1], N44 = -M[0][0] - M[1][1] + M[2][2];
+        // upstream stores N in a Matrix4f: the solver sees the float-rounded entries
+        double Nm[4][4] = {{(float)N11, (float)N12, (float)N13, (float)N14}, {(float)N12, (float)N22, (float)N23, (float)N24},
+                           {(float)N13, (float)N23, (float)N33, (float)N34}, {(float)N14, (float)N24, (float)N34, (float)N44}};
+        double q[4];
+        sym4_dominant_eigenvector(Nm, q);
+        const float e0 = (float)q[0];
+        float vec[3] = {(float)q[1], (float)q[2], (float)q[3]};
+        const float nrm = sqrtf((vec[0] * vec[0] + vec[1] * vec[1]) + vec[2] * vec[2]);
+        int valid = !(vec[0] == 0 && vec[1] == 0 && vec[2] == 0);   // :493-494 upstream keeps the previous iteration's transform
+        float R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, s12 = 1.f, t12[3] = {0, 0, 0};
+        if (valid) {
+            const double ang = atan2((double)nrm, (double)e0);
+            const float f = (float)(2 * ang);
+            for (int k = 0; k < 3; k++) vec[k] = vec[k] * f / nrm;   // angle-axis; the quaternion angle is the half
+            // Sophus::SO3f::exp(vec).matrix()
+            const float th2 = (vec[0] * vec[0] + vec[1] * vec[1]) + vec[2] * vec[2], th = sqrtf(th2), half = 0.5f * th;
+            float im, re;
+            if (th < 1e-5f) { const float th4 = th2 * th2; im = 0.5f - (1.f / 48.f) * th2 + (1.f / 3840.f) * th4; re = 1.f - (1.f / 8.f) * th2 + (1.f / 384.f) * th4; }
+            else { im = sinf(half) / th; re = cosf(half); }
+            const float qx = im * vec[0], qy = im * vec[1], qz = im * vec[2], qw = re;
+            const float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz, twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx,
+                        tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+            R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+            R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+            R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+            if (!A.fixScale) {                                      // :503-520
+                double nom = 0, den = 0;
+                float P3[3][3];
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) P3[r][c] = (R[r][0] * Pr2[0][c] + R[r][1] * Pr2[1][c]) + R[r][2] * Pr2[2][c];
+                float fn = 0, fd = 0;                               // Eigen's float array sums, column-major order
+                for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) { fn += Pr1[r][c] * P3[r][c]; fd += P3[r][c] * P3[r][c]; }
+                nom = fn; den = fd;
+                s12 = (float)(nom / den);
+            }
+            for (int r = 0; r < 3; r++) {                           // mt12i = O1 - ms12i * mR12i * O2
+                const float ro = ((s12 * R[r][0]) * O2[0] + (s12 * R[r][1]) * O2[1]) + (s12 * R[r][2]) * O2[2];
+                t12[r] = O1[r] - ro;
+            }
+        }
+        const float sinv = (float)(1.0 / s12);
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) { sT12[r * 4 + c] = s12 * R[r][c]; sT21[r * 4 + c] = sinv * R[c][r]; }
+            sT12[r * 4 + 3] = t12[r];
+        }
+        for (int r = 0; r < 3; r++) sT21[r * 4 + 3] = -((sT21[r * 4 + 0] * t12[0] + sT21[r * 4 + 1] * t12[1]) + sT21[r * 4 + 2] * t12[2]);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Tout[r * 3 + c] = R[r][c];
+        Tout[9] = t12[0]; Tout[10] = t12[1]; Tout[11] = t12[2]; Tout[12] = s12; Tout[13] = (float)valid; Tout[14] = 0; Tout[15] = 0;
+        if (A.total > 0) {                                          // :338-347
+            double Rd[3][3];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rd[r][c] = (double)R[r][c];
+            const DSim3 Sc1c2{quat_from_matrix(Rd), {(double)t12[0], (double)t12[1], (double)t12[2]}, (double)s12};
+            sSw1w2 = sim3_mul(sim3_mul(sim3_inverse(sim3_from8(A.Skf)), Sc1c2), sim3_from8(A.Skf + 8));
+        }
+    }
+    __syncthreads();
+    // CheckInliers :542-562 (float, as upstream)
+    const float fx1 = A.K1[0], fy1 = A.K1[1], cx1 = A.K1[2], cy1 = A.K1[3], fx2 = A.K2[0], fy2 = A.K2[1], cx2 = A.K2[2], cy2 = A.K2[3];
+    int mine = 0;
+    for (int i = tid; i < A.n; i += 256) {
+        const float *a = A.X1 + (size_t)i * 3, *b = A.X2 + (size_t)i * 3;
+        const float u1 = fx1 * a[0] / a[2] + cx1, v1 = fy1 * a[1] / a[2] + cy1;            // mvP1im1
+        const float u2 = fx2 * b[0] / b[2] + cx2, v2 = fy2 * b[1] / b[2] + cy2;            // mvP2im2
+        float p[3], r[3];
+        for (int k = 0; k < 3; k++) {
+            p[k] = ((sT12[k * 4] * b[0] + sT12[k * 4 + 1] * b[1]) + sT12[k * 4 + 2] * b[2]) + sT12[k * 4 + 3];   // point 2 in camera 1
+            r[k] = ((sT21[k * 4] * a[0] + sT21[k * 4 + 1] * a[1]) + sT21[k * 4 + 2] * a[2]) + sT21[k * 4 + 3];   // point 1 in camera 2
+        }
+        const float d1x = u1 - (fx1 * p[0] / p[2] + cx1), d1y = v1 - (fy1 * p[1] / p[2] + cy1);
+        const float d2x = (fx2 * r[0] / r[2] + cx2) - u2, d2y = (fy2 * r[1] / r[2] + cy2) - v2;
+        const float err1 = d1x * d1x + d1y * d1y, err2 = d2x * d2x + d2y * d2y;
+        const bool in = err1 < A.thr1[i] && err2 < A.thr2[i];
+        if (A.inl) A.inl[(size_t)h * A.n + i] = in;
+        mine += in;
+    }
+    if (mine) atomicAdd(&sCnt, mine);
+    __syncthreads();
+    if (tid == 0) A.nIn[h] = sCnt;
+    if (A.total <= 0) return;
+    // ComputeInliersNum :564-664 under this hypothesis
+    double *comp = A.comp + (size_t)h * A.nPairs * 16;
+    int32_t *cnt = A.pairCnt + (size_t)h * A.nPairs;
+    for (int p = tid; p < A.nPairs; p += 256) {
+        sim3_to8(sim3_mul(sim3_from8(A.Sc1w1 + (size_t)p * 8), sSw1w2), comp + (size_t)p * 16);                       // gSc1w2 :621
+        sim3_to8(sim3_mul(sim3_from8(A.Sc2w2 + (size_t)p * 8), sim3_inverse(sSw1w2)), comp + (size_t)p * 16 + 8);     // gSc2w1 :620
+        cnt[p] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto reproj2 = [](const double *S, const float *K, const float *X, const float *kp) -> float {
+        const DQuat q{S[0], S[1], S[2], S[3]};
+        const D3 r = quat_rotate(q, D3{(double)X[0], (double)X[1], (double)X[2]});
+        const double s = S[7];
+        const double px = s * r.x + S[4], py = s * r.y + S[5], pz = s * r.z + S[6];
+        const float u = (float)((double)K[0] * px / pz + (double)K[2]), v = (float)((double)K[1] * py / pz + (double)K[3]);
+        const float dx = kp[0] - u, dy = kp[1] - v;
+        return dx * dx + dy * dy;
+    };
+    for (int i = tid; i < A.total; i += 256) {
+        const int pr = A.pairOf[i];
+        const float err1 = reproj2(comp + (size_t)pr * 16, A.sK1, A.sX2 + (size_t)i * 3, A.kp1 + (size_t)i * 2);
+        const float err2 = reproj2(comp + (size_t)pr * 16 + 8, A.sK2, A.sX1 + (size_t)i * 3, A.kp2 + (size_t)i * 2);
+        const bool ok1 = (double)err1 < 2 * 9.210 * (double)A.sg1[i] || A.e2[i];
+        const bool ok2 = (double)err2 < 2 * 9.210 * (double)A.sg2[i] || A.e1[i];
+        if (ok1 && ok2) atomicAdd(&cnt[pr], 1);
+    }
+}
+
+
+// ==================================================================================================================
 // OptimizeSim3 / OptimizeCloudSim3 (R/lib_src/Optimizer.cc:1920-2167, :2169-2471): one Sim3 vertex, fixed points, two reprojection
 // edges per correspondence, numeric Jacobians (G/core/base_binary_edge.hpp:131-203, delta 1e-9, through VertexSim3Expmap::oplusImpl).
 // One 256-thread workgroup runs both optimize() calls.  The transform an edge applies depends only on its key-frame pair and on the
@@ -1830,6 +2004,87 @@ extern "C" int rumi_sim3_inliers(RumiOptimizer *o, int32_t n_pairs, const int32_
     if (ratio_out) std::memcpy(ratio_out, ratio.data(), (size_t)n_pairs * sizeof(float));
     std::sort(ratio.begin(), ratio.end());                                    // :654-662
     *median_out = ratio[n_pairs / 2];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_sim3_ransac(RumiOptimizer *o, int32_t n, const float *X3Dc1, const float *X3Dc2, const float *sigma2_1, const float *sigma2_2,
+                                const float *K4_1, const float *K4_2, int32_t fix_scale, int32_t n_hyp, const int32_t *triples,
+                                const RumiSim3ScoreSet *score, float *T12_out, int32_t *n_inliers_out, uint8_t *inlier_out, float *ratio_out,
+                                float *median_out) {
+    if (!o || n < 3 || n_hyp < 0 || !X3Dc1 || !X3Dc2 || !sigma2_1 || !sigma2_2 || !K4_1 || !K4_2 || !T12_out || !n_inliers_out) return RUMI_E_INVALID;
+    if (n_hyp == 0) return RUMI_OK;
+    if (!triples) return RUMI_E_INVALID;
+    for (int i = 0; i < 3 * n_hyp; i++) if (triples[i] < 0 || triples[i] >= n) { g_lastError = "rumi_sim3_ransac: correspondence index out of range"; return RUMI_E_INVALID; }
+    int total = 0, np = 0;
+    if (score) {
+        np = score->n_pairs;
+        if (np < 1 || !score->pair_start || !score->pair_denominator || !score->S_c1w1 || !score->S_c2w2 || !score->S_kf1w || !score->S_kf2w || !score->K4_1 ||
+            !score->K4_2 || !median_out) return RUMI_E_INVALID;
+        total = score->pair_start[np];
+        if (total < 0 || (total > 0 && (!score->X1 || !score->X2 || !score->kp1 || !score->kp2 || !score->sigma2_1 || !score->sigma2_2 || !score->edge1 || !score->edge2)))
+            return RUMI_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(o->device));
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t N = (size_t)n, H = (size_t)n_hyp, T = (size_t)total, NP = (size_t)np;
+    const size_t oX1 = 0, oX2 = al(oX1 + N * 12), oT1 = al(oX2 + N * 12), oT2 = al(oT1 + N * 4), oK = al(oT2 + N * 4), oTri = al(oK + 64), oKf = al(oTri + H * 12),
+                 oA = al(oKf + 128), oB = al(oA + NP * 64), oP = al(oB + NP * 64), sX1 = al(oP + T * 4), sX2 = al(sX1 + T * 12), sK1 = al(sX2 + T * 12),
+                 sK2 = al(sK1 + T * 8), sS1 = al(sK2 + T * 8), sS2 = al(sS1 + T * 4), sE1 = al(sS2 + T * 4), sE2 = al(sE1 + T), inBytes = al(sE2 + T);
+    const size_t rT = 0, rN = al(rT + H * 64), rC = al(rN + H * 4), rI = al(rC + H * NP * 4), outBytes = al(rI + (inlier_out ? H * N : 0)),
+                 rComp = outBytes, scratchEnd = al(rComp + H * NP * 128);
+    if (inBytes > o->baStageCap || scratchEnd > o->baStageCap) { g_lastError = "rumi_sim3_ransac: more correspondences / hypotheses than the optimiser's arenas hold"; return RUMI_E_CAPACITY; }
+    uint8_t *h = o->hBa;
+    std::memcpy(h + oX1, X3Dc1, N * 12); std::memcpy(h + oX2, X3Dc2, N * 12);
+    float *t1 = reinterpret_cast<float *>(h + oT1), *t2 = reinterpret_cast<float *>(h + oT2);
+    for (int i = 0; i < n; i++) {        // mvnMaxError1/2 are vector<size_t> upstream (Sim3Solver.h:77-78): 9.210 * sigma2 truncated, compared as float
+        t1[i] = (float)(size_t)(9.210 * (double)sigma2_1[i]);
+        t2[i] = (float)(size_t)(9.210 * (double)sigma2_2[i]);
+    }
+    std::memcpy(h + oK, K4_1, 16); std::memcpy(h + oK + 16, K4_2, 16);
+    std::memcpy(h + oTri, triples, H * 12);
+    if (score) {
+        std::memcpy(h + oK + 32, score->K4_1, 16); std::memcpy(h + oK + 48, score->K4_2, 16);
+        std::memcpy(h + oKf, score->S_kf1w, 64); std::memcpy(h + oKf + 64, score->S_kf2w, 64);
+        std::memcpy(h + oA, score->S_c1w1, NP * 64); std::memcpy(h + oB, score->S_c2w2, NP * 64);
+        int32_t *pairOf = reinterpret_cast<int32_t *>(h + oP);
+        for (int p = 0; p < np; p++) {
+            if (score->pair_start[p] > score->pair_start[p + 1] || score->pair_start[p] < 0) { g_lastError = "rumi_sim3_ransac: pair_start is not ascending"; return RUMI_E_INVALID; }
+            for (int i = score->pair_start[p]; i < score->pair_start[p + 1]; i++) pairOf[i] = p;
+        }
+        if (total) {
+            std::memcpy(h + sX1, score->X1, T * 12); std::memcpy(h + sX2, score->X2, T * 12); std::memcpy(h + sK1, score->kp1, T * 8); std::memcpy(h + sK2, score->kp2, T * 8);
+            std::memcpy(h + sS1, score->sigma2_1, T * 4); std::memcpy(h + sS2, score->sigma2_2, T * 4); std::memcpy(h + sE1, score->edge1, T); std::memcpy(h + sE2, score->edge2, T);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(o->dBa, h, inBytes, hipMemcpyHostToDevice, nullptr));
+    uint8_t *d = o->dBa, *r = o->dBaOut;
+    RansacArgs A;
+    A.n = n; A.nHyp = n_hyp; A.fixScale = fix_scale != 0;
+    A.X1 = (const float *)(d + oX1); A.X2 = (const float *)(d + oX2); A.thr1 = (const float *)(d + oT1); A.thr2 = (const float *)(d + oT2);
+    A.K1 = (const float *)(d + oK); A.K2 = (const float *)(d + oK + 16); A.tri = (const int32_t *)(d + oTri);
+    A.T12 = (float *)(r + rT); A.nIn = (int32_t *)(r + rN); A.inl = inlier_out ? r + rI : nullptr;
+    A.nPairs = np; A.total = score ? (total > 0 ? total : 0) : 0;
+    A.pairOf = (const int32_t *)(d + oP); A.Sc1w1 = (const double *)(d + oA); A.Sc2w2 = (const double *)(d + oB); A.Skf = (const double *)(d + oKf);
+    A.sK1 = (const float *)(d + oK + 32); A.sK2 = (const float *)(d + oK + 48); A.sX1 = (const float *)(d + sX1); A.sX2 = (const float *)(d + sX2);
+    A.kp1 = (const float *)(d + sK1); A.kp2 = (const float *)(d + sK2); A.sg1 = (const float *)(d + sS1); A.sg2 = (const float *)(d + sS2);
+    A.e1 = d + sE1; A.e2 = d + sE2; A.pairCnt = (int32_t *)(r + rC); A.comp = (double *)(r + rComp);
+    hipLaunchKernelGGL(k_sim3_ransac, dim3(n_hyp), dim3(256), 0, nullptr, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(o->hBa, r, outBytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(T12_out, o->hBa + rT, H * 64);
+    std::memcpy(n_inliers_out, o->hBa + rN, H * 4);
+    if (inlier_out) std::memcpy(inlier_out, o->hBa + rI, H * N);
+    if (score) {                                                              // :643-662 per hypothesis
+        const int32_t *cnt = reinterpret_cast<const int32_t *>(o->hBa + rC);
+        std::vector<float> ratio(np);
+        for (int hh = 0; hh < n_hyp; hh++) {
+            for (int p = 0; p < np; p++) ratio[p] = (total > 0 && score->pair_denominator[p]) ? (float)cnt[(size_t)hh * np + p] / (float)score->pair_denominator[p] : 0.f;
+            if (ratio_out) std::memcpy(ratio_out + (size_t)hh * np, ratio.data(), NP * sizeof(float));
+            std::sort(ratio.begin(), ratio.end());
+            median_out[hh] = ratio[np / 2];
+        }
+    }
     return RUMI_OK;
 }
 

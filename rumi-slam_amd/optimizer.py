@@ -6,8 +6,15 @@ import numpy as np
 
 from . import capi
 
+
+class RumiSim3ScoreSet(C.Structure):
+    """include/rumi_opt.h RumiSim3ScoreSet"""
+    _fields_ = [("n_pairs", C.c_int32)] + [(k, C.c_void_p) for k in ("pair_start", "pair_denominator", "S_c1w1", "S_c2w2", "S_kf1w", "S_kf2w", "K4_1", "K4_2",
+                                                                   "X1", "X2", "kp1", "kp2", "sigma2_1", "sigma2_2", "edge1", "edge2")]
+
+
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
-               "rumi_optimize_sim3", "rumi_opt_stage_ms"]
+               "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms"]
 
 
 def _lib():
@@ -25,6 +32,7 @@ def _lib():
     L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
+    L.rumi_sim3_ransac.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_optimize_sim3.argtypes = [vp, i32, vp, i32] + [vp] * 12 + [C.c_float, i32, i32, vp, vp, vp]
     L._opt_ready = True
     return L
@@ -108,6 +116,36 @@ class Optimizer:
         capi.check(self._lib.rumi_sim3_inliers(self._h, n_pairs, capi.ptr(ps), capi.ptr(pd), capi.ptr(A), capi.ptr(B), *[capi.ptr(a) for a in arrs],
                                                capi.ptr(inl), capi.ptr(ratio), C.byref(med)))
         return med.value, ratio[:n_pairs], inl[:total]
+
+    def Sim3Ransac(self, X3Dc1, X3Dc2, sigma2_1, sigma2_2, K4_1, K4_2, triples, fix_scale=False, score=None, want_inliers=True):
+        """The hypotheses of one block of Sim3Solver::iterate (R/lib_src/Sim3Solver.cc:159-404; include/rumi_opt.h, rumi_sim3_ransac).
+        triples [n_hyp,3] = the minimal sets.  score: None or a dict with the ComputeInliersNum data (pair_start, pair_denominator, S_c1w1, S_c2w2,
+        S_kf1w, S_kf2w, K4_1, K4_2, X1, X2, kp1, kp2, sigma2_1, sigma2_2, edge1, edge2).
+        Returns dict(R [h,3,3], t [h,3], s [h], valid [h], n_inliers [h], inliers [h,n] or None, ratio [h,n_pairs] or None, median [h] or None)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        X1, X2, s1, s2, K1, K2 = f32(X3Dc1).reshape(-1, 3), f32(X3Dc2).reshape(-1, 3), f32(sigma2_1), f32(sigma2_2), f32(K4_1), f32(K4_2)
+        tri = np.ascontiguousarray(triples, np.int32).reshape(-1, 3)
+        n, H = len(X1), len(tri)
+        T = np.zeros((max(H, 1), 16), np.float32); nin = np.zeros(max(H, 1), np.int32)
+        inl = np.zeros((max(H, 1), n), np.uint8) if want_inliers else None
+        sc, keep, ratio, med = None, [], None, None
+        if score is not None:
+            f64 = lambda a: np.ascontiguousarray(a, np.float64)
+            u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+            ps, pd = np.ascontiguousarray(score["pair_start"], np.int32), np.ascontiguousarray(score["pair_denominator"], np.int32)
+            keep = [ps, pd, f64(score["S_c1w1"]), f64(score["S_c2w2"]), f64(score["S_kf1w"]), f64(score["S_kf2w"]), f32(score["K4_1"]), f32(score["K4_2"]),
+                    f32(score["X1"]), f32(score["X2"]), f32(score["kp1"]), f32(score["kp2"]), f32(score["sigma2_1"]), f32(score["sigma2_2"]),
+                    u8(score["edge1"]), u8(score["edge2"])]
+            sc = RumiSim3ScoreSet(len(ps) - 1, *[a.ctypes.data_as(C.c_void_p) for a in keep])
+            ratio = np.zeros((max(H, 1), len(ps) - 1), np.float32); med = np.zeros(max(H, 1), np.float32)
+        P = capi.ptr
+        capi.check(self._lib.rumi_sim3_ransac(self._h, n, P(X1), P(X2), P(s1), P(s2), P(K1), P(K2), int(bool(fix_scale)), H, P(tri),
+                                              C.byref(sc) if sc is not None else None, P(T), P(nin), P(inl) if inl is not None else None,
+                                              P(ratio) if ratio is not None else None, P(med) if med is not None else None))
+        T = T[:H]
+        return dict(R=T[:, :9].reshape(-1, 3, 3).copy(), t=T[:, 9:12].copy(), s=T[:, 12].copy(), valid=T[:, 13] != 0, n_inliers=nin[:H].copy(),
+                    inliers=inl[:H].astype(bool) if inl is not None else None, ratio=ratio[:H] if ratio is not None else None,
+                    median=med[:H] if med is not None else None)
 
     def OptimizeSim3(self, S8, P1c, P2c, obs1, obs2, inv_sigma2_1, inv_sigma2_2, K4_1, K4_2, th2=10.0, fix_scale=False, robust_first_pass=True,
                      pair_of=None, S_c1w=None, S_c2w=None, skip12=None, skip21=None):

@@ -414,6 +414,55 @@ def sim3_inliers(pair_start, pair_denominator, S_c1w2, S_c2w1, K4_1, K4_2, X1, X
     return med, ratio[:n_pairs], inl[:total]
 
 
+def libc_srand(seed):
+    """srand() of the C library this process (and liboracle's rand()) uses."""
+    C.CDLL(None).srand(C.c_uint(int(seed)))
+
+
+def libc_rand():
+    return int(C.CDLL(None).rand())
+
+
+def sim3_draw_triples(seed, n, n_hyp):
+    """srand(seed), then the minimal sets of n_hyp Sim3Solver iterations (orc_sim3_draw_triples)."""
+    L = _olib()
+    L.orc_sim3_draw_triples.restype = None
+    L.orc_sim3_draw_triples.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    tri = np.zeros((n_hyp, 3), np.int32)
+    libc_srand(seed)
+    L.orc_sim3_draw_triples(n, n_hyp, _p(tri))
+    return tri
+
+
+def sim3_ransac(X1, X2, sigma2_1, sigma2_2, K4_1, K4_2, triples, fix_scale=False, score=None):
+    """orc_sim3_ransac: per hypothesis ComputeSim3 + CheckInliers (+ ComputeInliersNum).  Same result dict as Optimizer.Sim3Ransac."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    X1, X2 = f32(X1).reshape(-1, 3), f32(X2).reshape(-1, 3)
+    tri = np.ascontiguousarray(triples, np.int32).reshape(-1, 3)
+    n, H = len(X1), len(tri)
+    T = np.zeros((max(H, 1), 16), np.float32); nin = np.zeros(max(H, 1), np.int32); inl = np.zeros((max(H, 1), n), np.uint8)
+    if score is not None:
+        ps, pd = np.ascontiguousarray(score["pair_start"], np.int32), np.ascontiguousarray(score["pair_denominator"], np.int32)
+        sc = [ps, pd, f64(score["S_c1w1"]), f64(score["S_c2w2"]), f64(score["S_kf1w"]), f64(score["S_kf2w"]), f32(score["K4_1"]), f32(score["K4_2"]),
+              f32(score["X1"]), f32(score["X2"]), f32(score["kp1"]), f32(score["kp2"]), f32(score["sigma2_1"]), f32(score["sigma2_2"]), u8(score["edge1"]),
+              u8(score["edge2"])]
+        npairs = len(ps) - 1
+        ratio = np.zeros((max(H, 1), npairs), np.float32); med = np.zeros(max(H, 1), np.float32)
+    else:
+        sc, npairs, ratio, med = [None] * 16, 0, None, None
+    L = _olib()
+    L.orc_sim3_ransac.restype = None
+    L.orc_sim3_ransac.argtypes = [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 16 + [C.c_void_p] * 5
+    arrs = [X1, X2, f32(sigma2_1), f32(sigma2_2), f32(K4_1), f32(K4_2)]
+    L.orc_sim3_ransac(n, *[_p(a) for a in arrs], int(bool(fix_scale)), H, _p(tri), npairs, *[_p(a) if a is not None else None for a in sc],
+                      _p(T), _p(nin), _p(inl), _p(ratio) if ratio is not None else None, _p(med) if med is not None else None)
+    T = T[:H]
+    return dict(R=T[:, :9].reshape(-1, 3, 3).copy(), t=T[:, 9:12].copy(), s=T[:, 12].copy(), valid=T[:, 13] != 0, n_inliers=nin[:H].copy(),
+                inliers=inl[:H].astype(bool), ratio=ratio[:H] if ratio is not None else None, median=med[:H] if med is not None else None)
+
+
 def optimize_sim3(S8, P1c, P2c, obs1, obs2, w1, w2, K4_1, K4_2, th2=10.0, fix_scale=False, robust_first_pass=True, pair_of=None, S_c1w=None,
                   S_c2w=None, skip12=None, skip21=None):
     """orc_optimize_sim3: Optimizer::OptimizeSim3 / OptimizeCloudSim3.  Returns (nIn, nBad, early, S8, status)."""

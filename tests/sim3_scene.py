@@ -72,3 +72,52 @@ def sim3_cloud_problem(seed=0, n_pairs=6, per_pair=150, scale=1.0, outlier_frac=
     return dict(S0=S0, S_true=np.concatenate([qS, tS, [scale]]), pair_of=np.array(pair_of, np.int32), S_c1w=np.stack(A), S_c2w=np.stack(B), P1c=cat(P1c, 3),
                 P2c=cat(P2c, 3), obs1=cat(o1, 2), obs2=cat(o2, 2), w1=cat(w1, 0), w2=cat(w2, 0), K=K_TUM,
                 skip12=(rng.random(n) < edge_frac).astype(np.uint8), skip21=(rng.random(n) < edge_frac).astype(np.uint8))
+
+
+def sim3_ransac_problem(seed=0, n_pairs=5, per_pair=120, n_solver=90, scale=1.25, outlier_frac=0.3):
+    """Sim3Solver::iterate of the sub-map merge: the solver's key-frame pair with matched map points in the two camera frames (a share of
+    them wrong matches), and the score set of ComputeInliersNum: every key-frame pair's matched key-points with the points' world positions."""
+    rng = np.random.default_rng(seed)
+    qS = quat_from_rotvec(np.array([0.05, -0.2, 0.08])); tS = np.array([0.4, -0.2, 0.3]); RS = _R(qS)
+
+    def pair(m):
+        q1 = quat_from_rotvec(rng.normal(size=3) * 0.08); t1 = rng.normal(size=3) * 0.3; R1 = _R(q1)
+        q2 = quat_from_rotvec(rng.normal(size=3) * 0.08); R2 = _R(q2)
+        Pc1 = np.stack([rng.uniform(-1.5, 1.5, m), rng.uniform(-1, 1, m), rng.uniform(3, 8, m)], 1)
+        Pw1 = (Pc1 - t1) @ R1
+        Pw2 = ((Pw1 - tS) @ RS) / scale
+        c2 = Pw2.mean(0) - R2.T @ np.array([0, 0, 5.0 / scale])
+        t2 = -R2 @ c2
+        return np.concatenate([q1, t1, [1.0]]), np.concatenate([q2, t2, [1.0]]), Pc1, Pw1, Pw2, Pw2 @ R2.T + t2
+
+    S1, S2, Pc1, _, _, Pc2 = pair(n_solver)
+    X1 = Pc1 + rng.normal(0, 0.004, Pc1.shape); X2 = Pc2 + rng.normal(0, 0.004, Pc2.shape)
+    bad = rng.random(n_solver) < outlier_frac
+    X2[bad] = np.stack([rng.uniform(-1.5, 1.5, int(bad.sum())), rng.uniform(-1, 1, int(bad.sum())), rng.uniform(2, 6, int(bad.sum()))], 1)
+    sg = lambda m: (np.float32(1.2) ** (2 * rng.integers(0, 8, m))).astype(np.float32)
+    A, B, ps, pd, W1, W2, k1, k2 = [S1], [S2], [0], [], [], [], [], []
+    for p in range(n_pairs):
+        m = per_pair + int(rng.integers(-15, 15))
+        a, b, c1, w1, w2, c2 = pair(m)
+        if p:
+            A.append(a); B.append(b)
+        else:                                   # pair 0 is seen from the solver's own key-frames
+            a, b = S1, S2
+            R1, R2 = _R(S1[:4]), _R(S2[:4])
+            c1, c2 = w1 @ R1.T + S1[4:7], w2 @ R2.T + S2[4:7]
+        o1 = _project(c1) + rng.normal(0, 0.7, (m, 2)); o2 = _project(c2) + rng.normal(0, 0.7, (m, 2))
+        wrong = rng.random(m) < 0.2
+        o2[wrong] += rng.uniform(25, 80, (int(wrong.sum()), 2)) * rng.choice([-1, 1], (int(wrong.sum()), 2))
+        W1.append(w1); W2.append(w2); k1.append(o1); k2.append(o2)
+        ps.append(ps[-1] + m); pd.append(m + int(rng.integers(0, 10)))
+    total = ps[-1]
+    score = dict(pair_start=np.array(ps, np.int32), pair_denominator=np.array(pd, np.int32), S_c1w1=np.stack(A), S_c2w2=np.stack(B), S_kf1w=S1, S_kf2w=S2,
+                 K4_1=K_TUM, K4_2=K_TUM, X1=np.concatenate(W1).astype(np.float32), X2=np.concatenate(W2).astype(np.float32),
+                 kp1=np.concatenate(k1).astype(np.float32), kp2=np.concatenate(k2).astype(np.float32), sigma2_1=sg(total), sigma2_2=sg(total),
+                 edge1=(rng.random(total) < 0.03).astype(np.uint8), edge2=(rng.random(total) < 0.03).astype(np.uint8))
+    # gSc1c2 that the solver should find: camera-2 coordinates -> camera-1 coordinates
+    R1, R2 = _R(S1[:4]), _R(S2[:4])
+    R12 = R1 @ RS @ R2.T
+    t12 = R1 @ (tS - scale * RS @ R2.T @ S2[4:7]) + S1[4:7]
+    return dict(X1=X1.astype(np.float32), X2=X2.astype(np.float32), sigma2_1=sg(n_solver), sigma2_2=sg(n_solver), K=K_TUM, bad=bad, score=score,
+                R12=R12, t12=t12, s12=scale)
