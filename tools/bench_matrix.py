@@ -211,6 +211,20 @@ def main():
                               "gpu_us": round(median_call(lambda: opt.OptimizeSim3(*ac_), 20) * 1e6, 1),
                               "cpu_oracle_us": round(median_call(lambda: O.optimize_sim3(*ac_), 5) * 1e6, 1)}}
 
+    # ---- Sim3Solver::iterate of the sub-map merge: a block of RANSAC iterations per launch (each one: Horn + CheckInliers + ComputeInliersNum) ----
+    from sim3_scene import sim3_ransac_problem
+    rp = sim3_ransac_problem(0, n_pairs=10, per_pair=150, n_solver=200)
+    ra_ = (rp["X1"], rp["X2"], rp["sigma2_1"], rp["sigma2_2"], rp["K"], rp["K"])
+    doc["sim3_ransac_host_api"] = {"note": "Sim3Solver::iterate (rumination overload): every iteration scores its hypothesis over all key-frame pairs; one workgroup "
+                                           "per iteration, host arrays in/out; oracle = scalar CPU restatement of the same iterations",
+                                   "correspondences": int(len(rp["X1"])), "scored_matches": int(rp["score"]["pair_start"][-1]),
+                                   "key_frame_pairs": int(len(rp["score"]["pair_start"]) - 1)}
+    for H in (20, 300):
+        tri = O.sim3_draw_triples(0, len(rp["X1"]), H)
+        doc["sim3_ransac_host_api"][f"iterations_{H}"] = {
+            "gpu_us": round(median_call(lambda: opt.Sim3Ransac(*ra_, tri, score=rp["score"]), 20) * 1e6, 1),
+            "cpu_oracle_us": round(median_call(lambda: O.sim3_ransac(*ra_, tri, score=rp["score"]), 3) * 1e6, 1)}
+
     # ---- CPU oracle, all cores (config 5: one frame per thread) ----
     T = args.cpu_threads
     orcs = [O.OracleExtractor(1000, 1.2, 8, 20, 7) for _ in range(T)]

@@ -42,7 +42,7 @@ for k, v in out["kernels"].items():
 m = json.load(open(os.path.join(P, "r01_bench_matrix.json")))
 print([(r["frames_per_launch"], r["extract_fps"], r["extract_match_fps"]) for r in m["batch_sweep_1000_features"]])
 print([(r["nfeatures"], r["input"][:12], r["extract_fps"]) for r in m["feature_sweep"]])
-for k in ("single_frame_host_api", "bruteforce", "windowed_matchers_host_api", "search_local_points_host_api", "tracking_frame_host_api", "optimize_sim3_host_api", "cpu_oracle_extract"):
+for k in ("single_frame_host_api", "bruteforce", "windowed_matchers_host_api", "search_local_points_host_api", "tracking_frame_host_api", "optimize_sim3_host_api", "sim3_ransac_host_api", "cpu_oracle_extract"):
     print(k, m[k])
 b = json.load(open(os.path.join(P, "r01_bench_line.json")))
 print({k: b[k] for k in ("value", "ms_per_step", "roofline", "stage_ms_per_step", "cpu_baseline", "lba", "pose_opt")})
