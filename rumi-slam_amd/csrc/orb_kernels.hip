@@ -370,50 +370,56 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const unsigned Mdw = magic_of(dw);
     for (int idx = lane * 4; idx < (dh + 2) * SP; idx += 256) *reinterpret_cast<uint32_t *>(&sc[idx]) = 0;
     wave_lds_fence();
-    const int tlow = max(1, min(P->iniTh, P->minTh));
     const int npx = dw * dh;
     uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
     uint16_t *sl = cl + 512;
-    int nScored;
-    switch (TP) {                                                // compile-time pitches for the common geometries
-        case 48: nScored = fast_score_cell<48>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        case 52: nScored = fast_score_cell<52>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        case 56: nScored = fast_score_cell<56>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-        default: nScored = fast_score_cell<0>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, tlow, lane); break;
-    }
-    wave_lds_fence();
-    // NMS + emission over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
-    // kScoredCap scored pixels scans its whole score map instead
-    const bool listed = nScored <= kScoredCap;
-    const int nItems = listed ? nScored : npx;
-    const int iters = (nItems + 63) >> 6;
-    const int iniTh = P->iniTh, minTh = P->minTh;
-    int ti = 0, tm = 0;
-    for (int it = 0; it < iters; it++) {
-        const int k = it * 64 + lane;
-        bool isMax = false;
-        int v = 0;
-        if (k < nItems) {
-            const int idx = listed ? (int)sl[k] : k;
-            const bool dup = listed && k > 0 && (int)sl[k - 1] == idx;        // second entry of a pixel scored for both polarities
-            const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
-            const uint8_t *s = &sc[mul24(py + 1, SP) + px + 1];
-            v = s[0];
-            isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
-                    v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+    // Two passes, as upstream calls cv::FAST (:771-785): threshold iniThFAST first, and minThFAST only when the cell yields no key-point (after
+    // NMS) at iniThFAST.  A pixel below the pass's threshold can neither be emitted nor suppress a neighbour (cv::FAST's score rows hold 0
+    // for it, and NMS needs a strictly larger neighbour), so each pass scores only what reaches ITS threshold: at iniThFAST the quick test
+    // passes a fraction of the pixels it passes at minThFAST, and textured cells never run the second pass.
+    int thr = max(1, P->iniTh);
+    int nScored, nItems, iters, found;
+    bool listed;
+#pragma nounroll
+    for (int pass = 0;; pass++) {
+        switch (TP) {                                                // compile-time pitches for the common geometries
+            case 48: nScored = fast_score_cell<48>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
+            case 52: nScored = fast_score_cell<52>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
+            case 56: nScored = fast_score_cell<56>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
+            default: nScored = fast_score_cell<0>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
         }
-        const unsigned long long bi = __ballot(isMax && v >= iniTh);
-        const unsigned long long bm = __ballot(isMax && v >= minTh);
-        ti += __popcll(bi); tm += __popcll(bm);
-        if (lane == 0) { balI[it] = bi; balM[it] = bm; }
+        wave_lds_fence();
+        // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
+        // kScoredCap scored pixels scans its whole score map instead
+        listed = nScored <= kScoredCap;
+        nItems = listed ? nScored : npx;
+        iters = (nItems + 63) >> 6;
+        found = 0;
+        for (int it = 0; it < iters; it++) {
+            const int k = it * 64 + lane;
+            bool isMax = false;
+            if (k < nItems) {
+                const int idx = listed ? (int)sl[k] : k;
+                const bool dup = listed && k > 0 && (int)sl[k - 1] == idx;        // second entry of a pixel scored for both polarities
+                const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
+                const uint8_t *s = &sc[mul24(py + 1, SP) + px + 1];
+                const int v = s[0];
+                isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
+                        v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+            }
+            const unsigned long long bi = __ballot(isMax);
+            found += __popcll(bi);
+            if (lane == 0) balI[it] = bi;
+        }
+        wave_lds_fence();
+        if (found > 0 || pass == 1) break;                           // retry with minThFAST only if the first call found nothing (:783)
+        thr = max(1, P->minTh);                                      // scores of the first pass that are still in the map are rewritten with the same values
     }
-    wave_lds_fence();
-    const bool useMin = ti == 0;                  // retry with minThFAST only if the first call found nothing (:783)
-    if (lane == 0) cellCnt[cellIdx] = useMin ? tm : ti;
+    if (lane == 0) cellCnt[cellIdx] = found;
     uint32_t *out = cellBuf + cellIdx * P->maxCellCand;
     int run = 0;
     for (int it = 0; it < iters; it++) {
-        const unsigned long long b = useMin ? balM[it] : balI[it];
+        const unsigned long long b = balI[it];
         if ((b >> lane) & 1ull) {
             const int k = it * 64 + lane;
             const int idx = listed ? (int)sl[k] : k;
