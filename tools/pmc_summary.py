@@ -5,11 +5,11 @@
 The factor 2 on the read side is the gfx950 correction of the guide, re-calibrated here with tools/pmc_calib.hip for BOTH
 16 B/lane and 4 B/lane coalesced streaming reads of 1 GiB (FETCH_SIZE * 1024 = 0.5000 x bytes read in both cases).
 usage: pmc_summary.py <dir-with-FETCH_SIZE-run> <dir-with-WRITE_SIZE-run> <out.json> [frames_per_launch]"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)     # gpurun merges every run into the same directory
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = re.sub(r"<.*?>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()   # template arguments / return type dropped
