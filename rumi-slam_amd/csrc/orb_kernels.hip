@@ -235,11 +235,26 @@ __device__ __forceinline__ int fast_score_polar(const uint8_t *t, const int TP, 
 // bit set can never reach the threshold; the others are compacted (one entry per polarity) and scored exactly for that polarity.
 typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s pair_at(const uint8_t *t, const int o) { return __builtin_bit_cast(v2s, (uint32_t)t[o] | ((uint32_t)t[o + 1] << 16)); }
-__device__ __forceinline__ int fast_quick_pair(const uint8_t *t, const int TP, const int thr) {
+__device__ __forceinline__ int fast_quick_pair(const uint8_t *t, const int TP, const int thr, int &probe) {
     const v2s v = pair_at(t, 0);
     v2s e[8];
-    e[0] = v - pair_at(t, 3 * TP);  e[1] = v - pair_at(t, 2 * TP + 2);  e[2] = v - pair_at(t, 3);   e[3] = v - pair_at(t, -2 * TP + 2);
-    e[4] = v - pair_at(t, -3 * TP); e[5] = v - pair_at(t, -2 * TP - 2); e[6] = v - pair_at(t, -3);  e[7] = v - pair_at(t, 2 * TP - 2);
+    e[0] = v - pair_at(t, 3 * TP);  e[2] = v - pair_at(t, 3);   e[4] = v - pair_at(t, -3 * TP); e[6] = v - pair_at(t, -3);
+    // four consecutive even positions always include two ADJACENT compass positions (0, 4, 8, 12): when no lane of the wave has such a
+    // pair beyond the threshold on either side, the other four loads and the arc search are skipped for all 128 pixels (flat image regions).
+    // The pre-test costs a fifth of the full test, so a cell only keeps running it while it pays (probe)
+    if (probe > 0) {                                  // probe: 3 = undecided (counts down on every miss), 4 = the pre-test has skipped at least once in this cell, 0 = given up
+        const v2s a = __builtin_elementwise_min(e[0], e[2]), b = __builtin_elementwise_min(e[2], e[4]), c = __builtin_elementwise_min(e[4], e[6]),
+                  d = __builtin_elementwise_min(e[6], e[0]);
+        const v2s A4 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+        const v2s a2 = __builtin_elementwise_max(e[0], e[2]), b2 = __builtin_elementwise_max(e[2], e[4]), c2 = __builtin_elementwise_max(e[4], e[6]),
+                  d2 = __builtin_elementwise_max(e[6], e[0]);
+        const v2s B4 = __builtin_elementwise_min(__builtin_elementwise_min(a2, b2), __builtin_elementwise_min(c2, d2));
+        const v2s th = {(short)thr, (short)thr}, th1 = {(short)(thr - 1), (short)(thr - 1)};
+        const uint32_t da = ~__builtin_bit_cast(uint32_t, A4 - th), db = __builtin_bit_cast(uint32_t, B4 + th1);
+        if (__ballot(((da | db) & 0x80008000u) != 0) == 0) { probe = 4; return 0; }
+        if (probe < 4) probe--;                       // a cell whose first three steps never skip is textured: stop paying for the pre-test
+    }
+    e[1] = v - pair_at(t, 2 * TP + 2);  e[3] = v - pair_at(t, -2 * TP + 2); e[5] = v - pair_at(t, -2 * TP - 2); e[7] = v - pair_at(t, 2 * TP - 2);
     v2s lo2[8], hi2[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { lo2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 7]); hi2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 7]); }
@@ -291,16 +306,17 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
     const int pw = (dw + 1) >> 1, npairs = pw * dh;       // pixel pairs per row / per cell (the last pair of an odd row is half empty)
     const unsigned Mpw = magic_of(pw);
     int head = 0, pending = 0;                         // circular ring: entries wait in cl[(head + k) & 511], k < pending (< 64 between steps)
-    int nScored = 0;
+    int nScored = 0, probe = 3;
     for (int base = 0; base < npairs; base += 64) {
         const int ip = base + lane;
         int pass = 0, idx = 0;
         if (ip < npairs) {
             const int py = magic_div(ip, Mpw), px = (ip - mul24(py, pw)) * 2;
             idx = mul24(py, dw) + px;
-            pass = fast_quick_pair(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, tlow + 1);
+            pass = fast_quick_pair(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, tlow + 1, probe);
             if (px + 1 >= dw) pass &= 5;                // second pixel of the pair lies outside the detection region
         }
+        if (probe == 4 && __ballot(pass != 0) == 0) continue;   // flat stretch of a cell that has them: nothing to append (wave-uniform)
         // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1).  A lane adds
         // 0..4 entries: the exclusive prefix of that count over the lanes comes from three bit-plane ballots (v_mbcnt) instead of four
         // per-flag ballots with a masked popcount each
