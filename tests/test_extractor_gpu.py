@@ -212,3 +212,13 @@ def test_level_with_more_keys_than_the_register_path_holds():
     _assert_same(gout, oout, "noise 800x600")
     for l in range(8):
         assert g.stage_keypoints(l, 1).tobytes() == o.keypoints(l, True).tobytes(), f"selected key-points level {l}"
+
+
+@pytest.mark.parametrize("ini,mn", [(20, 20), (7, 20), (30, 5), (12, 7), (40, 1)])
+def test_threshold_pairs(ini, mn):
+    """The two cv::FAST calls per cell (ORBextractor.cc:771-785) with unusual threshold pairs: equal, inverted (the retry can only find a subset
+    of nothing), far apart, and minThFAST = 1; textured and low-texture frames (the latter live on the retry)."""
+    g, o = _pair(ini=ini, mn=mn)
+    for seed, kw in [(31, {}), (32, dict(n_rect=60, contrast=(8, 25), noise=1)), (33, dict(n_rect=12, contrast=(5, 14), noise=0))]:
+        img = synth_frame(seed, **kw)
+        _assert_same(g(img, None, (0, 1000)), o.extract(img, (0, 1000)), f"thresholds {ini}/{mn} seed {seed}")
