@@ -194,13 +194,14 @@ __global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict_
 // pairs that get the exact score (fast_quick_pair / fast_score_polar).
 // ------------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <cstdlib>
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 // One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
 // sub-image as aligned dwords, scores 64 pixels per step, and emits in index order with a running offset.  LDS per wave is
 // sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
-struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
+struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave, exp; };
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -208,187 +209,287 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// FAST 9/16 corner score of the pixel at t (tile pitch TP) for ONE polarity: sign = +1 scores the "darker ring" arcs
-// (contrast v - p), sign = -1 the "brighter ring" arcs (p - v).  cv::cornerScore<16> = max of the two, minus 1: max over the 16
-// arcs of 9 contiguous circle pixels of the minimum contrast (a pixel is a corner at threshold T iff score >= T).
-__device__ __forceinline__ int fast_score_polar(const uint8_t *t, const int TP, const int sign) {
-    const int sv = sign * (int)t[0], ns = -sign;
-    int d[16];
-    d[0] = sv + ns * t[3 * TP];       d[1] = sv + ns * t[3 * TP + 1];   d[2] = sv + ns * t[2 * TP + 2];   d[3] = sv + ns * t[TP + 3];
-    d[4] = sv + ns * t[3];            d[5] = sv + ns * t[-TP + 3];      d[6] = sv + ns * t[-2 * TP + 2];  d[7] = sv + ns * t[-3 * TP + 1];
-    d[8] = sv + ns * t[-3 * TP];      d[9] = sv + ns * t[-3 * TP - 1];  d[10] = sv + ns * t[-2 * TP - 2]; d[11] = sv + ns * t[-TP - 3];
-    d[12] = sv + ns * t[-3];          d[13] = sv + ns * t[TP - 3];      d[14] = sv + ns * t[2 * TP - 2];  d[15] = sv + ns * t[3 * TP - 1];
-    int lo3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    int A = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2)
-        A = max3i(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]), min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
-    return A - 1;
-}
-
-// Necessary condition for score >= thr - 1, per polarity: every arc of 9 contains 4 consecutive of the 8 EVEN circle positions,
-// so the best "4 consecutive even positions" contrast bounds that polarity's score from above.  Evaluated for TWO horizontally
-// adjacent pixels per lane in packed 16-bit halves (v_pk_sub/min/max_i16: contrasts are in [-255, 255]).  Returns bit 0 / bit 1 =
-// the darker-ring polarity of pixel 0 / pixel 1 can reach thr, bit 2 / bit 3 = the brighter-ring polarity can.  Pixels with no
-// bit set can never reach the threshold; the others are compacted (one entry per polarity) and scored exactly for that polarity.
-typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2s pair_at(const uint8_t *t, const int o) { return __builtin_bit_cast(v2s, (uint32_t)t[o] | ((uint32_t)t[o + 1] << 16)); }
-__device__ __forceinline__ int fast_quick_pair(const uint8_t *t, const int TP, const int thr, int &probe) {
-    const v2s v = pair_at(t, 0);
-    v2s e[8];
-    e[0] = v - pair_at(t, 3 * TP);  e[2] = v - pair_at(t, 3);   e[4] = v - pair_at(t, -3 * TP); e[6] = v - pair_at(t, -3);
-    // four consecutive even positions always include two ADJACENT compass positions (0, 4, 8, 12): when no lane of the wave has such a
-    // pair beyond the threshold on either side, the other four loads and the arc search are skipped for all 128 pixels (flat image regions).
-    // The pre-test costs a fifth of the full test, so a cell only keeps running it while it pays (probe)
-    if (probe > 0) {                                  // probe: 3 = undecided (counts down on every miss), 4 = the pre-test has skipped at least once in this cell, 0 = given up
-        const v2s a = __builtin_elementwise_min(e[0], e[2]), b = __builtin_elementwise_min(e[2], e[4]), c = __builtin_elementwise_min(e[4], e[6]),
-                  d = __builtin_elementwise_min(e[6], e[0]);
-        const v2s A4 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
-        const v2s a2 = __builtin_elementwise_max(e[0], e[2]), b2 = __builtin_elementwise_max(e[2], e[4]), c2 = __builtin_elementwise_max(e[4], e[6]),
-                  d2 = __builtin_elementwise_max(e[6], e[0]);
-        const v2s B4 = __builtin_elementwise_min(__builtin_elementwise_min(a2, b2), __builtin_elementwise_min(c2, d2));
-        const v2s th = {(short)thr, (short)thr}, th1 = {(short)(thr - 1), (short)(thr - 1)};
-        const uint32_t da = ~__builtin_bit_cast(uint32_t, A4 - th), db = __builtin_bit_cast(uint32_t, B4 + th1);
-        if (__ballot(((da | db) & 0x80008000u) != 0) == 0) { probe = 4; return 0; }
-        if (probe < 4) probe--;                       // a cell whose first three steps never skip is textured: stop paying for the pre-test
-    }
-    e[1] = v - pair_at(t, 2 * TP + 2);  e[3] = v - pair_at(t, -2 * TP + 2); e[5] = v - pair_at(t, -2 * TP - 2); e[7] = v - pair_at(t, 2 * TP - 2);
-    v2s lo2[8], hi2[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { lo2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 7]); hi2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 7]); }
-    v2s A = __builtin_elementwise_min(lo2[0], lo2[2]), Bn = __builtin_elementwise_max(hi2[0], hi2[2]);
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        A = __builtin_elementwise_max(A, __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 7]));
-        Bn = __builtin_elementwise_min(Bn, __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 7]));
-    }
-    // A >= thr  <=>  sign(A - thr) clear;   -Bn >= thr  <=>  Bn + (thr - 1) < 0  <=>  sign set
-    const v2s th = {(short)thr, (short)thr}, th1 = {(short)(thr - 1), (short)(thr - 1)};
-    const uint32_t da = ~__builtin_bit_cast(uint32_t, A - th), db = __builtin_bit_cast(uint32_t, Bn + th1);
-    return (int)(((da >> 15) & 1u) | ((da >> 30) & 2u) | ((db >> 13) & 4u) | ((db >> 28) & 8u));
-}
-
-// exact scores of up to 64 ring entries (entry = pixel index | polarity << 15).  A pixel that passed both quick tests has two
-// entries, darker first; darker entries store their score, then brighter entries keep the maximum (their darker twin sits
-// earlier in the ring, i.e. in this batch or a previous one).
-// Every pixel whose score reaches tlow is also appended to the cell's SCORED LIST sl (pixel indices, ascending because the ring is
-// filled in pixel order; a pixel scored for both polarities appears twice in a row): NMS and emission then walk a few hundred
-// listed pixels instead of the whole score map.  nScored counts all appends; entries beyond kScoredCap are dropped and the caller
-// falls back to scanning the map.
+// ---- quick test and exact score, second formulation (round 2) -------------------------------------------------------------------
+// Instruction classes on gfx950 (tools/valu_rate.hip, profiles/r02_valu_issue_rates.txt): plain add / sub / and / or / xor / right shift /
+// mov issue in ~2.4 cycles per wave once two waves share a SIMD; every min / max, three-operand, packed, SDWA and DPP form takes ~4.2.
+// So the quick test makes its decisions with SUBTRACTIONS and LOGIC instead of packed min / max, and the exact score, which cannot avoid
+// min / max, uses the packed three-input forms gfx950 adds (v_pk_minimum3_f16 / v_pk_maximum3_f16) on two entries per lane.
+//
+// Quick test (necessary condition, per polarity): every arc of 9 contains 4 consecutive of the 8 EVEN circle positions, so a pixel can
+// reach contrast thr on the darker-ring side only if 4 consecutive even positions all have v - p_k >= thr (brighter ring: p_k - v >= thr).
+// A lane takes 4 horizontally adjacent pixels of one ALIGNED tile dword; its operands come from 11 aligned dword reads of LDS (the
+// centre row and rows +-2 with their left / right neighbours, rows +-3) instead of 36 byte reads.  The pixels (0, 2) and (1, 3) travel as
+// 16-bit halves of two registers ("even" / "odd" pair); with V + (0x8000 - thr) in each half, ONE 32-bit subtraction of the packed ring
+// pixels leaves "v - p >= thr" in bit 15 / 31 (the halves never borrow from each other: every half stays within 0x8000 +- 511), and
+// the "4 consecutive" rule is 23 ANDs / ORs of those words per polarity.
+// Ring entries = tile offset of the pixel | polarity << 15; a pixel's darker entry always precedes its brighter one.
+constexpr int kRingCap = 640;        // linear: < 128 entries wait between steps, a step appends up to 512 (64 lanes x 4 pixels x 2 polarities)
 constexpr int kScoredCap = 512;
-template <int CTP>
-__device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *sc, uint16_t *sl, int &nScored, int entry, bool active, int tp, int SP,
-                                                 int shx, int dw, unsigned Mdw, int tlow, int lane) {
-    const int TP = CTP ? CTP : tp;
-    const int i2 = entry & 0x7FFF, bright = entry >> 15;
-    const int py = magic_div(i2, Mdw), px = i2 - mul24(py, dw);
-    int s = 0;
-    if (active) s = fast_score_polar(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, bright ? -1 : 1);
-    uint8_t *dst = &sc[mul24(py + 1, SP) + px + 1];
-    const bool hit = active && s >= tlow;
-    if (hit && !bright) *dst = (uint8_t)s;
-    const unsigned long long bh = __ballot(hit);
-    const int pos = nScored + __popcll(bh & ((1ull << lane) - 1ull));
-    if (hit && pos < kScoredCap) sl[pos] = (uint16_t)i2;
-    nScored += __popcll(bh);
-    wave_lds_fence();
-    if (hit && bright && s > (int)*dst) *dst = (uint8_t)s;
+constexpr uint32_t kF16Bias = 0x4100u;   // contrasts d in [-255, 255] travel as 0x4100 + d: positive normal f16 bit patterns of one exponent, ordered like the integers
+
+__device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) {       // per 16-bit half: a * b + c
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// inclusive prefix sum over the wave's 64 lanes: four row shifts and two row broadcasts (v_add_u32 with a DPP operand each)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
-// score map of one cell: quick test on every pixel (two per lane), exact score on the compacted survivors (CTP != 0: compile-time
-// tile pitch).  Ring entries = pixel index | polarity << 15; a pixel's darker entry always precedes its brighter one.
+// bit 15 / 31 of the result: 4 consecutive of the 8 flag words have theirs set (circular)
+__device__ __forceinline__ uint32_t four_consecutive(const uint32_t (&f)[8]) {
+    uint32_t c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = f[k] & f[(k + 1) & 7];
+    uint32_t any = c[0] & c[2];
+#pragma unroll
+    for (int k = 1; k < 8; k++) any |= c[k] & c[(k + 2) & 7];
+    return any;
+}
+
+// exact scores of up to 128 ring entries, two per lane.
+// Per entry: the 16 circle contrasts of ITS polarity as 0x4100 + d in a 16-bit half (v_pk_mad_i16 by -1 / +1), then
+// max over the 16 arcs of 9 of the minimum: 16 + 16 packed three-input minima and 8 maxima for both entries together.
+// Darker entries store their score; after a wave fence brighter entries keep the maximum (their darker twin sits earlier in the ring).
+// Every entry whose score reaches tlow is appended to the cell's SCORED LIST sl (tile offsets, ascending because the ring is filled in
+// pixel order; a pixel scored for both polarities appears twice in a row): NMS and emission then walk a few hundred listed pixels
+// instead of the whole score map.  nScored counts all appends; entries beyond kScoredCap are dropped and the caller scans the map.
 template <int CTP>
-__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int SP, int shx, int dw, int dh,
-                                               unsigned Mdw, int tlow, int lane) {
+__device__ __forceinline__ void fast_score_batch2(const uint8_t *tile, uint8_t *sc, uint16_t *sl, int &nScored, const uint16_t *ring, int n, int tp, int scDelta,
+                                                  int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
-    const int pw = (dw + 1) >> 1, npairs = pw * dh;       // pixel pairs per row / per cell (the last pair of an odd row is half empty)
-    const unsigned Mpw = magic_of(pw);
-    int head = 0, pending = 0;                         // circular ring: entries wait in cl[(head + k) & 511], k < pending (< 64 between steps)
-    int nScored = 0, probe = 3;
-    for (int base = 0; base < npairs; base += 64) {
+    // lane takes entries `lane` and `lane + 64` of the batch: one LDS instruction then serves 64 CONSECUTIVE entries, which lie within a few
+    // tile rows (fewer bank conflicts than 64 entries spread over the whole batch)
+    const bool act0 = lane < n, act1 = lane + 64 < n;
+    const uint32_t e0 = ring[lane], e1 = ring[lane + 64];
+    const int a0 = act0 ? (int)(e0 & 0x7FFFu) : 3 * TP + 4, a1 = act1 ? (int)(e1 & 0x7FFFu) : 3 * TP + 4;
+    const uint32_t b0 = e0 >> 15, b1 = e1 >> 15;                     // 1 = brighter-ring polarity
+    const uint8_t *t0 = tile + a0 - 3 * TP - 3, *t1 = tile + a1 - 3 * TP - 3;   // top-left corner of the 7 x 7 neighbourhood: every offset below is >= 0
+    // multiplier -1 (darker ring: v - p) or +1 (brighter ring: p - v) per half, and the matching constant 0x4100 +- v
+    const uint32_t S = (b0 ? 1u : 0xFFFFu) | ((b1 ? 1u : 0xFFFFu) << 16);
+    const uint32_t v0 = t0[3 * TP + 3], v1 = t1[3 * TP + 3];
+    const uint32_t C = ((b0 ? kF16Bias - v0 : kF16Bias + v0) & 0xFFFFu) | ((b1 ? kF16Bias - v1 : kF16Bias + v1) << 16);
+    uint32_t d[16];
+#define RUMI_RING(k, dx, dy) d[k] = pk_mad_i16((uint32_t)t0[(3 + (dy)) * TP + 3 + (dx)] | ((uint32_t)t1[(3 + (dy)) * TP + 3 + (dx)] << 16), S, C);
+    RUMI_RING(0, 0, 3)    RUMI_RING(1, 1, 3)    RUMI_RING(2, 2, 2)     RUMI_RING(3, 3, 1)
+    RUMI_RING(4, 3, 0)    RUMI_RING(5, 3, -1)   RUMI_RING(6, 2, -2)    RUMI_RING(7, 1, -3)
+    RUMI_RING(8, 0, -3)   RUMI_RING(9, -1, -3)  RUMI_RING(10, -2, -2)  RUMI_RING(11, -3, -1)
+    RUMI_RING(12, -3, 0)  RUMI_RING(13, -3, 1)  RUMI_RING(14, -2, 2)   RUMI_RING(15, -1, 3)
+#undef RUMI_RING
+    uint32_t lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo3[k] = pk_min3_f16(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    uint32_t arc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) arc[k] = pk_min3_f16(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    uint32_t A = pk_max3_f16(arc[0], arc[1], arc[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) A = pk_max3_f16(A, arc[k], arc[k + 1]);
+    A = pk_max3_f16(A, arc[15], arc[15]);
+    const int s0 = (int)(A & 0xFFFFu) - (int)kF16Bias - 1, s1 = (int)(A >> 16) - (int)kF16Bias - 1;
+    const bool hit0 = act0 && s0 >= tlow, hit1 = act1 && s1 >= tlow;
+    uint8_t *dst0 = &sc[a0 + scDelta], *dst1 = &sc[a1 + scDelta];
+    if (hit0 && !b0) *dst0 = (uint8_t)s0;
+    if (hit1 && !b1) *dst1 = (uint8_t)s1;
+    const unsigned long long h0 = __ballot(hit0), h1 = __ballot(hit1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int pos0 = nScored + __popcll(h0 & below), pos1 = nScored + __popcll(h0) + __popcll(h1 & below);   // ring order: entries 0..63, then 64..127
+    if (hit0 && pos0 < kScoredCap) sl[pos0] = (uint16_t)a0;
+    if (hit1 && pos1 < kScoredCap) sl[pos1] = (uint16_t)a1;
+    nScored += __popcll(h0) + __popcll(h1);
+    wave_lds_fence();
+    if (hit0 && b0 && s0 > (int)*dst0) *dst0 = (uint8_t)s0;
+    if (hit1 && b1 && s1 > (int)*dst1) *dst1 = (uint8_t)s1;
+}
+
+// score map of one cell (CTP != 0: compile-time tile pitch; the score map shares the tile's pitch, so a pixel's score byte sits at
+// its tile offset + scDelta).  Returns the number of scored-list appends.
+template <int CTP>
+__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int shx, int dw, int dh,
+                                               int tlow, int lane, int exp) {
+    const int TP = CTP ? CTP : tp;
+    const int c0 = 3 + shx, c1 = c0 + dw;                 // tile columns of the detection region
+    const int g0 = c0 >> 2, ng = ((c1 + 3) >> 2) - g0;    // aligned 4-pixel groups per row that touch it
+    const int nItems = (exp & 4) ? 0 : ng * dh;
+    const unsigned Mng = magic_of(ng);
+    const int scDelta = -2 * TP - 2 - shx;                // tile offset (py + 3) * TP + px + 3 + shx  ->  score byte (py + 1) * TP + px + 1
+    // entry masks (2 bits per pixel) of the first / last group of a row: pixels left of c0 / from c1 on lie outside the region
+    const uint32_t mFirst = (0xFFu << (2 * (c0 & 3))) & 0xFFu, mLast = 0xFFu >> (2 * (3 - ((c1 - 1) & 3)));
+    const uint32_t T2 = (uint32_t)(tlow + 1) * 0x10001u, kD = 0x80008000u - T2;
+    uint32_t *cl32 = reinterpret_cast<uint32_t *>(cl);
+    int pending = 0, nScored = 0;
+    for (int base = 0; base < nItems; base += 64) {
         const int ip = base + lane;
-        int pass = 0, idx = 0;
-        if (ip < npairs) {
-            const int py = magic_div(ip, Mpw), px = (ip - mul24(py, pw)) * 2;
-            idx = mul24(py, dw) + px;
-            pass = fast_quick_pair(&tile[mul24(py + 3, TP) + px + 3 + shx], TP, tlow + 1, probe);
-            if (px + 1 >= dw) pass &= 5;                // second pixel of the pair lies outside the detection region
-        }
-        if (probe == 4 && __ballot(pass != 0) == 0) continue;   // flat stretch of a cell that has them: nothing to append (wave-uniform)
-        // ring positions: entries of lower lanes first; within a lane darker(px0), brighter(px0), darker(px1), brighter(px1).  A lane adds
-        // 0..4 entries: the exclusive prefix of that count over the lanes comes from three bit-plane ballots (v_mbcnt) instead of four
-        // per-flag ballots with a masked popcount each
-        const int cnt = __popc(pass);
-        const unsigned long long c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
-        const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c0, 0u));
-        const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c1, 0u));
-        const int p2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(c2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c2, 0u));
-        int pos = head + pending + p0 + 2 * p1 + 4 * p2;
-        if (pass & 1) cl[pos++ & 511] = (uint16_t)idx;
-        if (pass & 4) cl[pos++ & 511] = (uint16_t)(idx | 0x8000);
-        if (pass & 2) cl[pos++ & 511] = (uint16_t)(idx + 1);
-        if (pass & 8) cl[pos & 511] = (uint16_t)((idx + 1) | 0x8000);
-        pending += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
-        while (pending >= 64) {                        // a full wave of entries: score them exactly
-            wave_lds_fence();
-            const int e = cl[(head + lane) & 511];
-            fast_score_batch<CTP>(tile, sc, sl, nScored, e, true, tp, SP, shx, dw, Mdw, tlow, lane);
-            head = (head + 64) & 511;
-            pending -= 64;
+        const bool live = ip < nItems;
+        const int row = live ? magic_div(ip, Mng) : 0, gi = live ? ip - mul24(row, ng) : 0;
+        const int A = mul24(row + 3, TP) + 4 * (gi + g0);                     // tile offset of the group's first pixel
+        const uint8_t *t = tile + A;
+#define RUMI_DW(off) (*reinterpret_cast<const uint32_t *>(t + (off)))
+        const uint32_t cM3 = RUMI_DW(-3 * TP), cP3 = RUMI_DW(3 * TP);
+        const uint32_t l0 = RUMI_DW(-4), cc = RUMI_DW(0), r0 = RUMI_DW(4);
+        const uint32_t lM2 = RUMI_DW(-2 * TP - 4), cM2 = RUMI_DW(-2 * TP), rM2 = RUMI_DW(-2 * TP + 4);
+        const uint32_t lP2 = RUMI_DW(2 * TP - 4), cP2 = RUMI_DW(2 * TP), rP2 = RUMI_DW(2 * TP + 4);
+#undef RUMI_DW
+        // ring pixels of the (0, 2) pair ("e") and the (1, 3) pair ("o") as 16-bit halves, even circle positions in circular order:
+        // (0,+3) (+2,+2) (+3,0) (+2,-2) (0,-3) (-2,-2) (-3,0) (-2,+2).  v_perm_b32 over {right | centre} or {centre | left} picks a shifted
+        // pair in one instruction; the unshifted ones are an AND / shift + AND.
+        uint32_t pe[8], po[8];
+        pe[0] = cP3 & 0x00FF00FFu;                               po[0] = (cP3 >> 8) & 0x00FF00FFu;
+        pe[1] = __builtin_amdgcn_perm(rP2, cP2, 0x0c040c02u);    po[1] = __builtin_amdgcn_perm(rP2, cP2, 0x0c050c03u);
+        pe[2] = __builtin_amdgcn_perm(r0, cc, 0x0c050c03u);      po[2] = __builtin_amdgcn_perm(r0, cc, 0x0c060c04u);
+        pe[3] = __builtin_amdgcn_perm(rM2, cM2, 0x0c040c02u);    po[3] = __builtin_amdgcn_perm(rM2, cM2, 0x0c050c03u);
+        pe[4] = cM3 & 0x00FF00FFu;                               po[4] = (cM3 >> 8) & 0x00FF00FFu;
+        pe[5] = __builtin_amdgcn_perm(cM2, lM2, 0x0c040c02u);    po[5] = __builtin_amdgcn_perm(cM2, lM2, 0x0c050c03u);
+        pe[6] = __builtin_amdgcn_perm(cc, l0, 0x0c030c01u);      po[6] = __builtin_amdgcn_perm(cc, l0, 0x0c040c02u);
+        pe[7] = __builtin_amdgcn_perm(cP2, lP2, 0x0c040c02u);    po[7] = __builtin_amdgcn_perm(cP2, lP2, 0x0c050c03u);
+        const uint32_t ve = cc & 0x00FF00FFu, vo = (cc >> 8) & 0x00FF00FFu;
+        uint32_t f[8];
+        const uint32_t vde = ve + kD, vdo = vo + kD, kbe = kD - ve, kbo = kD - vo;
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = vde - pe[k];          // bit 15 / 31: v - p >= thr
+        const uint32_t aDe = four_consecutive(f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = pe[k] + kbe;          // bit 15 / 31: p - v >= thr
+        const uint32_t aBe = four_consecutive(f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = vdo - po[k];
+        const uint32_t aDo = four_consecutive(f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = po[k] + kbo;
+        const uint32_t aBo = four_consecutive(f);
+        // entry mask: bit 2 i + polarity for pixel i of the group (pixel order 0, 1, 2, 3 = even.lo, odd.lo, even.hi, odd.hi)
+        const uint32_t u = ((aDe & 0x80008000u) >> 15) | ((aBe & 0x80008000u) >> 14) | ((aDo & 0x80008000u) >> 13) | ((aBo & 0x80008000u) >> 12);
+        uint32_t m = (u | (u >> 12)) & 0xFFu;
+        if (gi == 0) m &= mFirst;
+        if (gi == ng - 1) m &= mLast;
+        if (!live) m = 0;
+        if (exp & 2) m = 0;
+        if (__ballot(m != 0) != 0) {
+            // ring positions: entries of lower lanes first; within a lane pixel by pixel, darker before brighter
+            const int cnt = __popc(m);
+            const int incl = wave_incl_scan(cnt);
+            uint16_t *w = cl + pending + incl - cnt;
+            uint32_t e = (uint32_t)A;
+            if (!(exp & 8))
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (m & (1u << (2 * i))) *w++ = (uint16_t)e;
+                if (m & (2u << (2 * i))) *w++ = (uint16_t)(e | 0x8000u);
+                e++;
+            }
+            pending += __builtin_amdgcn_readlane(incl, 63);
+            int head = 0;
+            while (pending >= 128) {                       // a full batch: score it exactly
+                wave_lds_fence();
+                if (!(exp & 1)) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
+                head += 128;
+                pending -= 128;
+            }
+            if (head) {                                    // the entries still waiting move to the front (fewer than 128, from beyond them)
+                wave_lds_fence();
+                const uint32_t q = cl32[(head >> 1) + lane];
+                wave_lds_fence();
+                if (2 * lane < pending) cl32[lane] = q;
+            }
         }
     }
     wave_lds_fence();
-    fast_score_batch<CTP>(tile, sc, sl, nScored, lane < pending ? cl[(head + lane) & 511] : 0, lane < pending, tp, SP, shx, dw, Mdw, tlow, lane);
+    if (pending && !(exp & 1)) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
     return nScored;
 }
 
-// TPC / SPC: tile and score-map pitches as compile-time constants: the sixteen circle offsets and the NMS neighbours then are immediate LDS
-// offsets instead of one address add each (-1 % kernel time; rounding the pitches up to 64 instead costs +13 %: LDS footprint); 0 = run-time
-template <int TPC, int SPC>
-__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
-                                                    uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int cell = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
-    if (cell >= P->totalCells) return;
-    uint8_t *tile = fl + (size_t)wave * F.perWave;
-    uint8_t *sc = tile + F.tileBytes;
-    unsigned long long *balI = reinterpret_cast<unsigned long long *>(sc + F.scBytes), *balM = balI + F.maxIters;
+// One cell's place in its frame.
+struct FastCell {
+    const uint8_t *img;              // first staged byte: row iniY, column iniX rounded down to a dword
+    long long cellIdx;
+    int pitch, rows, cols, shx, nd;  // image pitch; sub-image size; iniX & 3; dwords per staged row
+    int ox, oy;                      // cell origin relative to (16, 16): ci_j * wCell, ci_i * hCell
+    bool live;
+};
+__device__ __forceinline__ FastCell fast_cell_geom(const DevParams *__restrict__ P, const ImgSrc &src, int cell, int frame, int32_t *__restrict__ cellCnt, int lane) {
+    FastCell g;
+    g.live = false;
+    if (cell >= P->totalCells) return g;
     int level = 0;
     for (int l = 1; l < P->nlevels; l++)
         if (cell >= P->lv[l].cellBase) level = l;
     const DevLevel &L = P->lv[level];
     const int ci = cell - L.cellBase;
     const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
-    const long long cellIdx = (long long)frame * P->totalCells + cell;
+    g.cellIdx = (long long)frame * P->totalCells + cell;
     const int iniY = kBorder + ci_i * L.hCell, iniX = kBorder + ci_j * L.wCell;
     const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
-    const int cols = maxX - iniX, rows = maxY - iniY;
+    g.cols = maxX - iniX; g.rows = maxY - iniY;
     // skip rules of ORBextractor.cc:752,760 and cv::FAST's 3-px margins
-    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || cols < 7 || rows < 7) {
-        if (lane == 0) cellCnt[cellIdx] = 0;
-        return;
+    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || g.cols < 7 || g.rows < 7) {
+        if (lane == 0) cellCnt[g.cellIdx] = 0;
+        return g;
     }
-    const int TP = TPC ? TPC : F.tp, SP = SPC ? SPC : F.sp;
-    int pitch;
-    const int shx = iniX & 3;
-    const uint8_t *img = level_base(src, P, level, frame, &pitch) + (long long)iniY * pitch + (iniX - shx);
-    const int nd = (shx + cols + 3) >> 2;
-    const unsigned Mnd = magic_of(nd);
-    for (int idx = lane; idx < rows * nd; idx += 64) {
-        const int r = magic_div(idx, Mnd), c = idx - mul24(r, nd);
-        *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = *reinterpret_cast<const uint32_t *>(img + mul24(r, pitch) + 4 * c);
+    g.shx = iniX & 3;
+    g.img = level_base(src, P, level, frame, &g.pitch) + (long long)iniY * g.pitch + (iniX - g.shx);
+    g.nd = (g.shx + g.cols + 3) >> 2;
+    g.ox = ci_j * L.wCell; g.oy = ci_i * L.hCell;
+    g.live = true;
+    return g;
+}
+// The first 512 dwords of a sub-image (all of it for cells up to ~44 x 44), eight per lane, all in flight together
+__device__ __forceinline__ void fast_cell_load(const FastCell &g, uint32_t (&v)[8], int lane) {
+    const int total = g.rows * g.nd;
+    const unsigned Mnd = magic_of(g.nd);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int idx = min(j * 64 + lane, total - 1);
+        const int r = magic_div(idx, Mnd), c = idx - mul24(r, g.nd);
+        v[j] = *reinterpret_cast<const uint32_t *>(g.img + mul24(r, g.pitch) + 4 * c);
     }
-    const int dw = cols - 6, dh = rows - 6;
-    const unsigned Mdw = magic_of(dw);
-    for (int idx = lane * 4; idx < (dh + 2) * SP; idx += 256) *reinterpret_cast<uint32_t *>(&sc[idx]) = 0;
+}
+__device__ __forceinline__ void fast_cell_store(const FastCell &g, uint8_t *tile, const int TP, const uint32_t (&v)[8], int lane) {
+    const int total = g.rows * g.nd;
+    const unsigned Mnd = magic_of(g.nd);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int idx = j * 64 + lane;
+        const int r = magic_div(min(idx, total - 1), Mnd), c = min(idx, total - 1) - mul24(r, g.nd);
+        if (idx < total) *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = v[j];
+    }
+    for (int idx = 512 + lane; idx < total; idx += 64) {         // larger sub-images: the rest, one round trip per 64 dwords
+        const int r = magic_div(idx, Mnd), c = idx - mul24(r, g.nd);
+        *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = *reinterpret_cast<const uint32_t *>(g.img + mul24(r, g.pitch) + 4 * c);
+    }
+}
+
+// everything after the staging of one cell: score map, NMS, ordered emission
+template <int TPC>
+__device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ P, const FastLds &F, const FastCell &g, uint8_t *tile, uint8_t *sc,
+                                                  uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt, int lane) {
+    const int TP = TPC ? TPC : F.tp;
+    const int shx = g.shx;
+    const int dw = g.cols - 6, dh = g.rows - 6;
+    const unsigned Mdw = magic_of(dw), Mtp = magic_of(TP);
+    for (int idx = lane * 4; idx < (dh + 2) * TP; idx += 256) *reinterpret_cast<uint32_t *>(&sc[idx]) = 0;
     wave_lds_fence();
     const int npx = dw * dh;
-    uint16_t *cl = reinterpret_cast<uint16_t *>(balM + F.maxIters);
-    uint16_t *sl = cl + 512;
+    const int scDelta = -2 * TP - 2 - shx;                           // tile offset of a detection pixel -> its byte in the score map
+    uint16_t *cl = reinterpret_cast<uint16_t *>(sc + F.scBytes);
+    uint16_t *sl = cl + kRingCap;
+    unsigned long long *balI = reinterpret_cast<unsigned long long *>(cl);      // NMS ballots: the ring is dead once the scores are final
     // Two passes, as upstream calls cv::FAST (:771-785): threshold iniThFAST first, and minThFAST only when the cell yields no key-point (after
     // NMS) at iniThFAST.  A pixel below the pass's threshold can neither be emitted nor suppress a neighbour (cv::FAST's score rows hold 0
     // for it, and NMS needs a strictly larger neighbour), so each pass scores only what reaches ITS threshold: at iniThFAST the quick test
@@ -398,12 +499,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     bool listed;
 #pragma nounroll
     for (int pass = 0;; pass++) {
-        switch (TP) {                                                // compile-time pitches for the common geometries
-            case 48: nScored = fast_score_cell<48>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
-            case 52: nScored = fast_score_cell<52>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
-            case 56: nScored = fast_score_cell<56>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
-            default: nScored = fast_score_cell<0>(tile, sc, cl, sl, TP, SP, shx, dw, dh, Mdw, thr, lane); break;
-        }
+        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, shx, dw, dh, thr, lane, F.exp);
         wave_lds_fence();
         // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
         // kScoredCap scored pixels scans its whole score map instead
@@ -415,35 +511,73 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
             const int k = it * 64 + lane;
             bool isMax = false;
             if (k < nItems) {
-                const int idx = listed ? (int)sl[k] : k;
-                const bool dup = listed && k > 0 && (int)sl[k - 1] == idx;        // second entry of a pixel scored for both polarities
-                const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
-                const uint8_t *s = &sc[mul24(py + 1, SP) + px + 1];
+                int si;                                                          // score-map offset of the pixel
+                bool dup = false;
+                if (listed) {
+                    si = (int)sl[k] + scDelta;
+                    dup = k > 0 && sl[k - 1] == sl[k];                           // second entry of a pixel scored for both polarities
+                } else {
+                    const int py = magic_div(k, Mdw);
+                    si = mul24(py + 1, TP) + (k - mul24(py, dw)) + 1;
+                }
+                const uint8_t *s = &sc[si];
                 const int v = s[0];
-                isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
-                        v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+                isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
+                        v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
             }
             const unsigned long long bi = __ballot(isMax);
             found += __popcll(bi);
             if (lane == 0) balI[it] = bi;
         }
         wave_lds_fence();
-        if (found > 0 || pass == 1) break;                           // retry with minThFAST only if the first call found nothing (:783)
+        if (found > 0 || pass == 1 || (F.exp & 16)) break;           // retry with minThFAST only if the first call found nothing (:783)
         thr = max(1, P->minTh);                                      // scores of the first pass that are still in the map are rewritten with the same values
     }
-    if (lane == 0) cellCnt[cellIdx] = found;
-    uint32_t *out = cellBuf + cellIdx * P->maxCellCand;
+    if (lane == 0) cellCnt[g.cellIdx] = found;
+    uint32_t *out = cellBuf + g.cellIdx * P->maxCellCand;
     int run = 0;
     for (int it = 0; it < iters; it++) {
         const unsigned long long b = balI[it];
         if ((b >> lane) & 1ull) {
             const int k = it * 64 + lane;
-            const int idx = listed ? (int)sl[k] : k;
-            const int py = magic_div(idx, Mdw), px = idx - mul24(py, dw);
-            const uint32_t x = (uint32_t)(px + 3 + ci_j * L.wCell), y = (uint32_t)(py + 3 + ci_i * L.hCell);
-            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[mul24(py + 1, SP) + px + 1] << 24);
+            int si;
+            if (listed) si = (int)sl[k] + scDelta;
+            else { const int py = magic_div(k, Mdw); si = mul24(py + 1, TP) + (k - mul24(py, dw)) + 1; }
+            const int py1 = magic_div(si, Mtp), px1 = si - mul24(py1, TP);       // score-map row / column = detection row / column + 1
+            const uint32_t x = (uint32_t)(px1 + 2 + g.ox), y = (uint32_t)(py1 + 2 + g.oy);
+            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[si] << 24);
         }
         run += __popcll(b);
+    }
+}
+
+// One WAVE per two consecutive cells of a frame, eight cells per 256-thread workgroup, no workgroup barrier anywhere.  The second cell's
+// sub-image is loaded into registers BEFORE the first cell is processed, so its memory round trip runs under the first cell's arithmetic
+// (a wave's loads were the quarter of the kernel no other wave could cover: every wave starts with them).
+// TPC: tile pitch (= score-map pitch) as a compile-time constant: the circle offsets and the NMS neighbours then are immediate LDS
+// offsets instead of one address add each; 0 = run-time
+template <int TPC>
+__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
+                                                    uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int cell = (wg % gridDim.x) * 8 + wave * 2, frame = wg / gridDim.x;
+    uint8_t *tile = fl + (size_t)wave * F.perWave;
+    uint8_t *sc = tile + F.tileBytes;
+    const int TP = TPC ? TPC : F.tp;
+    const FastCell gA = fast_cell_geom(P, src, cell, frame, cellCnt, lane), gB = fast_cell_geom(P, src, cell + 1, frame, cellCnt, lane);
+    uint32_t v[8];
+    if (gA.live) {
+        fast_cell_load(gA, v, lane);
+        fast_cell_store(gA, tile, TP, v, lane);
+    }
+    if (gB.live) fast_cell_load(gB, v, lane);
+    if (gA.live) fast_cell_process<TPC>(P, F, gA, tile, sc, cellBuf, cellCnt, lane);
+    if (gB.live) {
+        wave_lds_fence();
+        fast_cell_store(gB, tile, TP, v, lane);
+        fast_cell_process<TPC>(P, F, gB, tile, sc, cellBuf, cellCnt, lane);
     }
 }
 
@@ -757,23 +891,24 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
     FastLds F;
-    F.tp = (wMax + 6 + 3 + 3 + 3) & ~3;                   // + alignment shift (<= 3) + dword tail, rounded to 4
-    F.sp = (wMax + 2 + 3) & ~3;
+    F.exp = std::getenv("RUMI_FAST_EXP") ? std::atoi(std::getenv("RUMI_FAST_EXP")) : 0;
+    F.tp = (wMax + 6 + 3 + 3) & ~3;                       // sub-image + alignment shift (<= 3), in whole dwords
+    F.sp = F.tp;                                          // the score map shares the tile's pitch (a pixel's score byte sits at its tile offset + a constant)
     F.tileBytes = (hMax + 6) * F.tp;
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
     F.maxIters = (wMax * hMax + 63) / 64 + 1;
     F.tileBytes = (F.tileBytes + 15) & ~15;
-    // tile | score map | two ballot arrays | ring of (pixel, polarity) entries that passed the quick test (circular, 512 x uint16: 63 waiting + up to 4 per lane and step) |
+    // tile | score map | ring of (pixel, polarity) entries that passed the quick test (linear, kRingCap x uint16; the NMS ballots reuse it) |
     // list of scored pixels (kScoredCap x uint16)
-    F.perWave = (F.tileBytes + F.scBytes + 2 * F.maxIters * 8 + 512 * 2 + 512 * 2 + 15) & ~15;
-    // pitches of the common image sizes as compile-time constants (640x480 / 752x480 / 1241x376 / 1024x768: 52, 44; 1280x720: 52, 40;
-    // 1920x1080: 48, 40; 848x480: 56, 44; 600x350: 60, 48); anything else takes the run-time instantiation
-    const dim3 grid((hP.totalCells + 3) / 4, nframes);
+    F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
+    // tile pitches of the common image sizes as compile-time constants (640x480 / 752x480 / 1241x376 / 1024x768 / 1280x720: 52;
+    // 1920x1080: 48; 848x480: 56; 600x350: 60); anything else takes the run-time instantiation
+    const dim3 grid((hP.totalCells + 7) / 8, nframes);
     const size_t lds = (size_t)4 * F.perWave;
-#define RUMI_FAST_CASE(T, S) if (F.tp == T && F.sp == S) { hipLaunchKernelGGL((k_fast_cells<T, S>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt); return; }
-    RUMI_FAST_CASE(52, 44) RUMI_FAST_CASE(52, 40) RUMI_FAST_CASE(48, 40) RUMI_FAST_CASE(56, 44) RUMI_FAST_CASE(60, 48)
+#define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt); return; }
+    RUMI_FAST_CASE(48) RUMI_FAST_CASE(44) RUMI_FAST_CASE(52) RUMI_FAST_CASE(56)
 #undef RUMI_FAST_CASE
-    hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt);
+    hipLaunchKernelGGL((k_fast_cells<0>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st) {
