@@ -201,7 +201,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
 // sub-image as aligned dwords, scores 64 pixels per step, and emits in index order with a running offset.  LDS per wave is
 // sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
-struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave, exp; };
+struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -323,11 +323,11 @@ __device__ __forceinline__ void fast_score_batch2(const uint8_t *tile, uint8_t *
 // its tile offset + scDelta).  Returns the number of scored-list appends.
 template <int CTP>
 __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int shx, int dw, int dh,
-                                               int tlow, int lane, int exp) {
+                                               int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
     const int c0 = 3 + shx, c1 = c0 + dw;                 // tile columns of the detection region
     const int g0 = c0 >> 2, ng = ((c1 + 3) >> 2) - g0;    // aligned 4-pixel groups per row that touch it
-    const int nItems = (exp & 4) ? 0 : ng * dh;
+    const int nItems = ng * dh;
     const unsigned Mng = magic_of(ng);
     const int scDelta = -2 * TP - 2 - shx;                // tile offset (py + 3) * TP + px + 3 + shx  ->  score byte (py + 1) * TP + px + 1
     // entry masks (2 bits per pixel) of the first / last group of a row: pixels left of c0 / from c1 on lie outside the region
@@ -380,14 +380,12 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         if (gi == 0) m &= mFirst;
         if (gi == ng - 1) m &= mLast;
         if (!live) m = 0;
-        if (exp & 2) m = 0;
         if (__ballot(m != 0) != 0) {
             // ring positions: entries of lower lanes first; within a lane pixel by pixel, darker before brighter
             const int cnt = __popc(m);
             const int incl = wave_incl_scan(cnt);
             uint16_t *w = cl + pending + incl - cnt;
             uint32_t e = (uint32_t)A;
-            if (!(exp & 8))
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (m & (1u << (2 * i))) *w++ = (uint16_t)e;
@@ -398,7 +396,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
             int head = 0;
             while (pending >= 128) {                       // a full batch: score it exactly
                 wave_lds_fence();
-                if (!(exp & 1)) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
+                fast_score_batch2<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
                 head += 128;
                 pending -= 128;
             }
@@ -411,7 +409,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         }
     }
     wave_lds_fence();
-    if (pending && !(exp & 1)) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
+    if (pending) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
     return nScored;
 }
 
@@ -499,7 +497,7 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
     bool listed;
 #pragma nounroll
     for (int pass = 0;; pass++) {
-        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, shx, dw, dh, thr, lane, F.exp);
+        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, shx, dw, dh, thr, lane);
         wave_lds_fence();
         // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
         // kScoredCap scored pixels scans its whole score map instead
@@ -530,7 +528,7 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
             if (lane == 0) balI[it] = bi;
         }
         wave_lds_fence();
-        if (found > 0 || pass == 1 || (F.exp & 16)) break;           // retry with minThFAST only if the first call found nothing (:783)
+        if (found > 0 || pass == 1) break;                        // retry with minThFAST only if the first call found nothing (:783)
         thr = max(1, P->minTh);                                      // scores of the first pass that are still in the map are rewritten with the same values
     }
     if (lane == 0) cellCnt[g.cellIdx] = found;
@@ -891,7 +889,6 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
     FastLds F;
-    F.exp = std::getenv("RUMI_FAST_EXP") ? std::atoi(std::getenv("RUMI_FAST_EXP")) : 0;
     F.tp = (wMax + 6 + 3 + 3) & ~3;                       // sub-image + alignment shift (<= 3), in whole dwords
     F.sp = F.tp;                                          // the score map shares the tile's pitch (a pixel's score byte sits at its tile offset + a constant)
     F.tileBytes = (hMax + 6) * F.tp;
