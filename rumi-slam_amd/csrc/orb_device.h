@@ -20,7 +20,7 @@ struct DevLevel {
     float patchSize;               // (float)(int)(31 * scale)  (ORBextractor.cc:816)
     int candCap;
     int coefX, coefY, xmax;        // resize tables (int16 units into the coefficient buffer)
-    int rowTab;                    // first entry of the level's output-row table (RowTap units, row -kFrameRows first)
+    int rowTab;                    // first entry of the level's output-row table (RowTap units, row 0 first)
 };
 
 struct DevParams {
@@ -31,19 +31,17 @@ struct DevParams {
     DevLevel lv[kMaxLevels];
 };
 
-// Where the kernels find pixels: every level (0 included: k_pyr0 copies the caller's frame in) lives in `pyr` with a
-// REFLECT_101 frame of kPadX x kPadY around it, the blurred levels in `blur` (same geometry, frame unused).
+// Where the kernels find pixels: level 0 IS the caller's frame (4-byte aligned base / pitch / frame stride; the host stages a frame
+// that is not), levels 1.. live in `pyr`, the blurred levels (0 included) in `blur` with the same per-level offsets.  No borders anywhere.
 struct ImgSrc {
-    const uint8_t *l0;             // caller's frames (read once by k_pyr0)
+    const uint8_t *l0;             // caller's frames = level 0
     long long l0FrameStride;
     int l0Pitch;
     uint8_t *pyr;
     uint8_t *blur;
 };
 
-void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
-void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
-struct RowTap { int32_t off0, off1; uint32_t bh0, bh1; };   // byte offsets of the two source rows, vertical taps << 16
+struct RowTap { int32_t r0, r1; uint32_t bh0, bh1; };   // the two (clamped) source rows, vertical taps << 16
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,

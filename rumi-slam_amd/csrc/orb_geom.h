@@ -16,10 +16,8 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD
 constexpr int kBorder = kEdge - 3; // minBorderX/Y = 16
 constexpr int kMaxLevels = 16;
 constexpr int kCellTileMax = 96;   // largest FAST sub-image side the cell kernel stages in LDS
-constexpr int kPadX = 32;          // REFLECT_101 frame kept around every pyramid level in HBM: >= EDGE_THRESHOLD, keeps rows 4-B aligned
-constexpr int kPadY = kEdge;       // 19 rows reserved, as the reference's copyMakeBorder
-constexpr int kFrameRows = 3;      // frame rows / columns actually MATERIALISED around a level: the only reader outside the level is the
-constexpr int kFrameCols = 4;      // 7x7 blur (3 px); the 19-px border of mvImagePyramid is synthesised on export (rumi_orb_pyramid_level)
+// No border is materialised around a level: the only reader outside a level is the 7x7 blur, which mirrors (BORDER_REFLECT_101) at the
+// edges itself; the 19-px border of mvImagePyramid is synthesised on export (rumi_orb_pyramid_level).
 
 inline int cv_round_host(double v) { return (int)std::lrint(v); }
 
@@ -39,8 +37,8 @@ RUMI_GEOM_HD int magic_div(int idx, unsigned M) { return (int)(((unsigned)idx * 
 RUMI_GEOM_HD int mul24(int a, int b) { return a * b; }
 
 struct LevelGeom {
-    int w, h, pitch;            // level size, row pitch in bytes (64-B aligned, includes the 2 x kPadX frame)
-    long long off;              // byte offset of the level's pixel (0,0) inside one frame's arena (the frame lies before / around it)
+    int w, h, pitch;            // level size, row pitch in bytes (64-B aligned)
+    long long off;              // byte offset of the level's pixel (0,0) inside one frame's arena
     int nCols, nRows, wCell, hCell;
     int cellBase, nCells;       // first cell id of this level in the frame's cell list
     int maxBX, maxBY;           // w-16, h-16
@@ -103,9 +101,9 @@ inline bool make_geometry(const OrbTables &t, int w, int h, std::vector<LevelGeo
         LevelGeom &L = g[l];
         L.w = cv_round_host((float)w * t.invScale[l]);
         L.h = cv_round_host((float)h * t.invScale[l]);
-        L.pitch = (L.w + 2 * kPadX + 63) & ~63;
-        L.off = off + (long long)kPadY * L.pitch + kPadX;
-        off += (long long)L.pitch * (L.h + 2 * kPadY);
+        L.pitch = (L.w + 63) & ~63;
+        L.off = off;
+        off += (long long)L.pitch * L.h + 64;             // + slack: the resize reads 8-byte windows that may end a few bytes past a row
         L.maxBX = L.w - kBorder; L.maxBY = L.h - kBorder;
         const float width = (float)(L.maxBX - kBorder), height = (float)(L.maxBY - kBorder);
         L.nCols = (int)(width / 35.f); L.nRows = (int)(height / 35.f);

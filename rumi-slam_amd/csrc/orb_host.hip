@@ -66,7 +66,8 @@ struct RumiOrb {
     int16_t *dCoef = nullptr;
     RowTap *dRowTab = nullptr; int capRowTab = 0;   // per level and output row: source rows and vertical taps of the resize
     // HBM arenas (sized for max_batch frames unless noted)
-    uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame)
+    uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame, rows padded to a multiple of 4 bytes)
+    uint8_t *dL0 = nullptr;          // staging for device frames whose base / pitch / frame stride is not 4-byte aligned (allocated on first use)
     uint8_t *hIn = nullptr, *hOut1 = nullptr, *dOut1 = nullptr;   // pinned image / pinned + device [counts | kp | desc] block of that API
     size_t out1Bytes = 0;             // > 0 while rumi_orb_extract wants the block copied back before the call's one synchronisation
     uint8_t *dPyr = nullptr, *dBlur = nullptr;
@@ -151,15 +152,13 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
             D.coefY = (int)coef.size();
             coef.insert(coef.end(), ofs.begin(), ofs.end());
             coef.insert(coef.end(), taps.begin(), taps.end());
-            // output rows -kFrameRows .. h + kFrameRows - 1 (the frame rows resample the mirrored row): clamped source rows as byte offsets
-            // into the previous level, taps << 16
+            // per output row: the two clamped source rows (cv clips the ROW indices when it fetches them) and the taps << 16
             D.rowTab = (int)rowTab.size();
-            const int sh = g[l - 1].h, sp = g[l - 1].pitch;
-            auto reflect = [](int i, int n) { while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; };   // BORDER_REFLECT_101, as the kernels' reflect101
-            for (int oy = -kFrameRows; oy < G.h + kFrameRows; oy++) {
-                const int dy = reflect(oy, G.h), sy = ofs[dy];
+            const int sh = g[l - 1].h;
+            for (int oy = 0; oy < G.h; oy++) {
+                const int sy = ofs[oy];
                 const int sy0 = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0, sy1r = sy + 1, sy1 = sy1r >= 0 ? (sy1r < sh ? sy1r : sh - 1) : 0;
-                rowTab.push_back(RowTap{sy0 * sp, sy1 * sp, (uint32_t)taps[dy * 2] << 16, (uint32_t)taps[dy * 2 + 1] << 16});
+                rowTab.push_back(RowTap{sy0, sy1, (uint32_t)taps[oy * 2] << 16, (uint32_t)taps[oy * 2 + 1] << 16});
             }
         }
     }
@@ -192,7 +191,7 @@ extern "C" int rumi_orb_tables(const RumiOrbConfig *cfg, float *scale, float *in
 extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dIn, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
+    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
                    h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
                    h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -253,7 +252,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     h->capCand = candSum + 64;
     h->capCoef = coefN + 64 * cfg->nlevels;
     h->capRowTab = 0;
-    for (int l = 1; l < cfg->nlevels; l++) h->capRowTab += g[l].h + 2 * kFrameRows + 8;
+    for (int l = 1; l < cfg->nlevels; l++) h->capRowTab += g[l].h + 8;
     h->capSel = cfg->nfeatures + 4 * cfg->nlevels + 64;   // the quadtree may return a few more than N per level
     // scratch arenas: frames of one pass, rounded up to a multiple of 12 so that 2, 3 or 4 equal slots hold ceil(frames / parts) each
     const size_t B = (size_t)cfg->max_batch, C = (size_t)scratch_frames(cfg->max_batch);
@@ -262,7 +261,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dP, 1));
     TRY_ALLOC(dev_alloc(&h->dCoef, (size_t)h->capCoef));
     TRY_ALLOC(dev_alloc(&h->dRowTab, (size_t)std::max(h->capRowTab, 1)));
-    TRY_ALLOC(dev_alloc(&h->dIn, (size_t)cfg->max_width * cfg->max_height));
+    TRY_ALLOC(dev_alloc(&h->dIn, (size_t)((cfg->max_width + 3) & ~3) * cfg->max_height));
     TRY_ALLOC(dev_alloc(&h->dPyr, (size_t)h->capArena * B));
     TRY_ALLOC(dev_alloc(&h->dBlur, (size_t)h->capArena * B));
     TRY_ALLOC(dev_alloc(&h->dCellBuf, C * h->capCells * h->capCellCand));
@@ -277,7 +276,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dDesc, (size_t)h->capSel * 32));
     TRY_ALLOC(dev_alloc(&h->dCounts, 2));
     TRY_ALLOC(dev_alloc(&h->dOut1, (size_t)16 + (size_t)h->capSel * 60));
-    if (hipHostMalloc((void **)&h->hIn, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&h->hIn, (size_t)((cfg->max_width + 3) & ~3) * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->hOut1, (size_t)16 + (size_t)h->capSel * 60, hipHostMallocDefault) != hipSuccess) {
         rumi_orb_destroy(h); g_lastError = "pinned staging"; return RUMI_E_NO_DEVICE;
     }
@@ -331,6 +330,16 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     if (rc != RUMI_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     const DevParams &P = h->hP;
+    // Level 0 is read where the caller has it, as aligned dwords.  Frames whose base, pitch or frame stride is not a multiple of 4 are
+    // first copied into an aligned staging arena (the only case that costs a copy).
+    if ((reinterpret_cast<uintptr_t>(d_imgs) & 3) || (stride & 3) || (frame_stride & 3)) {
+        const int wp = (w + 3) & ~3;
+        if (!h->dL0) HIP_TRY(hipMalloc((void **)&h->dL0, (size_t)((h->cfg.max_width + 3) & ~3) * h->cfg.max_height * h->cfg.max_batch));
+        for (int f = 0; f < nframes; f++)
+            HIP_TRY(hipMemcpy2DAsync(h->dL0 + (size_t)f * wp * hgt, wp, (const uint8_t *)d_imgs + (long long)f * frame_stride, stride, w, hgt,
+                                     hipMemcpyDeviceToDevice, st));
+        d_imgs = h->dL0; stride = wp; frame_stride = (int64_t)wp * hgt;
+    }
     ImgSrc src{(const uint8_t *)d_imgs, frame_stride, stride, h->dPyr, h->dBlur};
     const bool prof = h->profiling;
     float acc[8] = {0};
@@ -348,9 +357,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
     auto stage_a = [&](const ImgSrc &ps, int n, hipStream_t s, int side) -> int {
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
-        launch_pyr0(h->dP, P, ps, n, s);
         for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
-        launch_frame_cols(h->dP, P, ps, n, s);
         if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
         hipStream_t bs = serial ? s : (side ? h->partSide[side - 1] : h->sideStream);
         hipEvent_t fork = side ? h->evSideFork[side - 1] : h->evFork, join = side ? h->evSideJoin[side - 1] : h->evJoin;
@@ -469,13 +476,14 @@ extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32
     if (stride < w || w > h->cfg.max_width || hgt > h->cfg.max_height) { g_lastError = "image size"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(h->device));
     // image -> pinned -> device (async), kernels, [counts | key-points | descriptors] -> pinned: one synchronisation in all
-    for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
-    HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)w * hgt, hipMemcpyHostToDevice, nullptr));
+    const int wp = (w + 3) & ~3;                                     // rows padded so that level 0 can be read as aligned dwords
+    for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);
+    HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)wp * hgt, hipMemcpyHostToDevice, nullptr));
     int32_t *dC = reinterpret_cast<int32_t *>(h->dOut1);
     RumiKeyPoint *dK = reinterpret_cast<RumiKeyPoint *>(h->dOut1 + 16);
     uint8_t *dD = h->dOut1 + 16 + (size_t)h->capSel * sizeof(RumiKeyPoint);
     h->out1Bytes = (size_t)16 + (size_t)h->capSel * 60;
-    const int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, w, (int64_t)w * hgt, lap0, lap1, dK, dD, dC, h->capSel, nullptr);
+    const int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, wp, (int64_t)wp * hgt, lap0, lap1, dK, dD, dC, h->capSel, nullptr);
     h->out1Bytes = 0;
     if (rc != RUMI_OK) return rc;
     const int32_t *counts = reinterpret_cast<const int32_t *>(h->hOut1);
@@ -500,12 +508,15 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
     if (!out) return RUMI_OK;
     if (out_stride < L.w + 2 * border) return RUMI_E_CAPACITY;
     HIP_TRY(hipSetDevice(h->device));
-    // the arena materialises only the 3-px frame the blur reads; the 19-px border copyMakeBorder(..., BORDER_REFLECT_101) gives
-    // mvImagePyramid (ORBextractor.cc:1105-1108) is synthesised here from the interior, which is the same pixels by definition
+    // no border is stored; the 19-px border copyMakeBorder(..., BORDER_REFLECT_101) gives mvImagePyramid (ORBextractor.cc:1105-1108)
+    // is synthesised here from the interior, which is the same pixels by definition
     if (border > (which ? 0 : kEdge)) { g_lastError = which ? "blurred levels carry no border" : "border larger than EDGE_THRESHOLD (19)"; return RUMI_E_INVALID; }
-    const uint8_t *srcp = (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off;
+    // level 0 is the caller's frame itself (it must still be alive); the other levels and every blurred level come from the arenas
+    const bool own = !which && level == 0;
+    const uint8_t *srcp = own ? h->lastSrc.l0 + (long long)frame * h->lastSrc.l0FrameStride
+                              : (which ? h->lastSrc.blur : h->lastSrc.pyr) + (long long)frame * h->hP.arenaStride + L.off;
     uint8_t *inner = out + (size_t)border * out_stride + border;
-    HIP_TRY(hipMemcpy2D(inner, out_stride, srcp, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(inner, out_stride, srcp, own ? h->lastSrc.l0Pitch : L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
     auto refl = [](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p; return p; };
     for (int y = 0; y < L.h; y++) {
         uint8_t *row = inner + (size_t)y * out_stride;

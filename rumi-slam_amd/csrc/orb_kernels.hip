@@ -30,9 +30,13 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned total) {
 
 struct __attribute__((packed)) U64 { uint64_t v; };      // possibly unaligned 8-byte global access
 
-// pixel (0,0) of a pyramid level; a REFLECT_101 frame of kPadX x kPadY pixels surrounds it in memory
+// pixel (0,0) of a pyramid level: level 0 is the caller's frame itself, the others live in the pyramid arena
 __device__ __forceinline__ const uint8_t *level_base(const ImgSrc &s, const DevParams *P, int level, int frame,
                                                       int *pitch) {
+    if (level == 0) {
+        *pitch = s.l0Pitch;
+        return s.l0 + (long long)frame * s.l0FrameStride;
+    }
     *pitch = P->lv[level].pitch;
     return s.pyr + (long long)frame * P->arenaStride + P->lv[level].off;
 }
@@ -44,39 +48,11 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pyramid.  Every level is stored with the reference's BORDER_REFLECT_101 frame (copyMakeBorder,
-// ORBextractor.cc:1105-1110) so that the blur and every gather run without edge cases.
-//   k_pyr0    level 0 = the caller's frame + frame; a lane moves 4 pixels.
-//   k_resize  level l from level l-1 (cv::resize INTER_LINEAR 8U; taps from host tables that follow cv's coefficient
-//             rule, orb_geom.h); a lane produces 4 horizontally adjacent pixels of the FRAMED output (frame pixels
-//             recompute their mirror pixel) and stores one dword.  HBM-bound: 1.19 B written, ~1.44 B read per pixel.
+// Pyramid: level l from level l-1 (cv::resize INTER_LINEAR 8U; taps from host tables that follow cv's coefficient rule, orb_geom.h),
+// level 1 straight from the caller's frame.  A lane produces 4 horizontally adjacent pixels of kResizeRows consecutive rows and stores
+// one dword per row: the column tables are loaded once and the 2 x kResizeRows source-row loads are issued back to back.
+// No border pixels are written: the blur mirrors at the edges itself.
 // ------------------------------------------------------------------------------------------------
-// k_pyr0 / k_resize write the pixel columns [0, w) of the rows [-kFrameRows, h + kFrameRows) (the frame rows above and below are
-// computed like any other row, from the mirrored source row); k_frame_cols then mirrors the left / right frame columns of
-// every level of every frame in ONE launch (no level reads another level's frame columns).
-__global__ __launch_bounds__(256) void k_pyr0(const DevParams *__restrict__ P, ImgSrc src) {
-    const DevLevel &D = P->lv[0];
-    const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
-    const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
-    const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oy = by * 4 + (threadIdx.x >> 6) - kFrameRows;
-    if (ox >= D.w || oy >= D.h + kFrameRows) return;
-    const uint8_t *in = src.l0 + (long long)frame * src.l0FrameStride + (long long)reflect101(oy, D.h) * src.l0Pitch + ox;
-    uint8_t *out = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)oy * D.pitch + ox;
-    uint32_t v;
-    if (ox + 3 < D.w && (reinterpret_cast<uintptr_t>(in) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(in);
-    else {
-        v = in[0];
-        if (ox + 1 < D.w) v |= (uint32_t)in[1] << 8;
-        if (ox + 2 < D.w) v |= (uint32_t)in[2] << 16;
-        if (ox + 3 < D.w) v |= (uint32_t)in[3] << 24;
-    }
-    *reinterpret_cast<uint32_t *>(out) = v;                                  // columns >= w are rewritten by k_frame_cols
-}
-
-// Each lane produces 4 pixels of kResizeRows consecutive rows: the column tables are loaded once and the 2 x kResizeRows
-// source-row loads are issued back to back, so a wave has 8 x more bytes in flight per dependent round trip than with one row
-// (the kernel is latency-bound: two dependent table -> pixel round trips per wave).
 constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
                                                 const int16_t *__restrict__ coef, const RowTap *__restrict__ rowTab, int level) {
@@ -85,37 +61,39 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
     const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows - kFrameRows;
-    if (ox >= D.w || oyBase >= D.h + kFrameRows) return;
-    const uint8_t *sb = src.pyr + (long long)frame * P->arenaStride + S.off;
+    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows;
+    if (ox >= D.w || oyBase >= D.h) return;
+    int sp;
+    const uint8_t *sb = level_base(src, P, level - 1, frame, &sp);
     uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + ox;
     const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
-    // per output row (frame rows included): the two source rows and the vertical taps come ready from a host-built table (the mirrored
-    // row, the clamps and the row pitch products are the same for every lane of every frame)
+    // per output row: the two source rows and the vertical taps come ready from a host-built table (the clamps are the same for every
+    // lane of every frame)
     const uint8_t *r0p[kResizeRows], *r1p[kResizeRows];
     uint32_t bh0[kResizeRows], bh1[kResizeRows];
     bool live[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) {
         const int oy = oyBase + r;
-        live[r] = oy < D.h + kFrameRows;
-        const RowTap t = rowTab[D.rowTab + (live[r] ? oy : 0) + kFrameRows];
-        r0p[r] = sb + t.off0; r1p[r] = sb + t.off1;
+        live[r] = oy < D.h;
+        const RowTap t = rowTab[D.rowTab + (live[r] ? oy : 0)];
+        r0p[r] = sb + (long long)t.r0 * sp; r1p[r] = sb + (long long)t.r1 * sp;
         bh0[r] = t.bh0; bh1[r] = t.bh1;
     }
     const bool whole = ox + 3 < D.w;
     const int sx0 = xofs[ox];
     if (whole && ox + 3 < D.xmax && xofs[ox + 3] + 1 - sx0 <= 7) {
         // the 4 outputs read source bytes sx0 .. sx0+7 of two rows -> two (unaligned) 8-byte loads per row; offsets and taps
-        // come as one 8-byte and one 16-byte table load
+        // come as one 8-byte and one 16-byte table load.  The window never leaves the source row (the last lanes slide it left).
+        const int wx0 = min(sx0, S.w - 8);
         const uint64_t ofs = reinterpret_cast<const U64 *>(xofs + ox)->v;
         const U64 *t8 = reinterpret_cast<const U64 *>(xa + 2 * ox);
         const uint64_t ta = t8[0].v, tb = t8[1].v;
         uint64_t s0[kResizeRows], s1[kResizeRows];
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
-            s0[r] = reinterpret_cast<const U64 *>(r0p[r] + sx0)->v;
-            s1[r] = reinterpret_cast<const U64 *>(r1p[r] + sx0)->v;
+            s0[r] = reinterpret_cast<const U64 *>(r0p[r] + wx0)->v;
+            s1[r] = reinterpret_cast<const U64 *>(r1p[r] + wx0)->v;
         }
         // horizontal pass as a 2-element dot product: the two source bytes of an output are adjacent, v_perm_b32 spreads them into
         // 16-bit halves and v_dot2_u32_u16 multiplies by the (non-negative, <= 2048) tap pair as it lies in the table
@@ -125,7 +103,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         uint32_t sel[4], tap[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t k = (uint32_t)((int)(int16_t)(ofs >> (16 * i)) - sx0);          // 0 .. 6
+            const uint32_t k = (uint32_t)((int)(int16_t)(ofs >> (16 * i)) - wx0);          // 0 .. 6
             sel[i] = k | 0x0c000c00u | ((k + 1u) << 16);
             const uint64_t tt = i < 2 ? ta : tb;
             tap[i] = (uint32_t)(tt >> (32 * (i & 1)));
@@ -165,22 +143,6 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
             *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
     }
-}
-
-// left / right REFLECT_101 frame columns of all levels: thread = (frame, level, framed row, one of 3 aligned dword strips)
-__global__ __launch_bounds__(256) void k_frame_cols(const DevParams *__restrict__ P, ImgSrc src) {
-    const int level = blockIdx.y, frame = blockIdx.z;
-    const DevLevel &D = P->lv[level];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int strip = t % 3, row = t / 3 - kFrameRows;
-    if (row >= D.h + kFrameRows) return;
-    uint8_t *rp = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)row * D.pitch;
-    // strip 0: x = -4..-1; strips 1, 2: x = (w & ~3) .. (w & ~3) + 7 (covers w .. w+3 and re-writes <= 3 interior pixels)
-    const int x0 = strip == 0 ? -kFrameCols : (D.w & ~3) + 4 * (strip - 1);
-    uint32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) v |= (uint32_t)rp[reflect101(x0 + i, D.w)] << (8 * i);
-    *reinterpret_cast<uint32_t *>(rp + x0) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -652,24 +614,25 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
 
 // ------------------------------------------------------------------------------------------------
 // Gaussian blur 7x7, sigma 2, fixed point: taps {18,34,48,56,48,34,18}/256, row pass to u16, column
-// pass to u32, (v + 32768) >> 16, REFLECT_101 at the level's own edges.
+// pass to u32, (v + 32768) >> 16, BORDER_REFLECT_101 at the level's own edges.
 // ------------------------------------------------------------------------------------------------
 // Register formulation: a lane owns a 4-pixel column strip, a wave walks kBlurRows output rows top to bottom.
 // Per source row: ONE aligned dword load per lane; the left / right neighbours' dwords arrive by DPP shuffles (the two
 // outer lanes load their halo dwords); the 7-tap row pass runs on the 10 unpacked bytes, the column pass on a 7-deep
-// register ring of row results; 4 output pixels leave as one dword store.  No LDS, no barriers, and no edge cases: the
-// REFLECT_101 frame stored around every level IS the border GaussianBlur(..., BORDER_REFLECT_101) would synthesise.
+// register ring of row results; 4 output pixels leave as one dword store.  No LDS, no barriers.
+// Edges (no border is stored around a level): rows above / below the level are the mirrored rows (a row index, wave-uniform); the three
+// columns left of column 0 are bytes 3, 2, 1 of the first dword (one v_perm_b32 in the first strip block); columns from w on are mirrored
+// bytes fetched by the few lanes whose dword touches them (byte loads of the same cache lines, only in waves that hold the right edge).
 constexpr int kBlurRows = 16;
 
 // all levels in one launch: workgroup `lin` of a frame belongs to the level whose [base, base + gx * gy) range holds it
-struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; };
+struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; int bw[kMaxLevels]; };   // bw: pixels a wave's strips cover (256, or less: see launch_blur)
 // a * b + c on 24-bit operands as ONE v_mad_u32_u24 (the compiler splits the C expression into a multiply and a 3-input add)
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -679,15 +642,37 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
         if (lin >= G.base[l]) level = l;
     const DevLevel &L = P->lv[level];
     const int bx = (lin - G.base[level]) % G.gx[level], by = (lin - G.base[level]) / G.gx[level];
-    const int xa = bx * 256 + lane * 4;                          // first pixel of my strip
+    const int bw = G.bw[level];
+    const int xa = bx * bw + lane * 4;                           // first pixel of my strip (lanes from bw / 4 on only feed their left neighbour's halo)
     const int y0 = (by * 4 + wave) * kBlurRows;
     if (y0 >= L.h) return;                                       // whole wave (wave-uniform)
     int pitch;
     const uint8_t *img = level_base(src, P, level, frame, &pitch);
     uint8_t *out = src.blur + (long long)frame * P->arenaStride + L.off;
     const int w = L.w, h = L.h;
-    // strips that start beyond the row still feed their neighbours' halos; clamp their address inside the framed row
-    const int xl = min(xa, ((w + kPadX - 4) & ~3));
+    // Right edge.  The dword that holds column w - 1 may be partial and the one after it lies wholly beyond the row, yet both feed the
+    // halos of the last strips: their missing bytes are the mirrored columns 2 (w - 1) - x, which sit in the same lane or one / two lanes to
+    // the left.  In the wave that holds the edge every lane rebuilds its dword from {own, left, left-left} with two v_perm_b32 whose
+    // selectors are fixed per lane (identity away from the edge).  The host picks the strip width of a level (G.bw) so that the partial dword
+    // is never lane 0 or 1 of a wave and a wave's last producing lane never needs a halo dword from beyond the row edge out of memory.
+    const int xLast = (w - 1) & ~3;                              // last dword that holds a pixel of the row
+    const int xl = min(xa, xLast);
+    const bool firstBlock = bx == 0;
+    const bool edgeWave = bx * bw + bw + 4 > w;                  // a dword of this wave (its right halo included) reaches column w or beyond (wave-uniform)
+    const bool produce = lane * 4 < bw && xa < w;
+    uint32_t selA = 0x03020100u, selB = 0x07060504u;             // identity: keep my own four bytes
+    if (edgeWave && xa + 3 >= w && xa <= xLast + 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = xa + i;
+            if (x < w) continue;
+            const int sx = 2 * (w - 1) - x, d = (xa - (sx & ~3)) >> 2;                 // mirrored column, lanes to the left (0, 1 or 2 for every byte that is used)
+            const uint32_t a = (d == 1 ? 4u : 0u) + (uint32_t)(sx & 3);                 // byte of {left-left (0-3), left (4-7)}
+            const uint32_t b = d == 0 ? 4u + (uint32_t)(sx & 3) : (uint32_t)i;          // byte of {gathered (0-3), own (4-7)}
+            selA = (selA & ~(0xFFu << (8 * i))) | (a << (8 * i));
+            selB = (selB & ~(0xFFu << (8 * i))) | (b << (8 * i));
+        }
+    }
     int ring[7][4];                                              // row results of the last seven source rows; slot = source row mod 7 of this walk
 #pragma unroll
     for (int k = 0; k < 7; k++)
@@ -696,18 +681,23 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
     const int yEnd = min(y0 + kBlurRows, h), rEnd = yEnd + 3;
     // the walk is unrolled by seven so that the ring never moves: source row r0 + j lands in slot j, and the taps of the output row it
     // completes sit at compile-time slots (a runtime ring costs 24 register moves per row)
-    const uint8_t *row = img + (long long)(y0 - 3) * pitch - pitch;   // running pointers: one add per row instead of a 64-bit multiply-add
     uint8_t *orow = out + (long long)(y0 - 6) * L.pitch + xa - L.pitch;
     for (int r0 = y0 - 3; r0 < rEnd; r0 += 7) {
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int r = r0 + j;
             if (r >= rEnd) break;                                // wave-uniform
-            row += pitch; orow += L.pitch;                       // rows -3..-1 and h..h+2 are frame rows
-            const uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
+            orow += L.pitch;
+            const int rr = r < 0 ? -r : (r >= h ? 2 * (h - 1) - r : r);           // rows -3..-1 and h..h+2 mirror into the level
+            const uint8_t *row = img + (long long)rr * pitch;
+            uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
+            if (edgeWave) {
+                const uint32_t c1 = __shfl_up(C, 1), c2 = __shfl_up(c1, 1);
+                C = __builtin_amdgcn_perm(C, __builtin_amdgcn_perm(c1, c2, selA), selB);
+            }
             uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
-            if (lane == 0) Lw = *reinterpret_cast<const uint32_t *>(row + xl - 4);
-            if (lane == 63) Rw = *reinterpret_cast<const uint32_t *>(row + min(xl + 4, (w + kPadX - 4) & ~3));
+            if (lane == 0) Lw = firstBlock ? __builtin_amdgcn_perm(C, C, 0x01020300u) : *reinterpret_cast<const uint32_t *>(row + xl - 4);
+            if (lane == 63 && !edgeWave && bw == 256) Rw = *reinterpret_cast<const uint32_t *>(row + xl + 4);   // (only a 256-pixel wave has a producing lane 63)
             // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
             // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
             constexpr uint32_t tA = 18u | (34u << 8) | (48u << 16) | (56u << 24), tB = 48u | (34u << 8) | (18u << 16);
@@ -718,7 +708,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
             ring[j][2] = (int)__builtin_amdgcn_udot4(B2, tB, __builtin_amdgcn_udot4(A2, tA, 0u, false), false);
             ring[j][3] = (int)__builtin_amdgcn_udot4(Rw, tB, __builtin_amdgcn_udot4(C, tA, 0u, false), false);
             const int y = r - 3;                                 // slots (j+1)%7 .. j now hold rows y-3 .. y+3
-            if (y >= y0 && xa < w) {
+            if (y >= y0 && produce) {
                 uint32_t o[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -731,7 +721,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
                     o[i] = acc;
                 }
                 // byte 2 of the four sums -> one dword (v_perm_b32: selectors 0-3 take from the second operand, 4-7 from the first, 0x0c = zero);
-                // the blurred arena has the same framed geometry, so a whole dword always fits in the row
+                // the blurred arena's rows are padded to 64 B, so a whole dword always fits in the row
                 const uint32_t p01 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
                 *reinterpret_cast<uint32_t *>(orow) = p01 | p23;         // orow = out + y * pitch + xa
             }
@@ -870,17 +860,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
 }
 
 // ---- launch wrappers (called from orb_host.hip) ----
-void launch_pyr0(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
-    dim3 g((hP.lv[0].w + 255) / 256, (hP.lv[0].h + 2 * kFrameRows + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_pyr0, g, dim3(256), 0, st, dP, src);
-}
-void launch_frame_cols(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
-    dim3 g(((hP.lv[0].h + 2 * kFrameRows) * 3 + 255) / 256, hP.nlevels, nframes);
-    hipLaunchKernelGGL(k_frame_cols, g, dim3(256), 0, st, dP, src);
-}
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st) {
-    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 2 * kFrameRows + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level);
 }
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
@@ -912,11 +894,24 @@ void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *ce
     hipLaunchKernelGGL(k_compact, dim3(nframes, nframes < 32 ? 8 : 1), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
                        cand, levelStart, overflow);
 }
+// strip width of a level's waves: 256 pixels unless that would put the row's partial dword into lane 0 or 1 of a wave (its mirrored bytes
+// then lie in the previous wave) or make a wave's lane 63 need a halo dword that reaches beyond the row edge; narrower waves leave their
+// last lanes as pure halo providers
+static int blur_strip_width(int w) {
+    for (int bw : {256, 240, 224, 208}) {
+        const int r = w % bw;
+        const bool partialInFirstLanes = r >= 1 && r <= 8;
+        const bool lane63Halo = bw == 256 && (r >= 253 || r <= 3);
+        if (!partialInFirstLanes && !lane63Halo) return bw;
+    }
+    return 192;
+}
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
     BlurGrid G{};
     int run = 0;
     for (int l = 0; l < hP.nlevels; l++) {
-        G.gx[l] = (hP.lv[l].w + 255) / 256;
+        G.bw[l] = blur_strip_width(hP.lv[l].w);
+        G.gx[l] = (hP.lv[l].w + G.bw[l] - 1) / G.bw[l];
         G.base[l] = run;
         run += G.gx[l] * ((hP.lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }

@@ -55,7 +55,8 @@ class ORBextractor:
         if image is None or image.size == 0:
             return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected"
-        image = np.ascontiguousarray(image)
+        if image.strides[1] != 1:                                   # rows must be dense; any row pitch goes through as `stride`
+            image = np.ascontiguousarray(image)
         h, w = image.shape
         cap = self.nfeatures + 4 * self.nlevels + 64
         kps = np.zeros(cap, KP_DTYPE)

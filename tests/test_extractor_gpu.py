@@ -73,7 +73,9 @@ def test_low_texture_retry_path():
         _assert_same(g(img, None, (0, 1000)), out, f"low texture {seed}")
 
 
-@pytest.mark.parametrize("wh", [(752, 480), (600, 350), (320, 240), (1241, 376)])
+# the second row: widths whose levels put the row edge at a wave boundary of the blur (w mod 256 in 253..255 / 0..8), where it picks narrower strips
+@pytest.mark.parametrize("wh", [(752, 480), (600, 350), (320, 240), (1241, 376),
+                                (768, 480), (520, 400), (509, 381), (1025, 400), (515, 387)])
 def test_other_sizes(wh):
     w, h = wh
     g, o = _pair(w=w, h=h)
@@ -83,12 +85,36 @@ def test_other_sizes(wh):
 
 def test_strided_input_and_empty():
     g, o = _pair()
-    big = np.zeros((480, 700), np.uint8)
-    big[:, :640] = synth_frame(8)
-    _assert_same(g(big[:, :640], None, (0, 1000)) if False else g(np.ascontiguousarray(big[:, :640]), None, (0, 1000)),
-                 o.extract(big[:, :640], (0, 1000)), "strided")
+    big = np.zeros((480, 701), np.uint8)
+    big[:, 3:643] = synth_frame(8)
+    view = big[:, 3:643]                                      # row pitch 701 (odd), first pixel at an odd address
+    assert not view.flags["C_CONTIGUOUS"]
+    _assert_same(g(view, None, (0, 1000)), o.extract(np.ascontiguousarray(view), (0, 1000)), "strided")
     mono, k, d = g(np.zeros((0, 0), np.uint8))
     assert mono == -1 and len(k) == 0
+
+
+@pytest.mark.parametrize("off,pitch", [(3, 701), (4, 704), (0, 641)])
+def test_batch_device_strided_views(off, pitch):
+    """rumi_orb_extract_batch_device on frames that are views into a wider buffer: unaligned base / odd pitch (staged through the aligned
+    arena) and an aligned view (read in place); every frame must come out as it does from a dense copy."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    B = 5
+    g, o = _pair(batch=B)
+    frames = synth_batch(B, seed0=640)
+    wide = torch.zeros((B, 481, pitch), dtype=torch.uint8, device="cuda")
+    wide[:, :480, off:off + 640] = torch.from_numpy(frames).cuda()
+    view = wide[:, :480, off:off + 640]
+    assert not view.is_contiguous() and view.stride(1) == pitch
+    kp, desc, counts = g.extract_batch(view)
+    torch.cuda.synchronize()
+    kp = kp.cpu().numpy(); desc = desc.cpu().numpy(); counts = counts.cpu().numpy()
+    for f in range(B):
+        om, ok, od = o.extract(frames[f], (0, 1000))
+        n = counts[f, 0]
+        gk = kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
+        _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"strided batch frame {f} off {off} pitch {pitch}")
 
 
 def test_batch_device_matches_single():
