@@ -19,7 +19,10 @@ struct DevLevel {
     float scale;                   // mvScaleFactor[level]
     float patchSize;               // (float)(int)(31 * scale)  (ORBextractor.cc:816)
     int candCap;
-    int coefX, coefY, xmax;        // resize tables (int16 units into the coefficient buffer)
+    int coefX, coefXT, coefY, xmax; // resize tables (int16 units into the coefficient buffer): column offsets, column tap pairs, row tables;
+                                   // the column tables carry 4 more entries than the level has columns (copies of the last one), so that the
+                                   // lane holding the row's last, partial dword computes 4 outputs like every other lane
+    int xmaxFast;                  // xmax, or w + 3 when no column clamps its second tap (then every lane's 4 outputs may take the fast path)
     int rowTab;                    // first entry of the level's output-row table (RowTap units, row 0 first)
 };
 

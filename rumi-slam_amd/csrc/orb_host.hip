@@ -140,13 +140,16 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
         D.nfeat = G.nfeat; D.scale = G.scale;
         D.patchSize = (float)(int)(kPatchSize * G.scale);
         D.candCap = std::min(G.candCap, 65535);
-        D.coefX = D.coefY = 0; D.xmax = G.w; D.rowTab = 0;
+        D.coefX = D.coefXT = D.coefY = 0; D.xmax = D.xmaxFast = G.w; D.rowTab = 0;
         if (l > 0) {
             std::vector<int16_t> ofs, taps;
             int dmax;
             make_resize_axis(g[l - 1].w, G.w, true, ofs, taps, &dmax);
             D.coefX = (int)coef.size(); D.xmax = dmax;
+            D.xmaxFast = dmax == G.w ? G.w + 3 : dmax;
+            for (int k = 0; k < 4; k++) { ofs.push_back(ofs[G.w - 1]); taps.push_back(taps[2 * G.w - 2]); taps.push_back(taps[2 * G.w - 1]); }
             coef.insert(coef.end(), ofs.begin(), ofs.end());
+            D.coefXT = (int)coef.size();
             coef.insert(coef.end(), taps.begin(), taps.end());
             make_resize_axis(g[l - 1].h, G.h, false, ofs, taps, &dmax);
             D.coefY = (int)coef.size();

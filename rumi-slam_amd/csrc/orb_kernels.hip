@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     int sp;
     const uint8_t *sb = level_base(src, P, level - 1, frame, &sp);
     uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + ox;
-    const int16_t *xofs = coef + D.coefX, *xa = xofs + D.w;
+    const int16_t *xofs = coef + D.coefX, *xa = coef + D.coefXT;
     // per output row: the two source rows and the vertical taps come ready from a host-built table (the clamps are the same for every
     // lane of every frame)
     const uint8_t *r0p[kResizeRows], *r1p[kResizeRows];
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         r0p[r] = sb + (long long)t.r0 * sp; r1p[r] = sb + (long long)t.r1 * sp;
         bh0[r] = t.bh0; bh1[r] = t.bh1;
     }
-    const bool whole = ox + 3 < D.w;
     const int sx0 = xofs[ox];
-    if (whole && ox + 3 < D.xmax && xofs[ox + 3] + 1 - sx0 <= 7) {
+    // (the row's last dword may be partial: its surplus outputs come from the padded table entries and land in the row's padding)
+    if (ox + 3 < D.xmaxFast && xofs[ox + 3] + 1 - sx0 <= 7) {
         // the 4 outputs read source bytes sx0 .. sx0+7 of two rows -> two (unaligned) 8-byte loads per row; offsets and taps
         // come as one 8-byte and one 16-byte table load.  The window never leaves the source row (the last lanes slide it left).
         const int wx0 = min(sx0, S.w - 8);
