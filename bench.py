@@ -126,7 +126,7 @@ def main():
     pending = [None]
 
     def step():
-        kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap)
+        kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
         # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
         # (views of the extractor's output: the successor of frame i is the same buffer one record further, no copy; the last pair wraps)
         match = (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
@@ -150,6 +150,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     drain()
+    ext.sync()
     torch.cuda.synchronize()
     n_kp = float(out[2].reshape(-1, 2)[:, 0].float().mean().item())
 
@@ -160,6 +161,7 @@ def main():
     for _ in range(args.steps):
         out = step()
     drain()
+    ext.sync()                                    # waits for the last step and raises on any device-side capacity condition of the K steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -79,11 +79,21 @@ int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int
  * runs the same extractor on them).  All pointers are DEVICE pointers; frames are `frame_stride`
  * bytes apart.  Outputs: d_kp [nframes][cap], d_desc [nframes][cap][32], d_counts [nframes][2] =
  * {n, monoIndex}; slots >= n are left untouched.  Work is enqueued on `hip_stream` (a hipStream_t, NULL =
- * default stream); the call returns after the last kernel is enqueued, except while the quadtree
- * stage runs on the host (RUMI_ORB_OCTREE_HOST), where it synchronises the stream internally. */
+ * default stream).  Frames whose base address, `stride` or `frame_stride` is not a multiple of 4 are first copied
+ * into an aligned staging arena; aligned frames are read in place (and must stay alive until the work has run).
+ * This form BLOCKS until the work has run and returns its status. */
 int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
                                   int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
                                   void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream);
+/* The same without waiting: returns once everything is enqueued (argument errors are still reported at once), so the
+ * caller can queue the next batch, or other work, behind it.  Device-side conditions (candidate / selection capacity,
+ * quadtree limits) accumulate until rumi_orb_sync, which waits for every call enqueued since the last one and returns
+ * the first such condition.  Consecutive un-waited calls on one handle must use the same stream (another stream, the
+ * profiled path, the taps below and rumi_orb_destroy wait first by themselves). */
+int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                        int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                        void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream);
+int rumi_orb_sync(RumiOrb *h);
 
 /* Backs the public member mvImagePyramid (ORBextractor.h:86): copies level `level` of frame `frame`
  * of the last call to host memory, with `border` replicated pixels of BORDER_REFLECT_101 on each side

@@ -50,7 +50,7 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st);
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
-                    uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st);
+                    uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st);
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,

@@ -74,7 +74,7 @@ struct RumiOrb {
     uint32_t *dCellBuf = nullptr;    // kChunk frames
     int32_t *dCellCnt = nullptr;
     uint32_t *dCand = nullptr;       // kChunk frames x capCand
-    int32_t *dLevelStart = nullptr, *dOverflow = nullptr;
+    int32_t *dLevelStart = nullptr;
     uint32_t *dSelPacked = nullptr, *dSelMeta = nullptr;   // kChunk frames x capSel
     int32_t *dSelCount = nullptr;
     RumiKeyPoint *dKp = nullptr;     // outputs of the single-frame host API
@@ -83,11 +83,14 @@ struct RumiOrb {
     uint16_t *dOwner = nullptr;      // kChunk frames x capCand: quadtree node id of every candidate
     uint32_t *dSelLevel = nullptr;   // kChunk frames x nlevels x selLevelCap: quadtree output per level
     int32_t *dSelLevelCnt = nullptr;
-    int32_t *dErr = nullptr;         // device error word (bit 0/1/2/3: roots, node pool, level cap, selection cap)
+    int32_t *dErr = nullptr;         // device error word (bit 0/1/2/3: roots, node pool, level cap, selection cap; bit 4: FAST candidate capacity);
+                                     // sticky over the asynchronous calls since the last rumi_orb_sync
+    bool pending = false;            // an asynchronous call has been enqueued and not yet waited for
+    hipStream_t pendingStream = nullptr;
     int selLevelCap = 0;
     size_t octLds = 0;
     // pinned host words
-    int32_t *hOverflow = nullptr, *hErr = nullptr;
+    int32_t *hErr = nullptr;
     // host copies fetched lazily by the stage taps
     std::vector<uint32_t> tapCand, tapSelPacked, tapSelMeta;
     std::vector<int32_t> tapLevelStart, tapSelCount;
@@ -194,11 +197,12 @@ extern "C" int rumi_orb_tables(const RumiOrbConfig *cfg, float *scale, float *in
 extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->pending) (void)hipStreamSynchronize(h->pendingStream);
     void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
-                   h->dOverflow, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
+                   h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
                    h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *pin[] = {h->hOverflow, h->hErr};
+    void *pin[] = {h->hErr};
     for (void *p : pin) if (p) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
@@ -271,7 +275,6 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dCellCnt, C * h->capCells));
     TRY_ALLOC(dev_alloc(&h->dCand, C * h->capCand));
     TRY_ALLOC(dev_alloc(&h->dLevelStart, C * (kMaxLevels + 1)));
-    TRY_ALLOC(dev_alloc(&h->dOverflow, B));
     TRY_ALLOC(dev_alloc(&h->dSelPacked, C * h->capSel));
     TRY_ALLOC(dev_alloc(&h->dSelMeta, C * h->capSel));
     TRY_ALLOC(dev_alloc(&h->dSelCount, C));
@@ -290,7 +293,6 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dSelLevel, C * cfg->nlevels * h->selLevelCap));
     TRY_ALLOC(dev_alloc(&h->dSelLevelCnt, C * cfg->nlevels));
     TRY_ALLOC(dev_alloc(&h->dErr, 1));
-    TRY_ALLOC(pin_alloc(&h->hOverflow, B));
     TRY_ALLOC(pin_alloc(&h->hErr, 1));
 #undef TRY_ALLOC
     for (auto &e : h->ev)
@@ -319,9 +321,31 @@ extern "C" int rumi_orb_stage_ms(RumiOrb *h, float ms[8]) {
     return RUMI_OK;
 }
 
+extern "C" int rumi_orb_sync(RumiOrb *h) {
+    if (!h) return RUMI_E_INVALID;
+    if (!h->pending) return RUMI_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->pendingStream));
+    h->pending = false;
+    const int err = *h->hErr;
+    if (err & 16) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
+    if (err & 1) { g_lastError = "aspect ratio gives 0 or more than 16 quadtree roots"; return RUMI_E_INVALID; }
+    if (err & 2) { g_lastError = "quadtree node pool exhausted"; return RUMI_E_INVALID; }
+    if (err & (4 | 8)) { g_lastError = "more key-points than the handle's selection capacity"; return RUMI_E_CAPACITY; }
+    return RUMI_OK;
+}
+
 extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
                                              int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
                                              void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream) {
+    const int rc = rumi_orb_extract_batch_device_async(h, d_imgs, nframes, w, hgt, stride, frame_stride, lap0, lap1, d_kp, d_desc, d_counts, cap, hip_stream);
+    if (rc != RUMI_OK) { if (h && h->pending) (void)rumi_orb_sync(h); return rc; }
+    return rumi_orb_sync(h);
+}
+
+extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                                   int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                                   void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream) {
     if (!h || !d_imgs || !d_kp || !d_desc || !d_counts || nframes < 1 || cap < 1 || stride < w) {
         g_lastError = "rumi_orb_extract_batch_device: bad argument";
         return RUMI_E_INVALID;
@@ -329,9 +353,13 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     if (w <= 0 || hgt <= 0) return RUMI_E_EMPTY;
     if (nframes > h->cfg.max_batch) { g_lastError = "nframes > max_batch"; return RUMI_E_CAPACITY; }
     HIP_TRY(hipSetDevice(h->device));
-    int rc = set_geometry(h, w, hgt);
+    int rc;
+    if (h->pending && (h->gw != w || h->gh != hgt) && (rc = rumi_orb_sync(h)) != RUMI_OK) return rc;   // new tables must not overtake running kernels
+    rc = set_geometry(h, w, hgt);
     if (rc != RUMI_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
+    // calls not yet waited for share the scratch arenas in stream order: another stream (or the profiled path) waits for them first
+    if (h->pending && (st != h->pendingStream || h->profiling)) { rc = rumi_orb_sync(h); if (rc != RUMI_OK) return rc; }
     const DevParams &P = h->hP;
     // Level 0 is read where the caller has it, as aligned dwords.  Frames whose base, pitch or frame stride is not a multiple of 4 are
     // first copied into an aligned staging arena (the only case that costs a copy).
@@ -357,7 +385,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     // latency-bound, few waves) sit beside the wide VALU-bound ones of the others.  Profiling and RUMI_SERIAL keep one stream.
     static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 4;
     const int parts = (!prof && !serial) ? std::min(std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts), std::max(nframes / 32, 1)) : 1;
-    HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
+    if (!h->pending) HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
     auto stage_a = [&](const ImgSrc &ps, int n, hipStream_t s, int side) -> int {
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
@@ -373,7 +401,6 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         HIP_TRY(hipGetLastError());
         return RUMI_OK;
     };
-    HIP_TRY(hipMemsetAsync(h->dOverflow, 0, nframes * sizeof(int32_t), st));
     if (parts == 1) { rc = stage_a(src, nframes, st, 0); if (rc != RUMI_OK) return rc; }
 
     // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [frame0, frame0 + n) of the batch on stream s, in the scratch
@@ -394,7 +421,7 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
         if (timed) HIP_TRY(hipEventRecord(h->ev[3], s));
         launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[4], s));
-        launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dOverflow + frame0, n, s);
+        launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
         launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)scr0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
         launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
@@ -444,14 +471,14 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
             h->lastChunkBase = base; h->lastChunkFrames = nf; h->lastChunkSlot = 0;
         }
     }
-    HIP_TRY(hipMemcpyAsync(h->hOverflow, h->dOverflow, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    // One synchronisation per call: the error word and the frames' overflow words (and, for the single-frame host
-    // API, its result block).
+    // The call's error word (and, for the single-frame host API, its result block) follow the kernels on the stream; rumi_orb_sync waits
+    // for them.  Nothing here blocks, so a caller can queue the next batch while this one runs.
     if (h->out1Bytes) HIP_TRY(hipMemcpyAsync(h->hOut1, h->dOut1, h->out1Bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    h->pending = true; h->pendingStream = st;
     if (prof) {
         float ms;
+        HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); acc[0] = ms;
         HIP_TRY(hipEventElapsedTime(&ms, h->evB0, h->evB1)); acc[3] = ms;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[7])); acc[6] = ms;
@@ -460,12 +487,6 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     h->lastSrc = src; h->lastFrames = nframes;
     h->lastKp = (RumiKeyPoint *)d_kp; h->lastOutCap = cap;
     h->lastCounts = (int32_t *)d_counts;
-    for (int f = 0; f < nframes; f++)
-        if (h->hOverflow[f]) { g_lastError = "FAST candidate capacity exceeded (more than 65535 in one level)"; return RUMI_E_CAPACITY; }
-    const int err = *h->hErr;
-    if (err & 1) { g_lastError = "aspect ratio gives 0 or more than 16 quadtree roots"; return RUMI_E_INVALID; }
-    if (err & 2) { g_lastError = "quadtree node pool exhausted"; return RUMI_E_INVALID; }
-    if (err & (4 | 8)) { g_lastError = "more key-points than the handle's selection capacity"; return RUMI_E_CAPACITY; }
     return RUMI_OK;
 }
 
@@ -511,6 +532,7 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
     if (!out) return RUMI_OK;
     if (out_stride < L.w + 2 * border) return RUMI_E_CAPACITY;
     HIP_TRY(hipSetDevice(h->device));
+    if (h->pending) { const int rcs = rumi_orb_sync(h); if (rcs != RUMI_OK) return rcs; }
     // no border is stored; the 19-px border copyMakeBorder(..., BORDER_REFLECT_101) gives mvImagePyramid (ORBextractor.cc:1105-1108)
     // is synthesised here from the interior, which is the same pixels by definition
     if (border > (which ? 0 : kEdge)) { g_lastError = which ? "blurred levels carry no border" : "border larger than EDGE_THRESHOLD (19)"; return RUMI_E_INVALID; }
@@ -534,6 +556,7 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
 
 // Stage taps read the scratch arenas of the LAST chunk (device -> host on first use after a call).
 static int fetch_taps(RumiOrb *h) {
+    if (h->pending) { const int rc = rumi_orb_sync(h); if (rc != RUMI_OK) return rc; }
     if (h->tapValid) return RUMI_OK;
     const size_t nf = (size_t)h->lastChunkFrames;
     h->tapLevelStart.resize(nf * (kMaxLevels + 1));

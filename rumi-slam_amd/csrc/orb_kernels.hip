@@ -522,35 +522,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int cell = (wg % gridDim.x) * 8 + wave * 2, frame = wg / gridDim.x;
+    const int cell = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
     uint8_t *tile = fl + (size_t)wave * F.perWave;
     uint8_t *sc = tile + F.tileBytes;
     const int TP = TPC ? TPC : F.tp;
-    const FastCell gA = fast_cell_geom(P, src, cell, frame, cellCnt, lane), gB = fast_cell_geom(P, src, cell + 1, frame, cellCnt, lane);
+    const FastCell gA = fast_cell_geom(P, src, cell, frame, cellCnt, lane);
+    if (!gA.live) return;
     uint32_t v[8];
-    if (gA.live) {
-        fast_cell_load(gA, v, lane);
-        fast_cell_store(gA, tile, TP, v, lane);
-    }
-    if (gB.live) fast_cell_load(gB, v, lane);
-    if (gA.live) fast_cell_process<TPC>(P, F, gA, tile, sc, cellBuf, cellCnt, lane);
-    if (gB.live) {
-        wave_lds_fence();
-        fast_cell_store(gB, tile, TP, v, lane);
-        fast_cell_process<TPC>(P, F, gB, tile, sc, cellBuf, cellCnt, lane);
-    }
+    fast_cell_load(gA, v, lane);
+    fast_cell_store(gA, tile, TP, v, lane);
+    fast_cell_process<TPC>(P, F, gA, tile, sc, cellBuf, cellCnt, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Candidate compaction: one workgroup per frame concatenates the cell lists in cell order (levels
 // ascending, cells row-major) into cand[frame][...] and writes levelStart[frame][0..nlevels].
-// A level that would exceed its capacity is truncated and flagged (levelStart keeps the true count in
-// overflow[frame]); the host turns that into RUMI_E_CAPACITY.
+// A level that would exceed its capacity is truncated and flagged (bit 4 of the call's error word); the host turns that into
+// RUMI_E_CAPACITY.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCompactThreads = 1024;
 __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__restrict__ P, const uint32_t *__restrict__ cellBuf,
                                                  const int32_t *__restrict__ cellCnt, uint32_t *__restrict__ cand,
-                                                 int32_t *__restrict__ levelStart, int32_t *__restrict__ overflow) {
+                                                 int32_t *__restrict__ levelStart, int32_t *__restrict__ errFlag) {
     extern __shared__ int sStart[];          // totalCells + 1 exclusive prefix
     __shared__ int part[kCompactThreads];
     const int tid = threadIdx.x, frame = blockIdx.x;
@@ -595,7 +588,7 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
     }
     if (blockIdx.y == 0 && tid < P->nlevels) {
         const int c0 = P->lv[tid].cellBase, c1 = c0 + P->lv[tid].nCells;
-        if (sStart[c1] - sStart[c0] > P->lv[tid].candCap) atomicOr(&overflow[frame], 1 << tid);
+        if (sStart[c1] - sStart[c0] > P->lv[tid].candCap) atomicOr(errFlag, 16);
     }
     uint32_t *out = cand + (long long)frame * P->totalCand;
     // one lane per output element: its cell is the last one whose start is <= j (binary search in the LDS prefix), so every
@@ -882,7 +875,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
     // tile pitches of the common image sizes as compile-time constants (640x480 / 752x480 / 1241x376 / 1024x768 / 1280x720: 52;
     // 1920x1080: 48; 848x480: 56; 600x350: 60); anything else takes the run-time instantiation
-    const dim3 grid((hP.totalCells + 7) / 8, nframes);
+    const dim3 grid((hP.totalCells + 3) / 4, nframes);
     const size_t lds = (size_t)4 * F.perWave;
 #define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt); return; }
     RUMI_FAST_CASE(48) RUMI_FAST_CASE(44) RUMI_FAST_CASE(52) RUMI_FAST_CASE(56)
@@ -890,9 +883,9 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     hipLaunchKernelGGL((k_fast_cells<0>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
-                    uint32_t *cand, int32_t *levelStart, int32_t *overflow, int nframes, hipStream_t st) {
+                    uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_compact, dim3(nframes, nframes < 32 ? 8 : 1), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
-                       cand, levelStart, overflow);
+                       cand, levelStart, errFlag);
 }
 // strip width of a level's waves: 256 pixels unless that would put the row's partial dword into lane 0 or 1 of a wave (its mirrored bytes
 // then lie in the previous wave) or make a wave's lane 63 need a halo dword that reaches beyond the row edge; narrower waves leave their

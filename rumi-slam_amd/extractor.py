@@ -68,9 +68,11 @@ class ORBextractor:
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
     # ---- batched, device-resident form (torch tensors on the handle's GPU) ----
-    def extract_batch(self, frames, vLappingArea=(0, 1000), cap=None, stream=None):
-        """frames: torch.uint8 CUDA tensor [B,H,W] (contiguous rows).  Returns (kp [B,cap,7] f32 view of the
-        28-byte records, desc [B,cap,32] u8, counts [B,2] i32 = (n, monoIndex)) as CUDA tensors."""
+    def extract_batch(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, wait=True):
+        """frames: torch.uint8 CUDA tensor [B,H,W] (dense rows, any row pitch).  Returns (kp [B,cap,7] f32 view of the
+        28-byte records, desc [B,cap,32] u8, counts [B,2] i32 = (n, monoIndex)) as CUDA tensors.
+        wait=False only enqueues (rumi_orb_extract_batch_device_async): the outputs are valid in stream order, device-side
+        conditions are reported by the next ``sync()``; `frames` must stay alive until then."""
         import torch
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
         B, H, W = frames.shape
@@ -79,10 +81,15 @@ class ORBextractor:
         desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
         counts = torch.zeros((B, 2), dtype=torch.int32, device=frames.device)
         st = stream if stream is not None else torch.cuda.current_stream(frames.device)
-        capi.check(self._lib.rumi_orb_extract_batch_device(
+        fn = self._lib.rumi_orb_extract_batch_device if wait else self._lib.rumi_orb_extract_batch_device_async
+        capi.check(fn(
             self._h, frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0), int(vLappingArea[0]),
             int(vLappingArea[1]), kp.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, st.cuda_stream))
         return kp, desc, counts
+
+    def sync(self):
+        """Waits for every batch enqueued with wait=False and raises on a device-side condition (rumi_orb_sync)."""
+        capi.check(self._lib.rumi_orb_sync(self._h))
 
     # ---- taps ----
     def pyramid_level(self, level, frame=0, blurred=False, border=0):

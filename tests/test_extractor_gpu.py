@@ -117,6 +117,31 @@ def test_batch_device_strided_views(off, pitch):
         _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"strided batch frame {f} off {off} pitch {pitch}")
 
 
+def test_async_batches_match_blocking_calls():
+    """Three batches enqueued back to back without waiting (rumi_orb_extract_batch_device_async, scratch arenas shared in stream order),
+    one rumi_orb_sync at the end: every batch must equal what the blocking call gives."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    B = 70
+    g, _ = _pair(batch=B)
+    batches = [torch.from_numpy(synth_batch(B, seed0=900 + 100 * i)).cuda() for i in range(3)]
+    ref = []
+    for fr in batches:
+        kp, desc, counts = g.extract_batch(fr)
+        ref.append((kp.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()))
+    outs = [g.extract_batch(fr, wait=False) for fr in batches]
+    g.sync()
+    torch.cuda.synchronize()
+    for i, (kp, desc, counts) in enumerate(outs):
+        c = counts.cpu().numpy()
+        assert np.array_equal(c, ref[i][2]), f"batch {i}: counts"
+        k, d = kp.cpu().numpy(), desc.cpu().numpy()
+        for f in range(B):
+            n = c[f, 0]
+            assert k[f, :n].tobytes() == ref[i][0][f, :n].tobytes(), f"batch {i} frame {f}: key-points"
+            assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"batch {i} frame {f}: descriptors"
+
+
 def test_batch_device_matches_single():
     import torch
     from rumi_slam_amd.synth import synth_batch
