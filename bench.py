@@ -3,21 +3,26 @@
 
 Workload (BASELINE.json configs[1]+[2], the configuration the ">= 10 000 fps ORB extract+match at 1 GPU" target is quoted
 on): synthetic 640x480 frames, 8-level pyramid, 1000 features/frame, on 1 x MI355X.  One *step* = one batch of `--batch`
-frames (already resident in HBM) through the whole extractor (pyramid -> per-cell FAST+NMS -> quadtree -> IC_Angle ->
+DISTINCT frames (already resident in HBM) through the whole extractor (pyramid -> per-cell FAST+NMS -> quadtree -> IC_Angle ->
 Gaussian blur -> rBRIEF) followed by brute-force 256-bit Hamming matching of every frame against its successor in the
-batch; key-points, descriptors and match indices stay in HBM.
-With N > 1 (one process per GPU, RCCL) every rank extracts and matches its own `--batch` frames of the rumination queue
-(weak scaling, configs[4]) and the step ends with the all-gather of (counts, key-points, descriptors).
-The JSON line also carries an `lba` object: BASELINE.json configs[3] (20 key-frames x 3000 map points) on the GPU next to
-the CPU oracle, and `pose_opt` (PoseOptimization, 256 frames x 300 correspondences in one launch).
+batch; key-points, descriptors and match indices stay in HBM.  Steps are enqueued without waiting for each other
+(rumi_orb_extract_batch_device_async); the timed region ends with rumi_orb_sync + a device synchronisation.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (per-stage device time from HIP events
-on the stream the kernels run on); `cpu_baseline` is the CPU oracle (kind "port": the reference itself cannot
-be built in this image) timed single-threaded on a bounded sample of the same frames, rank 0, N = 1 only.
+N > 1 (one process per GPU, RCCL; `python bench.py --gpus N` starts the N ranks itself when it was not started by torchrun):
+BASELINE.json configs[4], the rumination queue of `--batch` frames sharded over the ranks in contiguous time-ordered blocks
+(`--scaling strong`, the default: 1024 frames in all, 1024 / N per rank) or `--batch` frames PER rank (`--scaling weak`); each rank
+writes fixed-capacity per-frame records and the step ends with the queue's ONE all-gather of them.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (per-stage device time from HIP events on the stream the
+kernels run on, every kernel alone on it); `cpu_baseline` is the CPU oracle (kind "port": the reference itself cannot be built in
+this image) timed single-threaded on a bounded sample of the same frames, rank 0, N = 1 only.  N = 1 also reports
+`value_h2d_inclusive` (the same step with the frames starting in pinned HOST memory, transfers overlapped with the kernels),
+`single_frame_host_api_fps`, a `batch_sweep`, and the `lba` / `pose_opt` side legs.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,13 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_MFMA_PEAK_TFLOPS = 78.6    # dense f64 matrix peak
 
 
 def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
     """4 752 128 + n*(1369+749+60) B for 640x480, 8 levels (general form below)."""
-    lv, ww, hh = [], w, h
+    lv = []
     import numpy as np
-    inv = np.float32(1.0)
     sc = np.float32(1.0)
     for l in range(8):
         if l:
@@ -58,15 +63,35 @@ def side_legs(args):
     g = []
     for _ in range(5):
         t0 = time.perf_counter(); stats, kp, mp, er = opt.LocalBundleAdjustment(*a); g.append(time.perf_counter() - t0)
-    dev_ms = float(opt.stage_ms()[5])
+    st = opt.stage_ms()
+    dev_ms = float(st[5])
     c = []
     for _ in range(3):
         t0 = time.perf_counter(); its, kpr, mpr, err = oracle_lib.local_ba(*a); c.append(time.perf_counter() - t0)
     rel = float(np.max(np.linalg.norm(mp - mpr, axis=1) / np.maximum(np.linalg.norm(mpr, axis=1), 1e-2)))
+    E, K, trials = int(len(b["e_mp"])), 20, max(int(stats[1]), 1)
     lba = {"workload": "LocalBundleAdjustment: 20 optimised + 5 fixed key-frames x 3000 map points (BASELINE.json configs[3])",
-           "edges": int(len(b["e_mp"])), "lm_iterations": int(stats[0]), "lm_trials": int(stats[1]),
+           "edges": E, "lm_iterations": int(stats[0]), "lm_trials": int(stats[1]),
            "gpu_ms_wall": round(min(g) * 1e3, 3), "gpu_ms_device": round(dev_ms, 3), "cpu_ms": round(min(c) * 1e3, 2),
            "speedup_wall": round(min(c) / min(g), 1), "max_rel_landmark_diff_vs_oracle": rel, "cpu_cores": 1}
+    # MFMA accounting of the two matrix kernels, from the per-kernel device times the library records with HIP events on its stream
+    # (stage_ms slots 8..: hpp, syrk, solve, summed over the call's trials): flops per trial over time per trial over the f64 matrix peak
+    try:
+        opt.set_profiling(True)
+        opt.LocalBundleAdjustment(*a)
+        opt.set_profiling(False)
+        det = opt.kernel_ms()
+        trials = max(det["trials"], 1)
+        syrk_flops = 2.0 * (3 * 3000) * (6 * K) * (6 * K) / 2          # upper tiles of G = Yt^T Yt
+        hpp_flops = 2.0 * (2 * E) * 36                                   # per key-frame Gram product of its [2 E_k] x 6 panel
+        lba["roofline"] = {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "syrk_us_per_trial": round(det["syrk"] * 1e3 / trials, 2),
+                           "syrk_mfma_util": round(syrk_flops / (det["syrk"] * 1e-3 / trials) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4) if det["syrk"] > 0 else None,
+                           "hpp_us_per_trial": round(det["hpp"] * 1e3 / trials, 2),
+                           "hpp_mfma_util": round(hpp_flops / (det["hpp"] * 1e-3 / trials) / 1e12 / F64_MFMA_PEAK_TFLOPS, 5) if det["hpp"] > 0 else None,
+                           "solve_us": round(det["solve"] * 1e3 / trials, 2)}
+    except Exception as e:                                               # older library without the per-kernel slots
+        lba["roofline"] = {"error": str(e)}
     probs = [pose_problem(100 + i, 300, 0.1) for i in range(256)]
     start = np.cumsum([0] + [len(p["inv_sigma2"]) for p in probs]).astype(np.int32)
     pa = (start, np.concatenate([p["Xw"] for p in probs]), np.concatenate([p["obs"] for p in probs]),
@@ -82,17 +107,49 @@ def side_legs(args):
     return {"lba": lba, "pose_opt": pose}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as fresh child processes (the parent never touches the GPU) and
+    pass rank 0's line through."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
+def make_frames(torch, np, dev, n, rank):
+    """n DISTINCT 640x480 frames on the device: 32 seeded synthetic frames (SURVEY.md section 8d generator, host) x cyclic shifts of them
+    (device), so that no two frames of a step share their pixels (host synthesis of 1024 frames would take minutes)."""
+    from rumi_slam_amd.synth import synth_frame
+    nb = min(32, n)
+    host = np.stack([synth_frame(1234 + rank * 100000 + i) for i in range(nb)])
+    base = torch.from_numpy(host).to(dev)
+    fr = torch.empty((n, 480, 640), dtype=torch.uint8, device=dev)
+    for k in range(n):
+        fr[k] = torch.roll(base[k % nb], shifts=(7 * (k // nb), 11 * (k // nb)), dims=(0, 1)) if k >= nb else base[k]
+    return fr, host
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (the rumination queue of BASELINE.json configs[4]; launches cover 256 frames)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames of the rumination queue per step (BASELINE.json configs[4]); per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: --batch frames in all (strong) or per rank (weak)")
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to --batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the side legs (profiling runs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import numpy as np
     import torch
@@ -101,7 +158,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -112,66 +169,78 @@ def main():
     from rumi_slam_amd.extractor import ORBextractor
     from rumi_slam_amd.matcher import bruteforce_batch
     from rumi_slam_amd import rumination
-    from rumi_slam_amd.synth import synth_frame
 
-    B, W, H = args.batch, 640, 480
-    uniq = min(args.unique, B)
-    host = np.stack([synth_frame(1234 + rank * 100000 + i) for i in range(uniq)])
-    frames = torch.from_numpy(host).to(dev)
-    frames = frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
+    W, H = 640, 480
+    if world > 1 and args.scaling == "strong":
+        n_queue = args.batch                                   # the whole queue; this rank owns a contiguous block of it
+        lo, hi = rumination.shard_bounds(n_queue, rank, world)
+        B = hi - lo
+    else:
+        n_queue, B = args.batch * world, args.batch
+    per = rumination.shard_capacity(n_queue, world)            # records per rank in the all-gather (blocks padded to it)
+    frames, host = make_frames(torch, np, dev, B, rank)
 
     ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
     cap = args.nfeatures + 4 * 8 + 64
 
     pending = [None]
 
-    def step():
-        kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
+    def match(desc, counts):
         # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
         # (views of the extractor's output: the successor of frame i is the same buffer one record further, no copy; the last pair wraps)
-        match = (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
-                 bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
-        if world > 1:
-            # the path's one exchange step: every GPU ends up with all key-points / descriptors.  It is launched
-            # here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of step i
-            # overlaps the extraction of step i + 1; drain() joins the last one inside the timed region.
-            prev, pending[0] = pending[0], rumination.all_gather_records_async(counts, kp, desc, B * world)
-            if prev is not None:
-                prev.wait()
-        return kp, desc, counts, match
+        return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
+                bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
+
+    def step():
+        if world == 1:
+            kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
+            return kp, desc, counts, match(desc, counts)
+        # N > 1: per-frame records written in place, then the path's one exchange step: every GPU ends up with all records.
+        # The all-gather is launched here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of
+        # step i overlaps the extraction of step i + 1; drain() joins the last one inside the timed region.
+        rec = torch.zeros((per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev)
+        ext.extract_batch_records(frames, (0, 1000), cap=cap, wait=False, out=rec)
+        kp, desc, counts = rumination.record_views(rec[:B], cap)
+        m = match(desc, counts)
+        prev, pending[0] = pending[0], rumination.all_gather_records_async(rec, n_queue)
+        if prev is not None:
+            prev.wait()
+        return kp, desc, counts, m
 
     def drain():
         if pending[0] is not None:
-            gc, gk, gd = pending[0].wait()
+            g = pending[0].wait()
             pending[0] = None
-            return gk, gd, gc
+            return g
         return None
 
-    for _ in range(args.warmup):
-        out = step()
-    drain()
-    ext.sync()
-    torch.cuda.synchronize()
-    n_kp = float(out[2].reshape(-1, 2)[:, 0].float().mean().item())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            out = fn()
+        drain(); ext.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        drain()
+        ext.sync()                                # waits for the last step and raises on any device-side capacity condition of the steps
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    drain()
-    ext.sync()                                    # waits for the last step and raises on any device-side capacity condition of the K steps
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, out = timed(step, args.steps, args.warmup)
+    n_kp = float(out[2][:, 0].float().mean().item())
 
-    # per-stage device time of one more (untimed) step, HIP events on the kernels' stream
+    # per-stage device time of one more (untimed) pass with every kernel ALONE on one stream in launches of up to 256 frames
+    # (rumi_orb_set_profiling: HIP events recorded by the library on the stream the kernels run on)
     ext.set_profiling(True)
     ext.extract_batch(frames, (0, 1000), cap=cap)
     torch.cuda.synchronize()
@@ -179,57 +248,91 @@ def main():
     ext.set_profiling(False)
 
     if rank == 0:
-        fps = B * world * args.steps / dt
+        fps = n_queue * args.steps / dt
         ab = algorithmic_bytes_per_frame(n_kp)
-        # dominant kernel by device time; algorithmic bytes of that kernel per launch (DESIGN.md §Roofline)
+        # dominant kernel by device time; algorithmic bytes of that kernel per launch (DESIGN.md §4)
         kern_bytes = {"fast": ab["fast_read"], "pyramid": ab["read_l0"] + 1.44 * ab["write_levels"] + ab["write_levels"],
                       "blur": ab["blur_rw"], "orient_desc": n_kp * ab["per_kp"], "quadtree": 0.0}
         kern_ms = {k: stage[k] for k in kern_bytes}
         dom = max(kern_ms, key=kern_ms.get)
-        # the profiled pass runs the batch in launches of up to 256 frames on one stream; stage times are sums over those launches
         per_launch = min(B, 256)
         n_launch = (B + 255) // 256
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
-        # HBM bytes per launch from the PMC counters: rocprofv3 cannot wrap this process from inside, so the number is the
-        # committed result of `tools/pmc_summary.py` on two --pmc passes of THIS command line (profiles/r01_pmc_traffic.json);
-        # it is used only when it was taken at the same frames-per-launch.
-        traffic = None
+        kname = {"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot wrap this process from inside, so these two numbers are the committed
+        # results of separate --pmc passes of this command line (profiles/r02_pmc_*.json); `*_source` says so, and they are used only when
+        # taken at the same frames-per-launch.
+        traffic, valu = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kname = {"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             if pm.get("frames_per_launch") == per_launch and kname in pm["kernels"]:
                 traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        # VALU issue accounting of the same kernel: wave-instructions per launch from the committed SQ_INSTS_VALU pass
-        # (profiles/r01_pmc_sq_counters.json) over the chip's measured integer issue rate (tools/valu_rate.hip: 4.2 cycles per wave64
-        # instruction and SIMD = 585 G wave-instructions/s) and this run's launch duration
-        valu = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.json")))["kernels"]
-            insts = sq[{"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]]["SQ_INSTS_VALU"]
-            if per_launch == 256 and kern_ms[dom] > 0:
-                valu = {"wave_insts_per_launch": int(insts), "issue_rate_G_per_s": 585.0,
-                        "issue_frac": round(insts / 585e9 / (kern_ms[dom] / n_launch * 1e-3), 4)}
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")))["kernels"][kname]
+            if per_launch == 256:
+                valu = {"wave_insts_per_launch": int(sq["SQ_INSTS_VALU"]), "lds_insts_per_launch": int(sq.get("SQ_INSTS_LDS", 0)),
+                        "lds_bank_conflict_cycles": int(sq.get("SQ_LDS_BANK_CONFLICT", 0)),
+                        "note": "instruction classes issue at 2.4 (add/sub/logic/shift-right) or 4.2 (min/max, 3-operand, packed) cycles per wave and SIMD: profiles/r02_valu_issue_rates.txt"}
         except Exception:
             valu = None
         line = {
             "metric": "frames/sec ORB extract+match", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ORB extract (640x480, 8-level pyramid, %d features/frame) + brute-force 256-bit Hamming match of consecutive frames (BASELINE.json configs[1]+[2])" % args.nfeatures,
-                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": round(n_kp, 1),
-                       "exchange": "all_gather(counts,keypoints,descriptors) over RCCL" if world > 1 else "none"},
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic (32 seeded frames per rank x cyclic shifts: every frame of a step distinct)",
+            "config": {"workload": "ORB extract (640x480, 8-level pyramid, %d features/frame) + brute-force 256-bit Hamming match of consecutive frames (BASELINE.json configs[1]+[2]%s)" % (args.nfeatures, "; queue sharded as configs[4]" if world > 1 else ""),
+                       "frames_per_step": n_queue, "frames_per_step_per_gpu": B, "scaling": args.scaling if world > 1 else "n/a (one GPU)",
+                       "mean_keypoints_per_frame": round(n_kp, 1),
+                       "exchange": "one all_gather_into_tensor of %d-byte per-frame records over RCCL, overlapped with the next step" % rumination.record_bytes(cap) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "committed profile profiles/r02_pmc_traffic.json (separate --pmc passes), not this run" if traffic else None,
                          "algorithmic_bytes_per_launch": int(kern_bytes[dom] * per_launch), "frames_per_launch": per_launch,
                          "launch_ms": round(kern_ms[dom] / n_launch, 4),
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
-                         "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu},
+                         "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu,
+                         "valu_source": "committed profile profiles/r02_pmc_sq_counters.json, not this run" if valu else None},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
-            "stage_ms_note": "one extra profiled step, every kernel alone on one stream (no overlap), summed over the step's launches",
+            "stage_ms_note": "one extra profiled step: every kernel alone on ONE stream (RUMI_SERIAL-equivalent: the blur too), launches of up to 256 frames, summed over the step's launches",
         }
         if world == 1 and not args.no_cpu:
+            # ---- the same step with the frames starting in pinned HOST memory (the queue as the reference holds it), transfers overlapped ----
+            hostq = frames.cpu().pin_memory()
+
+            def step_h2d():
+                kp, desc, counts = ext.extract_batch_host(hostq, (0, 1000), cap=cap)
+                return kp, desc, counts, match(desc, counts)
+            dth, _ = timed(step_h2d, max(3, args.steps // 2), 1)
+            line["value_h2d_inclusive"] = round(B * max(3, args.steps // 2) / dth, 1)
+            line["h2d_note"] = "%d x 307 200 B per step from pinned host memory, 64-frame groups on a copy stream under the kernels (rumi_orb_extract_batch_host)" % B
+            del hostq
+            # ---- one frame at a time through the drop-in host API (ORBextractor::operator(): host image in, host key-points out) ----
+            ext1 = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, device=local_rank)
+            for i in range(8):
+                ext1(host[i % len(host)], None, (0, 1000))
+            t0 = time.perf_counter()
+            for i in range(200):
+                ext1(host[i % len(host)], None, (0, 1000))
+            line["single_frame_host_api_fps"] = round(200 / (time.perf_counter() - t0), 1)
+            ext1.close()
+            # ---- frames per call: device-resident extract + match ----
+            sweep = {}
+            for nb in (64, 256, 1024):
+                if nb > B:
+                    continue
+                sub = frames[:nb]
+
+                def step_n():
+                    kp, desc, counts = ext.extract_batch(sub, (0, 1000), cap=cap, wait=False)
+                    return kp, desc, counts, (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]),
+                                              bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
+                reps = max(4, 2048 // nb)
+                dts, _ = timed(step_n, reps, 2)
+                sweep[str(nb)] = round(nb * reps / dts, 1)
+            line["batch_sweep_fps"] = sweep
+            # ---- CPU baseline ----
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib                      # the checker, timed as the CPU baseline (kind "port")
             orc = oracle_lib.OracleExtractor(args.nfeatures, 1.2, 8, 20, 7)

@@ -196,6 +196,11 @@ int rumi_search_local_points(RumiMatcher *m, const RumiFrameFeatures *F, const f
 int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
                                        int32_t count_stride, int32_t cap, int32_t nbatch, void *d_best_idx,
                                        void *d_best_dist, void *d_second_dist, void *hip_stream);
+/* The same for descriptor blocks that are not densely packed: frame b's descriptors start at d_query + b * query_stride bytes (likewise
+ * train); e.g. the per-frame records of rumi_orb_extract_batch_records_async (stride = record size, counts at count_stride = record size / 4). */
+int rumi_match_bruteforce_batch_device_strided(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
+                                               int32_t count_stride, int64_t query_stride, int64_t train_stride, int32_t cap, int32_t nbatch,
+                                               void *d_best_idx, void *d_best_dist, void *d_second_dist, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,11 @@ int rumi_merge_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t 
 /* Device time of the last rumi_local_ba call by stage, in ms (HIP events):
  * [0] linearise+Hll/Hpl, [1] pose block J^T W J on f64 MFMA, [2] Schur complement, [3] reduced solve, [4] update+chi2, [5] total */
 int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]);
+/* Opt-in per-kernel timing of the bundle adjustment: with profiling on, the next rumi_local_ba / rumi_merge_ba / rumi_bundle_adjustment call on
+ * the dense-panel path records HIP events around the pose-block Gram product (f64 MFMA), the Schur-complement SYRK (f64 MFMA) and the
+ * reduced solve of every LM trial; rumi_opt_kernel_ms returns their sums in ms and the trial count: [0] hpp, [1] syrk, [2] solve, [3] trials. */
+int rumi_opt_set_profiling(RumiOptimizer *o, int32_t on);
+int rumi_opt_kernel_ms(RumiOptimizer *o, float ms[4]);
 
 /* Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) — R/lib_src/Optimizer.cc:54-351, monocular edges: the
  * full BA behind GlobalBundleAdjustemnt (map initialisation, Tracking.cc CreateInitialMapMonocular: 2 key-frames, 20 iterations; loop /

@@ -95,6 +95,24 @@ int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t 
                                         void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream);
 int rumi_orb_sync(RumiOrb *h);
 
+/* The same work with ONE fixed-capacity record per frame as output,
+ *   { int32 n; int32 monoIndex; RumiKeyPoint kp[cap]; uint8 desc[cap][32]; }  = 8 + 60 * cap bytes (record_bytes >= that, multiple of 4),
+ * so that the exchange step of the sharded rumination queue is a single all-gather of d_records.  Asynchronous like
+ * rumi_orb_extract_batch_device_async. */
+int rumi_orb_extract_batch_records_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                         int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                         void *d_records, int64_t record_bytes, int32_t cap, void *hip_stream);
+
+/* The queue as the reference holds it: `imgs[f]` are HOST frames (CloudImageSampler.cc:148-170 keeps cv::Mats), `stride` bytes per row.
+ * Frames go to the device in groups of 64 on a copy stream; a group's extraction waits only for its own transfer, so transfers and
+ * kernels overlap.  Pinned frames (hipHostMalloc / hipHostRegister) are copied in place, pageable ones through pinned staging slots filled
+ * by cfg.host_threads threads.  Results are written to the DEVICE arrays d_kp / d_desc / d_counts as by rumi_orb_extract_batch_device (the
+ * all-gather payload) and, when h_kp / h_desc / h_counts are not NULL, copied to those host arrays of the same shape too.  Blocks until
+ * everything has arrived. */
+int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
+                                int32_t lap0, int32_t lap1, void *d_kp, void *d_desc, void *d_counts, int32_t cap,
+                                RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream);
+
 /* Backs the public member mvImagePyramid (ORBextractor.h:86): copies level `level` of frame `frame`
  * of the last call to host memory, with `border` replicated pixels of BORDER_REFLECT_101 on each side
  * (the reference uses 19); which = 0 pyramid, 1 Gaussian-blurred working image (ORBextractor.cc:1057-1058).

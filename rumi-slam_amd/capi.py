@@ -35,7 +35,7 @@ _lib = None
 
 # every symbol include/rumi_orb.h declares (tests check the library exports all of them)
 ORB_SYMBOLS = ["rumi_last_error", "rumi_device_count", "rumi_orb_create", "rumi_orb_destroy", "rumi_orb_tables",
-               "rumi_orb_extract", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync",
+               "rumi_orb_extract", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync", "rumi_orb_extract_batch_records_async", "rumi_orb_extract_batch_host",
                "rumi_orb_pyramid_level",
                "rumi_orb_stage_keypoints", "rumi_orb_set_profiling", "rumi_orb_stage_ms"]
 
@@ -67,6 +67,8 @@ def lib():
     L.rumi_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, vp, vp, i32, vp]
     L.rumi_orb_extract_batch_device_async.argtypes = L.rumi_orb_extract_batch_device.argtypes
     L.rumi_orb_sync.argtypes = [vp]
+    L.rumi_orb_extract_batch_records_async.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, i64, i32, vp]
+    L.rumi_orb_extract_batch_host.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     L.rumi_orb_pyramid_level.argtypes = [vp, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.rumi_orb_stage_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.rumi_orb_set_profiling.argtypes = [vp, i32]
@@ -86,10 +88,10 @@ def ptr(a):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_local_points", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_local_points", "rumi_match_bruteforce_batch_device", "rumi_match_bruteforce_batch_device_strided"]
 
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
-               "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms"]
+               "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms", "rumi_opt_set_profiling", "rumi_opt_kernel_ms"]
 
 VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_transform_features",
                "rumi_voc_transform_batch_device", "rumi_voc_transform"]

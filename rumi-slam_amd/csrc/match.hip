@@ -870,7 +870,7 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ qd, const int32_t *__restrict__ nqArr,
                                                     const uint8_t *__restrict__ td, const int32_t *__restrict__ ntArr,
-                                                    int countStride, int cap, int32_t *__restrict__ bestIdx,
+                                                    int countStride, long long qStride, long long tStride, int cap, int32_t *__restrict__ bestIdx,
                                                     int32_t *__restrict__ bestDist, int32_t *__restrict__ secondDist) {
     __shared__ uint4 tile[256 * 2];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
     if (blockIdx.x * 256 >= nq) return;
     uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qi < nq) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(qd + ((size_t)b * cap + qi) * 32);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qd + (size_t)b * qStride + (size_t)qi * 32);
         const uint4 a = src[0], c = src[1];
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = c.x; q[5] = c.y; q[6] = c.z; q[7] = c.w;
     }
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
         const int m = min(256, nt - t0);
         __syncthreads();
         if (tid < m) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(td + ((size_t)b * cap + t0 + tid) * 32);
+            const uint4 *src = reinterpret_cast<const uint4 *>(td + (size_t)b * tStride + (size_t)(t0 + tid) * 32);
             tile[tid * 2] = src[0];
             tile[tid * 2 + 1] = src[1];
         }
@@ -1531,14 +1531,23 @@ extern "C" int rumi_search_local_points(RumiMatcher *m, const RumiFrameFeatures 
     return RUMI_OK;
 }
 
+extern "C" int rumi_match_bruteforce_batch_device_strided(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
+                                                          int32_t count_stride, int64_t query_stride, int64_t train_stride, int32_t cap, int32_t nbatch,
+                                                          void *d_best_idx, void *d_best_dist, void *d_second_dist, void *hip_stream) {
+    if (!d_query || !d_nq || !d_train || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || cap > 65535 || nbatch < 1 || count_stride < 1 ||
+        query_stride < 32ll * cap || train_stride < 32ll * cap || (query_stride & 3) || (train_stride & 3) ||
+        (reinterpret_cast<uintptr_t>(d_query) & 3) || (reinterpret_cast<uintptr_t>(d_train) & 3))
+        return RUMI_E_INVALID;                                 // the kernel packs the train index into 16 bits next to the distance
+    hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nbatch), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_query,
+                       (const int32_t *)d_nq, (const uint8_t *)d_train, (const int32_t *)d_nt, count_stride, (long long)query_stride, (long long)train_stride, cap,
+                       (int32_t *)d_best_idx, (int32_t *)d_best_dist, (int32_t *)d_second_dist);
+    HIP_TRY(hipGetLastError());
+    return RUMI_OK;
+}
+
 extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
                                                   int32_t count_stride, int32_t cap, int32_t nbatch, void *d_best_idx,
                                                   void *d_best_dist, void *d_second_dist, void *hip_stream) {
-    if (!d_query || !d_nq || !d_train || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || cap > 65535 || nbatch < 1 || count_stride < 1)
-        return RUMI_E_INVALID;                                 // the kernel packs the train index into 16 bits next to the distance
-    hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nbatch), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_query,
-                       (const int32_t *)d_nq, (const uint8_t *)d_train, (const int32_t *)d_nt, count_stride, cap, (int32_t *)d_best_idx,
-                       (int32_t *)d_best_dist, (int32_t *)d_second_dist);
-    HIP_TRY(hipGetLastError());
-    return RUMI_OK;
+    return rumi_match_bruteforce_batch_device_strided(d_query, d_nq, d_train, d_nt, count_stride, 32ll * cap, 32ll * cap, cap, nbatch, d_best_idx, d_best_dist,
+                                                      d_second_dist, hip_stream);
 }

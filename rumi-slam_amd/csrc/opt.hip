@@ -1529,6 +1529,11 @@ struct RumiOptimizer {
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
     float stageMs[8] = {0};
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // opt-in per-kernel timing of the bundle adjustment (rumi_opt_set_profiling): event pairs around the pose-block Gram product, the Schur
+    // SYRK and the reduced solve of every trial, summed after the trial's own synchronisation
+    bool profiling = false;
+    hipEvent_t evK[6] = {nullptr};
+    float kernelMs[4] = {0};          // hpp, syrk, solve (ms over the call), trials
 };
 
 template <class T> static int oalloc(T **p, size_t n) {
@@ -1597,7 +1602,19 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
         }
     }
     for (auto &e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    for (auto &e : o->evK) if (hipEventCreate(&e) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
     *out = o;
+    return RUMI_OK;
+}
+
+extern "C" int rumi_opt_set_profiling(RumiOptimizer *o, int32_t on) {
+    if (!o) return RUMI_E_INVALID;
+    o->profiling = on != 0;
+    return RUMI_OK;
+}
+extern "C" int rumi_opt_kernel_ms(RumiOptimizer *o, float ms[4]) {
+    if (!o || !ms) return RUMI_E_INVALID;
+    for (int i = 0; i < 4; i++) ms[i] = o->kernelMs[i];
     return RUMI_OK;
 }
 
@@ -1830,6 +1847,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         return RUMI_OK;
     };
     HIP_TRY(hipEventRecord(o->ev[0], st));
+    const bool prof = o->profiling;
+    bool hppFresh = false;
+    for (auto &k : o->kernelMs) k = 0.f;
     int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
     bool ranChi2 = false;
     auto lm = [&](int maxIt) -> int {                       // g2o optimize(maxIt)
@@ -1849,7 +1869,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             hipLaunchKernelGGL(k_ba_zero, dim3((zmax + 255) / 256), dim3(256), 0, st, Z);
         }
         if (nE > 0) hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur]);
+        if (prof) HIP_TRY(hipEventRecord(o->evK[0], st));
         if (nOpt > 0) hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt, kHppSlices), dim3(256), 0, st, B);
+        if (prof) { HIP_TRY(hipEventRecord(o->evK[1], st)); hppFresh = true; }
         if (it == 0) {
             HIP_TRY(hipMemsetAsync(o->dScal + 2, 0, sizeof(double), st));
             const int nd = nOpt * 6 + nMP * 3;
@@ -1870,18 +1892,28 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             else {
             if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
             if (nE > 0) hipLaunchKernelGGL(k_ba_yfill, dim3(gE), dim3(256), 0, st, B, o->dYt, NP, o->dLp);
+            if (prof) HIP_TRY(hipEventRecord(o->evK[2], st));
             if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
+            if (prof) { HIP_TRY(hipEventRecord(o->evK[3], st)); HIP_TRY(hipEventRecord(o->evK[4], st)); }
             if (n > 0) {
                 if (useLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(1024), ldsSolve, st, B, lambda, o->dG, NP, o->dAglob);
                 else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(1024), 0, st, B, lambda, o->dG, NP, o->dAglob);
             }
             else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
+            if (prof) HIP_TRY(hipEventRecord(o->evK[5], st));
             }
             hipLaunchKernelGGL(k_ba_update, dim3(((nMP + nKF) * kLmLanes + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
             hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            if (prof && !big) {
+                float ms;
+                if (hppFresh) { HIP_TRY(hipEventElapsedTime(&ms, o->evK[0], o->evK[1])); o->kernelMs[0] += ms; hppFresh = false; }
+                HIP_TRY(hipEventElapsedTime(&ms, o->evK[2], o->evK[3])); o->kernelMs[1] += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, o->evK[4], o->evK[5])); o->kernelMs[2] += ms;
+                o->kernelMs[3] += 1.f;
+            }
             const bool ok2 = n == 0 || o->hScal[3] != 0.0;
             double tempChi = o->hScal[0];
             if (!ok2) tempChi = std::numeric_limits<double>::max();

@@ -53,14 +53,14 @@ void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *ce
                     uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st);
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
-                        const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
-                        int outCap, int nframes, hipStream_t st);
+                        const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
+                        long long descStride, int outCap, int nframes, hipStream_t st);   // strides: bytes from one frame's outputs to the next
 
 void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *cand, const int32_t *levelStart,
                    uint16_t *owner, uint32_t *selLevel, int32_t *selLevelCnt, int selLevelCap, int32_t *errFlag,
                    int nframes, size_t ldsBytes, hipStream_t st);
 void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,
-                     int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts,
+                     int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts, long long countsStride,
                      int32_t *errFlag, int nframes, hipStream_t st);
 size_t octree_lds_for(const DevParams &hP);
 

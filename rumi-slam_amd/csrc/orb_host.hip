@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -85,6 +86,14 @@ struct RumiOrb {
     int32_t *dSelLevelCnt = nullptr;
     int32_t *dErr = nullptr;         // device error word (bit 0/1/2/3: roots, node pool, level cap, selection cap; bit 4: FAST candidate capacity);
                                      // sticky over the asynchronous calls since the last rumi_orb_sync
+    // host-resident batches (rumi_orb_extract_batch_host): device landing arena, pinned staging slots, copy stream; `feed`, when set, makes the
+    // frames [0, upto) of the running call resident and lets stream s wait for them
+    uint8_t *dHostIn = nullptr; size_t dHostInBytes = 0;
+    static constexpr int kFeedSlots = 4, kFeedFrames = 64;
+    uint8_t *hFeed[kFeedSlots] = {nullptr}; size_t hFeedBytes = 0;
+    hipEvent_t evFeed[kFeedSlots] = {nullptr};
+    hipStream_t copyStream = nullptr;
+    std::function<int(int, hipStream_t)> feed;
     bool pending = false;            // an asynchronous call has been enqueued and not yet waited for
     hipStream_t pendingStream = nullptr;
     int selLevelCap = 0;
@@ -99,6 +108,7 @@ struct RumiOrb {
     ImgSrc lastSrc{};
     int lastFrames = 0, lastChunkBase = 0, lastChunkFrames = 0, lastChunkSlot = 0;   // frames / scratch slot the stage taps can read
     RumiKeyPoint *lastKp = nullptr;  // device pointer the last call wrote key-points to
+    long long lastKpStride = 0;      // bytes between the key-points of consecutive frames there
     int32_t *lastCounts = nullptr;
     int lastOutCap = 0;
     bool profiling = false;
@@ -216,6 +226,10 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     for (auto &e : h->evSideFork) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->evSideJoin) if (e) (void)hipEventDestroy(e);
     if (h->evPartFork) (void)hipEventDestroy(h->evPartFork);
+    if (h->dHostIn) (void)hipFree(h->dHostIn);
+    for (auto &p : h->hFeed) if (p) (void)hipHostFree(p);
+    for (auto &e : h->evFeed) if (e) (void)hipEventDestroy(e);
+    if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->hIn) (void)hipHostFree(h->hIn);
     if (h->hOut1) (void)hipHostFree(h->hOut1);
     if (h->dOut1) (void)hipFree(h->dOut1);
@@ -343,9 +357,13 @@ extern "C" int rumi_orb_extract_batch_device(RumiOrb *h, const void *d_imgs, int
     return rumi_orb_sync(h);
 }
 
-extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
-                                                   int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
-                                                   void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream) {
+// Output addressing of one call: frame f's key-points start at kp + f * kpStride (bytes), likewise descriptors and the {n, monoIndex} pair.
+// The three-array form has strides cap * 28 / cap * 32 / 8; the record form (one all-gather payload) has the record size for all three.
+struct OutLayout { void *kp; long long kpStride; void *desc; long long descStride; void *counts; long long countsStride; };
+
+static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride, int64_t frame_stride,
+                              int32_t lap0, int32_t lap1, const OutLayout &out, int32_t cap, void *hip_stream) {
+    void *d_kp = out.kp, *d_desc = out.desc, *d_counts = out.counts;
     if (!h || !d_imgs || !d_kp || !d_desc || !d_counts || nframes < 1 || cap < 1 || stride < w) {
         g_lastError = "rumi_orb_extract_batch_device: bad argument";
         return RUMI_E_INVALID;
@@ -401,7 +419,11 @@ extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_img
         HIP_TRY(hipGetLastError());
         return RUMI_OK;
     };
-    if (parts == 1) { rc = stage_a(src, nframes, st, 0); if (rc != RUMI_OK) return rc; }
+    if (parts == 1) {
+        if (h->feed && (rc = h->feed(nframes, st)) != RUMI_OK) return rc;
+        rc = stage_a(src, nframes, st, 0);
+        if (rc != RUMI_OK) return rc;
+    }
 
     // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [frame0, frame0 + n) of the batch on stream s, in the scratch
     // arenas from frame slot scr0 on (every scratch array is indexed by frame slot, so disjoint slot ranges can run on different streams)
@@ -425,11 +447,12 @@ extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_img
         if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
         launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)scr0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
         launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
-                        (int32_t *)d_counts + 2 * (size_t)frame0, h->dErr, n, s);
+                        (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
         HIP_TRY(hipStreamWaitEvent(s, side ? h->evSideJoin[side - 1] : h->evJoin, 0));   // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
-                           (RumiKeyPoint *)d_kp + (size_t)frame0 * cap, (uint8_t *)d_desc + (size_t)frame0 * cap * 32, cap, n, s);
+                           (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
+                           (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
         return RUMI_OK;
     };
@@ -443,6 +466,7 @@ extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_img
             const int n = std::min(sub, nframes - base), slot = j % parts;
             hipStream_t s = slot ? h->partStream[slot - 1] : st;
             if (j < parts && slot) HIP_TRY(hipStreamWaitEvent(s, h->evPartFork, 0));
+            if (h->feed && (rc = h->feed(base + n, s)) != RUMI_OK) return rc;
             rc = run_part(base, n, slot * slotFrames, s, false, slot, true);
             if (rc != RUMI_OK) return rc;
             used = std::max(used, slot + 1);
@@ -485,9 +509,108 @@ extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_img
         for (int i = 0; i < 8; i++) h->stageMs[i] = acc[i];
     }
     h->lastSrc = src; h->lastFrames = nframes;
-    h->lastKp = (RumiKeyPoint *)d_kp; h->lastOutCap = cap;
+    h->lastKp = (RumiKeyPoint *)d_kp; h->lastKpStride = out.kpStride; h->lastOutCap = cap;
     h->lastCounts = (int32_t *)d_counts;
     return RUMI_OK;
+}
+
+extern "C" int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                                   int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                                   void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream) {
+    const OutLayout out{d_kp, (long long)cap * (long long)sizeof(RumiKeyPoint), d_desc, (long long)cap * 32, d_counts, 8};
+    return extract_async_impl(h, d_imgs, nframes, w, hgt, stride, frame_stride, lap0, lap1, out, cap, hip_stream);
+}
+
+// One fixed-capacity record per frame, {int32 n; int32 monoIndex; RumiKeyPoint kp[cap]; uint8 desc[cap][32]} = 8 + 60 cap bytes: the payload of the
+// rumination queue's single all-gather.  record_bytes >= that size and a multiple of 4.
+extern "C" int rumi_orb_extract_batch_records_async(RumiOrb *h, const void *d_imgs, int32_t nframes, int32_t w, int32_t hgt,
+                                                    int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
+                                                    void *d_records, int64_t record_bytes, int32_t cap, void *hip_stream) {
+    if (!d_records || cap < 1 || record_bytes < 8 + 60ll * cap || (record_bytes & 3)) { g_lastError = "rumi_orb_extract_batch_records: bad record size"; return RUMI_E_INVALID; }
+    uint8_t *r = (uint8_t *)d_records;
+    const OutLayout out{r + 8, record_bytes, r + 8 + (size_t)cap * sizeof(RumiKeyPoint), record_bytes, r, record_bytes};
+    return extract_async_impl(h, d_imgs, nframes, w, hgt, stride, frame_stride, lap0, lap1, out, cap, hip_stream);
+}
+
+// Host-resident batch: the rumination queue holds its frames as host cv::Mats (CloudImageSampler.cc:148-170).  The frames travel to the device
+// in groups of 64 on a copy stream of their own, each group's extraction waits only for its own group, so the transfers run under the kernels
+// of the groups before it.  Pinned sources (hipHostMalloc / hipHostRegister) are copied from where they lie; pageable ones pass through four
+// pinned staging slots filled by the handle's host threads.
+extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
+                                           int32_t lap0, int32_t lap1, void *d_kp, void *d_desc, void *d_counts, int32_t cap,
+                                           RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream) {
+    if (!h || !imgs || !d_kp || !d_desc || !d_counts || nframes < 1 || cap < 1 || stride < w) {
+        g_lastError = "rumi_orb_extract_batch_host: bad argument";
+        return RUMI_E_INVALID;
+    }
+    if (w <= 0 || hgt <= 0) return RUMI_E_EMPTY;
+    if (nframes > h->cfg.max_batch) { g_lastError = "nframes > max_batch"; return RUMI_E_CAPACITY; }
+    for (int f = 0; f < nframes; f++) if (!imgs[f]) { g_lastError = "rumi_orb_extract_batch_host: null frame"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if (h->pending && (rc = rumi_orb_sync(h)) != RUMI_OK) return rc;
+    const int wp = (w + 3) & ~3;
+    const size_t frameBytes = (size_t)wp * hgt;
+    if (h->dHostInBytes < frameBytes * nframes) {
+        if (h->dHostIn) HIP_TRY(hipFree(h->dHostIn));
+        h->dHostIn = nullptr; h->dHostInBytes = 0;
+        HIP_TRY(hipMalloc((void **)&h->dHostIn, frameBytes * h->cfg.max_batch));
+        h->dHostInBytes = frameBytes * h->cfg.max_batch;
+    }
+    if (!h->copyStream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+        for (auto &e : h->evFeed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // is the source pinned?  (one answer for the whole queue: the frames of a queue come from one allocator)
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, imgs[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    constexpr int G = RumiOrb::kFeedFrames, S = RumiOrb::kFeedSlots;
+    if (!pinned && h->hFeedBytes < frameBytes * G) {
+        for (auto &p : h->hFeed) { if (p) HIP_TRY(hipHostFree(p)); p = nullptr; }
+        for (auto &p : h->hFeed) HIP_TRY(hipHostMalloc((void **)&p, (size_t)((h->cfg.max_width + 3) & ~3) * h->cfg.max_height * G, hipHostMallocDefault));
+        h->hFeedBytes = (size_t)((h->cfg.max_width + 3) & ~3) * h->cfg.max_height * G;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    int fed = 0, group = 0;                                    // frames already on their way, groups enqueued
+    h->feed = [&](int upto, hipStream_t s) -> int {
+        while (fed < upto) {
+            const int n = std::min(G, nframes - fed), slot = group % S;
+            if (group >= S) HIP_TRY(hipEventSynchronize(h->evFeed[slot]));       // the slot's previous group has left the pinned buffer / its event is free again
+            bool dense = pinned && stride == wp;                               // one buffer, frames back to back: one transfer per group
+            for (int f = 1; dense && f < n; f++) dense = imgs[fed + f] == imgs[fed] + (size_t)f * frameBytes;
+            if (dense) {
+                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, imgs[fed], frameBytes * n, hipMemcpyHostToDevice, h->copyStream));
+            } else if (pinned) {
+                for (int f = 0; f < n; f++)
+                    HIP_TRY(hipMemcpy2DAsync(h->dHostIn + (size_t)(fed + f) * frameBytes, wp, imgs[fed + f], stride, w, hgt, hipMemcpyHostToDevice, h->copyStream));
+            } else {
+                uint8_t *dst = h->hFeed[slot];
+                const int nt = std::max(1, std::min(h->hostThreads, n));
+                auto work = [&](int t) {
+                    for (int f = t; f < n; f += nt)
+                        for (int y = 0; y < hgt; y++) std::memcpy(dst + (size_t)f * frameBytes + (size_t)y * wp, imgs[fed + f] + (size_t)y * stride, (size_t)w);
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+                work(0);
+                for (auto &x : th) x.join();
+                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, dst, frameBytes * n, hipMemcpyHostToDevice, h->copyStream));
+            }
+            HIP_TRY(hipEventRecord(h->evFeed[slot], h->copyStream));
+            fed += n; group++;
+        }
+        // copies complete in order on the copy stream: waiting for the newest group covers every frame below `upto`
+        HIP_TRY(hipStreamWaitEvent(s, h->evFeed[(group - 1) % S], 0));
+        return RUMI_OK;
+    };
+    rc = rumi_orb_extract_batch_device_async(h, h->dHostIn, nframes, w, hgt, wp, (int64_t)frameBytes, lap0, lap1, d_kp, d_desc, d_counts, cap, hip_stream);
+    h->feed = nullptr;
+    if (rc != RUMI_OK) { if (h->pending) (void)rumi_orb_sync(h); return rc; }
+    if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (h_kp) HIP_TRY(hipMemcpyAsync(h_kp, d_kp, (size_t)nframes * cap * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, st));
+    if (h_desc) HIP_TRY(hipMemcpyAsync(h_desc, d_desc, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, st));
+    return rumi_orb_sync(h);
 }
 
 extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int32_t stride, int32_t lap0,
@@ -603,7 +726,7 @@ extern "C" int rumi_orb_stage_keypoints(RumiOrb *h, int32_t frame, int32_t level
             const int slot = (int)(meta >> 8);
             RumiKeyPoint kp;
             if (slot >= ocap) return RUMI_E_CAPACITY;
-            HIP_TRY(hipMemcpy(&kp, h->lastKp + (size_t)frame * ocap + slot, sizeof kp, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&kp, (const uint8_t *)h->lastKp + (size_t)frame * h->lastKpStride + (size_t)slot * sizeof kp, sizeof kp, hipMemcpyDeviceToHost));
             kp.x = (float)(cand_x(pk) + kBorder); kp.y = (float)(cand_y(pk) + kBorder);
             if (out && n < cap) out[n] = kp;
             n++;

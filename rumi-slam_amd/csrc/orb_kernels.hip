@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
-                                                     RumiKeyPoint *__restrict__ kpOut, uint8_t *__restrict__ descOut,
-                                                     int outCap) {
+                                                     RumiKeyPoint *__restrict__ kpOut, long long kpStride, uint8_t *__restrict__ descOut,
+                                                     long long descStride, int outCap) {
     // per key-point: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged
     // with aligned dword loads that are all in flight together (one memory latency instead of 24 dependent byte gathers)
     __shared__ __attribute__((aligned(16))) uint8_t sDisc[kKpPerWg][31 * kDiscP];
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
             uint32_t w = bits[0];
 #pragma unroll
             for (int j = 1; j < 8; j++) if (lane == j) w = bits[j];
-            reinterpret_cast<uint32_t *>(descOut + ((long long)frame * outCap + slot) * 32)[lane] = w;
+            reinterpret_cast<uint32_t *>(descOut + frame * descStride + (long long)slot * 32)[lane] = w;
         }
         if (lane == 0) {
             RumiKeyPoint kp;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict
             kp.response = (float)score;
             kp.octave = level;
             kp.class_id = -1;
-            kpOut[(long long)frame * outCap + slot] = kp;
+            reinterpret_cast<RumiKeyPoint *>(reinterpret_cast<uint8_t *>(kpOut) + frame * kpStride)[slot] = kp;
         }
     }
 }
@@ -912,11 +912,11 @@ void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nfram
     hipLaunchKernelGGL(k_blur, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
 }
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
-                        const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, uint8_t *descOut,
-                        int outCap, int nframes, hipStream_t st) {
+                        const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
+                        long long descStride, int outCap, int nframes, hipStream_t st) {
     if (maxSel <= 0) return;
     hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + kKpPerWg - 1) / kKpPerWg, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
-                       selCount, selCap, kpOut, descOut, outCap);
+                       selCount, selCap, kpOut, kpStride, descOut, descStride, outCap);
 }
 
 }  // namespace rumi

@@ -528,11 +528,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restr
 __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ P, const uint32_t *__restrict__ selLevel,
                                                   const int32_t *__restrict__ selLevelCnt, int selLevelCap, int lap0,
                                                   int lap1, uint32_t *__restrict__ selPacked, uint32_t *__restrict__ selMeta,
-                                                  int32_t *__restrict__ selCount, int selCap, int32_t *__restrict__ counts,
+                                                  int32_t *__restrict__ selCount, int selCap, int32_t *__restrict__ countsBase, long long countsStride,
                                                   int32_t *__restrict__ errFlag) {
     __shared__ int lvStart[kMaxLevels + 1];
     __shared__ int part[256];
     const int tid = threadIdx.x, frame = blockIdx.x;
+    int32_t *counts = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(countsBase) + frame * countsStride);   // {n, monoIndex} of this frame
     const int nl = P->nlevels;
     if (tid == 0) {
         int run = 0;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ 
     __syncthreads();
     const int total = lvStart[nl];
     if (total > selCap) {
-        if (tid == 0) { selCount[frame] = 0; counts[2 * frame] = total; counts[2 * frame + 1] = 0; atomicOr(errFlag, 8); }
+        if (tid == 0) { selCount[frame] = 0; counts[0] = total; counts[1] = 0; atomicOr(errFlag, 8); }
         return;
     }
     const int chunk = (total + 255) / 256;
@@ -562,8 +563,8 @@ __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ 
         int run = 0;
         for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; }
         selCount[frame] = total;
-        counts[2 * frame] = total;
-        counts[2 * frame + 1] = total - run;      // monoIndex
+        counts[0] = total;
+        counts[1] = total - run;      // monoIndex
     }
     __syncthreads();
     int before = part[tid];                       // flagged key-points before k0
@@ -628,10 +629,10 @@ void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *can
                        selLevelCnt, selLevelCap, errFlag);
 }
 void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,
-                     int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts,
+                     int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts, long long countsStride,
                      int32_t *errFlag, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), 0, st, dP, selLevel, selLevelCnt, selLevelCap, lap0, lap1,
-                       selPacked, selMeta, selCount, selCap, counts, errFlag);
+                       selPacked, selMeta, selCount, selCap, counts, countsStride, errFlag);
 }
 size_t octree_lds_for(const DevParams &hP) {
     size_t mx = 0;

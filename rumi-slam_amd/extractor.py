@@ -87,6 +87,58 @@ class ORBextractor:
             int(vLappingArea[1]), kp.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, st.cuda_stream))
         return kp, desc, counts
 
+    def extract_batch_records(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, wait=True, out=None):
+        """Like ``extract_batch`` with ONE fixed-capacity record per frame as output (``rumination.record_bytes(cap)`` bytes each:
+        n, monoIndex, key-points, descriptors): a torch u8 CUDA tensor [B, record_bytes], the payload of the queue's single all-gather.
+        ``rumination.record_views`` gives (kp, desc, counts) views of it.  `out`: a tensor to write into (e.g. a padded block)."""
+        import torch
+        from . import rumination
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
+        B, H, W = frames.shape
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        rb = rumination.record_bytes(cap)
+        rec = out if out is not None else torch.zeros((B, rb), dtype=torch.uint8, device=frames.device)
+        assert rec.is_cuda and rec.dtype == torch.uint8 and rec.shape[0] >= B and rec.shape[1] == rb and rec.is_contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(frames.device)
+        capi.check(self._lib.rumi_orb_extract_batch_records_async(
+            self._h, frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0), int(vLappingArea[0]), int(vLappingArea[1]),
+            rec.data_ptr(), rb, cap, st.cuda_stream))
+        if wait:
+            self.sync()
+        return rec
+
+    def extract_batch_host(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, to_host=False):
+        """The rumination queue as the reference holds it: `frames` is a list of HOST images (numpy u8 [H,W], dense rows, one shape) or one
+        host array / CPU tensor [B,H,W] (pinned memory is copied in place).  Transfers overlap the extraction (rumi_orb_extract_batch_host).
+        Returns the device tensors of ``extract_batch``; with to_host=True also numpy copies (kp, desc, counts) as a second tuple."""
+        import torch
+        if hasattr(frames, "numpy") and not isinstance(frames, np.ndarray):      # CPU torch tensor (possibly pinned)
+            assert not frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
+            B, H, W = frames.shape
+            ptrs = [frames.data_ptr() + f * frames.stride(0) for f in range(B)]
+            pitch, keep = frames.stride(1), frames
+        else:
+            lst = list(frames)
+            keep = [a if a.strides[1] == 1 else np.ascontiguousarray(a) for a in lst]
+            B, (H, W) = len(keep), keep[0].shape
+            assert all(a.dtype == np.uint8 and a.shape == (H, W) and a.strides[0] == keep[0].strides[0] for a in keep)
+            ptrs, pitch = [a.ctypes.data for a in keep], keep[0].strides[0]
+        arr = (C.c_void_p * B)(*ptrs)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kp = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+        counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        hk = hd = hc = None
+        if to_host:
+            hk, hd, hc = np.zeros((B, cap), KP_DTYPE), np.zeros((B, cap, 32), np.uint8), np.zeros((B, 2), np.int32)
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        capi.check(self._lib.rumi_orb_extract_batch_host(
+            self._h, arr, B, W, H, pitch, int(vLappingArea[0]), int(vLappingArea[1]), kp.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap,
+            capi.ptr(hk) if to_host else None, capi.ptr(hd) if to_host else None, capi.ptr(hc) if to_host else None, st.cuda_stream))
+        del keep
+        return ((kp, desc, counts), (hk, hd, hc)) if to_host else (kp, desc, counts)
+
     def sync(self):
         """Waits for every batch enqueued with wait=False and raises on a device-side condition (rumi_orb_sync)."""
         capi.check(self._lib.rumi_orb_sync(self._h))

@@ -22,7 +22,8 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device",
+                 "rumi_match_bruteforce_batch_device_strided"]
 
 
 def _lib():
@@ -51,6 +52,7 @@ def _lib():
     L.rumi_search_local_points.argtypes = [vp, C.POINTER(RumiFrameFeatures), vp, vp, vp, vp, f32, i32, f32, i32] + [vp] * 7 + [f32, i32, f32, f32] + [vp] * 6 + [C.POINTER(i32), vp, C.POINTER(i32)]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.rumi_match_bruteforce_batch_device_strided.argtypes = [vp, vp, vp, vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
     return L
 
@@ -273,12 +275,16 @@ def isInFrustum(m, Rcw9, tcw3, Ow3, K4, w, h, log_sf, nlevels, cos_limit, pts):
 
 
 def bruteforce_batch(desc_q, counts_q, desc_t, counts_t, stream=None):
-    """desc_*: torch u8 CUDA [B,cap,32]; counts_*: torch i32 CUDA [B,2] (extractor counts).  Returns best_idx, best, second [B,cap]."""
+    """desc_*: torch u8 CUDA [B,cap,32] (frames may be strided views, e.g. of the per-frame records); counts_*: torch i32 CUDA [B,2]
+    (extractor counts, any frame stride).  Returns best_idx, best, second [B,cap]."""
     import torch
     B, cap, _ = desc_q.shape
+    assert desc_q.stride(1) == 32 and desc_q.stride(2) == 1 and desc_t.stride(1) == 32 and desc_t.stride(2) == 1
+    assert counts_q.stride(0) == counts_t.stride(0) or B == 1
     out = [torch.empty((B, cap), dtype=torch.int32, device=desc_q.device) for _ in range(3)]
     st = stream if stream is not None else torch.cuda.current_stream(desc_q.device)
-    capi.check(_lib().rumi_match_bruteforce_batch_device(desc_q.data_ptr(), counts_q.data_ptr(), desc_t.data_ptr(), counts_t.data_ptr(),
-                                                         counts_q.stride(0), cap, B, out[0].data_ptr(), out[1].data_ptr(),
-                                                         out[2].data_ptr(), st.cuda_stream))
+    capi.check(_lib().rumi_match_bruteforce_batch_device_strided(desc_q.data_ptr(), counts_q.data_ptr(), desc_t.data_ptr(), counts_t.data_ptr(),
+                                                                 counts_q.stride(0), desc_q.stride(0) if B > 1 else 32 * cap,
+                                                                 desc_t.stride(0) if B > 1 else 32 * cap, cap, B, out[0].data_ptr(),
+                                                                 out[1].data_ptr(), out[2].data_ptr(), st.cuda_stream))
     return out

@@ -14,7 +14,7 @@ class RumiSim3ScoreSet(C.Structure):
 
 
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
-               "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms"]
+               "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms", "rumi_opt_set_profiling", "rumi_opt_kernel_ms"]
 
 
 def _lib():
@@ -32,6 +32,8 @@ def _lib():
     L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_opt_stage_ms.argtypes = [vp, vp]
+    L.rumi_opt_set_profiling.argtypes = [vp, i32]
+    L.rumi_opt_kernel_ms.argtypes = [vp, vp]
     L.rumi_sim3_ransac.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_optimize_sim3.argtypes = [vp, i32, vp, i32] + [vp] * 12 + [C.c_float, i32, i32, vp, vp, vp]
     L._opt_ready = True
@@ -167,6 +169,15 @@ class Optimizer:
         capi.check(self._lib.rumi_optimize_sim3(self._h, n, P(po), len(A) if world else 0, P(A), P(B), P(P1c), P(P2c), P(obs1), P(obs2), P(w1), P(w2),
                                                 P(s12), P(s21), P(K1), P(K2), float(th2), int(fix_scale), int(robust_first_pass), P(S), P(status), P(res)))
         return int(res[0]), int(res[1]), bool(res[2]), S, status[:n]
+
+    def set_profiling(self, on=True):
+        capi.check(self._lib.rumi_opt_set_profiling(self._h, int(on)))
+
+    def kernel_ms(self):
+        """Per-kernel device time of the last bundle adjustment run with profiling on: dict(hpp, syrk, solve in ms over the call, trials)."""
+        ms = np.zeros(4, np.float32)
+        capi.check(self._lib.rumi_opt_kernel_ms(self._h, capi.ptr(ms)))
+        return dict(hpp=float(ms[0]), syrk=float(ms[1]), solve=float(ms[2]), trials=int(ms[3]))
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)

@@ -142,6 +142,28 @@ def test_async_batches_match_blocking_calls():
             assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"batch {i} frame {f}: descriptors"
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batch_bit_exact_300_frames(pinned):
+    """rumi_orb_extract_batch_host: 300 host frames (pageable: through the pinned staging slots; pinned: copied in place), transfers
+    overlapped with the extraction group by group; every frame bit-exact against the oracle, device and host outputs alike."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    B = 300
+    g, o = _pair(batch=B)
+    frames = synth_batch(B, seed0=3000)
+    src = torch.from_numpy(frames).pin_memory() if pinned else [frames[f] for f in range(B)]
+    (kp, desc, counts), (hk, hd, hc) = g.extract_batch_host(src, to_host=True)
+    torch.cuda.synchronize()
+    kp = kp.cpu().numpy(); desc = desc.cpu().numpy(); counts = counts.cpu().numpy()
+    assert np.array_equal(counts, hc)
+    for f in range(B):
+        om, ok, od = o.extract(frames[f], (0, 1000))
+        n = counts[f, 0]
+        gk = kp[f, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
+        _assert_same((int(counts[f, 1]), gk, desc[f, :n]), (om, ok, od), f"host batch frame {f}")
+        assert hk[f, :n].tobytes() == gk.tobytes() and np.array_equal(hd[f, :n], desc[f, :n]), f"host copies of frame {f}"
+
+
 def test_batch_device_matches_single():
     import torch
     from rumi_slam_amd.synth import synth_batch

@@ -1,5 +1,6 @@
-"""world_size-2 gloo test of the rumination sharding + all-gather (the N > 1 path of bench.py); extraction itself is stood in
-for by the CPU oracle here (no GPU in this container) — what is under test is the partition and the exchange step."""
+"""gloo tests (world sizes 2 and 3) of the rumination sharding + the single all-gather of per-frame records (the N > 1 path of bench.py);
+extraction itself is stood in for by the CPU oracle here (no GPU in this container) — what is under test is the partition, the record
+layout and the exchange step."""
 import os
 import socket
 
@@ -25,7 +26,7 @@ def _records(frames):
         counts[i] = (len(k), mono)
         kp[i, :len(k)] = k.view(np.float32).reshape(-1, 7)
         desc[i, :len(k)] = d
-    return torch.from_numpy(kp), torch.from_numpy(desc), torch.from_numpy(counts)
+    return rumination.pack_records(torch.from_numpy(kp), torch.from_numpy(desc), torch.from_numpy(counts))
 
 
 def _worker(rank, world, port, n_frames, out_dir):
@@ -34,15 +35,15 @@ def _worker(rank, world, port, n_frames, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = rumination.shard_bounds(n_frames, rank, world)
     frames = [synth_frame(300 + i, w=320, h=240) for i in range(lo, hi)]
-    counts, kp, desc = rumination.extract_queue(_records, frames, n_frames)
-    # the pipelined form bench.py uses: two exchanges in flight order, joined later, must give the same queue
-    k2, d2, c2 = _records(frames)
-    h1 = rumination.all_gather_records_async(c2, k2, d2, n_frames)
-    h2 = rumination.all_gather_records_async(c2, k2, d2, n_frames)
+    rec = rumination.extract_queue(_records, frames, n_frames)
+    assert rec.shape == (n_frames, rumination.record_bytes(CAP))
+    # the pipelined form bench.py uses: two exchanges in flight, joined later, must give the same queue
+    mine = _records(frames)
+    h1 = rumination.all_gather_records_async(mine, n_frames)
+    h2 = rumination.all_gather_records_async(mine, n_frames)
     for h in (h1, h2):
-        gc, gk, gd = h.wait()
-        assert torch.equal(gc, counts) and gk.numpy().tobytes() == kp.numpy().tobytes() and torch.equal(gd, desc)
-    np.savez(os.path.join(out_dir, f"r{rank}.npz"), counts=counts.numpy(), kp=kp.numpy(), desc=desc.numpy())
+        assert torch.equal(h.wait(), rec)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), rec.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,12 +56,24 @@ def test_shard_bounds_cover_the_queue():
             assert rumination.shard_capacity(n, w) == max(h - l for l, h in b)
 
 
-@pytest.mark.parametrize("n_frames", [4, 5])
-def test_two_rank_all_gather_matches_single_process(tmp_path, n_frames):
+def test_record_views_round_trip():
+    rng = np.random.default_rng(5)
+    kp = torch.from_numpy(rng.standard_normal((3, CAP, 7)).astype(np.float32))
+    desc = torch.from_numpy(rng.integers(0, 256, (3, CAP, 32), dtype=np.uint8))
+    counts = torch.from_numpy(rng.integers(0, CAP, (3, 2)).astype(np.int32))
+    rec = rumination.pack_records(kp, desc, counts)
+    assert rec.shape == (3, 8 + 60 * CAP)
+    k, d, c = rumination.record_views(rec, CAP)
+    assert torch.equal(k, kp) and torch.equal(d, desc) and torch.equal(c, counts)
+    raw = rec.numpy()                                   # the layout the kernels write: n, monoIndex, key-points, descriptors
+    assert np.array_equal(raw[:, :8].view(np.int32), counts.numpy())
+    assert raw[1, 8:8 + 28 * CAP].tobytes() == kp[1].numpy().tobytes() and raw[2, 8 + 28 * CAP:].tobytes() == desc[2].numpy().tobytes()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 4), (2, 5), (3, 6), (3, 7)])
+def test_all_gather_matches_single_process(tmp_path, world, n_frames):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
-    kp, desc, counts = _records([synth_frame(300 + i, w=320, h=240) for i in range(n_frames)])
-    for r in range(2):
-        g = np.load(tmp_path / f"r{r}.npz")
-        assert np.array_equal(g["counts"], counts.numpy()), f"rank {r} counts"
-        assert g["kp"].tobytes() == kp.numpy().tobytes() and np.array_equal(g["desc"], desc.numpy()), f"rank {r} records"   # kp holds int fields: compare bytes
+    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    ref = _records([synth_frame(300 + i, w=320, h=240) for i in range(n_frames)]).numpy()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), ref), f"rank {r}: gathered records"
