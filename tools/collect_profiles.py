@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag r01) and prints a summary.
-Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r01.json, bench_matrix.json, stage_serial.log."""
+"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag r02) and prints a summary.
+Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r02.json, stage_serial.log, host_batch.log, r02_valu_issue_rates.txt."""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -10,15 +10,15 @@ def newest(pattern):
     return max(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
 
 
-shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, "r01_extract_match_kernel_stats.csv"))
-shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, "r01_extract_match_serial_kernel_stats.csv"))
-shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, "r01_lba_20kf_3000mp_kernel_stats.csv"))
+shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_kernel_stats.csv"))
+shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_serial_kernel_stats.csv"))
+shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, "r02_lba_20kf_3000mp_kernel_stats.csv"))
 for d, tmp in (("pmc_fetch", "/tmp/_pf"), ("pmc_write", "/tmp/_pw")):
     shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/x")
     shutil.copy(newest(d + "/*/*counter_collection.csv"), tmp + "/x/")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "/tmp/_pf", "/tmp/_pw", os.path.join(P, "r01_pmc_traffic.json"), "256"],
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "/tmp/_pf", "/tmp/_pw", os.path.join(P, "r02_pmc_traffic.json"), "256"],
                       stdout=subprocess.DEVNULL)
-out = {"command": "RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc <4 counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu (two passes)",
+out = {"command": "RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 bench.py --steps 2 --warmup 1 --batch 256 --no-cpu (two passes)",
        "unit": "counter value per launch (256 frames), averaged over the sampled launches", "kernels": {}}
 for d in ("pmc_a", "pmc_b"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -28,21 +28,17 @@ for d in ("pmc_a", "pmc_b"):
             agg[n.replace("rumi::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for n, c in agg.items():
         out["kernels"].setdefault(n, {}).update({k: round(sum(v) / len(v)) for k, v in c.items()})
-json.dump(out, open(os.path.join(P, "r01_pmc_sq_counters.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "bench_r01.json"), os.path.join(P, "r01_bench_line.json"))
-shutil.copy(os.path.join(G, "bench_matrix.json"), os.path.join(P, "r01_bench_matrix.json"))
-shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, "r01_stage_ms_standalone.txt"))
-for f in ("r01_extract_match_kernel_stats.csv", "r01_extract_match_serial_kernel_stats.csv", "r01_lba_20kf_3000mp_kernel_stats.csv"):
+json.dump(out, open(os.path.join(P, "r02_pmc_sq_counters.json"), "w"), indent=1)
+shutil.copy(os.path.join(G, "bench_r02.json"), os.path.join(P, "r02_bench_line.json"))
+shutil.copy(os.path.join(G, "host_batch.log"), os.path.join(P, "r02_host_batch_probe.txt"))
+shutil.copy(os.path.join(G, "r02_valu_issue_rates.txt"), os.path.join(P, "r02_valu_issue_rates.txt"))
+shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, "r02_stage_ms_standalone.txt"))
+for f in ("r02_extract_match_kernel_stats.csv", "r02_extract_match_serial_kernel_stats.csv", "r02_lba_20kf_3000mp_kernel_stats.csv"):
     print(f)
     for r in list(csv.DictReader(open(os.path.join(P, f))))[:12]:
         print("   ", r["Name"][:42].ljust(44), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us", r["Percentage"])
-t = json.load(open(os.path.join(P, "r01_pmc_traffic.json")))["kernels"]
+t = json.load(open(os.path.join(P, "r02_pmc_traffic.json")))["kernels"]
 for k, v in out["kernels"].items():
     print(k.ljust(16), "VALU", round(v.get("SQ_INSTS_VALU", 0) / 1e6, 1), "M  LDS", round(v.get("SQ_INSTS_LDS", 0) / 1e6, 1), "M  HBM", round(t.get(k, {}).get("hbm_bytes_per_launch", 0) / 1e6, 1), "MB")
-m = json.load(open(os.path.join(P, "r01_bench_matrix.json")))
-print([(r["frames_per_launch"], r["extract_fps"], r["extract_match_fps"]) for r in m["batch_sweep_1000_features"]])
-print([(r["nfeatures"], r["input"][:12], r["extract_fps"]) for r in m["feature_sweep"]])
-for k in ("single_frame_host_api", "bruteforce", "windowed_matchers_host_api", "search_local_points_host_api", "tracking_frame_host_api", "optimize_sim3_host_api", "sim3_ransac_host_api", "cpu_oracle_extract"):
-    print(k, m[k])
-b = json.load(open(os.path.join(P, "r01_bench_line.json")))
-print({k: b[k] for k in ("value", "ms_per_step", "roofline", "stage_ms_per_step", "cpu_baseline", "lba", "pose_opt")})
+b = json.load(open(os.path.join(P, "r02_bench_line.json")))
+print({k: b.get(k) for k in ("value", "value_h2d_inclusive", "single_frame_host_api_fps", "batch_sweep_fps", "ms_per_step", "roofline", "stage_ms_per_step", "cpu_baseline", "lba", "pose_opt")})
