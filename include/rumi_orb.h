@@ -48,8 +48,14 @@ typedef struct RumiOrbConfig {
     int32_t max_height;
     int32_t max_batch;      /* largest number of frames per batched call (>= 1) */
     int32_t device;         /* HIP device ordinal, -1 = current */
-    int32_t host_threads;   /* reserved (0) */
+    int32_t host_threads;   /* threads that fill the pinned staging slots of rumi_orb_extract_batch_host (0 = up to 16) */
+    int32_t blur_variant;   /* which cv::GaussianBlur(7x7, sigma 2) of 8-bit images to reproduce -- the reference only says "OpenCV 3.4" (R/CMakeLists.txt:35),
+                             * and the two differ by +-1 grey level, which can flip rBRIEF bits:
+                             * 0 = RUMI_BLUR_FIXED_POINT  OpenCV >= 3.4.2 / 4.x bit-exact fixed-point path: taps {18,34,48,56,48,34,18} / 256 (sum 256)
+                             * 1 = RUMI_BLUR_SEPFILTER    OpenCV 3.4.0 / 3.4.1 sepFilter2D path: the float kernel scaled by 256 and rounded tap by tap,
+                             *                            {18,34,49,55,49,34,18} / 256 (sum 257), result saturated */
 } RumiOrbConfig;
+enum { RUMI_BLUR_FIXED_POINT = 0, RUMI_BLUR_SEPFILTER = 1 };
 
 typedef struct RumiOrb RumiOrb;
 

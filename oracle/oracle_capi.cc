@@ -13,6 +13,7 @@ void *orc_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, i
     return new OrbExtractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
 }
 void orc_orb_destroy(void *h) { delete (OrbExtractor *)h; }
+void orc_orb_set_blur_variant(void *h, int v) { ((OrbExtractor *)h)->blurVariant = v; }
 
 // returns monoIndex (>=0) or -1 (empty image) or -2 (capacity too small); *n_out = number of key-points
 int orc_orb_extract(void *h, const uint8_t *img, int w, int hgt, int stride, int lap0, int lap1,
@@ -77,6 +78,13 @@ void orc_resize_linear(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw,
     orc::Image s, d;
     s.w = sw; s.h = sh; s.d.assign(src, src + (size_t)sw * sh);
     orc::resize_linear_u8(s, d, dw, dh);
+    std::memcpy(dst, d.d.data(), d.d.size());
+}
+
+void orc_gaussian_blur_variant(const uint8_t *src, int w, int h, uint8_t *dst, int variant) {
+    orc::Image s, d;
+    s.w = w; s.h = h; s.d.assign(src, src + (size_t)w * h);
+    orc::gaussian_blur_7x7_s2(s, d, variant);
     std::memcpy(dst, d.d.data(), d.d.size());
 }
 

@@ -108,34 +108,39 @@ static inline int reflect101(int i, int n) {   // BORDER_REFLECT_101: gfedcb|abc
     return i;
 }
 
-// cv::GaussianBlur(Size(7,7), 2, 2, BORDER_REFLECT_101) on CV_8UC1 — the bit-exact fixed-point path
-// (OpenCV >= 3.4.14 / 4.5.2 kernel with error diffusion): taps {18,34,48,56,48,34,18}/256, 8.8 row
-// pass into u16, 16.16 column pass, one rounding at the end: (v + 32768) >> 16.
-void gaussian_blur_7x7_s2(const Image &src, Image &dst) {
-    static const int k[7] = {18, 34, 48, 56, 48, 34, 18};
+// cv::GaussianBlur(Size(7,7), 2, 2, BORDER_REFLECT_101) on CV_8UC1.  The reference pins "OpenCV 3.4" only (R/CMakeLists.txt:35) and two
+// implementations exist in that series; `variant` selects which one is restated (parity unpinned either way: the reference holds no vector):
+//   0  the bit-exact fixed-point path (3.4.2 and later, 4.x): kernel quantised to 8 fractional bits with the sum corrected to 256,
+//      taps {18,34,48,56,48,34,18}/256, 8.8 row pass into u16, 16.16 column pass, one rounding at the end: (v + 32768) >> 16;
+//   1  the sepFilter2D path of 3.4.0 / 3.4.1: getGaussianKernel(7, 2, CV_32F) = {.070159,.131075,.190713,.216106,...} converted tap by tap with
+//      convertTo(CV_32S, 256) -> {18,34,49,55,49,34,18} (sum 257), integer row and column passes, FixedPtCastEx: saturate((v + 32768) >> 16).
+void gaussian_blur_7x7_s2(const Image &src, Image &dst, int variant) {
+    static const int kFixed[7] = {18, 34, 48, 56, 48, 34, 18}, kSep[7] = {18, 34, 49, 55, 49, 34, 18};
+    const int *k = variant ? kSep : kFixed;
     const int w = src.w, h = src.h;
     dst.w = w; dst.h = h; dst.d.assign((size_t)w * h, 0);
-    std::vector<uint16_t> tmp((size_t)w * h);
+    std::vector<uint32_t> tmp((size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t *S = src.row(y);
-        uint16_t *T = tmp.data() + (size_t)y * w;
+        uint32_t *T = tmp.data() + (size_t)y * w;
         for (int x = 0; x < w; x++) {
             int acc = 0;
             if (x >= 3 && x + 3 < w)
                 for (int i = 0; i < 7; i++) acc += k[i] * S[x + i - 3];
             else
                 for (int i = 0; i < 7; i++) acc += k[i] * S[reflect101(x + i - 3, w)];
-            T[x] = (uint16_t)acc;
+            T[x] = (uint32_t)acc;
         }
     }
     for (int y = 0; y < h; y++) {
-        const uint16_t *R[7];
+        const uint32_t *R[7];
         for (int j = 0; j < 7; j++) R[j] = tmp.data() + (size_t)reflect101(y + j - 3, h) * w;
         uint8_t *D = dst.row(y);
         for (int x = 0; x < w; x++) {
             uint32_t acc = 0;
             for (int j = 0; j < 7; j++) acc += (uint32_t)k[j] * R[j][x];
-            D[x] = (uint8_t)((acc + 32768u) >> 16);
+            const uint32_t v = (acc + 32768u) >> 16;
+            D[x] = (uint8_t)(v > 255u ? 255u : v);
         }
     }
 }
@@ -475,7 +480,7 @@ int OrbExtractor::extract(const uint8_t *img, int w, int h, int stride, int lap0
     int mono = 0, stereo = total - 1;
     for (int l = 0; l < nlevels; l++) {
         if (sel[l].empty()) { blurred[l] = Image{}; continue; }
-        gaussian_blur_7x7_s2(pyr[l], blurred[l]);
+        gaussian_blur_7x7_s2(pyr[l], blurred[l], blurVariant);
         const float s = scale[l];
         for (const KeyPoint &k0 : sel[l]) {
             uint8_t d[32];

@@ -41,7 +41,7 @@ struct Image {
 int cv_round(double v);                                   // round-half-to-even (lrint / cvtsd2si)
 float fast_atan2_deg(float y, float x);                   // cv::fastAtan2
 void resize_linear_u8(const Image &src, Image &dst, int dw, int dh);   // cv::resize INTER_LINEAR 8UC1
-void gaussian_blur_7x7_s2(const Image &src, Image &dst);  // cv::GaussianBlur(7x7, 2, 2, REFLECT_101), fixed point
+void gaussian_blur_7x7_s2(const Image &src, Image &dst, int variant = 0);  // cv::GaussianBlur(7x7, 2, 2, REFLECT_101); variant: see the .cc
 int fast_corner_score(const uint8_t *p, int stride);      // max(A,B)-1, 0-threshold form (see .cc)
 // cv::FAST(sub-image, threshold, nonmax=true): appends (x, y, score) relative to the sub-image origin.
 void fast_9_16_nms(const uint8_t *img, int stride, int cols, int rows, int threshold,
@@ -64,6 +64,7 @@ public:
     void orb_descriptor(const Image &blurred, const KeyPoint &kp, uint8_t *desc32) const;
 
     int nfeatures, nlevels, iniTh, minTh;
+    int blurVariant = 0;  // 0 = fixed-point GaussianBlur (OpenCV >= 3.4.2), 1 = sepFilter2D path of 3.4.0 / 3.4.1 (orb_oracle.cc)
     double scaleFactor;  // the reference stores the float ctor argument in a double member
     std::vector<float> scale, invScale, sigma2, invSigma2;
     std::vector<int> featuresPerLevel, umax;

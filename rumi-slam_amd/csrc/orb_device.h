@@ -51,7 +51,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
                  hipStream_t st);
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st);
-void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st);
+void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st);
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
                         long long descStride, int outCap, int nframes, hipStream_t st);   // strides: bytes from one frame's outputs to the next

@@ -240,7 +240,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     if (!out) return RUMI_E_INVALID;
     *out = nullptr;
     if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 1 || cfg->max_batch < 1 ||
-        cfg->max_width < 1 || cfg->max_height < 1 || !(cfg->scale_factor > 1.0f)) {
+        cfg->max_width < 1 || cfg->max_height < 1 || !(cfg->scale_factor > 1.0f) || cfg->blur_variant < 0 || cfg->blur_variant > 1) {
         g_lastError = "invalid RumiOrbConfig";
         return RUMI_E_INVALID;
     }
@@ -413,7 +413,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         HIP_TRY(hipEventRecord(fork, s));
         HIP_TRY(hipStreamWaitEvent(bs, fork, 0));
         if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
-        launch_blur(h->dP, P, ps, n, bs);
+        launch_blur(h->dP, P, ps, n, h->cfg.blur_variant, bs);
         if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
         HIP_TRY(hipEventRecord(join, bs));
         HIP_TRY(hipGetLastError());

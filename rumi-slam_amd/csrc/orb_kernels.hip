@@ -626,7 +626,11 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// VARIANT: RumiOrbConfig.blur_variant -- 0: taps {18,34,48,56,..}/256 of the fixed-point GaussianBlur of OpenCV >= 3.4.2; 1: the integer-scaled float
+// kernel {18,34,49,55,..}/256 of 3.4.0 / 3.4.1 (sum 257: the result is saturated)
+template <int VARIANT>
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
+    constexpr uint32_t kT2 = VARIANT ? 49u : 48u, kT3 = VARIANT ? 55u : 56u;      // taps at distance 1 and 0 (18 and 34 are common)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = wg / gridDim.x, lin = wg % gridDim.x;
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
             if (lane == 63 && !edgeWave && bw == 256) Rw = *reinterpret_cast<const uint32_t *>(row + xl + 4);   // (only a 256-pixel wave has a producing lane 63)
             // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
             // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
-            constexpr uint32_t tA = 18u | (34u << 8) | (48u << 16) | (56u << 24), tB = 48u | (34u << 8) | (18u << 16);
+            constexpr uint32_t tA = 18u | (34u << 8) | (kT2 << 16) | (kT3 << 24), tB = kT2 | (34u << 8) | (18u << 16);
             const uint32_t A0 = __builtin_amdgcn_alignbyte(C, Lw, 1), A1 = __builtin_amdgcn_alignbyte(C, Lw, 2), A2 = __builtin_amdgcn_alignbyte(C, Lw, 3);
             const uint32_t B0 = __builtin_amdgcn_alignbyte(Rw, C, 1), B1 = __builtin_amdgcn_alignbyte(Rw, C, 2), B2 = __builtin_amdgcn_alignbyte(Rw, C, 3);
             ring[j][0] = (int)__builtin_amdgcn_udot4(B0, tB, __builtin_amdgcn_udot4(A0, tA, 0u, false), false);
@@ -707,10 +711,11 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
                 for (int i = 0; i < 4; i++) {
                     // rounding constant folded into the first multiply-add; the result's byte 2 is the output pixel (sum <= 255 * 65536 + 32768)
                     // row sums are <= 65 280 and their pairs <= 130 560: 24-bit multiply-adds (v_mad_u32_u24: tap and accumulation in one instruction)
-                    uint32_t acc = mad_u24(56u, (uint32_t)ring[(j + 4) % 7][i], 32768u);
-                    acc = mad_u24(48u, (uint32_t)(ring[(j + 3) % 7][i] + ring[(j + 5) % 7][i]), acc);
+                    uint32_t acc = mad_u24(kT3, (uint32_t)ring[(j + 4) % 7][i], 32768u);
+                    acc = mad_u24(kT2, (uint32_t)(ring[(j + 3) % 7][i] + ring[(j + 5) % 7][i]), acc);
                     acc = mad_u24(34u, (uint32_t)(ring[(j + 2) % 7][i] + ring[(j + 6) % 7][i]), acc);
                     acc = mad_u24(18u, (uint32_t)(ring[(j + 1) % 7][i] + ring[j][i]), acc);
+                    if (VARIANT) acc = min(acc, 0x00FFFFFFu);            // taps sum to 257: saturate_cast<uchar>
                     o[i] = acc;
                 }
                 // byte 2 of the four sums -> one dword (v_perm_b32: selectors 0-3 take from the second operand, 4-7 from the first, 0x0c = zero);
@@ -899,7 +904,7 @@ static int blur_strip_width(int w) {
     }
     return 192;
 }
-void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, hipStream_t st) {
+void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st) {
     BlurGrid G{};
     int run = 0;
     for (int l = 0; l < hP.nlevels; l++) {
@@ -909,7 +914,8 @@ void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nfram
         run += G.gx[l] * ((hP.lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }
     G.base[hP.nlevels] = run;
-    hipLaunchKernelGGL(k_blur, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+    if (variant) hipLaunchKernelGGL(k_blur<1>, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+    else hipLaunchKernelGGL(k_blur<0>, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
 }
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,

@@ -14,10 +14,10 @@ class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width=640, max_height=480,
-                 max_batch=1, device=-1):
+                 max_batch=1, device=-1, blur_variant=0):
         self._lib = capi.lib()
         self.cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
-                                 max_batch, device, 0)
+                                 max_batch, device, 0, blur_variant)
         self._h = C.c_void_p()
         capi.check(self._lib.rumi_orb_create(C.byref(self.cfg), C.byref(self._h)))
         self.nfeatures, self.nlevels = nfeatures, nlevels
@@ -172,7 +172,7 @@ class ORBextractor:
 
 def tables(nfeatures=1000, scaleFactor=1.2, nlevels=8):
     """Constructor tables of the reference (host-only; works without a GPU)."""
-    cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, 20, 7, 640, 480, 1, -1, 0)
+    cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, 20, 7, 640, 480, 1, -1, 0, 0)
     f = [np.zeros(nlevels, np.float32) for _ in range(4)]
     per = np.zeros(nlevels, np.int32)
     umax = np.zeros(16, np.int32)

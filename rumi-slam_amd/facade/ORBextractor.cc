@@ -5,13 +5,24 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Which cv::GaussianBlur the linked OpenCV 3.4 build has (include/rumi_orb.h, RumiOrbConfig.blur_variant): 0 for 3.4.2 and later (fixed-point
+// path), 1 for 3.4.0 / 3.4.1.  A maintainer sets it from CV_VERSION at build time, e.g. -DRUMI_FACADE_BLUR_VARIANT=1; with real OpenCV headers it
+// is derived below.
+#ifndef RUMI_FACADE_BLUR_VARIANT
+#if defined(CV_VERSION_MAJOR) && CV_VERSION_MAJOR == 3 && CV_VERSION_MINOR == 4 && defined(CV_VERSION_REVISION) && CV_VERSION_REVISION < 2
+#define RUMI_FACADE_BLUR_VARIANT 1
+#else
+#define RUMI_FACADE_BLUR_VARIANT 0
+#endif
+#endif
+
 namespace ORB_SLAM3 {
 
 static const int EDGE_THRESHOLD = 19;
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
-    RumiOrbConfig cfg{nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, 640, 480, 1, -1, 0};
+    RumiOrbConfig cfg{nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, 640, 480, 1, -1, 0, RUMI_FACADE_BLUR_VARIANT};
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels); umax.resize(16);
     rumi_orb_tables(&cfg, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
@@ -27,7 +38,7 @@ void ORBextractor::ensureHandle(int width, int height) {
     handle_ = nullptr;
     capW_ = width > capW_ ? width : capW_;
     capH_ = height > capH_ ? height : capH_;
-    RumiOrbConfig cfg{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, capW_, capH_, 1, -1, 0};
+    RumiOrbConfig cfg{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, capW_, capH_, 1, -1, 0, RUMI_FACADE_BLUR_VARIANT};
     if (rumi_orb_create(&cfg, &handle_) != RUMI_OK) {
         // the reference has no error path here; a missing GPU must not degrade silently
         std::fprintf(stderr, "ORBextractor: %s\n", rumi_last_error());

@@ -41,6 +41,8 @@ def lib():
         _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
         _lib.orc_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         _lib.orc_gaussian_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.orc_gaussian_blur_variant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_orb_set_blur_variant.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_fast_score.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_fast_cell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib.orc_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -52,11 +54,13 @@ def _p(a):
 
 
 class OracleExtractor:
-    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0):
         self.L = lib()
         self.nlevels = nlevels
         self.nfeatures = nfeatures
         self.h = C.c_void_p(self.L.orc_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        if blur_variant:
+            self.L.orc_orb_set_blur_variant(self.h, int(blur_variant))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -96,6 +100,10 @@ class OracleExtractor:
         return out[:n]
 
 
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
 def resize_linear(src, dw, dh):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros((dh, dw), np.uint8)
@@ -103,10 +111,10 @@ def resize_linear(src, dw, dh):
     return dst
 
 
-def gaussian_blur(src):
+def gaussian_blur(src, variant=0):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros_like(src)
-    lib().orc_gaussian_blur(_p(src), src.shape[1], src.shape[0], _p(dst))
+    lib().orc_gaussian_blur_variant(_p(src), src.shape[1], src.shape[0], _p(dst), int(variant))
     return dst
 
 

@@ -9,10 +9,10 @@ from rumi_slam_amd.synth import synth_frame
 pytestmark = pytest.mark.gpu
 
 
-def _pair(nf=1000, sf=1.2, nl=8, ini=20, mn=7, w=640, h=480, batch=1):
+def _pair(nf=1000, sf=1.2, nl=8, ini=20, mn=7, w=640, h=480, batch=1, blur_variant=0):
     from rumi_slam_amd.extractor import ORBextractor
-    return (ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=batch),
-            oracle_lib.OracleExtractor(nf, sf, nl, ini, mn))
+    return (ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=batch, blur_variant=blur_variant),
+            oracle_lib.OracleExtractor(nf, sf, nl, ini, mn, blur_variant=blur_variant))
 
 
 def _assert_same(gpu_out, orc_out, tag=""):
@@ -47,6 +47,22 @@ def test_stages_bit_exact():
         assert gc.tobytes() == oc.tobytes(), f"candidate list level {l}"
         gs, os_ = g.stage_keypoints(l, 1), o.keypoints(l, True)
         assert gs.tobytes() == os_.tobytes(), f"selected key-points level {l}"
+
+
+def test_blur_variant_sepfilter_bit_exact():
+    """RumiOrbConfig.blur_variant = 1 (the sepFilter2D GaussianBlur of OpenCV 3.4.0 / 3.4.1: taps {18,34,49,55,..}/256, saturated) in kernel and
+    oracle alike: blurred levels, key-points and descriptors bit-exact; and the variant does change descriptors (it is a real switch)."""
+    g1, o1 = _pair(blur_variant=1)
+    g0, _ = _pair()
+    img = synth_frame(4322)
+    img[100:140, 200:260] = 255                                   # a saturated patch: 257 / 256 of 255 must clamp to 255
+    out1 = g1(img, None, (0, 1000))
+    _assert_same(out1, o1.extract(img, (0, 1000)), "blur variant 1")
+    for l in range(8):
+        assert np.array_equal(g1.pyramid_level(l, blurred=True), o1.level(l, blurred=True)), f"blurred level {l}, variant 1"
+    out0 = g0(img, None, (0, 1000))
+    assert out0[1].tobytes() == out1[1].tobytes(), "key-points do not depend on the blur"
+    assert not np.array_equal(out0[2], out1[2]), "the two GaussianBlur variants give different descriptors"
 
 
 def test_lapping_forward_order():

@@ -34,7 +34,7 @@ def test_create_without_gpu_fails_loudly():
     L = capi.lib()
     if L.rumi_device_count() > 0:
         pytest.skip("GPU present")
-    cfg = capi.RumiOrbConfig(1000, 1.2, 8, 20, 7, 640, 480, 1, -1, 0)
+    cfg = capi.RumiOrbConfig(1000, 1.2, 8, 20, 7, 640, 480, 1, -1, 0, 0)
     h = C.c_void_p()
     assert L.rumi_orb_create(C.byref(cfg), C.byref(h)) == capi.RUMI_E_NO_DEVICE
     assert b"no CPU fallback" in L.rumi_last_error()
@@ -43,8 +43,8 @@ def test_create_without_gpu_fails_loudly():
 def test_invalid_config_rejected():
     L = capi.lib()
     h = C.c_void_p()
-    for bad in (capi.RumiOrbConfig(0, 1.2, 8, 20, 7, 640, 480, 1, -1, 0), capi.RumiOrbConfig(1000, 1.0, 8, 20, 7, 640, 480, 1, -1, 0),
-                capi.RumiOrbConfig(1000, 1.2, 0, 20, 7, 640, 480, 1, -1, 0), capi.RumiOrbConfig(1000, 1.2, 17, 20, 7, 640, 480, 1, -1, 0)):
+    for bad in (capi.RumiOrbConfig(0, 1.2, 8, 20, 7, 640, 480, 1, -1, 0, 0), capi.RumiOrbConfig(1000, 1.0, 8, 20, 7, 640, 480, 1, -1, 0, 0),
+                capi.RumiOrbConfig(1000, 1.2, 0, 20, 7, 640, 480, 1, -1, 0, 0), capi.RumiOrbConfig(1000, 1.2, 17, 20, 7, 640, 480, 1, -1, 0, 0)):
         assert L.rumi_orb_create(C.byref(bad), C.byref(h)) == capi.RUMI_E_INVALID
 
 
