@@ -25,7 +25,7 @@
 namespace rumi {
 
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // Frame.h:42-43
-constexpr int kMaxSortN = 8192;
+constexpr int kMaxSortN = 16384;     // features per frame: the mono-initialisation extractor asks for 5 x nfeatures (Tracking.cc:581: 10 000 with TUM3.yaml)
 
 enum { MODE_MAPPOINTS = 0, MODE_FRAME = 1, MODE_BOW = 2, MODE_BOW_KF = 3, MODE_SIM3 = 4, MODE_RELOC = 5, MODE_INIT = 6, MODE_FUSE = 7 };
 
@@ -978,7 +978,7 @@ extern "C" int rumi_match_create(int32_t max_features, int32_t max_queries, int3
     if (!out) return RUMI_E_INVALID;
     *out = nullptr;
     if (max_features < 1 || max_features > kMaxSortN || max_queries < 1) {
-        g_lastError = "rumi_match_create: max_features must be in 1..8192, max_queries >= 1";
+        g_lastError = "rumi_match_create: max_features must be in 1..16384, max_queries >= 1";
         return RUMI_E_INVALID;
     }
     int ndev = 0;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ORBmatcher.h"
+#include "rumi_status.h"
 
 namespace rumi_facade {
 
@@ -42,12 +43,11 @@ std::vector<uint8_t> IsInFrustum(FrameT &F, const std::vector<MapPointT *> &vpMP
     F.PoseMatrices(R, t, Ow);                              // adapter of the mock data model (tests/cpp)
 #endif
     const float K4[4] = {F.fx, F.fy, F.cx, F.cy};
-    if (rumi_frame_is_in_frustum(ORB_SLAM3::ORBmatcher::arena(), R, t, Ow, K4, F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY, F.mfLogScaleFactor,
-                                 F.mnScaleLevels, viewingCosLimit, n, pos.data(), nrm.data(), mn.data(), mx.data(), inView.data(), px.data(),
-                                 py.data(), lvl.data(), vc.data(), depth.data()) != RUMI_OK) {
-        std::fprintf(stderr, "IsInFrustum: %s\n", rumi_last_error());
-        std::abort();                                       // no CPU fallback
-    }
+    if (RUMI_GUARDED("FrameFrustum::IsInFrustum / rumi_frame_is_in_frustum", &ORB_SLAM3::ORBmatcher::grow_arena,
+                     rumi_frame_is_in_frustum(ORB_SLAM3::ORBmatcher::arena(), R, t, Ow, K4, F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY, F.mfLogScaleFactor,
+                                              F.mnScaleLevels, viewingCosLimit, n, pos.data(), nrm.data(), mn.data(), mx.data(), inView.data(), px.data(),
+                                              py.data(), lvl.data(), vc.data(), depth.data())) != RUMI_OK)
+        std::fill(inView.begin(), inView.end(), (uint8_t)0);    // reported (rumi_status.h); no point is in view, as if the frustum were empty -- no CPU fallback
     for (int i = 0; i < n; i++) {
         MapPointT *p = vpMPs[i];
         p->mbTrackInView = inView[i] != 0;
@@ -109,12 +109,12 @@ int SearchLocalPoints(FrameT &F, const std::vector<MapPointT *> &vpLocalMapPoint
     const float K4[4] = {F.fx, F.fy, F.cx, F.cy};
     RumiFrameFeatures fv = ORB_SLAM3::ORBmatcher::view(F);
     int32_t nToMatch = 0, nmatches = 0;
-    if (rumi_search_local_points(ORB_SLAM3::ORBmatcher::arena(), &fv, R, t, Ow, K4, F.mfLogScaleFactor, F.mnScaleLevels, 0.5f, nid, skip.data(), pos.data(),
-                                 nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), th, bFarPoints, thFarPoints, nnratio, inView.data(), px.data(),
-                                 py.data(), lvl.data(), vc.data(), depth.data(), &nToMatch, frameMp.data(), &nmatches) != RUMI_OK) {
-        std::fprintf(stderr, "SearchLocalPoints: %s\n", rumi_last_error());
-        std::abort();                                       // no CPU fallback
-    }
+    if (RUMI_GUARDED("FrameFrustum::SearchLocalPoints / rumi_search_local_points", &ORB_SLAM3::ORBmatcher::grow_arena,
+                     rumi_search_local_points(ORB_SLAM3::ORBmatcher::arena(), &fv, R, t, Ow, K4, F.mfLogScaleFactor, F.mnScaleLevels, 0.5f, nid, skip.data(),
+                                              pos.data(), nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), th, bFarPoints, thFarPoints, nnratio,
+                                              inView.data(), px.data(), py.data(), lvl.data(), vc.data(), depth.data(), &nToMatch, frameMp.data(),
+                                              &nmatches)) != RUMI_OK)
+        return -1;                                          // reported (rumi_status.h); the frame keeps the matches it had -- no CPU fallback
     for (int i = 0; i < n; i++) {
         if (skip[i]) continue;
         MapPointT *p = vpLocalMapPoints[i];

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "rumi_voc.h"
+#include "rumi_status.h"
 #if defined(RUMI_HAVE_OPENCV)
 #include <opencv2/core/core.hpp>
 #else
@@ -29,10 +30,8 @@ public:
 
     bool loadFromTextFile(const std::string &filename) {
         if (h_) { rumi_voc_destroy(h_); h_ = nullptr; }
-        if (rumi_voc_load_text(filename.c_str(), -1, &h_) != RUMI_OK) {
-            std::fprintf(stderr, "ORBVocabulary: %s\n", rumi_last_error());     // no CPU fallback: a missing GPU is reported, not hidden
-            return false;
-        }
+        const int rc = rumi_voc_load_text(filename.c_str(), -1, &h_);
+        if (rc != RUMI_OK) { rumi_facade::report("ORBVocabulary::loadFromTextFile", rc); return false; }   // no CPU fallback: a missing GPU is reported, not hidden
         return true;
     }
     bool empty() const { return h_ == nullptr || rumi_voc_words(h_) == 0; }
@@ -52,8 +51,8 @@ public:
         int32_t nWords = 0, nNodes = 0;
         if (rumi_voc_transform(h_, desc.data(), n, levelsup, bowIds.data(), bowVals.data(), &nWords, fvNodes.data(), fvOff.data(), fvIdx.data(),
                                &nNodes) != RUMI_OK) {
-            std::fprintf(stderr, "ORBVocabulary::transform: %s\n", rumi_last_error());
-            std::abort();
+            rumi_facade::report("ORBVocabulary::transform", RUMI_E_NO_DEVICE);
+            return;                                          // empty BowVector / FeatureVector, as for an empty vocabulary
         }
         for (int k = 0; k < nWords; k++) v.insert(v.end(), typename BowVectorT::value_type(bowIds[k], bowVals[k]));
         for (int a = 0; a < nNodes; a++) {

@@ -1,5 +1,6 @@
 // Facade implementation: marshals cv types to the C ABI.  No image processing happens here.
 #include "ORBextractor.h"
+#include "rumi_status.h"
 
 #include <cassert>
 #include <cstdio>
@@ -39,10 +40,10 @@ void ORBextractor::ensureHandle(int width, int height) {
     capW_ = width > capW_ ? width : capW_;
     capH_ = height > capH_ ? height : capH_;
     RumiOrbConfig cfg{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, capW_, capH_, 1, -1, 0, RUMI_FACADE_BLUR_VARIANT};
-    if (rumi_orb_create(&cfg, &handle_) != RUMI_OK) {
-        // the reference has no error path here; a missing GPU must not degrade silently
-        std::fprintf(stderr, "ORBextractor: %s\n", rumi_last_error());
-        std::abort();
+    const int rc = rumi_orb_create(&cfg, &handle_);
+    if (rc != RUMI_OK) {                                    // the reference has no error path here: reported (rumi_status.h), operator() then returns -1
+        rumi_facade::report("ORBextractor: rumi_orb_create", rc);
+        handle_ = nullptr;
     }
 }
 
@@ -54,6 +55,7 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, st
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
     ensureHandle(image.cols, image.rows);
+    if (!handle_) { _keypoints.clear(); _descriptors.release(); return -1; }
 
     const int cap = nfeatures + 4 * nlevels + 64;
     static_assert(sizeof(cv::KeyPoint) == sizeof(RumiKeyPoint), "cv::KeyPoint must be the 28-byte POD");
@@ -63,9 +65,11 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, st
     const int rc = rumi_orb_extract(handle_, image.data, image.cols, image.rows, (int)image.step, vLappingArea[0], vLappingArea[1],
                                     reinterpret_cast<RumiKeyPoint *>(kps.data()), desc.data(), cap, &n, &mono);
     if (rc == RUMI_E_EMPTY) return -1;
-    if (rc != RUMI_OK) {
-        std::fprintf(stderr, "ORBextractor: %s\n", rumi_last_error());
-        std::abort();
+    if (rc != RUMI_OK) {                                    // reported (rumi_status.h); the frame gets no key-points -- no CPU fallback
+        rumi_facade::report("ORBextractor::operator()", rc);
+        _keypoints.clear();
+        _descriptors.release();
+        return -1;
     }
     kps.resize(n);
     _keypoints = kps;                                       // _keypoints = vector<cv::KeyPoint>(nkeypoints)   (:1044)

@@ -11,6 +11,7 @@
 
 #include "cv_shim.h"
 #include "rumi_match.h"
+#include "rumi_status.h"
 
 namespace ORB_SLAM3 {
 
@@ -26,10 +27,23 @@ public:
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return rumi_descriptor_distance(a.ptr(0), b.ptr(0)); }
 
     // One matcher arena per calling thread (handles are not re-entrant).
+    // (8192 features / 32768 queries to begin with; a call that needs more re-creates it twice as large -- features up to the library's
+    // 16384 per frame, queries up to 16 x: rumi_status.h)
+    static RumiMatcher *&arena_slot() { thread_local RumiMatcher *m = nullptr; return m; }
+    static int &arena_scale() { thread_local int s = 1; return s; }
     static RumiMatcher *arena() {
-        thread_local RumiMatcher *m = nullptr;
-        if (!m && rumi_match_create(8192, 32768, -1, &m) != RUMI_OK) return nullptr;
+        RumiMatcher *&m = arena_slot();
+        if (!m) {
+            const int rc = rumi_match_create(8192 * (arena_scale() > 1 ? 2 : 1), 32768 * arena_scale(), -1, &m);
+            if (rc != RUMI_OK) { rumi_facade::report("ORBmatcher: matcher arena", rc); m = nullptr; }
+        }
         return m;
+    }
+    static bool grow_arena() {
+        if (arena_scale() >= 16) return false;
+        if (arena_slot()) { rumi_match_destroy(arena_slot()); arena_slot() = nullptr; }
+        arena_scale() *= 2;
+        return arena() != nullptr;
     }
 
     // Search matches between Frame keypoints and projected MapPoints. Returns number of matches (TrackLocalMap)
@@ -68,9 +82,9 @@ public:
         // the kernel reads mp_obs[id] for every id a feature may hold, so pass the extended array; queries are the first nmp ids
         inView.resize(nid, 0); bad.resize(nid, 1); px.resize(nid, 0); py.resize(nid, 0); vc.resize(nid, 0); depth.resize(nid, 0);
         lvl.resize(nid, 0); desc.resize((size_t)nid * 32, 0);
-        if (rumi_search_by_projection_mappoints(arena(), &fv, nid, inView.data(), px.data(), py.data(), lvl.data(), vc.data(), depth.data(),
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_projection_mappoints", &ORBmatcher::grow_arena, rumi_search_by_projection_mappoints(arena(), &fv, nid, inView.data(), px.data(), py.data(), lvl.data(), vc.data(), depth.data(),
                                                 bad.data(), desc.data(), obsAll.data(), th, bFarPoints, thFarPoints, mfNNratio,
-                                                frameMp.data(), &nmatches) != RUMI_OK)
+                                                frameMp.data(), &nmatches)) != RUMI_OK)
             return -1;
         for (int f = 0; f < F.N; f++) F.mvpMapPoints[f] = frameMp[f] >= 0 ? byId[frameMp[f]] : nullptr;
         return nmatches;
@@ -105,9 +119,9 @@ public:
         const float K4[4] = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy};
         RumiFrameFeatures cv_ = view(CurrentFrame);
         int32_t nmatches = 0;
-        if (rumi_search_by_projection_frame(arena(), &cv_, T7, K4, reinterpret_cast<const RumiKeyPoint *>(LastFrame.mvKeysUn.data()), LastFrame.N,
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_projection_frame", &ORBmatcher::grow_arena, rumi_search_by_projection_frame(arena(), &cv_, T7, K4, reinterpret_cast<const RumiKeyPoint *>(LastFrame.mvKeysUn.data()), LastFrame.N,
                                             lastMp.data(), lastOut.data(), nmp, pos.data(), desc.data(), obs.data(), th, mbCheckOrientation,
-                                            curMp.data(), &nmatches) != RUMI_OK)
+                                            curMp.data(), &nmatches)) != RUMI_OK)
             return -1;
         for (int f = 0; f < CurrentFrame.N; f++) CurrentFrame.mvpMapPoints[f] = curMp[f] >= 0 ? byId[curMp[f]] : nullptr;
         return nmatches;
@@ -121,8 +135,8 @@ public:
         a.n = (int32_t)F1.mvKeysUn.size(); b.n = (int32_t)F2.mvKeysUn.size();
         vnMatches12.assign(F1.mvKeysUn.size(), -1);
         int32_t nmatches = 0;
-        if (rumi_search_for_initialization(arena(), &a, &b, reinterpret_cast<float *>(vbPrevMatched.data()), windowSize, mfNNratio, mbCheckOrientation,
-                                           vnMatches12.data(), &nmatches) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_for_initialization", &ORBmatcher::grow_arena, rumi_search_for_initialization(arena(), &a, &b, reinterpret_cast<float *>(vbPrevMatched.data()), windowSize, mfNNratio, mbCheckOrientation,
+                                           vnMatches12.data(), &nmatches)) != RUMI_OK)
             return -1;
         return nmatches;
     }
@@ -139,8 +153,8 @@ public:
         RumiFrameFeatures kv = view(*pKF), fv = view(F);
         std::vector<int32_t> matches(F.N, -1);
         int32_t nmatches = 0;
-        if (rumi_search_by_bow(arena(), &kv, &a.v, kfMp.data(), (int)bad.size(), bad.data(), &fv, &b.v, mfNNratio, mbCheckOrientation,
-                               matches.data(), &nmatches) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_bow", &ORBmatcher::grow_arena, rumi_search_by_bow(arena(), &kv, &a.v, kfMp.data(), (int)bad.size(), bad.data(), &fv, &b.v, mfNNratio, mbCheckOrientation,
+                               matches.data(), &nmatches)) != RUMI_OK)
             return -1;
         vpMapPointMatches.assign(F.N, static_cast<MapPointT *>(nullptr));
         for (int f = 0; f < F.N; f++) if (matches[f] >= 0) vpMapPointMatches[f] = vpMapPointsKF[matches[f]];
@@ -160,8 +174,8 @@ public:
         RumiFrameFeatures k1 = view(*pKF1), k2 = view(*pKF2);
         std::vector<int32_t> m12(pKF1->N, -1);
         int32_t nmatches = 0;
-        if (rumi_search_by_bow_kf(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), (int)bad.size(), bad.data(), mfNNratio,
-                                  mbCheckOrientation, m12.data(), &nmatches) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_bow_kf", &ORBmatcher::grow_arena, rumi_search_by_bow_kf(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), (int)bad.size(), bad.data(), mfNNratio,
+                                  mbCheckOrientation, m12.data(), &nmatches)) != RUMI_OK)
             return -1;
         vpMatches12.assign(v1.size(), static_cast<MapPointT *>(nullptr));
         for (size_t i = 0; i < v1.size() && i < m12.size(); i++) if (m12[i] >= 0) vpMatches12[i] = v2[m12[i]];
@@ -202,8 +216,8 @@ public:
         RumiFrameFeatures k1 = view(*pKF1), k2 = view(*pKF2);
         std::vector<int32_t> m12(pKF1->N, -1);
         int32_t nmatches = 0;
-        if (rumi_search_for_triangulation(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), F, e, bOnlyStereo, bCoarse, mbCheckOrientation,
-                                          m12.data(), &nmatches) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_for_triangulation", &ORBmatcher::grow_arena, rumi_search_for_triangulation(arena(), &k1, &a.v, m1.data(), &k2, &b.v, m2.data(), F, e, bOnlyStereo, bCoarse, mbCheckOrientation,
+                                          m12.data(), &nmatches)) != RUMI_OK)
             return -1;
         vMatchedPairs.clear();
         vMatchedPairs.reserve(nmatches > 0 ? nmatches : 0);
@@ -216,7 +230,11 @@ public:
     // then replayed in list order with the reference's own MapPoint / KeyFrame methods, re-evaluating the isBad / IsInKeyFrame
     // skips at the moment the reference would (a point replaced by an earlier iteration is bad by the time its turn comes).
     template <class KeyFrameT, class MapPointT>
-    int Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th = 3.0, const bool /*bRight*/ = false) {
+    int Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th = 3.0, const bool bRight = false) {
+        if (bRight) {      // second (fisheye) camera of a stereo rig: outside the monocular hot path -- say so instead of fusing against the wrong camera
+            rumi_facade::report("ORBmatcher::Fuse", RUMI_E_INVALID, "bRight = true: the second-camera branch (ORBmatcher.cc:1015-1180, mpCamera2) is not built; no point was fused");
+            return 0;
+        }
         const auto Tcw = pKF->GetPose();
         const auto q = Tcw.unit_quaternion();
         const auto t = Tcw.translation();
@@ -292,8 +310,8 @@ public:
         k1.n = N1; k2.n = N2;
         std::vector<int32_t> m12(N1 > 0 ? N1 : 1, -1);
         int32_t nFound = 0;
-        if (rumi_search_by_sim3(arena(), &k1, &k2, K4, pKF2->mfLogScaleFactor, a.skip.data(), a.pc.data(), a.mn.data(), a.mx.data(), a.desc.data(),
-                                b.skip.data(), b.pc.data(), b.mn.data(), b.mx.data(), b.desc.data(), th, m12.data(), &nFound) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_sim3", &ORBmatcher::grow_arena, rumi_search_by_sim3(arena(), &k1, &k2, K4, pKF2->mfLogScaleFactor, a.skip.data(), a.pc.data(), a.mn.data(), a.mx.data(), a.desc.data(),
+                                b.skip.data(), b.pc.data(), b.mn.data(), b.mx.data(), b.desc.data(), th, m12.data(), &nFound)) != RUMI_OK)
             return -1;
         for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = v2[m12[i1]];
         return nFound;
@@ -360,10 +378,10 @@ public:
         const float K4[4] = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy};
         RumiFrameFeatures cv_ = view(CurrentFrame);
         int32_t nmatches = 0;
-        if (rumi_search_by_projection_reloc(arena(), &cv_, CurrentFrame.mfLogScaleFactor, T7, Ow, K4,
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_projection_reloc", &ORBmatcher::grow_arena, rumi_search_by_projection_reloc(arena(), &cv_, CurrentFrame.mfLogScaleFactor, T7, Ow, K4,
                                             reinterpret_cast<const RumiKeyPoint *>(pKF->mvKeysUn.data()), nkf, kfMp.data(), nkf, skip.data(),
                                             pos.data(), mn.data(), mx.data(), desc.data(), th, ORBdist, mbCheckOrientation, curMp.data(),
-                                            &nmatches) != RUMI_OK)
+                                            &nmatches)) != RUMI_OK)
             return -1;
         for (int f = 0; f < CurrentFrame.N; f++) {
             if (curMp[f] == nkf) continue;                            // untouched pre-existing association
@@ -418,8 +436,8 @@ protected:
         const float K4[4] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy};
         RumiFrameFeatures kv = view(*pKF);
         int32_t nmatches = 0;
-        if (rumi_search_by_projection_sim3(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(),
-                                           mx.data(), desc.data(), th, ratioHamming, withKFs ? 1 : 0, matched.data(), &nmatches) != RUMI_OK)
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_projection_sim3", &ORBmatcher::grow_arena, rumi_search_by_projection_sim3(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(),
+                                           mx.data(), desc.data(), th, ratioHamming, withKFs ? 1 : 0, matched.data(), &nmatches)) != RUMI_OK)
             return -1;
         for (int f = 0; f < pKF->N; f++)
             if (matched[f] >= 0) { vpMatched[f] = vpPoints[matched[f]]; if (withKFs) vpMatchedKF[f] = vpPointsKFs[matched[f]]; }
@@ -447,8 +465,9 @@ protected:
         }
         const float K4[4] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy};
         RumiFrameFeatures kv = view(*pKF);
-        return rumi_fuse_candidates(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(), mx.data(),
-                                    desc.data(), th, reproj, best.data()) == RUMI_OK;
+        return RUMI_GUARDED("ORBmatcher / rumi_fuse_candidates", &ORBmatcher::grow_arena,
+                            rumi_fuse_candidates(arena(), &kv, pKF->mfLogScaleFactor, T7, Ow, K4, nmp, skip.data(), pos.data(), nrm.data(), mn.data(), mx.data(),
+                                                 desc.data(), th, reproj, best.data())) == RUMI_OK;
     }
     // Sophus::SE3f::inverse().translation(): conj(q) applied to -t with the same quaternion product form as so3.hpp:358-367
     static void camera_centre(const float *T7, float *Ow) {

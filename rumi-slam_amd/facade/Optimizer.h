@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rumi_opt.h"
+#include "rumi_status.h"
 
 // capacity of the per-thread optimiser arenas (key-frames incl. fixed ones, map points, observations of one call)
 #ifndef RUMI_OPT_MAX_KF
@@ -28,11 +29,28 @@
 namespace ORB_SLAM3 {
 
 class Optimizer {
+    // pFrame->mvuRight[i] >= 0 where the data model has stereo coordinates (the reference's Frame does; monocular mocks may not)
+    template <class F> static auto has_right_impl(const F &f, int i, int) -> decltype(f.mvuRight[i] >= 0, bool()) { return !f.mvuRight.empty() && f.mvuRight[i] >= 0; }
+    template <class F> static bool has_right_impl(const F &, int, long) { return false; }
+    template <class F> static bool has_right_coordinate(const F &f, int i) { return has_right_impl(f, i, 0); }
+
 public:
+    static RumiOptimizer *&arena_slot() { thread_local RumiOptimizer *o = nullptr; return o; }
+    static int &arena_scale() { thread_local int s = 1; return s; }
     static RumiOptimizer *arena() {
-        thread_local RumiOptimizer *o = nullptr;
-        if (!o && rumi_opt_create(1 << 16, 64, RUMI_OPT_MAX_KF, RUMI_OPT_MAX_MP, RUMI_OPT_MAX_EDGES, -1, &o) != RUMI_OK) return nullptr;
+        RumiOptimizer *&o = arena_slot();
+        if (!o) {
+            const int k = arena_scale();
+            const int rc = rumi_opt_create((1 << 16) * k, 64 * k, RUMI_OPT_MAX_KF * k, RUMI_OPT_MAX_MP * k, RUMI_OPT_MAX_EDGES * k, -1, &o);
+            if (rc != RUMI_OK) { rumi_facade::report("Optimizer: optimiser arena", rc); o = nullptr; }
+        }
         return o;
+    }
+    static bool grow_arena() {                      // a call that exceeds the arena re-creates it twice as large (rumi_status.h)
+        if (arena_scale() >= 16) return false;
+        if (arena_slot()) { rumi_opt_destroy(arena_slot()); arena_slot() = nullptr; }
+        arena_scale() *= 2;
+        return arena() != nullptr;
     }
 
     // int static PoseOptimization(Frame *pFrame)          Optimizer.cc:723-1001 (mono branch)
@@ -41,11 +59,13 @@ public:
         const int N = pFrame->N;
         std::vector<float> Xw, obs, w;
         std::vector<int> index;
+        int nStereo = 0;
         {
             std::unique_lock<std::mutex> lock(MapPointT::mGlobalMutex);
             for (int i = 0; i < N; i++) {
                 MapPointT *pMP = pFrame->mvpMapPoints[i];
                 if (!pMP) continue;
+                if (has_right_coordinate(*pFrame, i)) { nStereo++; continue; }   // EdgeStereoSE3ProjectXYZOnlyPose (:801-841): not built; reported below
                 pFrame->mvbOutlier[i] = false;
                 const auto &kpUn = pFrame->mvKeysUn[i];
                 const auto P = pMP->GetWorldPos();
@@ -55,6 +75,8 @@ public:
                 index.push_back(i);
             }
         }
+        if (nStereo > 0)
+            rumi_facade::report("Optimizer::PoseOptimization", RUMI_E_INVALID, "observations with a right-image coordinate (mvuRight >= 0) reached the monocular PoseOptimization and were left out: the stereo edge is not built (DESIGN.md section 7)");
         const int n = (int)index.size();
         if (n < 3) return 0;
         const auto Tcw = pFrame->GetPose();
@@ -64,7 +86,7 @@ public:
         const float K4[4] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy};
         std::vector<uint8_t> outlier(n);
         int32_t nGood = 0;
-        if (rumi_pose_optimization(arena(), Xw.data(), obs.data(), w.data(), n, K4, T7, outlier.data(), &nGood) != RUMI_OK) return 0;
+        if (RUMI_GUARDED("Optimizer / rumi_pose_optimization", &Optimizer::grow_arena, rumi_pose_optimization(arena(), Xw.data(), obs.data(), w.data(), n, K4, T7, outlier.data(), &nGood)) != RUMI_OK) return 0;
         for (int k = 0; k < n; k++) pFrame->mvbOutlier[index[k]] = outlier[k] != 0;
 #ifdef RUMI_HAVE_SOPHUS
         pFrame->SetPose(Sophus::SE3f(Eigen::Quaternionf(T7[3], T7[0], T7[1], T7[2]), Eigen::Vector3f(T7[4], T7[5], T7[6])));   // :996-998
@@ -134,9 +156,8 @@ public:
         const float K4[4] = {pMainKF->fx, pMainKF->fy, pMainKF->cx, pMainKF->cy};
         std::vector<uint8_t> erase(eMp.size() + 1);
         int32_t stats[4];
-        if (rumi_merge_ba(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(),
-                          eKf.data(), eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), erase.data(), stats) != RUMI_OK) {
-            std::fprintf(stderr, "Optimizer::LocalBundleAdjustment (merge): %s\n", rumi_last_error());
+        if (RUMI_GUARDED("Optimizer / rumi_merge_ba", &Optimizer::grow_arena, rumi_merge_ba(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(),
+                          eKf.data(), eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), erase.data(), stats)) != RUMI_OK) {
             return;
         }
         std::unique_lock<std::mutex> lock(pMainKF->GetMap()->mMutexMapUpdate);                // :4076
@@ -245,8 +266,8 @@ public:
         const float K4[4] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy};
         std::vector<uint8_t> erase(eMp.size() + 1);
         int32_t stats[4];
-        if (rumi_local_ba(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(),
-                          eKf.data(), eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), erase.data(), stats) != RUMI_OK)
+        if (RUMI_GUARDED("Optimizer / rumi_local_ba", &Optimizer::grow_arena, rumi_local_ba(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(),
+                          eKf.data(), eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), erase.data(), stats)) != RUMI_OK)
             return;
         if (stats[3]) return;
         std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                             // :1325
@@ -327,9 +348,8 @@ public:
         if (kfs.empty()) return;
         const float K4[4] = {kfs[0]->fx, kfs[0]->fy, kfs[0]->cx, kfs[0]->cy};
         int32_t stats[4];
-        if (rumi_bundle_adjustment(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(), eKf.data(),
-                                   eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), nIterations, bRobust, stats) != RUMI_OK) {
-            std::fprintf(stderr, "BundleAdjustment: %s\n", rumi_last_error());
+        if (RUMI_GUARDED("Optimizer / rumi_bundle_adjustment", &Optimizer::grow_arena, rumi_bundle_adjustment(arena(), (int)kfs.size(), kfPose.data(), kfFixed.data(), (int)mps.size(), mpPos.data(), (int)eMp.size(), eMp.data(), eKf.data(),
+                                   eObs.data(), eW.data(), K4, reinterpret_cast<const volatile uint8_t *>(pbStopFlag), nIterations, bRobust, stats)) != RUMI_OK) {
             return;
         }
         const bool direct = nLoopKF == (unsigned long)pMap->GetOriginKF()->mnId;
@@ -408,8 +428,8 @@ public:
         sim3_to8(g2oS12, S);
         std::vector<uint8_t> status(g.n() + 1);
         int32_t res[3] = {0, 0, 1};
-        if (rumi_optimize_sim3(arena(), g.n(), nullptr, 0, nullptr, nullptr, g.P1c.data(), g.P2c.data(), g.obs1.data(), g.obs2.data(), g.w1.data(), g.w2.data(),
-                               nullptr, nullptr, K1, K2, th2, bFixScale, 1, S, status.data(), res) != RUMI_OK) {
+        if (RUMI_GUARDED("Optimizer / rumi_optimize_sim3", &Optimizer::grow_arena, rumi_optimize_sim3(arena(), g.n(), nullptr, 0, nullptr, nullptr, g.P1c.data(), g.P2c.data(), g.obs1.data(), g.obs2.data(), g.w1.data(), g.w2.data(),
+                               nullptr, nullptr, K1, K2, th2, bFixScale, 1, S, status.data(), res)) != RUMI_OK) {
             std::fprintf(stderr, "OptimizeSim3: %s\n", rumi_last_error());
             return 0;
         }
@@ -451,8 +471,8 @@ public:
         sim3_to8(gSw1w2, S);
         std::vector<uint8_t> status(g.n() + 1);
         int32_t res[3] = {0, 0, 1};
-        if (rumi_optimize_sim3(arena(), g.n(), g.pairOf.data(), (int32_t)map2KFs.size(), A.data(), B.data(), g.P1c.data(), g.P2c.data(), g.obs1.data(),
-                               g.obs2.data(), g.w1.data(), g.w2.data(), g.skip12.data(), g.skip21.data(), K1, K2, th2, bFixScale, 0, S, status.data(), res) != RUMI_OK) {
+        if (RUMI_GUARDED("Optimizer / rumi_optimize_sim3", &Optimizer::grow_arena, rumi_optimize_sim3(arena(), g.n(), g.pairOf.data(), (int32_t)map2KFs.size(), A.data(), B.data(), g.P1c.data(), g.P2c.data(), g.obs1.data(),
+                               g.obs2.data(), g.w1.data(), g.w2.data(), g.skip12.data(), g.skip21.data(), K1, K2, th2, bFixScale, 0, S, status.data(), res)) != RUMI_OK) {
             std::fprintf(stderr, "OptimizeCloudSim3: %s\n", rumi_last_error());
             return 0.f;
         }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "Optimizer.h"
+#include "rumi_status.h"
 
 namespace rumi_facade {
 
@@ -54,11 +55,10 @@ float ComputeInliersNum(const std::vector<KeyFrameT *> &map1KFs, const std::vect
     if (nPairs == 0) return 0.f;
     std::vector<uint8_t> inl(e1.size() + 1);
     float median = 0.f;
-    if (rumi_sim3_inliers(ORB_SLAM3::Optimizer::arena(), nPairs, pairStart.data(), denom.data(), A.data(), B.data(), K1, K2, X1.data(), X2.data(), k1.data(),
-                          k2.data(), s1.data(), s2.data(), e1.data(), e2.data(), inl.data(), nullptr, &median) != RUMI_OK) {
-        std::fprintf(stderr, "ComputeInliersNum: %s\n", rumi_last_error());
-        std::abort();
-    }
+    if (RUMI_GUARDED("Sim3Scoring::ComputeInliersNum / rumi_sim3_inliers", &ORB_SLAM3::Optimizer::grow_arena,
+                     rumi_sim3_inliers(ORB_SLAM3::Optimizer::arena(), nPairs, pairStart.data(), denom.data(), A.data(), B.data(), K1, K2, X1.data(), X2.data(),
+                                       k1.data(), k2.data(), s1.data(), s2.data(), e1.data(), e2.data(), inl.data(), nullptr, &median)) != RUMI_OK)
+        return 0.f;                                         // reported (rumi_status.h); an alignment with no inliers
     return median;
 }
 

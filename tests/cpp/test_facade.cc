@@ -13,6 +13,7 @@
 
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "rumi_status.h"
 #include "Optimizer.h"
 #include "FrameFrustum.h"
 #include "orb_oracle.h"
@@ -212,6 +213,19 @@ int main(int argc, char **argv) {
             std::vector<MapPoint> cand(mps.size());
             std::vector<MapPoint *> vp;
             for (size_t i = 0; i < mps.size(); i++) { cand[i].pos = mps[i].pos; cand[i].desc = mps[i].desc; cand[i].nObs = 3; cand[i].obs.clear(); vp.push_back(i % 17 == 0 ? nullptr : &cand[i]); }
+            // error policy (facade/rumi_status.h): the second-camera branch is not built -> reported through the installed handler, 0 fused, nothing touched
+            {
+                static int hooked = 0; static int hookedStatus = 0;
+                rumi_facade::set_error_handler([](const char *, int status, const char *) { hooked++; hookedStatus = status; });
+                rumi_facade::clear_status();
+                const int nr = matcher.Fuse(&kf, vp, 15.f, true);
+                CHECK(nr == 0 && hooked == 1 && hookedStatus == RUMI_E_INVALID && rumi_facade::last_status() == RUMI_E_INVALID, "Fuse(bRight = true) is reported, not silently run as mono");
+                bool untouched = true;
+                for (auto &c : cand) untouched &= !c.bad && c.obs.empty();
+                CHECK(untouched, "Fuse(bRight = true) leaves the map alone");
+                rumi_facade::set_error_handler(nullptr);
+                rumi_facade::clear_status();
+            }
             const int nf = matcher.Fuse(&kf, vp, 15.f);
             int added = 0, replacedCand = 0, replacedResident = 0;
             for (auto &c : cand) { if (c.bad) replacedCand++; else if (c.IsInKeyFrame(&kf)) added++; }
@@ -384,6 +398,28 @@ int main(int argc, char **argv) {
         for (auto *p : pl2) for (auto &o2 : p->obs) remaining2 += kid2.count(o2.first) && o2.first->GetMapPoint(std::get<0>(o2.second)) ? 1 : 0;
         CHECK(remaining2 + erasedRef2 == em2.size(), "merge BA erased observations");
         std::printf("merge BA: edges %zu, iterations %d + %d, erased %d, dK %.2e dP %.2e\n", em2.size(), its2[0], its2[1], erasedRef2, dK2, dP2);
+    }
+    // ---- arena growth: 40 000 map points exceed the matcher arena's 32 768 queries; the facade re-creates the arena and repeats the call ----
+    {
+        const int before = ORB_SLAM3::ORBmatcher::arena_scale();
+        Frame F = fr[1];
+        F.mvpMapPoints.assign(F.N, nullptr);
+        std::vector<MapPoint> many(40000);
+        std::vector<MapPoint *> vpMany;
+        for (size_t i = 0; i < many.size(); i++) {
+            MapPoint &m = many[i];
+            m.desc = cv::Mat(1, 32, CV_8U); std::memset(m.desc.ptr(0), (int)(i & 255), 32);
+            const size_t src = i % (size_t)fr[1].N;
+            m.mbTrackInView = i < (size_t)fr[1].N;                      // the first N project onto the frame's own key-points
+            m.mTrackProjX = fr[1].mvKeysUn[src].pt.x; m.mTrackProjY = fr[1].mvKeysUn[src].pt.y; m.mnTrackScaleLevel = fr[1].mvKeysUn[src].octave;
+            if (m.mbTrackInView) std::memcpy(m.desc.ptr(0), fr[1].mDescriptors.ptr((int)src), 32);
+            vpMany.push_back(&m);
+        }
+        rumi_facade::clear_status();
+        ORB_SLAM3::ORBmatcher big(0.8f, true);
+        const int nm = big.SearchByProjection(F, vpMany, 3.f);
+        CHECK(nm > fr[1].N / 2 && ORB_SLAM3::ORBmatcher::arena_scale() > before && rumi_facade::last_status() == RUMI_OK, "matcher arena grows past 32768 queries instead of failing");
+        std::printf("arena growth: %d matches of %d in-view points, arena scale %d -> %d\n", nm, fr[1].N, before, ORB_SLAM3::ORBmatcher::arena_scale());
     }
     std::printf("facade test: %d failure(s); matches %d, pose inliers %d, LBA edges %d (erased %d) dK %.2e dP %.2e\n", fails, ngpu, good, nEdges, erasedRef, dK, dP);
     (void)erased;
