@@ -43,8 +43,8 @@ std::vector<uint8_t> IsInFrustum(FrameT &F, const std::vector<MapPointT *> &vpMP
     F.PoseMatrices(R, t, Ow);                              // adapter of the mock data model (tests/cpp)
 #endif
     const float K4[4] = {F.fx, F.fy, F.cx, F.cy};
-    if (RUMI_GUARDED("FrameFrustum::IsInFrustum / rumi_frame_is_in_frustum", &ORB_SLAM3::ORBmatcher::grow_arena,
-                     rumi_frame_is_in_frustum(ORB_SLAM3::ORBmatcher::arena(), R, t, Ow, K4, F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY, F.mfLogScaleFactor,
+    if (RUMI_GUARDED("FrameFrustum::IsInFrustum / rumi_frame_is_in_frustum", &RUMI_FACADE_NAMESPACE::ORBmatcher::grow_arena,
+                     rumi_frame_is_in_frustum(RUMI_FACADE_NAMESPACE::ORBmatcher::arena(), R, t, Ow, K4, F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY, F.mfLogScaleFactor,
                                               F.mnScaleLevels, viewingCosLimit, n, pos.data(), nrm.data(), mn.data(), mx.data(), inView.data(), px.data(),
                                               py.data(), lvl.data(), vc.data(), depth.data())) != RUMI_OK)
         std::fill(inView.begin(), inView.end(), (uint8_t)0);    // reported (rumi_status.h); no point is in view, as if the frustum were empty -- no CPU fallback
@@ -107,10 +107,10 @@ int SearchLocalPoints(FrameT &F, const std::vector<MapPointT *> &vpLocalMapPoint
     F.PoseMatrices(R, t, Ow);
 #endif
     const float K4[4] = {F.fx, F.fy, F.cx, F.cy};
-    RumiFrameFeatures fv = ORB_SLAM3::ORBmatcher::view(F);
+    RumiFrameFeatures fv = RUMI_FACADE_NAMESPACE::ORBmatcher::view(F);
     int32_t nToMatch = 0, nmatches = 0;
-    if (RUMI_GUARDED("FrameFrustum::SearchLocalPoints / rumi_search_local_points", &ORB_SLAM3::ORBmatcher::grow_arena,
-                     rumi_search_local_points(ORB_SLAM3::ORBmatcher::arena(), &fv, R, t, Ow, K4, F.mfLogScaleFactor, F.mnScaleLevels, 0.5f, nid, skip.data(),
+    if (RUMI_GUARDED("FrameFrustum::SearchLocalPoints / rumi_search_local_points", &RUMI_FACADE_NAMESPACE::ORBmatcher::grow_arena,
+                     rumi_search_local_points(RUMI_FACADE_NAMESPACE::ORBmatcher::arena(), &fv, R, t, Ow, K4, F.mfLogScaleFactor, F.mnScaleLevels, 0.5f, nid, skip.data(),
                                               pos.data(), nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), th, bFarPoints, thFarPoints, nnratio,
                                               inView.data(), px.data(), py.data(), lvl.data(), vc.data(), depth.data(), &nToMatch, frameMp.data(),
                                               &nmatches)) != RUMI_OK)

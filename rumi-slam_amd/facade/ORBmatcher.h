@@ -13,7 +13,12 @@
 #include "rumi_match.h"
 #include "rumi_status.h"
 
-namespace ORB_SLAM3 {
+// The classes live in ORB_SLAM3 when these headers REPLACE the reference's (member templates deduce the reference's own types at every call
+// site), or in a namespace of their own when the reference's headers stay and facade/shells/*.cc forward to them (-DRUMI_FACADE_NAMESPACE=...).
+#ifndef RUMI_FACADE_NAMESPACE
+#define RUMI_FACADE_NAMESPACE ORB_SLAM3
+#endif
+namespace RUMI_FACADE_NAMESPACE {
 
 class ORBmatcher {
 public:
@@ -511,4 +516,4 @@ protected:
     bool mbCheckOrientation;
 };
 
-}  // namespace ORB_SLAM3
+}  // namespace RUMI_FACADE_NAMESPACE

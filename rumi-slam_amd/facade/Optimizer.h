@@ -26,7 +26,12 @@
 #define RUMI_OPT_MAX_EDGES (1 << 20)
 #endif
 
-namespace ORB_SLAM3 {
+// The classes live in ORB_SLAM3 when these headers REPLACE the reference's (member templates deduce the reference's own types at every call
+// site), or in a namespace of their own when the reference's headers stay and facade/shells/*.cc forward to them (-DRUMI_FACADE_NAMESPACE=...).
+#ifndef RUMI_FACADE_NAMESPACE
+#define RUMI_FACADE_NAMESPACE ORB_SLAM3
+#endif
+namespace RUMI_FACADE_NAMESPACE {
 
 class Optimizer {
     // pFrame->mvuRight[i] >= 0 where the data model has stereo coordinates (the reference's Frame does; monocular mocks may not)
@@ -484,4 +489,4 @@ public:
 #endif
 };
 
-}  // namespace ORB_SLAM3
+}  // namespace RUMI_FACADE_NAMESPACE

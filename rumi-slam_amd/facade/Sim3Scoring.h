@@ -55,8 +55,8 @@ float ComputeInliersNum(const std::vector<KeyFrameT *> &map1KFs, const std::vect
     if (nPairs == 0) return 0.f;
     std::vector<uint8_t> inl(e1.size() + 1);
     float median = 0.f;
-    if (RUMI_GUARDED("Sim3Scoring::ComputeInliersNum / rumi_sim3_inliers", &ORB_SLAM3::Optimizer::grow_arena,
-                     rumi_sim3_inliers(ORB_SLAM3::Optimizer::arena(), nPairs, pairStart.data(), denom.data(), A.data(), B.data(), K1, K2, X1.data(), X2.data(),
+    if (RUMI_GUARDED("Sim3Scoring::ComputeInliersNum / rumi_sim3_inliers", &RUMI_FACADE_NAMESPACE::Optimizer::grow_arena,
+                     rumi_sim3_inliers(RUMI_FACADE_NAMESPACE::Optimizer::arena(), nPairs, pairStart.data(), denom.data(), A.data(), B.data(), K1, K2, X1.data(), X2.data(),
                                        k1.data(), k2.data(), s1.data(), s2.data(), e1.data(), e2.data(), inl.data(), nullptr, &median)) != RUMI_OK)
         return 0.f;                                         // reported (rumi_status.h); an alignment with no inliers
     return median;
