@@ -89,6 +89,15 @@ int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, const RumiFe
                        int32_t nmp, const uint8_t *mp_bad, const RumiFrameFeatures *F, const RumiFeatureVector *f_fv,
                        float nnratio, int32_t check_orientation, int32_t *matches, int32_t *nmatches_out);
 
+/* SearchByBoW(KF_k, F, matches_k) for K candidate key-frames against ONE frame in a single launch: what Tracking::Relocalization does candidate by
+ * candidate (Tracking.cc:3240-3260; each walk starts from an empty vpMapPointMatches, so the K searches are independent).  KFs / kf_fvs: arrays of K;
+ * kf_mp[k][i]: map-point index of key-frame k's feature i in ITS OWN numbering (-1 none), nmp[k] / mp_bad[k]: that numbering's size and bad
+ * flags (mp_bad[k] may be NULL).  matches [K][F->n]: the map-point index (key-frame k's numbering) matched to every frame feature, -1 none;
+ * nmatches_out [K].  Results are those of K rumi_search_by_bow calls. */
+int rumi_search_by_bow_batch(RumiMatcher *m, int32_t K, const RumiFrameFeatures *KFs, const RumiFeatureVector *kf_fvs, const int32_t *const *kf_mp,
+                             const int32_t *nmp, const uint8_t *const *mp_bad, const RumiFrameFeatures *F, const RumiFeatureVector *f_fv,
+                             float nnratio, int32_t check_orientation, int32_t *matches, int32_t *nmatches_out);
+
 /* SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) — loop / merge detection (ORBmatcher.cc:682-804).
  * kf1_mp / kf2_mp: GetMapPointMatches() of the two key-frames as ids (-1 NULL) into mp_bad[nmp].
  * matches12[KF1->n] out: index of the KF2 FEATURE whose map point the reference stores in vpMatches12[idx1] (-1 = NULL). */

@@ -29,11 +29,12 @@ typedef struct RumiVocabulary RumiVocabulary;
  * header's n2 / n1 (DBoW2::WeightingType TF_IDF=0, TF=1, IDF=2, BINARY=3; ScoringType L1_NORM=0 .. DOT_PRODUCT=5). */
 int rumi_voc_create(int32_t n_nodes, const int32_t *parent, const uint8_t *is_leaf, const uint8_t *desc, const double *weight,
                     int32_t weighting, int32_t scoring, int32_t device, RumiVocabulary **out);
-/* The same from an ORBvoc.txt-style file (first line "k L scoring weighting"). */
+/* The same from an ORBvoc.txt-style file (first line "k L scoring weighting"); m_L is the header's L, as in DBoW2, not the tree's depth. */
 int rumi_voc_load_text(const char *path, int32_t device, RumiVocabulary **out);
 void rumi_voc_destroy(RumiVocabulary *v);
 int32_t rumi_voc_words(const RumiVocabulary *v);
-int32_t rumi_voc_levels(const RumiVocabulary *v); /* m_L = depth of the deepest leaf */
+int32_t rumi_voc_levels(const RumiVocabulary *v); /* m_L: depth of the deepest leaf (rumi_voc_create) or the file header's L (rumi_voc_load_text) */
+int rumi_voc_set_levels(RumiVocabulary *v, int32_t L); /* override m_L (1..10), e.g. for a tree built in memory from a file's nodes */
 
 /* transform(feature, word_id, weight, &nid, levelsup) for n descriptors (host arrays).  node_id[i] = the node on the path at
  * level L - levelsup (0 = root when that level is <= 0; 0 as well where DBoW2 would leave it unset: a leaf above that level). */

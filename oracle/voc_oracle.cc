@@ -83,6 +83,7 @@ void *orc_voc_create(int nNodes, const int32_t *parent, const uint8_t *isLeaf, c
     return V;
 }
 void orc_voc_destroy(void *h) { delete static_cast<Voc *>(h); }
+void orc_voc_set_levels(void *h, int L) { static_cast<Voc *>(h)->L = L; }   // m_L as a file header gives it (TemplatedVocabulary.h:1367)
 
 void orc_voc_transform_features(void *h, const uint8_t *desc, int n, int levelsup, uint32_t *wordId, double *weight, uint32_t *nodeId) {
     const Voc &V = *static_cast<Voc *>(h);

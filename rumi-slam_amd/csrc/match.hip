@@ -916,6 +916,120 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW(KF_k, F) for K candidate key-frames against ONE frame in one launch (Tracking::Relocalization walks the candidates of
+// KeyFrameDatabase::DetectRelocalizationCandidates one by one, Tracking.cc:3240-3260; every walk starts from an empty vpMapPointMatches, so the
+// K searches are independent).  Within one search a frame feature is taken by the first query that wins it -- but a frame feature lies in
+// exactly ONE FeatureVector node, so that dependency never leaves a node: nodes run in parallel, the (few) key-frame features of a node
+// sequentially.  16 lanes per (key-frame, node): the lanes share out the frame's features of the node, compute their Hamming distances
+// to the current key-frame feature in parallel and reduce (best, second) with the reference's tie rules (ORBmatcher.cc:252-289).
+// ------------------------------------------------------------------------------------------------
+struct BowKF { int32_t n, nn, angle, desc, mp, good, nodes, off, idx, pad; };      // sizes and dword offsets of one key-frame's arrays in the block
+struct BowBatch {
+    const uint32_t *blk;          // the uploaded block (dword view)
+    int K, nf, nnF;
+    int fAngle, fDesc, fNodes, fOff, fIdx, kfTable;     // dword offsets
+    int32_t *matches;             // [K][nf]  map-point index (per key-frame numbering), -1 none
+    int8_t *rotBin;               // [K][nf]
+    int32_t *hist;                // [K][32]
+    int32_t *nmatch;              // [K]
+    int32_t *err;                 // bit 0: a node with more than 512 frame features
+    float nnratio;
+    int checkOri;
+};
+
+__global__ __launch_bounds__(256) void k_bow_batch_match(BowBatch B) {
+    const int k = blockIdx.y, lane = threadIdx.x & 15, a = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const BowKF *T = reinterpret_cast<const BowKF *>(B.blk + B.kfTable) + k;
+    if (a >= T->nn) return;
+    const uint32_t *kfNodes = B.blk + T->nodes, *fNodes = B.blk + B.fNodes;
+    const uint32_t node = kfNodes[a];
+    int lo = 0, hi = B.nnF;                                  // first frame node >= node (std::map order: ascending ids)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fNodes[mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo >= B.nnF || fNodes[lo] != node) return;
+    const int32_t *fOff = reinterpret_cast<const int32_t *>(B.blk + B.fOff), *kOff = reinterpret_cast<const int32_t *>(B.blk + T->off);
+    const int c0 = fOff[lo], nc = fOff[lo + 1] - c0;
+    if (nc > 512) { if (lane == 0) atomicOr(B.err, 1); return; }
+    const uint32_t *fIdx = B.blk + B.fIdx + c0, *kIdx = B.blk + T->idx;
+    const uint32_t *fDesc = B.blk + B.fDesc, *kDesc = B.blk + T->desc;
+    const float *fAngle = reinterpret_cast<const float *>(B.blk + B.fAngle), *kAngle = reinterpret_cast<const float *>(B.blk + T->angle);
+    const int32_t *kMp = reinterpret_cast<const int32_t *>(B.blk + T->mp);
+    const uint8_t *kGood = reinterpret_cast<const uint8_t *>(B.blk + T->good);
+    uint32_t taken = 0;                                      // bit j: my candidate lane + 16 j already holds a map point
+    for (int p = kOff[a]; p < kOff[a + 1]; p++) {
+        const int iKF = (int)kIdx[p];
+        if (!kGood[iKF]) continue;                           // no map point, or a bad one (:238-243)
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) q[w] = kDesc[(size_t)iKF * 8 + w];
+        uint32_t best = (256u << 16) | 0xFFFFu, second = 256u;
+        for (int j = 0, pos = lane; pos < nc; j++, pos += 16) {
+            if ((taken >> j) & 1u) continue;
+            const uint32_t *d = fDesc + (size_t)fIdx[pos] * 8;
+            uint32_t dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) dist += __popc(q[w] ^ d[w]);
+            const uint32_t key = (dist << 16) | (uint32_t)pos;
+            if (key < best) { second = best >> 16; best = key; }       // a strictly smaller distance, or the same at an earlier position
+            else if (dist < second) second = dist;
+        }
+        // 16-lane reduction: best = smallest key; second = second smallest distance of the union
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const uint32_t ob = __shfl_xor(best, o, 16), os = __shfl_xor(second, o, 16);
+            const uint32_t loser = max(best, ob) >> 16;
+            best = min(best, ob);
+            second = min(min(second, os), loser);
+        }
+        const int bestDist1 = (int)(best >> 16), bestDist2 = (int)second;
+        if (bestDist1 <= RUMI_TH_LOW && (float)bestDist1 < B.nnratio * (float)bestDist2) {
+            const int pos = (int)(best & 0xFFFFu), f = (int)fIdx[pos];
+            if (lane == (pos & 15)) taken |= 1u << (pos >> 4);
+            if (lane == 0) {
+                B.matches[(size_t)k * B.nf + f] = kMp[iKF];
+                if (B.checkOri) {
+                    const int bin = rot_bin(kAngle[iKF], fAngle[f]);
+                    B.rotBin[(size_t)k * B.nf + f] = (int8_t)bin;
+                    atomicAdd(&B.hist[k * 32 + bin], 1);
+                }
+            }
+        }
+    }
+}
+
+// rotation-histogram filter (ComputeThreeMaxima, ORBmatcher.cc:1795-1826) and the match count of every key-frame
+__global__ __launch_bounds__(256) void k_bow_batch_finish(BowBatch B) {
+    __shared__ int sKeep[RUMI_HISTO_LENGTH], sCount;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        sCount = 0;
+        for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = 1;
+        if (B.checkOri) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
+                const int s = B.hist[k * 32 + i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) ind3 = -1;
+            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = (i == ind1 || i == ind2 || i == ind3);
+        }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int f = tid; f < B.nf; f += 256) {
+        int32_t &m = B.matches[(size_t)k * B.nf + f];
+        if (m < 0) continue;
+        if (B.checkOri && !sKeep[B.rotBin[(size_t)k * B.nf + f]]) m = -1; else local++;
+    }
+    atomicAdd(&sCount, local);
+    __syncthreads();
+    if (tid == 0) B.nmatch[k] = sCount;
+}
+
 }  // namespace rumi
 
 using namespace rumi;
@@ -943,6 +1057,9 @@ struct RumiMatcher {
     uint8_t *hStage = nullptr, *dStage = nullptr;
     size_t stageCap = 0, stageUsed = 0;
     int nseg = 0;
+    // rumi_search_by_bow_batch: one pinned block up, one result block back (grown on demand)
+    uint8_t *hBow = nullptr, *dBow = nullptr; size_t bowCap = 0;
+    uint8_t *hBowOut = nullptr, *dBowOut = nullptr; size_t bowOutCap = 0;
     // k_grid of the uploaded frame, launched by flush_uploads once the key-points are in place
     bool gridPending = false; int gridN = 0; float gridMinX = 0, gridMinY = 0, gridWInv = 0, gridHInv = 0;
 };
@@ -965,6 +1082,10 @@ extern "C" void rumi_match_destroy(RumiMatcher *m) {
     for (void *q : p) if (q) (void)hipFree(q);
     if (m->hStage) (void)hipHostFree(m->hStage);
     if (m->hOut) (void)hipHostFree(m->hOut);
+    if (m->hBow) (void)hipHostFree(m->hBow);
+    if (m->hBowOut) (void)hipHostFree(m->hBowOut);
+    if (m->dBow) (void)hipFree(m->dBow);
+    if (m->dBowOut) (void)hipFree(m->dBowOut);
     delete m;
 }
 
@@ -1204,6 +1325,97 @@ extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, c
         hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
+}
+
+extern "C" int rumi_search_by_bow_batch(RumiMatcher *m, int32_t K, const RumiFrameFeatures *KFs, const RumiFeatureVector *kf_fvs,
+                                        const int32_t *const *kf_mp, const int32_t *nmp, const uint8_t *const *mp_bad, const RumiFrameFeatures *F,
+                                        const RumiFeatureVector *f_fv, float nnratio, int32_t check_orientation, int32_t *matches,
+                                        int32_t *nmatches_out) {
+    if (!m || K < 1 || !KFs || !kf_fvs || !kf_mp || !nmp || !mp_bad || !F || !f_fv || !matches || !nmatches_out || F->n < 0) return RUMI_E_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    const int nf = F->n, nnF = f_fv->n_nodes, nfe = nnF > 0 ? f_fv->offsets[nnF] : 0;
+    for (int k = 0; k < K; k++) {
+        nmatches_out[k] = 0;
+        if (KFs[k].n < 0 || kf_fvs[k].n_nodes < 0 || nmp[k] < 0 || (KFs[k].n > 0 && !kf_mp[k])) return RUMI_E_INVALID;
+    }
+    for (size_t i = 0; i < (size_t)K * std::max(nf, 0); i++) matches[i] = -1;
+    if (nf == 0 || nnF == 0) return RUMI_OK;
+    // ---- one block: [frame arrays | key-frame table | key-frame arrays], every array on a 16-byte boundary ----
+    size_t used = 0;
+    auto take = [&](size_t bytes) { const size_t o = used; used += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t oFA = take((size_t)nf * 4), oFD = take((size_t)nf * 32), oFN = take((size_t)nnF * 4), oFO = take((size_t)(nnF + 1) * 4), oFI = take((size_t)nfe * 4);
+    const size_t oT = take((size_t)K * sizeof(BowKF));
+    std::vector<BowKF> tab(K);
+    int maxNodes = 0;
+    for (int k = 0; k < K; k++) {
+        const int n = KFs[k].n, nn = kf_fvs[k].n_nodes, ne = nn > 0 ? kf_fvs[k].offsets[nn] : 0;
+        BowKF &t = tab[k];
+        t.n = n; t.nn = nn; t.pad = 0;
+        t.angle = (int32_t)(take((size_t)n * 4) / 4); t.desc = (int32_t)(take((size_t)n * 32) / 4); t.mp = (int32_t)(take((size_t)n * 4) / 4);
+        t.good = (int32_t)(take((size_t)n) / 4); t.nodes = (int32_t)(take((size_t)nn * 4) / 4); t.off = (int32_t)(take((size_t)(nn + 1) * 4) / 4);
+        t.idx = (int32_t)(take((size_t)ne * 4) / 4);
+        maxNodes = std::max(maxNodes, nn);
+    }
+    if (used > m->bowCap) {
+        if (m->hBow) HIP_TRY(hipHostFree(m->hBow));
+        if (m->dBow) HIP_TRY(hipFree(m->dBow));
+        m->hBow = nullptr; m->dBow = nullptr; m->bowCap = 0;
+        HIP_TRY(hipHostMalloc((void **)&m->hBow, used * 2, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&m->dBow, used * 2));
+        m->bowCap = used * 2;
+    }
+    // outputs: [matches K nf | nmatch K | err 1 | hist K 32 | rotBin K nf bytes]; the first part comes back
+    const size_t outInts = (size_t)K * nf + K + 1, outBytes = (outInts + (size_t)K * 32) * 4 + (size_t)K * nf;
+    if (outBytes > m->bowOutCap) {
+        if (m->hBowOut) HIP_TRY(hipHostFree(m->hBowOut));
+        if (m->dBowOut) HIP_TRY(hipFree(m->dBowOut));
+        m->hBowOut = nullptr; m->dBowOut = nullptr; m->bowOutCap = 0;
+        HIP_TRY(hipHostMalloc((void **)&m->hBowOut, outBytes * 2, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&m->dBowOut, outBytes * 2));
+        m->bowOutCap = outBytes * 2;
+    }
+    uint8_t *h = m->hBow;
+    float *fa = reinterpret_cast<float *>(h + oFA);
+    for (int i = 0; i < nf; i++) fa[i] = F->keys_un[i].angle;
+    std::memcpy(h + oFD, F->desc, (size_t)nf * 32);
+    std::memcpy(h + oFN, f_fv->node_ids, (size_t)nnF * 4);
+    std::memcpy(h + oFO, f_fv->offsets, (size_t)(nnF + 1) * 4);
+    if (nfe > 0) std::memcpy(h + oFI, f_fv->indices, (size_t)nfe * 4);
+    std::memcpy(h + oT, tab.data(), (size_t)K * sizeof(BowKF));
+    for (int k = 0; k < K; k++) {
+        const BowKF &t = tab[k];
+        const int n = t.n, nn = t.nn, ne = nn > 0 ? kf_fvs[k].offsets[nn] : 0;
+        float *ka = reinterpret_cast<float *>(h + (size_t)t.angle * 4);
+        uint8_t *good = h + (size_t)t.good * 4;
+        for (int i = 0; i < n; i++) {
+            ka[i] = KFs[k].keys_un[i].angle;
+            const int mp = kf_mp[k][i];
+            good[i] = mp >= 0 && mp < nmp[k] && !(mp_bad[k] && mp_bad[k][mp]);
+        }
+        if (n > 0) { std::memcpy(h + (size_t)t.desc * 4, KFs[k].desc, (size_t)n * 32); std::memcpy(h + (size_t)t.mp * 4, kf_mp[k], (size_t)n * 4); }
+        if (nn > 0) { std::memcpy(h + (size_t)t.nodes * 4, kf_fvs[k].node_ids, (size_t)nn * 4); std::memcpy(h + (size_t)t.off * 4, kf_fvs[k].offsets, (size_t)(nn + 1) * 4); }
+        if (ne > 0) std::memcpy(h + (size_t)t.idx * 4, kf_fvs[k].indices, (size_t)ne * 4);
+    }
+    HIP_TRY(hipMemcpyAsync(m->dBow, m->hBow, used, hipMemcpyHostToDevice, nullptr));
+    int32_t *dOut = reinterpret_cast<int32_t *>(m->dBowOut);
+    HIP_TRY(hipMemsetAsync(dOut, 0xFF, (size_t)K * nf * 4, nullptr));                              // matches = -1
+    HIP_TRY(hipMemsetAsync(dOut + (size_t)K * nf, 0, ((size_t)K + 1 + (size_t)K * 32) * 4, nullptr));   // counts, error word, histograms
+    BowBatch B;
+    B.blk = reinterpret_cast<const uint32_t *>(m->dBow);
+    B.K = K; B.nf = nf; B.nnF = nnF;
+    B.fAngle = (int)(oFA / 4); B.fDesc = (int)(oFD / 4); B.fNodes = (int)(oFN / 4); B.fOff = (int)(oFO / 4); B.fIdx = (int)(oFI / 4); B.kfTable = (int)(oT / 4);
+    B.matches = dOut; B.nmatch = dOut + (size_t)K * nf; B.err = B.nmatch + K; B.hist = B.err + 1;
+    B.rotBin = reinterpret_cast<int8_t *>(B.hist + (size_t)K * 32);
+    B.nnratio = nnratio; B.checkOri = check_orientation;
+    if (maxNodes > 0) hipLaunchKernelGGL(k_bow_batch_match, dim3((maxNodes + 15) / 16, K), dim3(256), 0, nullptr, B);
+    hipLaunchKernelGGL(k_bow_batch_finish, dim3(K), dim3(256), 0, nullptr, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(m->hBowOut, dOut, outInts * 4, hipMemcpyDeviceToHost));
+    const int32_t *ho = reinterpret_cast<const int32_t *>(m->hBowOut);
+    if (ho[(size_t)K * nf + K] & 1) { g_lastError = "SearchByBoW batch: a FeatureVector node of the frame holds more than 512 features"; return RUMI_E_CAPACITY; }
+    std::memcpy(matches, ho, (size_t)K * nf * 4);
+    std::memcpy(nmatches_out, ho + (size_t)K * nf, (size_t)K * 4);
+    return RUMI_OK;
 }
 
 extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF1, const RumiFeatureVector *fv1, const int32_t *kf1_mp,

@@ -140,6 +140,12 @@ extern "C" int rumi_voc_create(int32_t n_nodes, const int32_t *parent, const uin
     return RUMI_OK;
 }
 
+extern "C" int rumi_voc_set_levels(RumiVocabulary *v, int32_t L) {
+    if (!v || L < 1 || L > 10) return RUMI_E_INVALID;
+    v->L = L;
+    return RUMI_OK;
+}
+
 extern "C" int rumi_voc_load_text(const char *path, int32_t device, RumiVocabulary **out) {
     if (!path || !out) return RUMI_E_INVALID;
     FILE *f = std::fopen(path, "r");
@@ -164,7 +170,11 @@ extern "C" int rumi_voc_load_text(const char *path, int32_t device, RumiVocabula
         parent.push_back(pid); leaf.push_back(isLeaf > 0); desc.insert(desc.end(), d, d + 32); weight.push_back(w);
     }
     std::fclose(f);
-    return rumi_voc_create((int32_t)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), n2, n1, device, out);
+    const int rc = rumi_voc_create((int32_t)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), n2, n1, device, out);
+    // DBoW2 keeps the HEADER's L as m_L (TemplatedVocabulary.h:1367) and uses it for the FeatureVector level (nid_level = m_L - levelsup, :1229),
+    // whatever the depth of the tree that follows: a file whose deepest leaf is shallower than its header says groups features differently
+    if (rc == RUMI_OK) (*out)->L = L;
+    return rc;
 }
 
 static int launch_descend(RumiVocabulary *v, const uint8_t *dDesc, const int32_t *dCounts, int cap, int nTotal, int levelsup, uint32_t *dWord,

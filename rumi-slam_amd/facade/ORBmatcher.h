@@ -166,6 +166,56 @@ public:
         return nmatches;
     }
 
+    // The walk of Tracking::Relocalization over its candidate key-frames (Tracking.cc:3240-3260: one SearchByBoW(pKF, mCurrentFrame,
+    // vvpMapPointMatches[i]) per candidate, each from an empty result) as ONE device call.  Candidates that are NULL or isBad() are left out
+    // (their entry of the result is -1 and their match vector stays untouched, as the caller's own `if (pKF->isBad())` branch has it).
+    // Returns the match count per candidate (-1: skipped or failed).
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    std::vector<int> SearchByBoW(const std::vector<KeyFrameT *> &vpCandidateKFs, FrameT &F, std::vector<std::vector<MapPointT *>> &vvpMapPointMatches) {
+        const int nKFs = (int)vpCandidateKFs.size();
+        std::vector<int> result(nKFs, -1);
+        vvpMapPointMatches.resize(nKFs);
+        std::vector<int> live;
+        std::vector<std::vector<MapPointT *>> mpsKF;
+        std::vector<std::vector<int32_t>> kfMp;
+        std::vector<std::vector<uint8_t>> bad;
+        std::vector<Csr> fvs;
+        std::vector<RumiFrameFeatures> views;
+        for (int i = 0; i < nKFs; i++) {
+            KeyFrameT *pKF = vpCandidateKFs[i];
+            if (!pKF || pKF->isBad()) continue;
+            live.push_back(i);
+            mpsKF.push_back(pKF->GetMapPointMatches());
+            const std::vector<MapPointT *> &v = mpsKF.back();
+            kfMp.emplace_back(v.size(), -1); bad.emplace_back(v.size(), 0);
+            for (size_t j = 0; j < v.size(); j++)
+                if (v[j]) { kfMp.back()[j] = (int)j; bad.back()[j] = v[j]->isBad(); }
+            fvs.push_back(csr(pKF->mFeatVec));
+            views.push_back(view(*pKF));
+        }
+        const int K = (int)live.size();
+        if (K == 0) return result;
+        std::vector<RumiFeatureVector> fvv(K);
+        std::vector<const int32_t *> mpPtr(K);
+        std::vector<const uint8_t *> badPtr(K);
+        std::vector<int32_t> nmp(K);
+        for (int k = 0; k < K; k++) { fvv[k] = fvs[k].v; mpPtr[k] = kfMp[k].data(); badPtr[k] = bad[k].data(); nmp[k] = (int32_t)bad[k].size(); }
+        Csr b = csr(F.mFeatVec);
+        RumiFrameFeatures fv = view(F);
+        std::vector<int32_t> matches((size_t)K * F.N, -1), nm(K, 0);
+        if (RUMI_GUARDED("ORBmatcher / rumi_search_by_bow_batch", &rumi_facade::no_growth,
+                         rumi_search_by_bow_batch(arena(), K, views.data(), fvv.data(), mpPtr.data(), nmp.data(), badPtr.data(), &fv, &b.v, mfNNratio,
+                                                  mbCheckOrientation, matches.data(), nm.data())) != RUMI_OK)
+            return result;
+        for (int k = 0; k < K; k++) {
+            std::vector<MapPointT *> &out = vvpMapPointMatches[live[k]];
+            out.assign(F.N, static_cast<MapPointT *>(nullptr));
+            for (int f = 0; f < F.N; f++) { const int32_t id = matches[(size_t)k * F.N + f]; if (id >= 0) out[f] = mpsKF[k][id]; }
+            result[live[k]] = nm[k];
+        }
+        return result;
+    }
+
     // Search matches between MapPoints seen in KF1 and KF2 by vocabulary node (loop / merge detection)   ORBmatcher.cc:682-804
     template <class KeyFrameT, class MapPointT>
     int SearchByBoW(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches12) {

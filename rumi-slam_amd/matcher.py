@@ -22,7 +22,7 @@ class RumiFeatureVector(C.Structure):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_match_bruteforce_batch_device",
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_by_bow_batch", "rumi_match_bruteforce_batch_device",
                  "rumi_match_bruteforce_batch_device_strided"]
 
 
@@ -52,6 +52,7 @@ def _lib():
     L.rumi_search_local_points.argtypes = [vp, C.POINTER(RumiFrameFeatures), vp, vp, vp, vp, f32, i32, f32, i32] + [vp] * 7 + [f32, i32, f32, f32] + [vp] * 6 + [C.POINTER(i32), vp, C.POINTER(i32)]
     L.rumi_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.rumi_search_by_bow_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp]
     L.rumi_match_bruteforce_batch_device_strided.argtypes = [vp, vp, vp, vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
     return L
@@ -173,6 +174,25 @@ class ORBmatcher:
                                                 C.byref(F.c), C.byref(f_fv.c), self.mfNNratio, int(self.mbCheckOrientation),
                                                 capi.ptr(matches), C.byref(nm)))
         return nm.value, matches
+
+
+def SearchByBoW_batch(m, KFs, kf_fvs, kf_mps, mp_bads, F, f_fv):
+    """SearchByBoW(KF_k, F) for K candidate key-frames against one frame in one launch (the walk over the relocalisation candidates,
+    Tracking.cc:3240-3260).  KFs / kf_fvs: lists of FrameFeatures / FeatureVector; kf_mps[k], mp_bads[k]: per key-frame arrays as for
+    ``ORBmatcher.SearchByBoW``.  Returns (nmatches [K], matches [K, F.n])."""
+    K = len(KFs)
+    kfa = (RumiFrameFeatures * K)(*[k.c for k in KFs])
+    fva = (RumiFeatureVector * K)(*[v.c for v in kf_fvs])
+    mps = [np.ascontiguousarray(a, np.int32) for a in kf_mps]
+    bads = [np.ascontiguousarray(a, np.uint8) for a in mp_bads]
+    mpp = (C.c_void_p * K)(*[a.ctypes.data for a in mps])
+    bdp = (C.c_void_p * K)(*[a.ctypes.data for a in bads])
+    nmp = np.array([len(a) for a in bads], np.int32)
+    matches = np.full((K, F.n), -1, np.int32)
+    nm = np.zeros(K, np.int32)
+    capi.check(m._lib.rumi_search_by_bow_batch(m._h, K, kfa, fva, mpp, capi.ptr(nmp), bdp, C.byref(F.c), C.byref(f_fv.c), m.mfNNratio,
+                                               int(m.mbCheckOrientation), capi.ptr(matches), capi.ptr(nm)))
+    return nm, matches
 
 
 def _f32(a):

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import capi
 
-VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_transform_features",
+VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_set_levels", "rumi_voc_transform_features",
                "rumi_voc_transform_batch_device", "rumi_voc_transform"]
 TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
 L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = range(6)
@@ -22,6 +22,7 @@ def _lib():
     L.rumi_voc_destroy.restype = None
     L.rumi_voc_words.argtypes = [vp]
     L.rumi_voc_levels.argtypes = [vp]
+    L.rumi_voc_set_levels.argtypes = [vp, i32]
     L.rumi_voc_transform_features.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.rumi_voc_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.rumi_voc_transform.argtypes = [vp, vp, i32, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]

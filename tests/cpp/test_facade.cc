@@ -193,6 +193,18 @@ int main(int argc, char **argv) {
         std::vector<MapPoint *> m12;
         const int nb = matcher.SearchByBoW(&ka, &kb, m12);
         CHECK(nb >= 0 && (int)m12.size() == ka.N, "SearchByBoW(KF,KF) runs");
+        // the relocalisation walk as one call: three candidates (one of them bad) against the frame == the single calls
+        {
+            Frame fq = fr[1];
+            fq.mFeatVec = kb.mFeatVec;
+            KeyFrame bad = ka; bad.bad = true;
+            std::vector<KeyFrame *> cands = {&ka, &bad, &ka};
+            std::vector<std::vector<MapPoint *>> vv;
+            const std::vector<int> nn = matcher.SearchByBoW(cands, fq, vv);
+            std::vector<MapPoint *> one;
+            const int n1 = matcher.SearchByBoW(&ka, fq, one);
+            CHECK(nn.size() == 3 && nn[0] == n1 && nn[2] == n1 && nn[1] == -1 && vv[0] == one && vv[2] == one && vv[1].empty(), "SearchByBoW over candidate key-frames == single calls");
+        }
         Frame cur = fr[1];
         cur.mvpMapPoints.assign(cur.N, nullptr);
         std::set<MapPoint *> found;

@@ -384,6 +384,10 @@ class OracleVocabulary:
         a = [np.ascontiguousarray(parent, np.int32), np.ascontiguousarray(is_leaf, np.uint8), np.ascontiguousarray(desc, np.uint8),
              np.ascontiguousarray(weight, np.float64)]
         self._h = L.orc_voc_create(len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(weighting), int(scoring))
+        L.orc_voc_set_levels.argtypes = [vp, i32]
+
+    def set_levels(self, levels):
+        self._L.orc_voc_set_levels(self._h, int(levels))
 
     def __del__(self):
         if getattr(self, "_h", None):

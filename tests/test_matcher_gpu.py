@@ -69,6 +69,43 @@ def test_search_by_bow(matcher, seed, nn):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("K,nodes", [(10, 600), (4, 60), (1, 25)])
+def test_search_by_bow_batch_matches_single_calls(matcher, K, nodes):
+    """rumi_search_by_bow_batch: K candidate key-frames against one frame in one launch == K single SearchByBoW calls == the oracle, per
+    candidate; `nodes` small puts dozens of features into every FeatureVector node (long sequential chains inside a node)."""
+    from rumi_slam_amd.matcher import FrameView, SearchByBoW_batch
+    scenes = [TrackingScene(40 + k) for k in range(K)]
+    base = scenes[0]
+    F = FrameView(base.cur_keys, base.cur_desc, base.w, base.h, base.sf)
+    _, fv_f0 = base.feature_vectors(nodes)
+    b = _fv(fv_f0)
+    KFs, fvs, mps, bads = [], [], [], []
+    for k, s in enumerate(scenes):
+        # candidate k: its own key-frame features; descriptors of some features replaced by the frame's so that true matches exist
+        kdesc = s.last_desc.copy()
+        n = min(len(kdesc), len(base.cur_desc))
+        take = np.random.default_rng(k).random(n) < 0.5
+        kdesc[:n][take] = base.cur_desc[:n][take]
+        node_kf = {}
+        fnode = {int(i): nd for nd, idxs in fv_f0.items() for i in idxs}
+        rng = np.random.default_rng(100 + k)
+        for i in range(len(kdesc)):
+            nd = fnode[i] if i < n and take[i] else int(rng.integers(0, nodes)) * 7 + 3
+            node_kf.setdefault(nd, []).append(i)
+        KFs.append(FrameView(s.last_keys, kdesc, s.w, s.h, s.sf)); fvs.append(_fv(node_kf)); mps.append(s.last_mp)
+        bads.append((np.random.default_rng(k).random(len(s.mp_obs)) < 0.05).astype(np.uint8))
+    for ori in (True, False):
+        m = matcher(0.75, ori)
+        nm, got = SearchByBoW_batch(m, KFs, fvs, mps, bads, F, b)
+        for k in range(K):
+            n_ref, ref = O.search_by_bow(KFs[k].keys, KFs[k].desc, mps[k], bads[k], (fvs[k].node_ids, fvs[k].offsets, fvs[k].indices), base.cur_keys,
+                                         base.cur_desc, (b.node_ids, b.offsets, b.indices), 0.75, ori)
+            n_one, one = m.SearchByBoW(KFs[k], fvs[k], mps[k], bads[k], F, b)
+            assert n_ref > 30, "scene gives matches"
+            assert nm[k] == n_ref == n_one, f"candidate {k}: count"
+            assert np.array_equal(got[k], ref) and np.array_equal(one, ref), f"candidate {k}: {np.count_nonzero(got[k] != ref)} features differ"
+
+
 def test_dense_conflicts_force_many_fixpoint_rounds(matcher):
     """Many identical descriptors in one window: every query wants the same feature, so the sequential 'already taken'
     rule cascades — the worst case for the parallel fix-point resolver."""

@@ -65,6 +65,23 @@ def test_text_file_loader_and_empty_input(tmp_path):
     assert len(bi) == 0 and len(fn) == 0 and list(fo) == [0]
 
 
+def test_header_levels_deeper_than_the_tree(tmp_path):
+    """A text file whose header says L = 5 over a tree of depth 3: DBoW2 keeps the header's L for the FeatureVector level (nid_level = m_L - levelsup),
+    so with levelsup = 3 the node ids are those of level 2, not of level 0."""
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary(7, 6, 3)
+    write_text(tmp_path / "voc.txt", voc, 6, 5)                 # header L = 5, deepest leaf at depth 3
+    g, o = ORBVocabulary(path=tmp_path / "voc.txt"), O.OracleVocabulary(*voc)
+    o.set_levels(5)
+    d = _features(voc, np.random.default_rng(2), 400)
+    for levelsup in (1, 3, 5, 6):
+        w1, v1, n1 = g.transform_features(d, levelsup)
+        w2, v2, n2 = o.transform_features(d, levelsup)
+        assert np.array_equal(w1, w2) and np.array_equal(n1, n2), f"levelsup {levelsup}"
+    o3 = O.OracleVocabulary(*voc)                               # the tree's own depth (3) would give other node ids at levelsup 3
+    assert not np.array_equal(g.transform_features(d, 3)[2], o3.transform_features(d, 3)[2])
+
+
 def test_batch_transform_feeds_search_by_bow():
     """Rumination batch: extract_batch -> transform_batch (all frames in one launch) == per-frame oracle transform; the
     resulting FeatureVectors drive SearchByBoW with the same matches as the oracle's."""
