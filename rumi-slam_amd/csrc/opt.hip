@@ -580,6 +580,16 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// The LM control flow lives on the host (it must poll the reference's stop flag between trials), and every trial ends with a decision on eight
+// scalars.  Instead of a device-to-host copy plus hipStreamSynchronize (~30 us of runtime latency per trial) the scalars are PUBLISHED into
+// fine-grained pinned host memory by a one-wave kernel, followed by a sequence number; the host spins on that number (a few us).
+__global__ void k_ba_publish(const double *__restrict__ scal, volatile double *hostScal, unsigned long long seq) {
+    if (threadIdx.x < 8) hostScal[threadIdx.x] = scal[threadIdx.x];
+    __threadfence_system();
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(const_cast<double *>(hostScal + 8)), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const double *G, int NP, double *Aglob) {
     extern __shared__ double sa[];
@@ -1524,7 +1534,9 @@ struct RumiOptimizer {
     double *dW = nullptr;            // H_pl L per edge, allocated by the first large-window call
     int32_t *dColOf = nullptr;       // column block of every edge's key-frame (-1 fixed), same
     int32_t *dPairs = nullptr; size_t pairCap = 0, pairOff = 0;   // Schur block descriptors + observation pairs of the large-window path
-    double *hScal = nullptr;
+    double *hScal = nullptr;         // fine-grained pinned: [0..7] the trial's scalars, [8] sequence number of the last publication (k_ba_publish)
+    double *dhScal = nullptr;        // the same memory as the device sees it
+    unsigned long long pubSeq = 0;
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
     float stageMs[8] = {0};
@@ -1585,7 +1597,9 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     TRYA(oalloc(&o->dAglob, (N + 2) * (N + 2) + 2 * N)); TRYA(oalloc(&o->dErase, E)); TRYA(oalloc(&o->dEOff, E));
     TRYA(oalloc(&o->dYt, 3 * M * (size_t)o->npCap)); TRYA(oalloc(&o->dG, (size_t)o->npCap * o->npCap)); TRYA(oalloc(&o->dLp, M * 6));
 #undef TRYA
-    if (hipHostMalloc((void **)&o->hScal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    if (hipHostMalloc((void **)&o->hScal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&o->dhScal, o->hScal, 0) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    std::memset(o->hScal, 0, 16 * sizeof(double));
     o->baStageCap = E * 48 + M * 32 + K * 80 + 1024;
     if (hipHostMalloc((void **)&o->hBa, o->baStageCap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&o->dBa, o->baStageCap) != hipSuccess ||
         hipMalloc((void **)&o->dBaOut, o->baStageCap) != hipSuccess) {
@@ -1809,11 +1823,26 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
     const int nSlices = 64;
     hipStream_t st = nullptr;
+    // the eight scalars of o->dScal -> o->hScal, without a runtime synchronisation (see k_ba_publish); falls back to one if the stream has
+    // drained without the number arriving (a failed launch)
+    auto fetch_scalars = [&]() -> int {
+        const unsigned long long seq = ++o->pubSeq;
+        hipLaunchKernelGGL(k_ba_publish, dim3(1), dim3(64), 0, st, o->dScal, o->dhScal, seq);
+        HIP_TRY(hipGetLastError());
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(o->hScal + 8);
+        for (unsigned spin = 0; *flag != seq; spin++) {
+            if ((spin & 0xFFFF) == 0xFFFF && hipStreamQuery(st) != hipErrorNotReady) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (*flag != seq) { HIP_TRY(hipMemcpy(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost)); break; }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return RUMI_OK;
+    };
     auto chi2_of = [&](int which, double *out) -> int {
         HIP_TRY(hipMemsetAsync(o->dScal, 0, sizeof(double), st));
         hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[which], o->dX[which]);
-        HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rcf = fetch_scalars(); if (rcf != RUMI_OK) return rcf; }
         *out = o->hScal[0];
         return RUMI_OK;
     };
@@ -1876,8 +1905,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             HIP_TRY(hipMemsetAsync(o->dScal + 2, 0, sizeof(double), st));
             const int nd = nOpt * 6 + nMP * 3;
             hipLaunchKernelGGL(k_ba_maxdiag, dim3((nd + 255) / 256), dim3(256), 0, st, B);
-            HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if ((rc = fetch_scalars()) != RUMI_OK) return rc;
             lambda = 1e-5 * o->hScal[2]; ni = 2; nBad = 0;
         }
         double rho = 0;
@@ -1905,8 +1933,8 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             hipLaunchKernelGGL(k_ba_update, dim3(((nMP + nKF) * kLmLanes + 255) / 256), dim3(256), 0, st, B, lambda, o->dT[cur], o->dX[cur], o->dT[trial], o->dX[trial]);
             hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[trial], o->dX[trial]);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if (prof) HIP_TRY(hipStreamSynchronize(st));              // the event pairs below must have completed
+            if ((rc = fetch_scalars()) != RUMI_OK) return rc;
             if (prof && !big) {
                 float ms;
                 if (hppFresh) { HIP_TRY(hipEventElapsedTime(&ms, o->evK[0], o->evK[1])); o->kernelMs[0] += ms; hppFresh = false; }
