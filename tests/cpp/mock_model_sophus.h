@@ -21,6 +21,7 @@ struct Map {
 };
 struct Camera {
     float fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;
+    float getParameter(int i) const { return i == 0 ? fx : i == 1 ? fy : i == 2 ? cx : cy; }     // GeometricCamera::getParameter
     Eigen::Vector2f project(const Eigen::Vector3f &p) const { return Eigen::Vector2f{{fx * p(0) / p(2) + cx, fy * p(1) / p(2) + cy}}; }
     Eigen::Matrix3f toK_() const { Eigen::Matrix3f K; K(0, 0) = fx; K(0, 2) = cx; K(1, 1) = fy; K(1, 2) = cy; return K; }
 };

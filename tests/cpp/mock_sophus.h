@@ -79,6 +79,13 @@ struct Quaternionf {
 };
 // stand-in for Eigen::Matrix<double, 7, 7> (OptimizeSim3's mAcumHessian)
 struct Matrix77d { double m[7][7]; void setZero() { for (auto &r : m) for (double &x : r) x = 0; } };
+struct Matrix4f {
+    float m[4][4];
+    float operator()(int r, int c) const { return m[r][c]; }
+    float &operator()(int r, int c) { return m[r][c]; }
+    static Matrix4f Identity() { Matrix4f I; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) I.m[r][c] = r == c ? 1.f : 0.f; return I; }
+};
+struct Matrix4d { double m[4][4]; };
 }  // namespace Eigen
 
 namespace Sophus {
