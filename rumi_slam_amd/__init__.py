@@ -1,12 +1,6 @@
-"""Importable alias for the package directory ``rumi-slam_amd/`` (a hyphen cannot be imported).
+"""MI355X-native ORB front-end / Hamming matcher / local-BA hot path of RUMI-SLAM.
 
-All code lives in ``rumi-slam_amd/``; this module only points ``__path__`` there and runs its
-``__init__``.
+Host side = ctypes over the C-ABI in ``include/*.h`` (``librumi_hip.so``, hand-written HIP for
+gfx950).  There is no CPU fallback: every operator raises if the HIP library is missing.
 """
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "rumi-slam_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _f
+__version__ = "0.1.0"

@@ -1,7 +1,7 @@
 """ctypes binding of librumi_hip.so — the C ABI declared in include/rumi_orb.h.
 
 Raises at import of the library if it has not been built (``python __graft_entry__.py`` or
-``make -C rumi-slam_amd/csrc``); there is no CPU fallback.
+``make -C rumi_slam_amd/csrc``); there is no CPU fallback.
 """
 import ctypes as C
 import os

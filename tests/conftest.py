@@ -36,7 +36,7 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session", autouse=True)
 def _build_libs():
     import subprocess
-    so = os.path.join(ROOT, "rumi-slam_amd", "librumi_hip.so")
+    so = os.path.join(ROOT, "rumi_slam_amd", "librumi_hip.so")
     if not os.path.exists(so):
         subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):

@@ -1,4 +1,4 @@
-// Compiles rumi-slam_amd/facade/shells/*.cc -- the NON-template definitions with the reference's exact signatures -- against the reference's class
+// Compiles rumi_slam_amd/facade/shells/*.cc -- the NON-template definitions with the reference's exact signatures -- against the reference's class
 // declarations (tests/cpp/ref_decls/: signatures only, over the mock data model) and calls through them on the GPU: the same two frames through
 // ORB_SLAM3::ORBmatcher (shell) and through the facade templates directly must give the same matches, and Optimizer::PoseOptimization (shell)
 // the same pose as the template.
@@ -16,10 +16,10 @@
 #include "ORBextractor.h"        // the facade extractor (replaces the reference's header and .cc as a whole)
 
 // the shells themselves (a maintainer builds them as translation units of their own)
-#include "../../rumi-slam_amd/facade/shells/ORBmatcher.cc"
-#include "../../rumi-slam_amd/facade/shells/Optimizer_hot.cc"
+#include "../../rumi_slam_amd/facade/shells/ORBmatcher.cc"
+#include "../../rumi_slam_amd/facade/shells/Optimizer_hot.cc"
 #define RUMI_SHELLS_NO_EIGEN_GEOMETRY 1      // Eigen::umeyama is the reference's own dependency (not in this image)
-#include "../../rumi-slam_amd/facade/shells/Sim3Solver.cc"
+#include "../../rumi_slam_amd/facade/shells/Sim3Solver.cc"
 
 static int fails = 0;
 #define CHECK(c, msg) do { if (!(c)) { std::printf("FAIL: %s (%s:%d)\n", msg, __FILE__, __LINE__); fails++; } } while (0)

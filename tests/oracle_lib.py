@@ -1,5 +1,5 @@
 """ctypes binding of oracle/liboracle.so — the CPU restatement used as the parity checker.
-TEST INFRASTRUCTURE ONLY: nothing under rumi-slam_amd/ may import this."""
+TEST INFRASTRUCTURE ONLY: nothing under rumi_slam_amd/ may import this."""
 import ctypes as C
 import os
 import subprocess

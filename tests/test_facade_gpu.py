@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def build_facade_test(out, source="test_facade.cc", extra_inc=()):
-    fac = os.path.join(ROOT, "rumi-slam_amd", "facade")
+    fac = os.path.join(ROOT, "rumi_slam_amd", "facade")
     inc = []
     for d in extra_inc:
         inc += ["-I", d]
     cmd = ["g++", "-O1", "-std=c++17", "-ffp-contract=off"] + inc + ["-I", fac, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
            "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", source), os.path.join(fac, "ORBextractor.cc"),
-           "-L", os.path.join(ROOT, "rumi-slam_amd"), "-lrumi_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle",
-           "-Wl,-rpath," + os.path.join(ROOT, "rumi-slam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-o", out]
+           "-L", os.path.join(ROOT, "rumi_slam_amd"), "-lrumi_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "rumi_slam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-o", out]
     subprocess.check_call(cmd)
 
 

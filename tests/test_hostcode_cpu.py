@@ -135,7 +135,7 @@ def test_atan2_and_round_equal_oracle():
 
 def test_pattern_tables_identical():
     a = open(os.path.join(ROOT, "oracle", "orb_pattern.inc")).read()
-    b = open(os.path.join(ROOT, "rumi-slam_amd", "csrc", "orb_pattern.inc")).read()
+    b = open(os.path.join(ROOT, "rumi_slam_amd", "csrc", "orb_pattern.inc")).read()
     assert a == b
     nums = [int(v) for v in re.findall(r"-?\d+", re.sub(r"//.*", "", a))]
     assert len(nums) == 1024 and max(map(abs, nums)) <= 13

@@ -3,7 +3,7 @@
 
 Reads the 256x4 integer table at /root/reference/src/rumi-slam/lib_src/ORBextractor.cc:145-403
 (numbers only; comments dropped) and writes it, 8 test pairs per line, to
-rumi-slam_amd/csrc/orb_pattern.inc and oracle/orb_pattern.inc.  Only runs where the reference
+rumi_slam_amd/csrc/orb_pattern.inc and oracle/orb_pattern.inc.  Only runs where the reference
 is mounted (the build container); the committed .inc files are what ships.
 """
 import re, sys, pathlib
@@ -34,9 +34,9 @@ def render(rows):
 if __name__ == "__main__":
     text = render(read_rows())
     if "--check" in sys.argv:
-        for p in ("rumi-slam_amd/csrc/orb_pattern.inc", "oracle/orb_pattern.inc"):
+        for p in ("rumi_slam_amd/csrc/orb_pattern.inc", "oracle/orb_pattern.inc"):
             assert (ROOT / p).read_text() == text, p
         print("pattern tables match the reference")
     else:
-        for p in ("rumi-slam_amd/csrc/orb_pattern.inc", "oracle/orb_pattern.inc"):
+        for p in ("rumi_slam_amd/csrc/orb_pattern.inc", "oracle/orb_pattern.inc"):
             (ROOT / p).write_text(text)
