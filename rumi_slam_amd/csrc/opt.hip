@@ -10,7 +10,8 @@
 //                   (v_mfma_f64_16x16x4_f64, one workgroup per key-frame) — the only GEMM-shaped piece of local BA
 //   k_ba_dinv/yfill one lane per landmark: D^-1 = (H_ll + lambda I)^-1 = L L^T, z = L^T b_l; one lane per edge: H_pl L into the dense panel Y
 //   k_ba_syrk_mfma  Schur complement Y Y^T (and Y z) as a split-K SYRK on the f64 matrix cores (the window's Y is ~75 % dense)
-//   k_ba_solve      reduced pose system (<= 137 unknowns in LDS, up to 255 in L2): blocked Cholesky (panel 8) with the right-hand
+//   k_ba_solve_tiles reduced pose system up to 175 unknowns: 16 x 16 tiles in LDS, panel factorisation in registers, MFMA trailing updates
+//   k_ba_solve      the same for 176..255 unknowns (matrix in L2): blocked Cholesky (panel 8) with the right-hand
 //                   side as an extra row, two barriers per panel, backward substitution on one wave
 //   k_ba_update     landmark back-substitution, oplus on poses / points into the TRIAL state, x^T(lambda x + b)
 //   k_ba_chi2       robustified chi2 of a state
@@ -19,6 +20,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -727,6 +731,263 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BADev B, double lambda, const
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int i = tid + 64 * q; if (i < n) B.x[i] = x[q]; }
         if (tid == 0) B.scal[3] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same system, tile formulation (NT = NP / 16 <= 11 tile rows, i.e. up to 29 optimised key-frames; one workgroup of 8 waves, everything
+// in LDS).  The lower triangle is held as 16 x 16 tiles, tile (I, J) at (I (I + 1) / 2 + J) * 256, COLUMN-major inside a tile: with that
+// layout every operand of v_mfma_f64_16x16x4_f64 below is 64 consecutive doubles per instruction (lane l <-> offset 64 s + l), so the rank-16
+// trailing update of a tile costs 12 conflict-free ds_read_b64, 4 MFMAs and 4 ds_write_b64 where the panel-8 kernel above spent 8 LDS reads
+// per ENTRY (it was bound by LDS bandwidth: 3.9 us of the 5.7 us per panel).  On gfx950 an f64 MFMA has the rate of the f64 vector FMA (64
+// cycles per 16x16x4): the matrix cores are used here for their operand bandwidth, not for flops.
+// Per panel p (16 columns):
+//   * every wave that owns rows of the panel keeps the 16 diagonal rows in lanes 0..15 and 48 rows below the block in lanes 16..63, one row
+//     per lane, 16 panel entries in registers, and runs the unblocked right-looking factorisation on them (panel_factor): the rows below are
+//     solved by the very instructions that factor the block - no separate triangular solve - and the waves (on different SIMDs) do not wait
+//     for each other.  The last wave feeds the rows of the identity through the same instructions and so obtains W_p = L_pp^-1, stored
+//     transposed in place of the diagonal tile (nobody reads L_pp again);
+//   * barrier; trailing tiles (I, J), p < J <= I, C^T -= L_J L_I^T on the matrix cores (transposed product: its result layout is again
+//     lane l <-> offset 64 r + l); barrier.
+// The right-hand side rides along as row n (its panel entries are y = L^-1 b).  Backward substitution by tiles with the W_p on one wave,
+// no barrier (see there).  Measured on the 20 key-frame window (120 unknowns): 36 us per call against 104 us for the panel-8 kernel;
+// 81 k cycles = assembly 10 k (two global round trips), eight panels x (load 0.5 k + factor 4.5 k, a dependent chain of ~270 cycles per
+// pivot) 43 k, trailing updates 18 k, substitution 9 k.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSolveTilesMax = 11;
+constexpr int kSolveThreads = 512, kSolveWaves = kSolveThreads / 64;      // 8 waves: 256 registers each (the panel step and the substitution want ~150)
+__device__ __forceinline__ int tile_at(int I, int J) { return (I * (I + 1) / 2 + J) * 256; }
+
+// one 16-column panel on the rows a wave holds (one row per lane, `a` = its 16 panel entries): unblocked right-looking Cholesky, pivots and
+// multipliers by v_readlane from lanes 0..15.  Written software-pipelined - column j + 1 is updated first and its pivot's reciprocal square root
+// started before the rest of column j's rank-1 update - so that the update's instructions fill the latency of the pivot chain.
+// sum over the four rows of 16 lanes (lanes l, l ^ 16, l ^ 32, l ^ 48), result in all of them: the gfx950 row-swap instructions, no LDS
+__device__ __forceinline__ double rows_allreduce(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v); hi = __double2hiint(v);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// sum over the 16 lanes of a row, result in all of them: rotate-and-add by DPP
+__device__ __forceinline__ double row_allreduce(double v) {
+#define RUMI_ROR_ADD(ctl) v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctl, 0xf, 0xf, false), \
+                                                __builtin_amdgcn_update_dpp(0, __double2loint(v), ctl, 0xf, 0xf, false))
+    RUMI_ROR_ADD(0x128); RUMI_ROR_ADD(0x124); RUMI_ROR_ADD(0x122); RUMI_ROR_ADD(0x121);     // row_ror:8, 4, 2, 1
+#undef RUMI_ROR_ADD
+    return v;
+}
+
+// 1 / sqrt(d) for the pivots of k_ba_solve_tiles: v_rsq_f64 (5e-8 relative, tools/rsq_probe.hip) and ONE Newton step (4e-15): the second step
+// of fast_rsqrt buys 2.7e-16 for four more operations on the dependent chain of every pivot
+__device__ __forceinline__ double fast_rsqrt1(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    return y * __builtin_fma(-0.5 * d * y, y, 1.5);
+}
+
+// One 16-column panel on the rows a wave holds (one row per lane, `a` = its 16 panel entries; lanes 0..15 hold the diagonal block's rows):
+// unblocked right-looking Cholesky.  The dependent chain of a column - scale, update the next two columns, next pivot, reciprocal square
+// root - takes its pivot and multipliers from lanes 0..15 by v_readlane; the multipliers of the columns further right (not needed for two
+// more steps) go through a 16-double LDS buffer of the wave as broadcast reads, issued one step ahead of their use: 2 instructions per
+// pair less than readlane + hazard nop + fma, which is what bounds this single-wave loop.
+// Columns j >= w (padding of the last panel) run through the same instructions with the pivot forced to 1: they hold finite values that only
+// meet each other, so there is one straight-line instruction stream, no branch per column.
+__device__ __forceinline__ bool panel_factor(double (&a)[16], int w, int lane, double *buf) {
+    bool bad = false;
+    double d = readlane_f64(a[0], 0);                          // w >= 1
+    if (!(d > 0) || !isfinite(d)) bad = true;
+    double rs = fast_rsqrt1(d);
+    double mPrev[16], aPrev = 0.0;                             // multipliers and scaled column of the previous step (background work in flight)
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        double m[16];
+        a[j] *= rs;                                            // lane j: d * rs = sqrt(d); lanes above the diagonal carry values nobody reads
+        if (j + 3 < 16) {
+            if (lane < 16) buf[lane] = a[j];
+            // lanes talk through LDS inside one wave: the hardware keeps a wave's LDS operations in order, the fence tells the compiler that
+            // the loads below see another lane's store (without it they are "unchanged memory" for the lanes that did not store)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = j + 3; k < 16; k++) m[k] = buf[k];
+        }
+        if (j + 1 < 16) {
+            a[j + 1] = __builtin_fma(-a[j], readlane_f64(a[j], j + 1), a[j + 1]);
+            const double dn = readlane_f64(a[j + 1], j + 1);
+            d = j + 1 < w ? dn : 1.0;
+            if (!(d > 0) || !isfinite(d)) bad = true;
+            rs = fast_rsqrt1(d);
+        }
+        if (j + 2 < 16) a[j + 2] = __builtin_fma(-a[j], readlane_f64(a[j], j + 2), a[j + 2]);
+        if (j >= 1) {                                          // background of step j - 1: columns j + 2 .. 15
+#pragma unroll
+            for (int k = j + 2; k < 16; k++) a[k] = __builtin_fma(-aPrev, mPrev[k], a[k]);
+        }
+        aPrev = a[j];
+#pragma unroll
+        for (int k = j + 3; k < 16; k++) mPrev[k] = m[k];
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, const double *__restrict__ G, int NP) {
+    extern __shared__ double T[];                             // tiles | y[NT*16]
+    __shared__ int sFail;
+    __shared__ double sBuf[kSolveWaves][16];                           // per wave: the scaled pivot column of the panel step in flight
+    const int n = B.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = NP / 16;                                   // tile rows (the right-hand side is row n)
+    const int PT = (n + 15) / 16;                             // tile columns that hold pivots
+    const int nT = NT * (NT + 1) / 2;
+    double *ys = T + (size_t)nT * 256;
+    if (tid == 0) sFail = 0;
+    // ---- assemble: element (i, j) = -G[j][i] (+ b_p in row n), one wave per tile and all of a wave's loads in flight at once (G was just
+    // written: one L2 latency, not one per tile); then the 6x6 blocks of H_pp + lambda I are added by one thread per entry
+    {
+        constexpr int kU = (kSolveTilesMax * (kSolveTilesMax + 1) / 2 + kSolveWaves - 1) / kSolveWaves;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int m = lane & 15, cq = lane >> 4;
+        double v[kU][4];
+        double hpp[(kSolveTilesMax * 16 * 6 + kSolveThreads - 1) / kSolveThreads];     // the 6x6 blocks: n * 6 entries, loaded early
+#pragma unroll
+        for (int u = 0; u < (int)(sizeof(hpp) / sizeof(double)); u++) hpp[u] = B.Hpp[min(tid + kSolveThreads * u, n * 6 - 1)];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int t = wv + kSolveWaves * u;
+            if (t < nT) {
+                int I = 0, r = t;
+                while (r > I) { r -= I + 1; I++; }
+                const int i = I * 16 + m;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                  // loads without a branch around them (clamped addresses): all in flight together
+                    const int j = r * 16 + cq + 4 * q, jc = min(j, n - 1);
+                    const double gv = G[(size_t)jc * NP + min(i, n)], bv = B.bp[jc];
+                    v[u][q] = (i <= n && j < n) ? (i == n ? bv - gv : -gv) : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int t = wv + kSolveWaves * u;
+            if (t < nT) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) T[t * 256 + (cq + 4 * q) * 16 + m] = v[u][q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < (int)(sizeof(hpp) / sizeof(double)); u++) {
+            const int e = tid + kSolveThreads * u;
+            if (e >= n * 6) break;
+            const int kf = e / 36, ab = e - kf * 36, a6 = ab / 6, b6 = ab - a6 * 6;
+            const int i = kf * 6 + a6, j = kf * 6 + b6;
+            if ((i >> 4) >= (j >> 4)) {                        // the entry lies in a stored tile (upper entries of diagonal tiles included)
+                const double h = hpp[u] + (a6 == b6 ? lambda : 0.0);
+                T[tile_at(i >> 4, j >> 4) + (j & 15) * 16 + (i & 15)] += h;
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < PT; p++) {
+        const int w = min(16, n - p * 16);
+        // ---- panel.  Wave u < kSolveWaves - 1 owns the diagonal rows (lanes 0..15) and rows p*16 + 16 + 48 u + (lane - 16) below the block.  The last wave runs the
+        // same instructions on the diagonal rows and, in lanes 16..31, on the rows of the identity: "solving" e_c^T against L_pp^T leaves
+        // column c of L_pp^-1 in lane 16 + c - the inverse the backward substitution wants, for free.
+        const int rowsBelow = NT * 16 - (p + 1) * 16;
+        const bool inv = wave == kSolveWaves - 1;
+        const bool mine = inv || wave == 0 || wave * 48 < rowsBelow;
+        const int rrel = lane < 16 ? lane : 16 + 48 * wave + (lane - 16);         // row relative to the panel start
+        const int Ip = p + (rrel >> 4);
+        const bool live = mine && (lane < 16 || (!inv && Ip < NT));
+        double *src = T + tile_at(live ? Ip : p, p) + (rrel & 15);
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = src[c * 16];       // unconditional (the address is always inside the tile array): 16 reads in flight
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = live ? a[c] : (inv && lane == 16 + c ? 1.0 : 0.0);
+        __syncthreads();                                      // every wave holds the diagonal rows before the tile is overwritten
+        if (mine) {
+            const bool bad = panel_factor(a, w, lane, sBuf[wave]);
+            if (inv) {
+                // W^T in place of the diagonal tile: element (i, c) of W = L_pp^-1 at i * 16 + c; zero beyond w, so that the padding unknowns come out 0
+                if (lane >= 16 && lane < 32) {
+                    const int c = lane - 16;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) T[tile_at(p, p) + k * 16 + c] = (k < w && c < w) ? a[k] : 0.0;
+                }
+            } else if (live && lane >= 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) src[c * 16] = a[c];
+            }
+            if (!inv && live && p * 16 + rrel == n && (lane >= 16 || wave == 0)) {     // the right-hand side row: y = L^-1 b for these 16 columns
+#pragma unroll
+                for (int c = 0; c < 16; c++) ys[p * 16 + c] = c < w ? a[c] : 0.0;
+            }
+            if (wave == 0 && bad && lane == 0) sFail = 1;
+        }
+        __syncthreads();
+        if (sFail) break;
+        // ---- trailing tiles (I, J), p < J <= I < NT
+        const int m1 = NT - 1 - p, nTiles = m1 * (m1 + 1) / 2;
+        for (int t = wave; t < nTiles; t += kSolveWaves) {
+            int Ir = 0, r = t;
+            while (r > Ir) { r -= Ir + 1; Ir++; }
+            const int I = p + 1 + Ir, J = p + 1 + r;
+            const double *LJ = T + tile_at(J, p), *LI = T + tile_at(I, p);
+            double *C = T + tile_at(I, J);
+            v4f64 acc;
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = C[64 * q + lane];
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[64 * s + lane], LI[64 * s + lane], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) C[64 * q + lane] = acc[q];
+        }
+        __syncthreads();
+    }
+    if (sFail) {
+        if (tid == 0) B.scal[3] = 0.0;
+        for (int i = tid; i < n; i += kSolveThreads) B.x[i] = 0;
+        return;
+    }
+    // ---- backward substitution L^T x = y on wave 0, right-looking by tiles, no barrier: x_p = W_p^T (y_p - sum_{q > p} L(q, p)^T x_q).
+    // Two lane layouts alternate so that no value has to be fetched from another lane by address:
+    //   A  lane (c = lane & 15, g = lane >> 4) holds x_q[c]                                  (every g alike)
+    //   B  lane (*, g) holds the four values [4 g .. 4 g + 3] of a 16-vector                (every lane of the row alike)
+    // L(q, p)^T x_q:  lane (k = c, g) forms L[k][4 g + j] x_q[k] (A) and the sum over k is a rotate-and-add inside the row of 16 lanes -> B;
+    // W_p^T r:        lane (c, g) forms sum_j W[4 g + j][c] r[4 g + j] (B) and the sum over g is two v_permlane*_swap exchanges  -> A.
+    // As soon as x_q exists its products with ALL tiles (q, p < q) are accumulated (acc[p], unreduced), the tile (q, q - 1) first: only that
+    // one, one rotate-and-add reduction and W are on the dependent chain of a step.
+    if (wave == 0) {
+        const int c = lane & 15, g = lane >> 4;
+        double acc[kSolveTilesMax][4];
+#pragma unroll
+        for (int p = 0; p < kSolveTilesMax; p++) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0;
+#pragma unroll
+        for (int q = kSolveTilesMax - 1; q >= 0; q--) {
+            if (q < PT) {
+                // x_q from acc[q]
+                const double *yq = ys + q * 16 + 4 * g, *Wt = T + tile_at(q, q) + (4 * g) * 16 + c;
+                double xp = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) xp = __builtin_fma(Wt[j * 16], yq[j] - row_allreduce(acc[q][j]), xp);
+                const double x = rows_allreduce(xp);
+                if (g == 0 && q * 16 + c < n) B.x[q * 16 + c] = x;
+                // its products with the tiles to the left, nearest first
+#pragma unroll
+                for (int p = kSolveTilesMax - 2; p >= 0; p--) {
+                    if (p < q) {
+                        const double *Lt = T + tile_at(q, p) + (4 * g) * 16 + c;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[p][j] = __builtin_fma(Lt[j * 16], x, acc[p][j]);
+                    }
+                }
+            }
+        }
+        if (lane == 0) B.scal[3] = 1.0;
     }
 }
 
@@ -1703,6 +1964,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     for (int e = 0; e < nE; e++)
         if (e_mp[e] < 0 || e_mp[e] >= nMP || e_kf[e] < 0 || e_kf[e] >= nKF) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(o->device));
+    static const bool hostDbg = std::getenv("RUMI_HOSTDBG") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tA = now();
 
     // ---- host-side structure (g2o buildStructure): column blocks, edges by landmark, rows by key-frame ----
     std::vector<int32_t> poseCol(nKF, -1), ptStart(nMP + 1, 0), ptEdge(nE), rowSlot(nE, -1);
@@ -1717,6 +1981,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
     std::vector<int32_t> kfEdge((size_t)std::max(nE, 1), 0);      // edges grouped by optimised key-frame: kfEdge[rowSlot / 2]
     { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; kfEdge[fill[c] >> 1] = e; fill[c] += 2; } } }
+    const double tB = now();
     // one pinned block up: the kernels read the graph arrays straight from its device mirror; the initial state is copied on the
     // device into the first of the two state buffers
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -1743,7 +2008,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         }
         for (size_t i = 0; i < (size_t)nMP * 3; i++) X0[i] = mp_pos3[i];
     }
+    const double tC = now();
     HIP_TRY(hipMemcpyAsync(o->dBa, hs, upBytes, hipMemcpyHostToDevice, nullptr));
+    const double tD = now();
     HIP_TRY(hipMemcpyAsync(o->dT[0], o->dBa + oT, (size_t)nKF * 64, hipMemcpyDeviceToDevice, nullptr));
     if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dX[0], o->dBa + oX, (size_t)nMP * 24, hipMemcpyDeviceToDevice, nullptr));
     BADev B{};
@@ -1818,6 +2085,12 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     }
     const size_t ldsSolve = ((size_t)(n + 1) * (n + 1) + (size_t)n) * sizeof(double);
     const int useLds = !big && ldsSolve <= 158 * 1024;
+    // tile formulation (k_ba_solve_tiles) whenever its tiles fit in LDS; RUMI_BA_SOLVE_PANEL8=1 keeps the panel-8 kernel (A/B measurements)
+    static const bool forcePanel8 = std::getenv("RUMI_BA_SOLVE_PANEL8") != nullptr;
+    const size_t ldsTiles = ((size_t)(NT * (NT + 1) / 2) * 256 + (size_t)NT * 16) * sizeof(double);
+    const int useTiles = !big && n > 0 && NT <= kSolveTilesMax && !forcePanel8;
+    if (useTiles && ldsTiles > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTiles));
     // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses
     if (useLds && ldsSolve > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
@@ -1924,7 +2197,8 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
             if (prof) { HIP_TRY(hipEventRecord(o->evK[3], st)); HIP_TRY(hipEventRecord(o->evK[4], st)); }
             if (n > 0) {
-                if (useLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(1024), ldsSolve, st, B, lambda, o->dG, NP, o->dAglob);
+                if (useTiles) hipLaunchKernelGGL(k_ba_solve_tiles, dim3(1), dim3(kSolveThreads), ldsTiles, st, B, lambda, o->dG, NP);
+                else if (useLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(1024), ldsSolve, st, B, lambda, o->dG, NP, o->dAglob);
                 else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(1024), 0, st, B, lambda, o->dG, NP, o->dAglob);
             }
             else HIP_TRY(hipMemsetAsync(o->dScal + 3, 0, sizeof(double), st));
@@ -1970,7 +2244,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     return RUMI_OK;
     };
     int itersFirst = 0;
+    const double tE = now();
     if ((rc = lm(mode == 0 ? 10 : mode == 1 ? 5 : gbaIterations)) != RUMI_OK) return rc;
+    const double tF = now();
     itersFirst = iters;
     if (mode == 1 && !(stop_flag && *stop_flag)) {          // bDoMore
         if (nE > 0 && ranChi2) hipLaunchKernelGGL(k_ba_mark, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], o->dEOff);
@@ -1995,6 +2271,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
     }
     for (size_t i = 0; i < (size_t)nMP * 3; i++) mp_pos3[i] = (float)X1[i];
+    if (hostDbg) fprintf(stderr, "ba host us: structure %.1f stage %.1f h2d-call %.1f setup %.1f lm %.1f tail %.1f\n", tB - tA, tC - tB, tD - tC, tE - tD, tF - tE, now() - tF);
     if (stats) { stats[0] = mode == 1 ? itersFirst : iters; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 1 ? iters - itersFirst : 0; }
     return RUMI_OK;
 }

@@ -54,7 +54,13 @@ def test_pose_optimization_batch(opt):
 
 
 @pytest.mark.parametrize("cfg", [dict(seed=0, n_opt=20, n_fixed=5, n_points=3000), dict(seed=1, n_opt=6, n_fixed=2, n_points=500),
-                                 dict(seed=2, n_opt=1, n_fixed=3, n_points=200), dict(seed=3, n_opt=12, n_fixed=1, n_points=1500, outlier_frac=0.15)])
+                                 dict(seed=2, n_opt=1, n_fixed=3, n_points=200), dict(seed=3, n_opt=12, n_fixed=1, n_points=1500, outlier_frac=0.15),
+                                 # the tile solver's shapes: unknowns a multiple of 16 (the right-hand side alone in the last tile row: 8, 16, 24
+                                 # key-frames), a partial last panel (3, 27), the largest window it takes (29) and the first one it does not (30)
+                                 dict(seed=11, n_opt=8, n_fixed=2, n_points=400), dict(seed=12, n_opt=16, n_fixed=2, n_points=600),
+                                 dict(seed=13, n_opt=24, n_fixed=3, n_points=700), dict(seed=14, n_opt=3, n_fixed=2, n_points=300),
+                                 dict(seed=15, n_opt=27, n_fixed=2, n_points=700), dict(seed=16, n_opt=29, n_fixed=2, n_points=700),
+                                 dict(seed=17, n_opt=30, n_fixed=2, n_points=700)])
 def test_local_bundle_adjustment(opt, cfg):
     b = ba_problem(**cfg)
     t0 = time.time()

@@ -1,0 +1,23 @@
+"""Local BA of BASELINE configs[3] (20 + 5 key-frames x 3000 points): wall / device ms and per-kernel event times per trial, for both solve kernels
+(RUMI_BA_SOLVE_PANEL8=1 selects the older one in a fresh process)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+from ba_scene import ba_problem
+from rumi_slam_amd.optimizer import Optimizer
+opt = Optimizer()
+for n_opt in (int(x) for x in (sys.argv[1:] or ["20"])):
+    b = ba_problem(seed=0, n_opt=n_opt, n_fixed=5, n_points=3000)
+    a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
+    for _ in range(3): opt.LocalBundleAdjustment(*a)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter(); stats, *_ = opt.LocalBundleAdjustment(*a); ts.append((time.perf_counter() - t0) * 1e3)
+    dev = opt.stage_ms()[5]
+    opt.set_profiling(True)
+    opt.LocalBundleAdjustment(*a)
+    k = opt.kernel_ms()
+    opt.set_profiling(False)
+    print("n_opt %d  wall ms median %.3f min %.3f  device %.3f  stats %s  per trial us: hpp %.1f syrk %.1f solve %.1f" % (
+        n_opt, float(np.median(ts)), min(ts), dev, list(stats), 1e3 * k["hpp"] / max(k["trials"], 1), 1e3 * k["syrk"] / max(k["trials"], 1), 1e3 * k["solve"] / max(k["trials"], 1)))
