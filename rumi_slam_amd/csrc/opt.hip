@@ -437,22 +437,29 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
 // Lane l feeds element (row l>>4, column l&15) of a 4-row chunk as BOTH operands (A = chunk^T, B = chunk).
 // grid (nOpt, kHppSlices): every wave owns an interleaved subset of the 4-row chunks (4 loads in flight per wave); the
 // slices of one key-frame are combined with f64 atomics into the zeroed H_pp / b_p.
-constexpr int kHppSlices = 8;
+constexpr int kHppSlices = 16;
 __global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
     const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = B.kfRowStart[kf], r1 = B.kfRowStart[kf + 1];
     const int col = lane & 15, sub = lane >> 4;
     const int nw = kHppSlices * 4, w = blockIdx.y * 4 + wave;
+    constexpr int U = 16;                                  // 4-row chunks in flight per wave: the loop is bound by memory latency, not by the 64-cycle MFMAs
     v4f64 acc = {0, 0, 0, 0};
-    for (int r = r0 + w * 4; r < r1; r += nw * 16) {
-        double v[4];
+    if (r1 > r0) {
+        for (int r = r0 + w * 4; r < r1; r += nw * 4 * U) {
+            double v[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int row = r + u * nw * 4 + sub;
-            v[u] = (row < r1 && col < 8) ? B.panel[(size_t)row * 8 + col] : 0.0;
+            for (int u = 0; u < U; u++) {                  // clamped address, no branch around the load
+                const int row = r + u * nw * 4 + sub;
+                v[u] = B.panel[(size_t)min(row, r1 - 1) * 8 + (col & 7)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int row = r + u * nw * 4 + sub;
+                const double x = (row < r1 && col < 8) ? v[u] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
     }
     // D[row = sub + 4*reg][col]: rows 0..7 live in reg 0 and reg 1
 #pragma unroll
@@ -530,29 +537,101 @@ __global__ void k_ba_yfill(BADev B, double *Yt, int NP, const double *Lp) {
     }
 }
 
-// G += Yt^T Yt over a K-slice; one wave per (upper 16x16 tile, slice); grid (tiles, slices/4), 256 threads.
+// k_ba_dinv and k_ba_yfill in one launch (one round of kernel-launch and memory latency less per LM trial): threads [0, nMP) do the landmark
+// part; threads [nMP, nMP + nE) fill the panel from the factor of their landmark's block, which each recomputes (45 flops) rather than read.
+__device__ __forceinline__ void dinv_factor(const double *Hll, double lambda, double (&I)[9], double (&L)[6]) {
+    double D[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) D[i] = Hll[i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+    const double id = 1.0 / (D[0] * c00 + D[1] * c01 + D[2] * c02);        // Eigen Matrix3d::inverse (cofactors)
+    I[0] = c00 * id; I[1] = (D[2] * D[7] - D[1] * D[8]) * id; I[2] = (D[1] * D[5] - D[2] * D[4]) * id;
+    I[3] = c01 * id; I[4] = (D[0] * D[8] - D[2] * D[6]) * id; I[5] = (D[2] * D[3] - D[0] * D[5]) * id;
+    I[6] = c02 * id; I[7] = (D[1] * D[6] - D[0] * D[7]) * id; I[8] = (D[0] * D[4] - D[1] * D[3]) * id;
+    const double l00 = sqrt(I[0]), l10 = I[3] / l00, l20 = I[6] / l00;
+    const double l11 = sqrt(I[4] - l10 * l10), l21 = (I[7] - l20 * l10) / l11, l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
+    L[0] = l00; L[1] = l10; L[2] = l20; L[3] = l11; L[4] = l21; L[5] = l22;
+}
+__global__ __launch_bounds__(256) void k_ba_dinv_yfill(BADev B, double lambda, double *Yt, int NP, double *Lp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B.nMP) {
+        const int p = t;
+        double I[9], L[6];
+        dinv_factor(B.Hll + (size_t)p * 9, lambda, I, L);
+#pragma unroll
+        for (int i = 0; i < 9; i++) B.Dinv[(size_t)p * 9 + i] = I[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Lp[(size_t)p * 6 + i] = L[i];
+        const double b0 = B.bl[3 * p], b1 = B.bl[3 * p + 1], b2 = B.bl[3 * p + 2];
+        double *y0 = Yt + (size_t)(3 * p) * NP;
+        y0[B.n] = L[0] * b0 + L[1] * b1 + L[2] * b2; y0[NP + B.n] = L[3] * b1 + L[4] * b2; y0[2 * NP + B.n] = L[5] * b2;    // z = L^T b_l
+        return;
+    }
+    const int e = t - B.nMP;
+    if (e >= B.nE) return;
+    const int col = B.poseCol[B.eKF[e]];
+    if (col < 0) return;
+    const int p = B.eMP[e];
+    double I[9], L[6];
+    dinv_factor(B.Hll + (size_t)p * 9, lambda, I, L);
+    const double *h = B.Hpl + (size_t)e * 18;
+    double *y0 = Yt + (size_t)(3 * p) * NP + col * 6, *y1 = y0 + NP, *y2 = y1 + NP;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double h0 = h[a * 3], h1 = h[a * 3 + 1], h2 = h[a * 3 + 2];
+        y0[a] = h0 * L[0] + h1 * L[1] + h2 * L[2];
+        y1[a] = h1 * L[3] + h2 * L[4];
+        y2[a] = h2 * L[5];
+    }
+}
+
+// G += Yt^T Yt over a K-slice; one wave per (upper 16x16 tile, slice); grid tiles x slices/4, 256 threads.  A wave's 36-odd MFMAs take 2.3 k
+// cycles, one round trip to L2 / HBM about as long: the slice is walked in chunks of 64 rows (16 operand pairs per lane) with the loads of two
+// chunks in flight before the first MFMA, so the kernel pays the memory latency once per wave, not once per 16 rows.
 __global__ __launch_bounds__(256) void k_ba_syrk_mfma(const double *__restrict__ Yt, int K, int NP, int nSlices, double *G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NT = NP / 16;
-    int t = blockIdx.x, tr = 0;                         // upper-triangle tile index -> (tr, tc)
+    // 1-D grid of tiles x slice groups.  Workgroups go round-robin over the 8 XCDs, each with its own L2: the mapping below gives every XCD
+    // its own slice groups (all tiles of them), so that a row of Yt is fetched from memory by ONE L2 instead of by all eight
+    const int nTiles = NT * (NT + 1) / 2, nGroups = nSlices / 4;
+    int lin = blockIdx.x;
+    if (nGroups % 8 == 0) { const int xcd = lin & 7, within = lin >> 3, gpx = nGroups / 8; lin = (xcd * gpx + within / nTiles) * nTiles + within % nTiles; }
+    int t = lin % nTiles, tr = 0;                       // upper-triangle tile index -> (tr, tc)
     while (t >= NT - tr) { t -= NT - tr; tr++; }
     const int tc = tr + t;
-    const int slice = blockIdx.y * 4 + wave;
+    const int slice = (lin / nTiles) * 4 + wave;
     const int per = (((K + nSlices - 1) / nSlices) + 3) & ~3;
     const int k0 = slice * per, k1 = min(K, k0 + per);
+    if (k0 >= k1) return;
     const int i = lane & 15, kk = lane >> 4;
-    v4f64 acc = {0, 0, 0, 0};
-    for (int k = k0; k < k1; k += 16) {
-        double a[4], b[4];
+    constexpr int C = 16;                               // 4-row steps per chunk
+    const double *pa = Yt + tr * 16 + i, *pb = Yt + tc * 16 + i;
+    double a0[C], b0[C], a1[C], b1[C];
+    auto load = [&](double (&a)[C], double (&b)[C], int kb) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int row = k + u * 4 + kk;
-            const bool ok = row < k1;
-            a[u] = ok ? Yt[(size_t)row * NP + tr * 16 + i] : 0.0;
-            b[u] = ok ? Yt[(size_t)row * NP + tc * 16 + i] : 0.0;
+        for (int u = 0; u < C; u++) {
+            const size_t row = (size_t)min(kb + 4 * u + kk, k1 - 1);          // clamped: no branch around the loads
+            a[u] = pa[row * NP]; b[u] = pb[row * NP];
         }
+    };
+    v4f64 acc = {0, 0, 0, 0};
+    auto mma = [&](const double (&a)[C], const double (&b)[C], int kb) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < C; u++) {
+            const bool ok = kb + 4 * u + kk < k1;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? a[u] : 0.0, ok ? b[u] : 0.0, acc, 0, 0, 0);
+        }
+    };
+    load(a0, b0, k0);
+    if (k0 + 4 * C < k1) load(a1, b1, k0 + 4 * C);
+    for (int kb = k0; kb < k1; kb += 8 * C) {
+        mma(a0, b0, kb);
+        if (kb + 8 * C < k1) load(a0, b0, kb + 8 * C);
+        if (kb + 4 * C < k1) {
+            mma(a1, b1, kb + 4 * C);
+            if (kb + 12 * C < k1) load(a1, b1, kb + 12 * C);
+        }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
@@ -834,7 +913,7 @@ __device__ __forceinline__ bool panel_factor(double (&a)[16], int w, int lane, d
     return bad;
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, const double *__restrict__ G, int NP) {
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, double *__restrict__ G, int NP) {
     extern __shared__ double T[];                             // tiles | y[NT*16]
     __shared__ int sFail;
     __shared__ double sBuf[kSolveWaves][16];                           // per wave: the scaled pivot column of the panel step in flight
@@ -843,7 +922,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
     const int PT = (n + 15) / 16;                             // tile columns that hold pivots
     const int nT = NT * (NT + 1) / 2;
     double *ys = T + (size_t)nT * 256;
-    if (tid == 0) sFail = 0;
+    if (tid == 0) { sFail = 0; B.scal[0] = 0.0; B.scal[1] = 0.0; }      // chi2 and scale of the trial are accumulated by the kernels after this one
     // ---- assemble: element (i, j) = -G[j][i] (+ b_p in row n), one wave per tile and all of a wave's loads in flight at once (G was just
     // written: one L2 latency, not one per tile); then the 6x6 blocks of H_pp + lambda I are added by one thread per entry
     {
@@ -866,6 +945,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
                     const int j = r * 16 + cq + 4 * q, jc = min(j, n - 1);
                     const double gv = G[(size_t)jc * NP + min(i, n)], bv = B.bp[jc];
                     v[u][q] = (i <= n && j < n) ? (i == n ? bv - gv : -gv) : 0.0;
+                    if (i <= n && j < n) G[(size_t)j * NP + i] = 0.0;      // G is an accumulator of atomics: left zeroed for the next trial
+
                 }
             }
         }
@@ -1800,6 +1881,7 @@ struct RumiOptimizer {
     unsigned long long pubSeq = 0;
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
+    std::vector<int32_t> hFill;                                                                  // counting-sort cursors of ba_run
     float stageMs[8] = {0};
     hipEvent_t ev[2] = {nullptr, nullptr};
     // opt-in per-kernel timing of the bundle adjustment (rumi_opt_set_profiling): event pairs around the pose-block Gram product, the Schur
@@ -1961,41 +2043,46 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     for (int k = 0; k < nKF; k++) nFixed += kf_fixed[k] ? 1 : 0;
     if (nFixed == 0 && mode == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
     if (mode != 2 && stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                         // :1274-1276 / :3982-3984
-    for (int e = 0; e < nE; e++)
-        if (e_mp[e] < 0 || e_mp[e] >= nMP || e_kf[e] < 0 || e_kf[e] >= nKF) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(o->device));
     static const bool hostDbg = std::getenv("RUMI_HOSTDBG") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tA = now();
 
-    // ---- host-side structure (g2o buildStructure): column blocks, edges by landmark, rows by key-frame ----
-    std::vector<int32_t> poseCol(nKF, -1), ptStart(nMP + 1, 0), ptEdge(nE), rowSlot(nE, -1);
+    // ---- one pinned block up, in two parts.  Part A is the caller's data (edges, measurements, initial state): converted first and already
+    // on its way over PCIe while the host derives part B, the structure (g2o buildStructure: column blocks, edges by landmark, rows by
+    // key-frame), written straight into the pinned block: two passes over the edges, no temporaries.  The kernels read both parts from the
+    // device mirror; the initial state is copied on the device into the first of the two state buffers.
     int nOpt = 0;
-    for (int k = 0; k < nKF; k++) if (!kf_fixed[k]) poseCol[k] = nOpt++;
+    for (int k = 0; k < nKF; k++) nOpt += kf_fixed[k] ? 0 : 1;
     const int n = 6 * nOpt;
-    for (int e = 0; e < nE; e++) ptStart[e_mp[e] + 1]++;
-    for (int p = 0; p < nMP; p++) ptStart[p + 1] += ptStart[p];
-    { std::vector<int32_t> fill(ptStart.begin(), ptStart.end() - 1); for (int e = 0; e < nE; e++) ptEdge[fill[e_mp[e]]++] = e; }
-    std::vector<int32_t> kfRowStart(nOpt + 1, 0);
-    for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) kfRowStart[c + 1] += 2; }
-    for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
-    std::vector<int32_t> kfEdge((size_t)std::max(nE, 1), 0);      // edges grouped by optimised key-frame: kfEdge[rowSlot / 2]
-    { std::vector<int32_t> fill(kfRowStart.begin(), kfRowStart.end() - 1); for (int e = 0; e < nE; e++) { const int c = poseCol[e_kf[e]]; if (c >= 0) { rowSlot[e] = fill[c]; kfEdge[fill[c] >> 1] = e; fill[c] += 2; } } }
-    const double tB = now();
-    // one pinned block up: the kernels read the graph arrays straight from its device mirror; the initial state is copied on the
-    // device into the first of the two state buffers
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t oPC = 0, oPS = al(oPC + (size_t)nKF * 4), oKR = al(oPS + (size_t)(nMP + 1) * 4), oPE = al(oKR + (size_t)(nOpt + 1) * 4),
-                 oRS = al(oPE + (size_t)nE * 4), oEM = al(oRS + (size_t)nE * 4), oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4),
-                 oIn = al(oOb + (size_t)nE * 16), oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), oKE = al(oX + (size_t)nMP * 24),
-                 upBytes = al(oKE + (size_t)nE * 4);
+    const size_t oEM = 0, oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4), oIn = al(oOb + (size_t)nE * 16),
+                 oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), partA = al(oX + (size_t)nMP * 24),
+                 oPC = partA, oPS = al(oPC + (size_t)nKF * 4), oKR = al(oPS + (size_t)(nMP + 1) * 4), oPE = al(oKR + (size_t)(nOpt + 1) * 4),
+                 oRS = al(oPE + (size_t)nE * 4), upBytes = al(oRS + (size_t)nE * 4);
     if (upBytes > o->baStageCap) { g_lastError = "local BA: upload block larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
     uint8_t *hs = o->hBa;
-    std::memcpy(hs + oPC, poseCol.data(), (size_t)nKF * 4); std::memcpy(hs + oPS, ptStart.data(), (size_t)(nMP + 1) * 4);
-    std::memcpy(hs + oKR, kfRowStart.data(), (size_t)(nOpt + 1) * 4);
+    int32_t *poseCol = reinterpret_cast<int32_t *>(hs + oPC), *ptStart = reinterpret_cast<int32_t *>(hs + oPS),
+            *kfRowStart = reinterpret_cast<int32_t *>(hs + oKR), *ptEdge = reinterpret_cast<int32_t *>(hs + oPE),
+            *rowSlot = reinterpret_cast<int32_t *>(hs + oRS);
+    { int c = 0; for (int k = 0; k < nKF; k++) poseCol[k] = kf_fixed[k] ? -1 : c++; }
+    // pass 1: validate, count edges per landmark and rows per optimised key-frame
+    std::memset(ptStart, 0, (size_t)(nMP + 1) * 4);
+    std::memset(kfRowStart, 0, (size_t)(nOpt + 1) * 4);
+    {
+        unsigned badIdx = 0;
+        for (int e = 0; e < nE; e++) {
+            const unsigned mp = (unsigned)e_mp[e], kf = (unsigned)e_kf[e];
+            if (mp >= (unsigned)nMP || kf >= (unsigned)nKF) { badIdx = 1; break; }
+            ptStart[mp + 1]++;
+            const int c = poseCol[kf];
+            if (c >= 0) kfRowStart[c + 1] += 2;
+        }
+        if (badIdx) { g_lastError = "local BA: edge index out of range"; return RUMI_E_INVALID; }
+    }
+    // part A
     if (nE > 0) {
-        std::memcpy(hs + oPE, ptEdge.data(), (size_t)nE * 4); std::memcpy(hs + oRS, rowSlot.data(), (size_t)nE * 4);
-        std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4); std::memcpy(hs + oKE, kfEdge.data(), (size_t)nE * 4);
+        std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4);
         double *ob = reinterpret_cast<double *>(hs + oOb), *inf = reinterpret_cast<double *>(hs + oIn);
         for (int e = 0; e < nE; e++) { ob[2 * e] = e_obs[2 * e]; ob[2 * e + 1] = e_obs[2 * e + 1]; inf[e] = e_inv_sigma2[e]; }
     }
@@ -2008,11 +2095,30 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         }
         for (size_t i = 0; i < (size_t)nMP * 3; i++) X0[i] = mp_pos3[i];
     }
-    const double tC = now();
-    HIP_TRY(hipMemcpyAsync(o->dBa, hs, upBytes, hipMemcpyHostToDevice, nullptr));
-    const double tD = now();
+    const double tB = now();
+    HIP_TRY(hipMemcpyAsync(o->dBa, hs, partA, hipMemcpyHostToDevice, nullptr));
     HIP_TRY(hipMemcpyAsync(o->dT[0], o->dBa + oT, (size_t)nKF * 64, hipMemcpyDeviceToDevice, nullptr));
     if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dX[0], o->dBa + oX, (size_t)nMP * 24, hipMemcpyDeviceToDevice, nullptr));
+    if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, nullptr));
+    const double tC = now();
+    // part B, pass 2: prefix sums, then every edge into its landmark's list and its key-frame's rows (stable: input order inside a group)
+    for (int p2 = 0; p2 < nMP; p2++) ptStart[p2 + 1] += ptStart[p2];
+    for (int c = 0; c < nOpt; c++) kfRowStart[c + 1] += kfRowStart[c];
+    o->hFill.resize((size_t)nMP + nOpt + 2);
+    {
+        int32_t *fillP = o->hFill.data(), *fillK = fillP + nMP + 1;
+        std::memcpy(fillP, ptStart, (size_t)nMP * 4);
+        std::memcpy(fillK, kfRowStart, (size_t)nOpt * 4);
+        for (int e = 0; e < nE; e++) {
+            ptEdge[fillP[e_mp[e]]++] = e;
+            const int c = poseCol[e_kf[e]];
+            int slot = -1;
+            if (c >= 0) { slot = fillK[c]; fillK[c] = slot + 2; }
+            rowSlot[e] = slot;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(o->dBa + partA, hs + partA, upBytes - partA, hipMemcpyHostToDevice, nullptr));
+    const double tD = now();
     BADev B{};
     B.nKF = nKF; B.nMP = nMP; B.nE = nE; B.nOpt = nOpt; B.n = n;
     B.eMP = (const int32_t *)(o->dBa + oEM); B.eKF = (const int32_t *)(o->dBa + oEK); B.poseCol = (const int32_t *)(o->dBa + oPC);
@@ -2022,7 +2128,6 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     B.delta = mode == 0 ? (double)(float)std::sqrt(5.991) : (double)(float)std::sqrt(5.99);   // thHuberMono = sqrt(5.991) / thHuber2D = sqrt(5.99)
     B.dsqr = B.delta * B.delta;
     B.off = o->dEOff; B.robust = mode == 2 ? (gbaRobust ? 1 : 0) : 1;
-    if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, nullptr));
     B.Hll = o->dHll; B.bl = o->dBl; B.Hpl = o->dHpl; B.panel = o->dPanel; B.Hpp = o->dHpp; B.bp = o->dBp; B.Dinv = o->dDinv; B.S = o->dS;
     B.bs = o->dBs; B.x = o->dXv; B.lastChi2 = o->dChi; B.scal = o->dScal;
 
@@ -2150,7 +2255,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     };
     HIP_TRY(hipEventRecord(o->ev[0], st));
     const bool prof = o->profiling;
-    bool hppFresh = false;
+    bool hppFresh = false, gClean = false;
     for (auto &k : o->kernelMs) k = 0.f;
     int cur = 0, iters = 0, trials = 0, rc = RUMI_OK;
     bool ranChi2 = false;
@@ -2185,16 +2290,16 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         int qmax = 0;
         do {
             const int trial = cur ^ 1;
-            {
+            if (!useTiles || !gClean) {                        // k_ba_solve_tiles leaves G and the two accumulators of dScal zeroed itself
                 const ZeroList Z{{o->dG, o->dScal, nullptr, nullptr}, {big ? 0 : NP * NP, 2, 0, 0}};
                 hipLaunchKernelGGL(k_ba_zero, dim3(((big ? 2 : NP * NP) + 255) / 256), dim3(256), 0, st, Z);
+                gClean = true;
             }
             if (big) { if ((rc = solve_big(lambda)) != RUMI_OK) return rc; }
             else {
-            if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((nMP + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
-            if (nE > 0) hipLaunchKernelGGL(k_ba_yfill, dim3(gE), dim3(256), 0, st, B, o->dYt, NP, o->dLp);
+            if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv_yfill, dim3((nMP + nE + 255) / 256), dim3(256), 0, st, B, lambda, o->dYt, NP, o->dLp);
             if (prof) HIP_TRY(hipEventRecord(o->evK[2], st));
-            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2, nSlices / 4), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
+            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2 * (nSlices / 4)), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG);
             if (prof) { HIP_TRY(hipEventRecord(o->evK[3], st)); HIP_TRY(hipEventRecord(o->evK[4], st)); }
             if (n > 0) {
                 if (useTiles) hipLaunchKernelGGL(k_ba_solve_tiles, dim3(1), dim3(kSolveThreads), ldsTiles, st, B, lambda, o->dG, NP);
@@ -2271,7 +2376,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         se3_to_float7(DSE3{{t[0], t[1], t[2], t[3]}, {t[4], t[5], t[6]}}, kf_pose7 + (size_t)k * 7);
     }
     for (size_t i = 0; i < (size_t)nMP * 3; i++) mp_pos3[i] = (float)X1[i];
-    if (hostDbg) fprintf(stderr, "ba host us: structure %.1f stage %.1f h2d-call %.1f setup %.1f lm %.1f tail %.1f\n", tB - tA, tC - tB, tD - tC, tE - tD, tF - tE, now() - tF);
+    if (hostDbg) fprintf(stderr, "ba host us: pass1+partA %.1f h2d-A %.1f pass2+h2d-B %.1f setup %.1f lm %.1f tail %.1f\n", tB - tA, tC - tB, tD - tC, tE - tD, tF - tE, now() - tF);
     if (stats) { stats[0] = mode == 1 ? itersFirst : iters; stats[1] = trials; stats[2] = nOpt; stats[3] = mode == 1 ? iters - itersFirst : 0; }
     return RUMI_OK;
 }
