@@ -101,21 +101,22 @@ template <int N> __device__ __forceinline__ bool chol_solve_packed(const double 
     for (int i = 0; i < N; i++)
         for (int j = i; j < N; j++) { A[i][j] = H[p]; A[j][i] = H[p]; p++; }
     for (int i = 0; i < N; i++) A[i][i] += lambda;
+    double rd[N];                                          // reciprocals of the factor's diagonal (m_rsqrt: no IEEE divide / square root here)
     for (int j = 0; j < N; j++) {
         double d = A[j][j];
         for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
         if (!(d > 0) || !isfinite(d)) return false;
-        d = sqrt(d);
-        A[j][j] = d;
+        rd[j] = m_rsqrt(d);
+        A[j][j] = d * rd[j];
         for (int i = j + 1; i < N; i++) {
             double s = A[i][j];
             for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
-            A[i][j] = s / d;
+            A[i][j] = s * rd[j];
         }
     }
     double y[N];
-    for (int i = 0; i < N; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s / A[i][i]; }
-    for (int i = N - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < N; k++) s -= A[k][i] * x[k]; x[i] = s / A[i][i]; }
+    for (int i = 0; i < N; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s * rd[i]; }
+    for (int i = N - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < N; k++) s -= A[k][i] * x[k]; x[i] = s * rd[i]; }
     return true;
 }
 __device__ __forceinline__ bool chol6_solve(const double *H, double lambda, const double *b, double *x) { return chol_solve_packed<6>(H, lambda, b, x); }
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     scale += 1e-3;
                     rho /= scale;
                     if (rho > 0 && isfinite(tempChi)) {
-                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        const double tr = 2 * rho - 1;
+                        double alpha = 1. - tr * tr * tr;          // pow(2 rho - 1, 3) (levenberg.cpp:124): the generic pow is ~150 instructions of this serial section
                         alpha = fmin(alpha, 2. / 3.);
                         lambda *= fmax(1. / 3., alpha);
                         ni = 2;
@@ -1808,7 +1810,8 @@ __global__ __launch_bounds__(256) void k_sim3_opt(Sim3Args A) {
                 scale += 1e-3;
                 rho /= scale;
                 if (rho > 0 && isfinite(tempChi)) {
-                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    const double tr = 2 * rho - 1;
+                    double alpha = 1. - tr * tr * tr;
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha);
                     ni = 2;

@@ -19,6 +19,58 @@ struct DQuat { double x, y, z, w; };
 struct DSE3 { DQuat r; D3 t; };
 struct DCam { double fx, fy, cx, cy; };
 
+// ---- reciprocal, reciprocal square root, square root, sine / cosine of the serial sections ----
+// Every lane of a pose-optimisation workgroup executes the 6x6 solve and the SE(3) update of each LM trial, alone on its SIMD (about 5 cycles
+// per instruction): the IEEE f64 divide and square root are 25-35 instructions each, sin / cos well over 100, and there are ~40 of them per
+// trial.  On the device they are replaced by the hardware estimates (v_rcp_f64 / v_rsq_f64, 5e-8) with two Newton steps (3e-16 measured,
+// tools/rsq_probe.hip) and by Taylor polynomials for |x| <= 0.5 (LM rotation steps are far smaller; truncation below 1e-19).  The host side
+// (pose packing) keeps the libm forms.  Results move by a few 1e-16 relative: the parity bar of these kernels is 1e-4 (tests/test_optimizer_gpu.py).
+RUMI_HD double m_rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    return y;
+#else
+    return 1.0 / d;
+#endif
+}
+RUMI_HD double m_rsqrt(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    return y;
+#else
+    return 1.0 / std::sqrt(d);
+#endif
+}
+RUMI_HD double m_sqrt(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return d > 0 ? d * m_rsqrt(d) : (d == 0 ? 0.0 : __builtin_nan(""));
+#else
+    return std::sqrt(d);
+#endif
+}
+RUMI_HD void m_sincos(double x, double &s, double &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_fabs(x) <= 0.5) {
+        const double z = x * x;
+        double ps = -1.0 / 1307674368000.0;                                   // -1/15!
+        ps = __builtin_fma(ps, z, 1.0 / 6227020800.0); ps = __builtin_fma(ps, z, -1.0 / 39916800.0); ps = __builtin_fma(ps, z, 1.0 / 362880.0);
+        ps = __builtin_fma(ps, z, -1.0 / 5040.0); ps = __builtin_fma(ps, z, 1.0 / 120.0); ps = __builtin_fma(ps, z, -1.0 / 6.0);
+        s = __builtin_fma(ps * z, x, x);
+        double pc = 1.0 / 20922789888000.0;                                   // 1/16!
+        pc = __builtin_fma(pc, z, -1.0 / 87178291200.0); pc = __builtin_fma(pc, z, 1.0 / 479001600.0); pc = __builtin_fma(pc, z, -1.0 / 3628800.0);
+        pc = __builtin_fma(pc, z, 1.0 / 40320.0); pc = __builtin_fma(pc, z, -1.0 / 720.0); pc = __builtin_fma(pc, z, 1.0 / 24.0);
+        pc = __builtin_fma(pc, z, -0.5);
+        c = __builtin_fma(pc, z, 1.0);
+        return;
+    }
+#endif
+    s = sin(x); c = cos(x);
+}
+
 RUMI_HD D3 d3_cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 RUMI_HD D3 quat_rotate(const DQuat &q, D3 v) {          // Eigen _transformVector
@@ -34,8 +86,8 @@ RUMI_HD D3 se3_map(const DSE3 &T, D3 p) {
 }
 RUMI_HD void quat_normalize_pos(DQuat &q) {
     if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    const double rn = m_rsqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x *= rn; q.y *= rn; q.z *= rn; q.w *= rn;
 }
 RUMI_HD DQuat quat_mul(const DQuat &a, const DQuat &b) {
     return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
@@ -45,23 +97,23 @@ RUMI_HD DQuat quat_from_matrix(const double R[3][3]) {
     DQuat q;
     double t = R[0][0] + R[1][1] + R[2][2];
     if (t > 0) {
-        t = sqrt(t + 1.0);
-        q.w = 0.5 * t;
-        t = 0.5 / t;
+        const double r = m_rsqrt(t + 1.0);
+        q.w = 0.5 * ((t + 1.0) * r);
+        t = 0.5 * r;
         q.x = (R[2][1] - R[1][2]) * t; q.y = (R[0][2] - R[2][0]) * t; q.z = (R[1][0] - R[0][1]) * t;
     } else {
         // largest diagonal element decides the branch (written out: no runtime-indexed arrays on the device)
         if (R[0][0] >= R[1][1] && R[0][0] >= R[2][2]) {
-            t = sqrt(R[0][0] - R[1][1] - R[2][2] + 1.0);
-            q.x = 0.5 * t; t = 0.5 / t;
+            t = m_sqrt(R[0][0] - R[1][1] - R[2][2] + 1.0);
+            q.x = 0.5 * t; t = 0.5 * m_rcp(t);
             q.w = (R[2][1] - R[1][2]) * t; q.y = (R[1][0] + R[0][1]) * t; q.z = (R[2][0] + R[0][2]) * t;
         } else if (R[1][1] >= R[2][2]) {
-            t = sqrt(R[1][1] - R[2][2] - R[0][0] + 1.0);
-            q.y = 0.5 * t; t = 0.5 / t;
+            t = m_sqrt(R[1][1] - R[2][2] - R[0][0] + 1.0);
+            q.y = 0.5 * t; t = 0.5 * m_rcp(t);
             q.w = (R[0][2] - R[2][0]) * t; q.z = (R[2][1] + R[1][2]) * t; q.x = (R[0][1] + R[1][0]) * t;
         } else {
-            t = sqrt(R[2][2] - R[0][0] - R[1][1] + 1.0);
-            q.z = 0.5 * t; t = 0.5 / t;
+            t = m_sqrt(R[2][2] - R[0][0] - R[1][1] + 1.0);
+            q.z = 0.5 * t; t = 0.5 * m_rcp(t);
             q.w = (R[1][0] - R[0][1]) * t; q.x = (R[0][2] + R[2][0]) * t; q.y = (R[1][2] + R[2][1]) * t;
         }
     }
@@ -78,14 +130,19 @@ RUMI_HD void quat_to_matrix(const DQuat &q, double R[3][3]) {
 // SE3Quat::exp: u = (omega, upsilon)
 RUMI_HD DSE3 se3_exp(const double u[6]) {
     const double wx = u[0], wy = u[1], wz = u[2];
-    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double theta = m_sqrt(wx * wx + wy * wy + wz * wz);
     const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
     double O2[3][3], R[3][3], V[3][3];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
     double a = 1, b = 1, c = 1;
     const bool small = theta < 0.00001;
-    if (!small) { a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c = (theta - sin(theta)) / (theta * theta * theta); }
+    if (!small) {
+        double sn, cs;
+        m_sincos(theta, sn, cs);
+        const double it = m_rcp(theta), it2 = it * it;
+        a = sn * it; b = (1 - cs) * it2; c = (theta - sn) * (it2 * it);
+    }
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
             const double I = i == j ? 1.0 : 0.0;
@@ -119,17 +176,17 @@ RUMI_HD void se3_to_float7(const DSE3 &T, float *o) {     // Sophus::SE3f(q.cast
     o[4] = (float)T.t.x; o[5] = (float)T.t.y; o[6] = (float)T.t.z;
 }
 
-RUMI_HD void cam_project(const DCam &c, D3 p, double &u, double &v) { u = c.fx * p.x / p.z + c.cx; v = c.fy * p.y / p.z + c.cy; }
+RUMI_HD void cam_project(const DCam &c, D3 p, double &u, double &v) { const double iz = m_rcp(p.z); u = c.fx * p.x * iz + c.cx; v = c.fy * p.y * iz + c.cy; }
 
 // rho[0] = rho(e), rho[1] = rho'(e)
 RUMI_HD void huber(double e, double delta, double dsqr, double &rho0, double &rho1) {
     if (e <= dsqr) { rho0 = e; rho1 = 1.; }
-    else { const double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+    else { const double rs = m_rsqrt(e), s = e * rs; rho0 = 2 * s * delta - dsqr; rho1 = delta * rs; }
 }
 
 // d e / d (pose increment) = -projectJac(Xc) * [ -[Xc]x | I ]      (OptimizableTypes.cpp:47-61)
 RUMI_HD void jac_pose(const DCam &c, D3 p, double J0[6], double J1[6]) {
-    const double iz = 1.0 / p.z, iz2 = 1.0 / (p.z * p.z);
+    const double iz = m_rcp(p.z), iz2 = iz * iz;
     const double j00 = c.fx * iz, j02 = -c.fx * p.x * iz2, j11 = c.fy * iz, j12 = -c.fy * p.y * iz2;
     // rows of SE3deriv: [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
     J0[0] = -(j02 * p.y);            J0[1] = -(j00 * p.z - j02 * p.x); J0[2] = -(-j00 * p.y);
@@ -163,7 +220,7 @@ RUMI_HD DSim3 sim3_inverse(const DSim3 &a) {                                   /
 // Sim3(const Vector7d& update): (omega, upsilon, sigma)                          sim3.h:70-142
 RUMI_HD DSim3 sim3_exp(const double u[7]) {
     const double wx = u[0], wy = u[1], wz = u[2], sigma = u[6];
-    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double theta = m_sqrt(wx * wx + wy * wy + wz * wz);
     const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
     double O2[3][3], R[3][3];
     for (int i = 0; i < 3; i++)
