@@ -1763,3 +1763,298 @@ extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const voi
     return rumi_match_bruteforce_batch_device_strided(d_query, d_nq, d_train, d_nt, count_stride, 32ll * cap, 32ll * cap, cap, nbatch, d_best_idx, d_best_dist,
                                                       d_second_dist, hip_stream);
 }
+
+// ==================================================================================================================
+// One device-resident Tracking step (include/rumi_track.h): the extractor's record, the matcher's frame arrays (key-points, descriptors, grid,
+// mvpMapPoints = dFeatMp) and the pose optimiser's correspondence arrays never leave HBM between the five stages.
+// ==================================================================================================================
+namespace rumi {
+
+// Correspondences of Optimizer::PoseOptimization(Frame*) (Optimizer.cc:749-815, mono): the features with a map point, in feature order.
+// One workgroup, ordered compaction (ballot + wave offsets through LDS, chunks of 1024 features).
+__global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint *__restrict__ keys, const int32_t *__restrict__ featMp,
+                                                       const float *__restrict__ mpPos, const float *__restrict__ invSigma2, float *Xw, float *obs,
+                                                       float *w, int32_t *idx, int32_t *start) {
+    __shared__ int sWave[16], sBase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sBase = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int mp = i < n ? featMp[i] : -1;
+        const unsigned long long b = __ballot(mp >= 0);
+        if (lane == 0) sWave[wave] = __popcll(b);
+        __syncthreads();
+        int off = sBase;
+        for (int k = 0; k < wave; k++) off += sWave[k];
+        if (mp >= 0) {
+            const int c = off + __popcll(b & ((1ull << lane) - 1));
+            Xw[3 * c] = mpPos[3 * mp]; Xw[3 * c + 1] = mpPos[3 * mp + 1]; Xw[3 * c + 2] = mpPos[3 * mp + 2];
+            obs[2 * c] = keys[i].x; obs[2 * c + 1] = keys[i].y;
+            w[c] = invSigma2[keys[i].octave];
+            idx[c] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = sBase; for (int k = 0; k < 16; k++) t += sWave[k]; sBase = t; }
+        __syncthreads();
+    }
+    if (tid == 0) { start[0] = 0; start[1] = sBase; }
+}
+
+// After the first PoseOptimization (Tracking.cc:2489-2508) and the first loop of SearchLocalPoints (:2998-3010): every point the motion search
+// matched has been seen in this frame (inliers by SearchLocalPoints, outliers by the discard loop); outliers and bad points leave the frame.
+__global__ void k_track_after_motion(const int32_t *start, const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs,
+                                     const uint8_t *mpBad, uint8_t *seen, int32_t *counters /* [0] nmatchesMap */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= start[1]) return;
+    const int i = idx[c], mp = featMp[i];
+    seen[mp] = 1;
+    if (outlierC[c]) { featMp[i] = -1; return; }
+    if (mpObs[mp] > 0) atomicAdd(&counters[0], 1);
+    if (mpBad[mp]) featMp[i] = -1;
+}
+
+// skip flag of SearchLocalPoints' second loop: not a local map point, seen in this frame, or bad
+__global__ void k_track_skip(int nmp, const uint8_t *local, const uint8_t *seen, const uint8_t *bad, uint8_t *skip) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nmp) skip[j] = !local[j] || seen[j] || bad[j];
+}
+
+// Frame::UpdatePoseMatrices (Frame.cc:522-528) in Sophus' / Eigen's float arithmetic: Rcw = q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw)
+// (quaternion _transformVector); written as [Rcw9 | tcw3 | Ow3 | K4] for k_is_in_frustum
+__global__ void k_track_pose_matrices(const float *Tcw7, const float *K4, float *pose19) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    pose19[0] = 1.f - (tyy + tzz); pose19[1] = txy - twz; pose19[2] = txz + twy;
+    pose19[3] = txy + twz; pose19[4] = 1.f - (txx + tzz); pose19[5] = tyz - twx;
+    pose19[6] = txz - twy; pose19[7] = tyz + twx; pose19[8] = 1.f - (txx + tyy);
+    const float t0 = Tcw7[4], t1 = Tcw7[5], t2 = Tcw7[6];
+    pose19[9] = t0; pose19[10] = t1; pose19[11] = t2;
+    const float qx = -x, qy = -y, qz = -z, v0 = t0 * -1.f, v1 = t1 * -1.f, v2 = t2 * -1.f;
+    float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+    u0 += u0; u1 += u1; u2 += u2;
+    const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+    pose19[12] = (v0 + w * u0) + c0; pose19[13] = (v1 + w * u1) + c1; pose19[14] = (v2 + w * u2) + c2;
+    pose19[15] = K4[0]; pose19[16] = K4[1]; pose19[17] = K4[2]; pose19[18] = K4[3];
+}
+
+// after the second PoseOptimization: mvbOutlier per feature and mnMatchesInliers (Tracking.cc:2573-2586)
+__global__ void k_track_finish(const int32_t *start, const int32_t *idx, const uint8_t *outlierC, const int32_t *featMp, const int32_t *mpObs,
+                               uint8_t *outlierF, int32_t *counters /* [1] mnMatchesInliers */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= start[1]) return;
+    const int i = idx[c];
+    outlierF[i] = outlierC[c];
+    if (!outlierC[c] && mpObs[featMp[i]] > 0) atomicAdd(&counters[1], 1);
+}
+
+}  // namespace rumi
+
+#include "rumi_internal.h"
+#include "rumi_orb.h"
+#include "rumi_track.h"
+
+struct RumiTracker {
+    int device = 0, cap = 0, maxPts = 0, nlevels = 0;
+    RumiOrbConfig cfg{};
+    RumiOrb *ext = nullptr;
+    RumiMatcher *m = nullptr;
+    uint8_t *dImage = nullptr; size_t imageBytes = 0;
+    uint8_t *dRecord = nullptr; size_t recordBytes = 0;
+    float *dInvSigma2 = nullptr, *dXw = nullptr, *dObs = nullptr, *dW = nullptr, *dPose19 = nullptr, *dTout = nullptr;   // dTout: [motion 7 | local 7]
+    int32_t *dIdx = nullptr, *dStart = nullptr, *dNGood = nullptr, *dCounters = nullptr, *dMpMotion = nullptr;
+    uint8_t *dOutC = nullptr, *dOutF = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr;
+    double *dChi = nullptr;
+    uint8_t *hOut = nullptr, *dOut = nullptr; size_t outBytes = 0;      // result block: one copy back
+    float scale[64] = {0};
+};
+
+extern "C" void rumi_track_destroy(RumiTracker *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    rumi_orb_destroy(t->ext);
+    rumi_match_destroy(t->m);
+    void *p[] = {t->dImage, t->dRecord, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dPose19, t->dTout, t->dIdx, t->dStart, t->dNGood, t->dCounters,
+                 t->dMpMotion, t->dOutC, t->dOutF, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dOut};
+    for (void *q : p) if (q) (void)hipFree(q);
+    if (t->hOut) (void)hipHostFree(t->hOut);
+    delete t;
+}
+
+extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, int32_t device, RumiTracker **out) {
+    if (!out) return RUMI_E_INVALID;
+    *out = nullptr;
+    if (!cfg || max_points < 1 || cfg->nlevels < 1 || cfg->nlevels > 16) return RUMI_E_INVALID;
+    RumiTracker *t = new RumiTracker();
+    t->cfg = *cfg; t->cfg.max_batch = 1; t->cfg.device = device;
+    t->nlevels = cfg->nlevels;
+    t->cap = cfg->nfeatures + 4 * cfg->nlevels + 64;                // what the facade's ORBextractor::operator() reserves
+    t->maxPts = max_points;
+    int rc = rumi_orb_create(&t->cfg, &t->ext);
+    if (rc == RUMI_OK) rc = rumi_match_create(t->cap, std::max(max_points, t->cap), device, &t->m);
+    if (rc != RUMI_OK) { rumi_track_destroy(t); return rc; }
+    t->device = t->m->device;
+    const size_t C = t->cap, P = max_points;
+    t->imageBytes = (size_t)((cfg->max_width + 3) & ~3) * cfg->max_height;
+    t->recordBytes = 8 + 60 * C;
+    t->outBytes = 256 + C * 4 * 2 + C + P + 64;
+#define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_track_destroy(t); return rc; }
+    TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dRecord, t->recordBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
+    TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dPose19, 32)); TRYA(dalloc(&t->dTout, 16));
+    TRYA(dalloc(&t->dIdx, C)); TRYA(dalloc(&t->dStart, 4)); TRYA(dalloc(&t->dNGood, 4)); TRYA(dalloc(&t->dCounters, 4)); TRYA(dalloc(&t->dMpMotion, C));
+    TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dOutF, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P));
+    TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C)); TRYA(dalloc(&t->dOut, t->outBytes));
+#undef TRYA
+    if (hipHostMalloc((void **)&t->hOut, t->outBytes, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
+    float inv2[64] = {0};
+    rumi_orb_tables(cfg, t->scale, nullptr, nullptr, inv2, nullptr, nullptr);
+    if (hipMemcpy(t->dInvSigma2, inv2, sizeof(inv2), hipMemcpyHostToDevice) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
+    *out = t;
+    return RUMI_OK;
+}
+
+extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride, const float *K4, const float *Tcw_pred7,
+                                const RumiKeyPoint *last_keys_un, int32_t nlast, const int32_t *last_mp, const uint8_t *last_outlier,
+                                const RumiTrackPoints *pts, float th_motion, float th_local, int32_t far_points, float th_far_points,
+                                RumiKeyPoint *keys_out, uint8_t *desc_out, int32_t cap, int32_t *frame_mp_motion, int32_t *frame_mp, uint8_t *outlier,
+                                uint8_t *in_view, RumiTrackResult *res) {
+    if (!t || !img || !K4 || !Tcw_pred7 || !pts || !res || !keys_out || !desc_out || !frame_mp_motion || !frame_mp || !outlier || nlast < 0 || pts->n < 0 ||
+        stride < w || (nlast > 0 && (!last_keys_un || !last_mp || !last_outlier)) ||
+        (pts->n > 0 && (!pts->pos || !pts->normal || !pts->min_dist || !pts->max_dist || !pts->desc || !pts->obs || !pts->bad || !pts->local || !in_view)))
+        return RUMI_E_INVALID;
+    if (w <= 0 || h <= 0) return RUMI_E_EMPTY;
+    if (w > t->cfg.max_width || h > t->cfg.max_height) { g_lastError = "rumi_track_frame: image larger than the tracker was created for"; return RUMI_E_CAPACITY; }
+    RumiMatcher *m = t->m;
+    const int nmp = pts->n;
+    if (nlast > m->maxQ || nmp > t->maxPts || cap < t->cap) { g_lastError = "rumi_track_frame: more points / features than the tracker was created for, or cap too small"; return RUMI_E_CAPACITY; }
+    for (int i = 0; i < nlast; i++) if (last_mp[i] >= nmp) { g_lastError = "rumi_track_frame: last_mp index outside the point table"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    std::memset(res, 0, sizeof(*res));
+    res->mono_index = -1; res->th_motion = (int32_t)th_motion;
+
+    // ---- stage 1: ORBextractor::operator() on the device; only the two counts come back (launch sizes need n)
+    const int wp = (w + 3) & ~3;
+    HIP_TRY(hipMemcpy2DAsync(t->dImage, wp, img, stride, w, h, hipMemcpyHostToDevice, nullptr));
+    int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, t->dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
+    if (rc != RUMI_OK) return rc;
+    int32_t counts[2] = {0, -1};
+    HIP_TRY(hipMemcpy(counts, t->dRecord, 8, hipMemcpyDeviceToHost));
+    if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
+    const int n = counts[0];
+    res->n = n; res->mono_index = counts[1];
+    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(t->dRecord + 8);
+    const uint8_t *dDs = t->dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
+
+    // ---- uploads of the whole step: one pinned block, one copy, scattered on the device
+    RumiFrameFeatures F{};
+    F.n = 0;                                                   // key-points / descriptors are already on the device: nothing of the frame is staged
+    F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)w; F.max_y = (float)h;
+    FrameDev fd;
+    if ((rc = upload_frame(m, &F, &fd)) != RUMI_OK) return rc;
+    fd.n = n; m->gridN = n;
+    float pose[11];
+    std::memcpy(pose, Tcw_pred7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
+    H2D(m->dPose, pose, 11);
+    if (nmp > 0) {
+        H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dF[1], pts->normal, (size_t)nmp * 3); H2D(m->dF[2], pts->min_dist, nmp); H2D(m->dF[3], pts->max_dist, nmp);
+        H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
+    }
+    if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(m->dKeys, dKp, (size_t)n * sizeof(RumiKeyPoint), hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(m->dDesc, dDs, (size_t)n * 32, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemsetAsync(m->dFeatMp, 0xFF, (size_t)n * 4, nullptr));                 // fill(mvpMapPoints, NULL)   (Tracking.cc:2458)
+    }
+    HIP_TRY(hipMemsetAsync(t->dCounters, 0, 16, nullptr));
+    HIP_TRY(hipMemsetAsync(t->dNGood, 0, 16, nullptr));
+    if (nmp > 0) HIP_TRY(hipMemsetAsync(t->dSeen, 0, (size_t)nmp, nullptr));
+    if (n > 0) { HIP_TRY(hipMemsetAsync(t->dOutF, 0, (size_t)n, nullptr)); }
+    // the poses default to the prediction (PoseOptimization not reached / fewer than 3 correspondences)
+    HIP_TRY(hipMemcpyAsync(t->dTout, Tcw_pred7, 7 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(t->dTout + 7, Tcw_pred7, 7 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+
+    // ---- stage 2: SearchByProjection(Cur, Last, th, mono), once more with 2 * th below 20 matches (Tracking.cc:2466-2474)
+    int nm = 0;
+    std::vector<int32_t> tmpMp((size_t)std::max(n, 1));
+    for (int attempt = 0; attempt < 2 && n > 0 && nlast > 0 && nmp > 0; attempt++) {
+        const float th = attempt == 0 ? th_motion : 2 * th_motion;
+        if (attempt == 1) { HIP_TRY(hipMemsetAsync(m->dFeatMp, 0xFF, (size_t)n * 4, nullptr)); HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr)); }
+        FLUSH(m);
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
+                           m->dPose + 7, m->dScale, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+        if ((rc = run_search(m, MODE_FRAME, nlast, fd, m->dQDesc, m->dI[1], 0.f, 1, tmpMp.data(), &nm)) != RUMI_OK) return rc;
+        res->th_motion = (int32_t)th;
+        if (nm >= 20) break;
+    }
+    FLUSH(m);                                                  // (nothing searched: the staged uploads still have to land)
+    res->nmatches_motion = nm;
+    const int gC = std::max(1, (t->cap + 255) / 256);
+    uint8_t *dSkip = m->dU8b;
+    bool localRan = false;
+    if (nm >= 20) {
+        // ---- stage 3: PoseOptimization on the matches, outliers leave the frame
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, m->dKeys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dStart);
+        if ((rc = rumi::pose_opt_device(t->dStart, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, t->dTout, t->dOutC, t->dNGood, t->dActive, t->dChi, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dStart, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, t->dCounters);
+        HIP_TRY(hipMemcpyAsync(t->dMpMotion, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(t->dTout + 7, t->dTout, 7 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        // ---- stage 4: SearchLocalPoints with the optimised pose
+        hipLaunchKernelGGL(k_track_skip, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, t->dLocal, t->dSeen, t->dBad, dSkip);
+        hipLaunchKernelGGL(k_track_pose_matrices, dim3(1), dim3(64), 0, nullptr, t->dTout, m->dPose + 7, t->dPose19);
+        const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+        if (n16 * 21 > m->stageCap) { g_lastError = "rumi_track_frame: point table exceeds the staging block"; return RUMI_E_CAPACITY; }
+        uint8_t *dIn = m->dStage;
+        float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
+        int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
+        const float logSf = std::log(t->cfg.scale_factor);
+        hipLaunchKernelGGL(k_is_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, t->dPose19, fd.minX, fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f,
+                           m->dF[0], m->dF[1], m->dF[2], m->dF[3], dIn, dX, dY, dL, dC, dD, dSkip);
+        HIP_TRY(hipMemcpyAsync(t->dOut + 256 + (size_t)t->cap * 9, dIn, (size_t)nmp, hipMemcpyDeviceToDevice, nullptr));      // in_view, kept for the result block
+        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dIn, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
+                           far_points, th_far_points, m->dQ);
+        HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));
+        int nmLocal = 0;
+        if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
+        res->nmatches_local = nmLocal;
+        localRan = true;
+        // ---- stage 5: PoseOptimization on everything the frame now holds
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, m->dKeys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dStart);
+        if ((rc = rumi::pose_opt_device(t->dStart, t->dXw, t->dObs, t->dW, m->dPose + 7, t->dTout, t->dTout + 7, t->dOutC, t->dNGood + 1, t->dActive, t->dChi, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dStart, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dOutF, t->dCounters);
+    } else if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(t->dMpMotion, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
+    }
+    // ---- one block back: [poses 14 | pose matrices 19 | nGood 2 | counters 2 ...][mp after motion][mp][outlier][in_view]
+    const size_t C = t->cap, oA = 256, oB = oA + C * 4, oO = oB + C * 4, oV = oO + C;
+    HIP_TRY(hipMemcpyAsync(t->dOut, t->dTout, 14 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(t->dOut + 64, t->dPose19, 19 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(t->dOut + 160, t->dNGood, 8, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(t->dOut + 176, t->dCounters, 8, hipMemcpyDeviceToDevice, nullptr));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(t->dOut + oA, t->dMpMotion, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(t->dOut + oB, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(t->dOut + oO, t->dOutF, (size_t)n, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(keys_out, dKp, (size_t)n * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpyAsync(desc_out, dDs, (size_t)n * 32, hipMemcpyDeviceToHost, nullptr));
+    }
+    if (!localRan && nmp > 0) HIP_TRY(hipMemsetAsync(t->dOut + oV, 0, (size_t)nmp, nullptr));
+    HIP_TRY(hipMemcpy(t->hOut, t->dOut, oV + (size_t)nmp, hipMemcpyDeviceToHost));
+    const float *hp = reinterpret_cast<const float *>(t->hOut);
+    std::memcpy(res->Tcw_motion, hp, 28); std::memcpy(res->Tcw, hp + 7, 28);
+    const float *hm = reinterpret_cast<const float *>(t->hOut + 64);
+    std::memcpy(res->Rcw, hm, 36); std::memcpy(res->tcw, hm + 9, 12); std::memcpy(res->Ow, hm + 12, 12);
+    const int32_t *hg = reinterpret_cast<const int32_t *>(t->hOut + 160), *hc = reinterpret_cast<const int32_t *>(t->hOut + 176);
+    res->ngood_motion = hg[0]; res->ngood_local = hg[1]; res->nmatches_map = hc[0]; res->matches_inliers = hc[1];
+    if (n > 0) {
+        std::memcpy(frame_mp_motion, t->hOut + oA, (size_t)n * 4); std::memcpy(frame_mp, t->hOut + oB, (size_t)n * 4); std::memcpy(outlier, t->hOut + oO, (size_t)n);
+    }
+    if (nmp > 0) {
+        std::memcpy(in_view, t->hOut + oV, (size_t)nmp);
+        int nTo = 0;
+        for (int j = 0; j < nmp; j++) nTo += in_view[j];
+        res->n_to_match = nTo;
+    }
+    return RUMI_OK;
+}

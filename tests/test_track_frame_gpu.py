@@ -1,0 +1,134 @@
+"""rumi_track_frame (include/rumi_track.h): TrackWithMotionModel + TrackLocalMap data path in one device-resident call, against the ORACLE chain
+run stage by stage on the same inputs: extract -> SearchByProjection(Cur, Last) (retry at 2 th) -> PoseOptimization -> outliers leave the frame
+-> isInFrustum of the local points not seen in this frame -> SearchByProjection(Cur, local points) -> PoseOptimization.  Match indices, flags and
+counts must be identical, poses within 1e-4 relative.  The scene is the closed-loop plane sequence of test_tracking_loop_gpu.py; the map holds the
+frame-0 points (seen by the last frame) plus extra plane points only the local map knows, so the second search has something to add."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from rumi_slam_amd.synth import synth_frame, warp_homography
+from scene import K_TUM3
+from test_tracking_loop_gpu import PLANE_D, _homography, _pose_gt
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+W, H = 640, 480
+
+
+def _pose_close(T, Tref, what):
+    assert np.linalg.norm(T[:4] - Tref[:4]) <= RTOL and np.linalg.norm(T[4:] - Tref[4:]) <= RTOL * max(1e-2, np.linalg.norm(Tref[4:])), f"{what}: {T} vs {Tref}"
+
+
+def _pose_matrices(T):
+    """Frame::UpdatePoseMatrices in float32, operation by operation as k_track_pose_matrices / Eigen do it."""
+    f = np.float32
+    x, y, z, w = (f(v) for v in T[:4])
+    tx, ty, tz = f(2) * x, f(2) * y, f(2) * z
+    twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+    R = np.array([f(1) - (tyy + tzz), txy - twz, txz + twy, txy + twz, f(1) - (txx + tzz), tyz - twx, txz - twy, tyz + twx, f(1) - (txx + tyy)], np.float32)
+    t = np.array(T[4:], np.float32)
+    q = np.array([-x, -y, -z], np.float32); v = t * f(-1)
+    u = np.cross(q, v).astype(np.float32); u = u + u
+    c = np.cross(q, u).astype(np.float32)
+    return R, t, ((v + w * u) + c).astype(np.float32)
+
+
+def _oracle_step(orc, img, sf, inv_sigma2, T_pred, last, pts, th_local):
+    """The reference's sequence with the oracle's functions; returns everything rumi_track_frame reports."""
+    mono, keys, desc = orc.extract(img)
+    n = len(keys)
+    r = dict(n=n, mono_index=mono, keys=keys, desc=desc)
+    cur0 = np.full(n, -1, np.int32)
+    a = (keys, desc, W, H, sf, T_pred, K_TUM3, last["keys"], last["mp"], last["outlier"], pts["pos"], pts["desc"], pts["obs"], cur0)
+    th = 15.0
+    nm, cur = O.search_by_projection_frame(*a, th, True)
+    if nm < 20:
+        th = 30.0
+        nm, cur = O.search_by_projection_frame(*a, th, True)
+    r.update(th_motion=int(th), nmatches_motion=nm)
+    assert nm >= 20, "the scene is supposed to track"
+    idx = np.nonzero(cur >= 0)[0]
+    ng, T1, out = O.pose_optimization(pts["pos"][cur[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T_pred)
+    seen = np.zeros(len(pts["obs"]), np.uint8)
+    seen[cur[idx]] = 1
+    inl = idx[out == 0]
+    r.update(ngood_motion=ng, Tcw_motion=T1, nmatches_map=int((pts["obs"][cur[inl]] > 0).sum()))
+    cur[idx[out != 0]] = -1
+    cur[inl[pts["bad"][cur[inl]] != 0]] = -1
+    r["frame_mp_motion"] = cur.copy()
+    R, t, Ow = _pose_matrices(T1)
+    skip = ((pts["local"] == 0) | (seen != 0) | (pts["bad"] != 0)).astype(np.uint8)
+    log_sf = float(np.log(np.float32(1.2)))
+    fr = O.is_in_frustum(R, t, Ow, K_TUM3, W, H, log_sf, 8, 0.5, pts)
+    for k in fr:
+        fr[k] = np.where(skip != 0, np.array(-1 if k in ("proj_x", "proj_y") else 0, fr[k].dtype), fr[k])
+    r.update(in_view=fr["track_in_view"], n_to_match=int(fr["track_in_view"].sum()), Rcw=R, tcw=t, Ow=Ow)
+    nml, cur2 = O.search_by_projection_mappoints(keys, desc, W, H, sf, dict(fr, is_bad=skip, desc=pts["desc"], obs=pts["obs"]), cur, th_local, False, 0.0, 0.8)
+    idx2 = np.nonzero(cur2 >= 0)[0]
+    ng2, T2, out2 = O.pose_optimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)
+    outl = np.zeros(n, np.uint8)
+    outl[idx2] = out2
+    r.update(nmatches_local=nml, frame_mp=cur2, ngood_local=ng2, Tcw=T2, outlier=outl,
+             matches_inliers=int(((out2 == 0) & (pts["obs"][cur2[idx2]] > 0)).sum()))
+    return r
+
+
+@pytest.mark.parametrize("th_local", [1.0, 3.0])
+def test_track_frame_equals_oracle_chain(th_local):
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.tracker import Tracker
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    ext = ORBextractor(1000, 1.2, 8, 20, 7)
+    orc = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    sf, inv_sigma2 = ext.GetScaleFactors(), ext.GetInverseScaleSigmaSquares()
+    img0 = synth_frame(4242)
+    fx, fy, cx, cy = K_TUM3.astype(np.float64)
+    _, keys0, desc0 = ext(img0)
+    n0 = len(keys0)
+    rng = np.random.default_rng(7)
+    # map: the frame-0 points (half of them known to the last frame), all of them local; a few bad, a few never observed
+    pos = np.stack([(keys0["x"] - cx) / fx * PLANE_D, (keys0["y"] - cy) / fy * PLANE_D, np.full(n0, PLANE_D)], 1).astype(np.float32)
+    dist0 = np.linalg.norm(pos, axis=1).astype(np.float32)
+    lvl = keys0["octave"]
+    pts = dict(pos=pos, normal=(pos / dist0[:, None]).astype(np.float32),        # mean viewing direction: from the camera to the point
+               max_dist=(dist0 * sf[lvl]).astype(np.float32), min_dist=(dist0 * sf[lvl] / sf[7]).astype(np.float32), desc=desc0.copy(),
+               obs=np.where(rng.random(n0) < 0.05, 0, 1).astype(np.int32), bad=(rng.random(n0) < 0.03).astype(np.uint8), local=np.ones(n0, np.uint8))
+    known = rng.random(n0) < 0.5
+    last = dict(keys=keys0, mp=np.where(known, np.arange(n0), -1).astype(np.int32), outlier=np.zeros(n0, np.uint8))
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    for t in range(1, 6):
+        q_gt, t_gt = _pose_gt(t)
+        img = warp_homography(img0, _homography(q_gt, t_gt))
+        ref = _oracle_step(orc, img, sf, inv_sigma2, T, last, pts, th_local)
+        got = trk.track(img, K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts, 15.0, th_local)
+        assert got["n"] == ref["n"] and got["mono_index"] == ref["mono_index"] and got["keys"].tobytes() == ref["keys"].tobytes() \
+            and np.array_equal(got["desc"], ref["desc"]), f"frame {t}: extraction"
+        for k in ("th_motion", "nmatches_motion", "ngood_motion", "nmatches_map", "n_to_match", "nmatches_local", "ngood_local", "matches_inliers"):
+            assert got[k] == ref[k], f"frame {t}: {k} {got[k]} vs {ref[k]}"
+        for k in ("frame_mp_motion", "in_view", "frame_mp", "outlier"):
+            assert np.array_equal(got[k], ref[k]), f"frame {t}: {k}"
+        for k in ("Rcw", "tcw", "Ow"):
+            R, tt, Ow = _pose_matrices(got["Tcw_motion"])
+            assert np.array_equal(got[k], dict(Rcw=R, tcw=tt, Ow=Ow)[k]), f"frame {t}: {k} is not UpdatePoseMatrices of the device's pose"
+        _pose_close(got["Tcw_motion"], ref["Tcw_motion"], f"frame {t} pose after the motion model")
+        _pose_close(got["Tcw"], ref["Tcw"], f"frame {t} pose after the local map")
+        assert ref["nmatches_local"] > 50 and ref["matches_inliers"] > 100, "the local search is supposed to add matches"
+        # hand over: the frame becomes the last frame (mvpMapPoints with the outliers of the LAST optimisation still flagged, mono: Tracking.cc:2587)
+        last = dict(keys=got["keys"], mp=got["frame_mp"], outlier=got["outlier"])
+        T = got["Tcw"]
+
+
+def test_track_frame_lost_and_empty_inputs():
+    from rumi_slam_amd.tracker import Tracker
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 1024)
+    img = synth_frame(99)
+    none = dict(pos=np.zeros((0, 3), np.float32), normal=np.zeros((0, 3), np.float32), min_dist=np.zeros(0, np.float32), max_dist=np.zeros(0, np.float32),
+                desc=np.zeros((0, 32), np.uint8), obs=np.zeros(0, np.int32), bad=np.zeros(0, np.uint8), local=np.zeros(0, np.uint8))
+    from rumi_slam_amd.capi import KP_DTYPE
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    got = trk.track(img, K_TUM3, T, np.zeros(0, KP_DTYPE), np.zeros(0, np.int32), np.zeros(0, np.uint8), none)
+    assert got["n"] > 900 and got["nmatches_motion"] == 0 and got["ngood_motion"] == 0 and (got["frame_mp"] == -1).all() and np.array_equal(got["Tcw"], T)
+    orc = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    mono, keys, desc = orc.extract(img)
+    assert got["keys"].tobytes() == keys.tobytes() and np.array_equal(got["desc"], desc)
