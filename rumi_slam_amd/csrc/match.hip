@@ -1062,6 +1062,7 @@ struct RumiMatcher {
     uint8_t *hBowOut = nullptr, *dBowOut = nullptr; size_t bowOutCap = 0;
     // k_grid of the uploaded frame, launched by flush_uploads once the key-points are in place
     bool gridPending = false; int gridN = 0; float gridMinX = 0, gridMinY = 0, gridWInv = 0, gridHInv = 0;
+    const RumiKeyPoint *gridKeys = nullptr;      // key-points k_grid reads: dKeys, or a frame that already lies on the device (rumi_track_frame)
 };
 constexpr size_t kStageHeader = kMaxSegments * sizeof(Segment);
 
@@ -1165,7 +1166,7 @@ static int flush_uploads(RumiMatcher *m) {
         m->stageUsed = kStageHeader;
     }
     if (m->gridPending) {
-        hipLaunchKernelGGL(k_grid, dim3(1), dim3(1024), 0, nullptr, m->gridN, m->dKeys, m->gridMinX, m->gridMinY, m->gridWInv, m->gridHInv,
+        hipLaunchKernelGGL(k_grid, dim3(1), dim3(1024), 0, nullptr, m->gridN, m->gridKeys ? m->gridKeys : m->dKeys, m->gridMinX, m->gridMinY, m->gridWInv, m->gridHInv,
                            m->dSorted, m->dCellStart);
         m->gridPending = false;
     }
@@ -1191,7 +1192,7 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
     fd->wInv = (float)kGridCols / (float)(F->max_x - F->min_x);     // Frame.cc:322-323
     fd->hInv = (float)kGridRows / (float)(F->max_y - F->min_y);
     fd->sortedIdx = m->dSorted; fd->cellStart = m->dCellStart; fd->scale = m->dScale;
-    m->gridPending = true; m->gridN = F->n; m->gridMinX = fd->minX; m->gridMinY = fd->minY; m->gridWInv = fd->wInv; m->gridHInv = fd->hInv;
+    m->gridPending = true; m->gridKeys = nullptr; m->gridN = F->n; m->gridMinX = fd->minX; m->gridMinY = fd->minY; m->gridWInv = fd->wInv; m->gridHInv = fd->hInv;
     return RUMI_OK;
 }
 
@@ -1765,10 +1766,36 @@ extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const voi
 }
 
 // ==================================================================================================================
-// One device-resident Tracking step (include/rumi_track.h): the extractor's record, the matcher's frame arrays (key-points, descriptors, grid,
-// mvpMapPoints = dFeatMp) and the pose optimiser's correspondence arrays never leave HBM between the five stages.
+// One device-resident Tracking step (include/rumi_track.h): the extractor's record, the matcher's grid and map-point vector (mvpMapPoints =
+// dFeatMp) and the pose optimiser's correspondence arrays never leave HBM between the five stages.  A dispatch costs about 4.5 us on the
+// device whatever it does, so the step is built from as few as the data flow allows: no device-to-device copies (the matcher reads the
+// extractor's record in place, results are produced inside the block that travels back), fills and bookkeeping folded into neighbouring kernels.
 // ==================================================================================================================
 namespace rumi {
+
+constexpr int kTrackLdsEdges = 1024;     // = kPoseLdsEdges of opt.hip
+struct TrackBlock {                  // the result block's header, device and pinned host alike (arrays follow at byte offsets of RumiTracker)
+    float Tout[14];                  // pose after the motion model | after the local map
+    float pose19[20];                // Rcw9 tcw3 Ow3 K4 of the first (Frame::UpdatePoseMatrices)
+    int32_t nGood[2];                // PoseOptimization return values
+    int32_t counters[2];             // nmatchesMap, mnMatchesInliers
+    int32_t start[2];                // correspondences of the optimisation in flight: {0, count}
+    int32_t pad[2];
+};
+
+// fill(mvpMapPoints, NULL), cleared flags / counters, both poses = the prediction, result header of the search cleared
+__global__ void k_track_init(int n, int nmp, int full, int32_t *featMp, int32_t *searchHeader, uint8_t *seen, uint8_t *outF, int32_t *mpOut, const float *Tpred,
+                             TrackBlock *blk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { featMp[i] = -1; if (full) { outF[i] = 0; mpOut[i] = -1; } }
+    if (full && i < nmp) seen[i] = 0;
+    if (i < 4) searchHeader[i] = 0;
+    if (full && i == 0) {
+        for (int k = 0; k < 7; k++) { blk->Tout[k] = Tpred[k]; blk->Tout[7 + k] = Tpred[k]; }
+        for (int k = 0; k < 20; k++) blk->pose19[k] = 0.f;
+        blk->nGood[0] = blk->nGood[1] = 0; blk->counters[0] = blk->counters[1] = 0; blk->start[0] = blk->start[1] = 0;
+    }
+}
 
 // Correspondences of Optimizer::PoseOptimization(Frame*) (Optimizer.cc:749-815, mono): the features with a map point, in feature order.
 // One workgroup, ordered compaction (ballot + wave offsets through LDS, chunks of 1024 features).
@@ -1803,51 +1830,91 @@ __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint
 
 // After the first PoseOptimization (Tracking.cc:2489-2508) and the first loop of SearchLocalPoints (:2998-3010): every point the motion search
 // matched has been seen in this frame (inliers by SearchLocalPoints, outliers by the discard loop); outliers and bad points leave the frame.
-__global__ void k_track_after_motion(const int32_t *start, const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs,
-                                     const uint8_t *mpBad, uint8_t *seen, int32_t *counters /* [0] nmatchesMap */) {
+// Thread 0 also derives Frame::UpdatePoseMatrices (Frame.cc:522-528) of the optimised pose in Sophus' / Eigen's float arithmetic: Rcw =
+// q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw) (quaternion _transformVector), as [Rcw9 | tcw3 | Ow3 | K4] for k_is_in_frustum.
+__global__ void k_track_after_motion(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, const uint8_t *mpBad, uint8_t *seen,
+                                     const float *K4, TrackBlock *blk) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= start[1]) return;
+    if (c == 0) {
+        const float *Tcw7 = blk->Tout;
+        float *pose19 = blk->pose19;
+        const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
+        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+        const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        pose19[0] = 1.f - (tyy + tzz); pose19[1] = txy - twz; pose19[2] = txz + twy;
+        pose19[3] = txy + twz; pose19[4] = 1.f - (txx + tzz); pose19[5] = tyz - twx;
+        pose19[6] = txz - twy; pose19[7] = tyz + twx; pose19[8] = 1.f - (txx + tyy);
+        const float t0 = Tcw7[4], t1 = Tcw7[5], t2 = Tcw7[6];
+        pose19[9] = t0; pose19[10] = t1; pose19[11] = t2;
+        const float qx = -x, qy = -y, qz = -z, v0 = t0 * -1.f, v1 = t1 * -1.f, v2 = t2 * -1.f;
+        float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+        u0 += u0; u1 += u1; u2 += u2;
+        const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+        pose19[12] = (v0 + w * u0) + c0; pose19[13] = (v1 + w * u1) + c1; pose19[14] = (v2 + w * u2) + c2;
+        pose19[15] = K4[0]; pose19[16] = K4[1]; pose19[17] = K4[2]; pose19[18] = K4[3];
+    }
+    if (c >= blk->start[1]) return;
     const int i = idx[c], mp = featMp[i];
     seen[mp] = 1;
     if (outlierC[c]) { featMp[i] = -1; return; }
-    if (mpObs[mp] > 0) atomicAdd(&counters[0], 1);
+    if (mpObs[mp] > 0) atomicAdd(&blk->counters[0], 1);
     if (mpBad[mp]) featMp[i] = -1;
 }
 
-// skip flag of SearchLocalPoints' second loop: not a local map point, seen in this frame, or bad
-__global__ void k_track_skip(int nmp, const uint8_t *local, const uint8_t *seen, const uint8_t *bad, uint8_t *skip) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nmp) skip[j] = !local[j] || seen[j] || bad[j];
+// Frame::isInFrustum of the local points SearchLocalPoints' second loop evaluates (not seen in this frame, not bad), writing the skip flag the query
+// builder reads as isBad; also clears the search's result header and keeps a copy of the frame's map-point vector
+__global__ void k_track_frustum(int nmp, int n, const int32_t *featMp, int32_t *mpMotion, const uint8_t *local, const uint8_t *seen, const uint8_t *bad, uint8_t *skip,
+                                int32_t *searchHeader, const float *pose, float minX,
+                                float minY, float maxX, float maxY, float logScaleFactor, int nLevels, float viewingCosLimit, const float *mpPos, const float *mpNormal,
+                                const float *mpMinDist, const float *mpMaxDist, uint8_t *inView, float *projX, float *projY, int32_t *scaleLevel, float *viewCosOut,
+                                float *trackDepth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) searchHeader[i] = 0;
+    if (i < n) mpMotion[i] = featMp[i];                    // mvpMapPoints as TrackWithMotionModel leaves them (the local search may replace unobserved points)
+    if (i >= nmp) return;
+    const uint8_t sk = !local[i] || seen[i] || bad[i];
+    skip[i] = sk;
+    if (sk) { inView[i] = 0; projX[i] = -1; projY[i] = -1; scaleLevel[i] = 0; viewCosOut[i] = 0; trackDepth[i] = 0; return; }
+    const float *R = pose, *t = pose + 9, *Ow = pose + 12, *K = pose + 15;
+    const float *P = mpPos + (size_t)i * 3;
+    uint8_t in = 0;
+    float px = -1, py = -1, vc = 0, depth = 0;
+    int lvl = 0;
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Pc[r] = ((R[r * 3] * P[0] + R[r * 3 + 1] * P[1]) + R[r * 3 + 2] * P[2]) + t[r];
+    const float Pc_dist = sqrtf((Pc[0] * Pc[0] + Pc[1] * Pc[1]) + Pc[2] * Pc[2]);
+    if (!(Pc[2] < 0.0f)) {
+        const float u = K[0] * Pc[0] / Pc[2] + K[2], v = K[1] * Pc[1] / Pc[2] + K[3];
+        if (!(u < minX || u > maxX) && !(v < minY || v > maxY)) {
+            px = u; py = v;
+            const float maxD = 1.2f * mpMaxDist[i], minD = 0.8f * mpMinDist[i];
+            const float P0 = P[0] - Ow[0], P1 = P[1] - Ow[1], P2 = P[2] - Ow[2];
+            const float dist = sqrtf((P0 * P0 + P1 * P1) + P2 * P2);
+            if (!(dist < minD || dist > maxD)) {
+                const float *Pn = mpNormal + (size_t)i * 3;
+                const float viewCos = ((P0 * Pn[0] + P1 * Pn[1]) + P2 * Pn[2]) / dist;
+                if (!(viewCos < viewingCosLimit)) {
+                    lvl = predict_scale(mpMaxDist[i], dist, logScaleFactor, nLevels);
+                    in = 1; depth = Pc_dist; vc = viewCos;
+                }
+            }
+        }
+    }
+    inView[i] = in; projX[i] = px; projY[i] = py; scaleLevel[i] = lvl; viewCosOut[i] = vc; trackDepth[i] = depth;
 }
 
-// Frame::UpdatePoseMatrices (Frame.cc:522-528) in Sophus' / Eigen's float arithmetic: Rcw = q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw)
-// (quaternion _transformVector); written as [Rcw9 | tcw3 | Ow3 | K4] for k_is_in_frustum
-__global__ void k_track_pose_matrices(const float *Tcw7, const float *K4, float *pose19) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
-    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
-    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    pose19[0] = 1.f - (tyy + tzz); pose19[1] = txy - twz; pose19[2] = txz + twy;
-    pose19[3] = txy + twz; pose19[4] = 1.f - (txx + tzz); pose19[5] = tyz - twx;
-    pose19[6] = txz - twy; pose19[7] = tyz + twx; pose19[8] = 1.f - (txx + tyy);
-    const float t0 = Tcw7[4], t1 = Tcw7[5], t2 = Tcw7[6];
-    pose19[9] = t0; pose19[10] = t1; pose19[11] = t2;
-    const float qx = -x, qy = -y, qz = -z, v0 = t0 * -1.f, v1 = t1 * -1.f, v2 = t2 * -1.f;
-    float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
-    u0 += u0; u1 += u1; u2 += u2;
-    const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
-    pose19[12] = (v0 + w * u0) + c0; pose19[13] = (v1 + w * u1) + c1; pose19[14] = (v2 + w * u2) + c2;
-    pose19[15] = K4[0]; pose19[16] = K4[1]; pose19[17] = K4[2]; pose19[18] = K4[3];
-}
-
-// after the second PoseOptimization: mvbOutlier per feature and mnMatchesInliers (Tracking.cc:2573-2586)
-__global__ void k_track_finish(const int32_t *start, const int32_t *idx, const uint8_t *outlierC, const int32_t *featMp, const int32_t *mpObs,
-                               uint8_t *outlierF, int32_t *counters /* [1] mnMatchesInliers */) {
+// after the last PoseOptimization: mvpMapPoints and mvbOutlier per feature into the result block, mnMatchesInliers (Tracking.cc:2573-2586)
+__global__ void k_track_finish(const int32_t *idx, const uint8_t *outlierC, const int32_t *featMp, const int32_t *mpObs, uint8_t *outlierF, int32_t *mpOut,
+                               int countInliers, TrackBlock *blk) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= start[1]) return;
+    if (c >= blk->start[1]) return;
     const int i = idx[c];
-    outlierF[i] = outlierC[c];
-    if (!outlierC[c] && mpObs[featMp[i]] > 0) atomicAdd(&counters[1], 1);
+    mpOut[i] = featMp[i];
+    if (countInliers) {
+        outlierF[i] = outlierC[c];
+        if (!outlierC[c] && mpObs[featMp[i]] > 0) atomicAdd(&blk->counters[1], 1);
+    }
 }
 
 }  // namespace rumi
@@ -1862,12 +1929,12 @@ struct RumiTracker {
     RumiOrb *ext = nullptr;
     RumiMatcher *m = nullptr;
     uint8_t *dImage = nullptr; size_t imageBytes = 0;
-    uint8_t *dRecord = nullptr; size_t recordBytes = 0;
-    float *dInvSigma2 = nullptr, *dXw = nullptr, *dObs = nullptr, *dW = nullptr, *dPose19 = nullptr, *dTout = nullptr;   // dTout: [motion 7 | local 7]
-    int32_t *dIdx = nullptr, *dStart = nullptr, *dNGood = nullptr, *dCounters = nullptr, *dMpMotion = nullptr;
-    uint8_t *dOutC = nullptr, *dOutF = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr;
+    // ONE device block [TrackBlock | mp cap*4 | mp after the motion model cap*4 | outlier cap | in_view maxPts | record 8 + 60 cap] and its pinned mirror: one copy brings a frame's results back
+    uint8_t *dBlk = nullptr, *hBlk = nullptr; size_t oMp = 0, oMpM = 0, oOut = 0, oView = 0, oRec = 0, blkBytes = 0, recordBytes = 0;
+    float *dInvSigma2 = nullptr, *dXw = nullptr, *dObs = nullptr, *dW = nullptr;
+    int32_t *dIdx = nullptr;
+    uint8_t *dOutC = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr;
     double *dChi = nullptr;
-    uint8_t *hOut = nullptr, *dOut = nullptr; size_t outBytes = 0;      // result block: one copy back
     float scale[64] = {0};
 };
 
@@ -1876,10 +1943,9 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     (void)hipSetDevice(t->device);
     rumi_orb_destroy(t->ext);
     rumi_match_destroy(t->m);
-    void *p[] = {t->dImage, t->dRecord, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dPose19, t->dTout, t->dIdx, t->dStart, t->dNGood, t->dCounters,
-                 t->dMpMotion, t->dOutC, t->dOutF, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dOut};
+    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi};
     for (void *q : p) if (q) (void)hipFree(q);
-    if (t->hOut) (void)hipHostFree(t->hOut);
+    if (t->hBlk) (void)hipHostFree(t->hBlk);
     delete t;
 }
 
@@ -1897,17 +1963,16 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
     if (rc != RUMI_OK) { rumi_track_destroy(t); return rc; }
     t->device = t->m->device;
     const size_t C = t->cap, P = max_points;
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     t->imageBytes = (size_t)((cfg->max_width + 3) & ~3) * cfg->max_height;
     t->recordBytes = 8 + 60 * C;
-    t->outBytes = 256 + C * 4 * 2 + C + P + 64;
+    t->oMp = al(sizeof(TrackBlock)); t->oMpM = al(t->oMp + C * 4); t->oOut = al(t->oMpM + C * 4); t->oView = al(t->oOut + C); t->oRec = al(t->oView + P); t->blkBytes = al(t->oRec + t->recordBytes);
 #define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_track_destroy(t); return rc; }
-    TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dRecord, t->recordBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
-    TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dPose19, 32)); TRYA(dalloc(&t->dTout, 16));
-    TRYA(dalloc(&t->dIdx, C)); TRYA(dalloc(&t->dStart, 4)); TRYA(dalloc(&t->dNGood, 4)); TRYA(dalloc(&t->dCounters, 4)); TRYA(dalloc(&t->dMpMotion, C));
-    TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dOutF, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P));
-    TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C)); TRYA(dalloc(&t->dOut, t->outBytes));
+    TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dBlk, t->blkBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
+    TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dIdx, C));
+    TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C));
 #undef TRYA
-    if (hipHostMalloc((void **)&t->hOut, t->outBytes, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
+    if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
     float inv2[64] = {0};
     rumi_orb_tables(cfg, t->scale, nullptr, nullptr, inv2, nullptr, nullptr);
     if (hipMemcpy(t->dInvSigma2, inv2, sizeof(inv2), hipMemcpyHostToDevice) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
@@ -1933,27 +1998,31 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     HIP_TRY(hipSetDevice(t->device));
     std::memset(res, 0, sizeof(*res));
     res->mono_index = -1; res->th_motion = (int32_t)th_motion;
+    TrackBlock *dB = reinterpret_cast<TrackBlock *>(t->dBlk);
+    int32_t *dMpOut = reinterpret_cast<int32_t *>(t->dBlk + t->oMp), *dMpMotion = reinterpret_cast<int32_t *>(t->dBlk + t->oMpM);
+    uint8_t *dOutF = t->dBlk + t->oOut, *dView = t->dBlk + t->oView, *dRecord = t->dBlk + t->oRec;
 
     // ---- stage 1: ORBextractor::operator() on the device; only the two counts come back (launch sizes need n)
     const int wp = (w + 3) & ~3;
     HIP_TRY(hipMemcpy2DAsync(t->dImage, wp, img, stride, w, h, hipMemcpyHostToDevice, nullptr));
-    int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, t->dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
+    int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
     int32_t counts[2] = {0, -1};
-    HIP_TRY(hipMemcpy(counts, t->dRecord, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
     if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
     const int n = counts[0];
     res->n = n; res->mono_index = counts[1];
-    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(t->dRecord + 8);
-    const uint8_t *dDs = t->dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
+    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
+    const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
 
-    // ---- uploads of the whole step: one pinned block, one copy, scattered on the device
+    // ---- uploads of the whole step: one pinned block, one copy, scattered on the device; the frame itself is read where the extractor left it
     RumiFrameFeatures F{};
-    F.n = 0;                                                   // key-points / descriptors are already on the device: nothing of the frame is staged
+    F.n = 0;
     F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)w; F.max_y = (float)h;
     FrameDev fd;
     if ((rc = upload_frame(m, &F, &fd)) != RUMI_OK) return rc;
-    fd.n = n; m->gridN = n;
+    fd.n = n; fd.keys = dKp; fd.desc = dDs;
+    m->gridN = n; m->gridKeys = dKp;
     float pose[11];
     std::memcpy(pose, Tcw_pred7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
     H2D(m->dPose, pose, 11);
@@ -1962,99 +2031,71 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
     }
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(m->dKeys, dKp, (size_t)n * sizeof(RumiKeyPoint), hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(m->dDesc, dDs, (size_t)n * 32, hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemsetAsync(m->dFeatMp, 0xFF, (size_t)n * 4, nullptr));                 // fill(mvpMapPoints, NULL)   (Tracking.cc:2458)
-    }
-    HIP_TRY(hipMemsetAsync(t->dCounters, 0, 16, nullptr));
-    HIP_TRY(hipMemsetAsync(t->dNGood, 0, 16, nullptr));
-    if (nmp > 0) HIP_TRY(hipMemsetAsync(t->dSeen, 0, (size_t)nmp, nullptr));
-    if (n > 0) { HIP_TRY(hipMemsetAsync(t->dOutF, 0, (size_t)n, nullptr)); }
-    // the poses default to the prediction (PoseOptimization not reached / fewer than 3 correspondences)
-    HIP_TRY(hipMemcpyAsync(t->dTout, Tcw_pred7, 7 * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(t->dTout + 7, Tcw_pred7, 7 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    FLUSH(m);
+    const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
+    hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
 
     // ---- stage 2: SearchByProjection(Cur, Last, th, mono), once more with 2 * th below 20 matches (Tracking.cc:2466-2474)
     int nm = 0;
     std::vector<int32_t> tmpMp((size_t)std::max(n, 1));
     for (int attempt = 0; attempt < 2 && n > 0 && nlast > 0 && nmp > 0; attempt++) {
         const float th = attempt == 0 ? th_motion : 2 * th_motion;
-        if (attempt == 1) { HIP_TRY(hipMemsetAsync(m->dFeatMp, 0xFF, (size_t)n * 4, nullptr)); HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr)); }
-        FLUSH(m);
+        if (attempt == 1) hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 0, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
         hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
                            m->dPose + 7, m->dScale, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
         if ((rc = run_search(m, MODE_FRAME, nlast, fd, m->dQDesc, m->dI[1], 0.f, 1, tmpMp.data(), &nm)) != RUMI_OK) return rc;
         res->th_motion = (int32_t)th;
         if (nm >= 20) break;
     }
-    FLUSH(m);                                                  // (nothing searched: the staged uploads still have to land)
     res->nmatches_motion = nm;
-    const int gC = std::max(1, (t->cap + 255) / 256);
-    uint8_t *dSkip = m->dU8b;
+    const bool small = n <= kTrackLdsEdges;                    // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
     bool localRan = false;
     if (nm >= 20) {
         // ---- stage 3: PoseOptimization on the matches, outliers leave the frame
-        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, m->dKeys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dStart);
-        if ((rc = rumi::pose_opt_device(t->dStart, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, t->dTout, t->dOutC, t->dNGood, t->dActive, t->dChi, nullptr)) != RUMI_OK) return rc;
-        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dStart, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, t->dCounters);
-        HIP_TRY(hipMemcpyAsync(t->dMpMotion, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(t->dTout + 7, t->dTout, 7 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB);
         // ---- stage 4: SearchLocalPoints with the optimised pose
-        hipLaunchKernelGGL(k_track_skip, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, t->dLocal, t->dSeen, t->dBad, dSkip);
-        hipLaunchKernelGGL(k_track_pose_matrices, dim3(1), dim3(64), 0, nullptr, t->dTout, m->dPose + 7, t->dPose19);
         const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
         if (n16 * 21 > m->stageCap) { g_lastError = "rumi_track_frame: point table exceeds the staging block"; return RUMI_E_CAPACITY; }
-        uint8_t *dIn = m->dStage;
+        uint8_t *dSkip = m->dU8b;
         float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         const float logSf = std::log(t->cfg.scale_factor);
-        hipLaunchKernelGGL(k_is_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, t->dPose19, fd.minX, fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f,
-                           m->dF[0], m->dF[1], m->dF[2], m->dF[3], dIn, dX, dY, dL, dC, dD, dSkip);
-        HIP_TRY(hipMemcpyAsync(t->dOut + 256 + (size_t)t->cap * 9, dIn, (size_t)nmp, hipMemcpyDeviceToDevice, nullptr));      // in_view, kept for the result block
-        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dIn, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
+        hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
+        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
                            far_points, th_far_points, m->dQ);
-        HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));
         int nmLocal = 0;
         if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
         res->nmatches_local = nmLocal;
         localRan = true;
         // ---- stage 5: PoseOptimization on everything the frame now holds
-        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, m->dKeys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dStart);
-        if ((rc = rumi::pose_opt_device(t->dStart, t->dXw, t->dObs, t->dW, m->dPose + 7, t->dTout, t->dTout + 7, t->dOutC, t->dNGood + 1, t->dActive, t->dChi, nullptr)) != RUMI_OK) return rc;
-        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dStart, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dOutF, t->dCounters);
-    } else if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(t->dMpMotion, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB);
+    } else if (nm > 0) {                                       // fewer than 20 matches: the frame keeps them (the caller falls back to TrackReferenceKeyFrame)
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 0, dB);
     }
-    // ---- one block back: [poses 14 | pose matrices 19 | nGood 2 | counters 2 ...][mp after motion][mp][outlier][in_view]
-    const size_t C = t->cap, oA = 256, oB = oA + C * 4, oO = oB + C * 4, oV = oO + C;
-    HIP_TRY(hipMemcpyAsync(t->dOut, t->dTout, 14 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(t->dOut + 64, t->dPose19, 19 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(t->dOut + 160, t->dNGood, 8, hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(t->dOut + 176, t->dCounters, 8, hipMemcpyDeviceToDevice, nullptr));
+    // ---- one copy back: header, mvpMapPoints, mvbOutlier, mbTrackInView and the extractor's record
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint) + (size_t)n * 32, hipMemcpyDeviceToHost));
+    const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
+    std::memcpy(res->Tcw_motion, hB->Tout, 28); std::memcpy(res->Tcw, hB->Tout + 7, 28);
+    std::memcpy(res->Rcw, hB->pose19, 36); std::memcpy(res->tcw, hB->pose19 + 9, 12); std::memcpy(res->Ow, hB->pose19 + 12, 12);
+    res->ngood_motion = hB->nGood[0]; res->ngood_local = hB->nGood[1]; res->nmatches_map = hB->counters[0]; res->matches_inliers = hB->counters[1];
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(t->dOut + oA, t->dMpMotion, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(t->dOut + oB, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(t->dOut + oO, t->dOutF, (size_t)n, hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(keys_out, dKp, (size_t)n * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(desc_out, dDs, (size_t)n * 32, hipMemcpyDeviceToHost, nullptr));
+        std::memcpy(frame_mp, t->hBlk + t->oMp, (size_t)n * 4); std::memcpy(outlier, t->hBlk + t->oOut, (size_t)n);
+        std::memcpy(keys_out, t->hBlk + t->oRec + 8, (size_t)n * sizeof(RumiKeyPoint));
+        std::memcpy(desc_out, t->hBlk + t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), (size_t)n * 32);
     }
-    if (!localRan && nmp > 0) HIP_TRY(hipMemsetAsync(t->dOut + oV, 0, (size_t)nmp, nullptr));
-    HIP_TRY(hipMemcpy(t->hOut, t->dOut, oV + (size_t)nmp, hipMemcpyDeviceToHost));
-    const float *hp = reinterpret_cast<const float *>(t->hOut);
-    std::memcpy(res->Tcw_motion, hp, 28); std::memcpy(res->Tcw, hp + 7, 28);
-    const float *hm = reinterpret_cast<const float *>(t->hOut + 64);
-    std::memcpy(res->Rcw, hm, 36); std::memcpy(res->tcw, hm + 9, 12); std::memcpy(res->Ow, hm + 12, 12);
-    const int32_t *hg = reinterpret_cast<const int32_t *>(t->hOut + 160), *hc = reinterpret_cast<const int32_t *>(t->hOut + 176);
-    res->ngood_motion = hg[0]; res->ngood_local = hg[1]; res->nmatches_map = hc[0]; res->matches_inliers = hc[1];
-    if (n > 0) {
-        std::memcpy(frame_mp_motion, t->hOut + oA, (size_t)n * 4); std::memcpy(frame_mp, t->hOut + oB, (size_t)n * 4); std::memcpy(outlier, t->hOut + oO, (size_t)n);
-    }
+    int nTo = 0;
     if (nmp > 0) {
-        std::memcpy(in_view, t->hOut + oV, (size_t)nmp);
-        int nTo = 0;
+        if (localRan) std::memcpy(in_view, t->hBlk + t->oView, (size_t)nmp); else std::memset(in_view, 0, (size_t)nmp);
         for (int j = 0; j < nmp; j++) nTo += in_view[j];
-        res->n_to_match = nTo;
     }
+    res->n_to_match = nTo;
+    if (n > 0) std::memcpy(frame_mp_motion, localRan ? t->hBlk + t->oMpM : t->hBlk + t->oMp, (size_t)n * 4);
     return RUMI_OK;
 }

@@ -1987,11 +1987,11 @@ extern "C" int rumi_opt_stage_ms(RumiOptimizer *o, float ms[8]) {
 
 namespace rumi {
 int pose_opt_device(const int32_t *dStart, const float *dXw, const float *dObs, const float *dW, const float *dK4, const float *dTin, float *dTout,
-                    uint8_t *dOutlier, int32_t *dNGood, uint8_t *dActive, double *dLastChi2, hipStream_t st) {
+                    uint8_t *dOutlier, int32_t *dNGood, uint8_t *dActive, double *dLastChi2, bool fitsLds, hipStream_t st) {
     const PoseArgs A{dStart, dXw, dObs, dW, dK4, dTin, dTout, dOutlier, dNGood, dActive, dLastChi2, 1};
     // the frame's size is known to the device only: both instantiations are launched, the one the size does not belong to returns at once
     hipLaunchKernelGGL((k_pose_opt<true, 256>), dim3(1), dim3(256), 0, st, A);
-    hipLaunchKernelGGL((k_pose_opt<false, 256>), dim3(1), dim3(256), 0, st, A);
+    if (!fitsLds) hipLaunchKernelGGL((k_pose_opt<false, 256>), dim3(1), dim3(256), 0, st, A);
     return hipGetLastError() == hipSuccess ? RUMI_OK : RUMI_E_NO_DEVICE;
 }
 }  // namespace rumi
