@@ -60,6 +60,23 @@ int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t 
                   int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
                   const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats);
 
+/* R independent windows of Optimizer::LocalBundleAdjustment (Optimizer.cc:1003-1355) in one call.  A window does not shard over GPUs or
+ * workgroups ("replicas only"), but windows are independent: n_workers host threads, each with its own child handle
+ * (stream + arenas, created on the first call and kept by `o`), take the windows from a shared counter, so the kernels of one window run while
+ * another window's thread waits for the scalars of its LM trial.  Per window: the arguments of rumi_local_ba, stats[4] and the status of its
+ * own run.  Returns the worst status. */
+typedef struct RumiBaWindow {
+    int32_t n_kf; float *kf_pose7; const uint8_t *kf_fixed;
+    int32_t n_mp; float *mp_pos3;
+    int32_t n_edges; const int32_t *e_mp, *e_kf; const float *e_obs, *e_inv_sigma2;
+    const float *K4;
+    const volatile uint8_t *stop_flag;
+    uint8_t *erase_out;
+    int32_t stats[4];
+    int32_t status;
+} RumiBaWindow;
+int rumi_local_ba_batch(RumiOptimizer *o, int32_t n_windows, RumiBaWindow *windows, int32_t n_workers);
+
 /* Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vector<KeyFrame*> vpAdjustKF, vector<KeyFrame*> vpFixedKF, bool *pbStopFlag)
  * — the merge / welding-window bundle adjustment, R/lib_src/Optimizer.cc:3768-4183 (LoopClosing::MergeLocal, CloudMerging),
  * monocular edges.  Same flattened graph and the same outputs as rumi_local_ba; what differs is the procedure: optimize(5) with

@@ -20,7 +20,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1883,6 +1885,9 @@ struct RumiOptimizer {
     double *hScal = nullptr;         // fine-grained pinned: [0..7] the trial's scalars, [8] sequence number of the last publication (k_ba_publish)
     double *dhScal = nullptr;        // the same memory as the device sees it
     unsigned long long pubSeq = 0;
+    hipStream_t stream = nullptr;    // bundle adjustments of this handle (created non-blocking)
+    std::vector<RumiOptimizer *> workers;   // rumi_local_ba_batch: one child handle per worker thread, created on first use
+    int maxKFc = 0, maxMPc = 0, maxEc = 0;   // creation arguments (children are created alike)
     uint8_t *hPose = nullptr, *hPoseOut = nullptr, *dPoseIn = nullptr, *dPoseOut = nullptr;   // PoseOptimization transfer blocks
     uint8_t *hBa = nullptr, *dBa = nullptr, *dBaOut = nullptr; size_t baStageCap = 0;            // bundle-adjustment transfer blocks
     std::vector<int32_t> hFill;                                                                  // counting-sort cursors of ba_run
@@ -1904,6 +1909,9 @@ template <class T> static int oalloc(T **p, size_t n) {
 extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     if (!o) return;
     (void)hipSetDevice(o->device);
+    for (RumiOptimizer *w : o->workers) rumi_opt_destroy(w);
+    o->workers.clear();
+    if (o->stream) (void)hipStreamDestroy(o->stream);
     void *p[] = {o->dActive, o->dLastChi2, o->dT[0], o->dT[1], o->dX[0],
                  o->dX[1], o->dHll, o->dBl, o->dHpl, o->dPanel, o->dHpp, o->dBp, o->dDinv, o->dS, o->dBs, o->dXv, o->dChi, o->dScal,
                  o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW, o->dColOf};
@@ -1932,6 +1940,7 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     if (device >= 0) o->device = device; else if (hipGetDevice(&o->device) != hipSuccess) o->device = 0;
     if (hipSetDevice(o->device) != hipSuccess) { delete o; return RUMI_E_NO_DEVICE; }
     o->maxPoseEdges = max_pose_edges; o->maxPoseBatch = max_pose_batch; o->maxKF = max_kf; o->maxMP = max_mp; o->maxE = max_edges;
+    if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) { delete o; return RUMI_E_NO_DEVICE; }
     const size_t PE = max_pose_edges, PB = max_pose_batch, K = max_kf, M = max_mp, E = max_edges, N = 6 * K;
     int rc;
 #define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_opt_destroy(o); return rc; }
@@ -2059,6 +2068,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     if (nFixed == 0 && mode == 0) { g_lastError = "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"; return RUMI_E_INVALID; }   // Optimizer.cc:1057-1060
     if (mode != 2 && stop_flag && *stop_flag) { if (stats) stats[3] = 1; return RUMI_OK; }                                         // :1274-1276 / :3982-3984
     HIP_TRY(hipSetDevice(o->device));
+    // everything of a bundle adjustment runs on the handle's own (non-blocking) stream: handles on different host threads overlap on the device
+    // (rumi_local_ba_batch; Tracking / LocalMapping / LoopClosing threads with their thread-local arenas)
+    hipStream_t st = o->stream;
     static const bool hostDbg = std::getenv("RUMI_HOSTDBG") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tA = now();
@@ -2111,10 +2123,10 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         for (size_t i = 0; i < (size_t)nMP * 3; i++) X0[i] = mp_pos3[i];
     }
     const double tB = now();
-    HIP_TRY(hipMemcpyAsync(o->dBa, hs, partA, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(o->dT[0], o->dBa + oT, (size_t)nKF * 64, hipMemcpyDeviceToDevice, nullptr));
-    if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dX[0], o->dBa + oX, (size_t)nMP * 24, hipMemcpyDeviceToDevice, nullptr));
-    if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, nullptr));
+    HIP_TRY(hipMemcpyAsync(o->dBa, hs, partA, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->dT[0], o->dBa + oT, (size_t)nKF * 64, hipMemcpyDeviceToDevice, st));
+    if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dX[0], o->dBa + oX, (size_t)nMP * 24, hipMemcpyDeviceToDevice, st));
+    if (nE > 0) HIP_TRY(hipMemsetAsync(o->dEOff, 0, (size_t)nE, st));
     const double tC = now();
     // part B, pass 2: prefix sums, then every edge into its landmark's list and its key-frame's rows (stable: input order inside a group)
     for (int p2 = 0; p2 < nMP; p2++) ptStart[p2 + 1] += ptStart[p2];
@@ -2132,7 +2144,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             rowSlot[e] = slot;
         }
     }
-    HIP_TRY(hipMemcpyAsync(o->dBa + partA, hs + partA, upBytes - partA, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(o->dBa + partA, hs + partA, upBytes - partA, hipMemcpyHostToDevice, st));
     const double tD = now();
     BADev B{};
     B.nKF = nKF; B.nMP = nMP; B.nE = nE; B.nOpt = nOpt; B.n = n;
@@ -2197,8 +2209,9 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             o->pairCap = need + need / 4;
         }
         o->pairOff = blk.size();
-        if (!blk.empty()) HIP_TRY(hipMemcpy(o->dPairs, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(o->dPairs + blk.size(), pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!blk.empty()) HIP_TRY(hipMemcpyAsync(o->dPairs, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(o->dPairs + blk.size(), pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                 // blk / pairs are temporaries
         if (!o->dW) { int rcw = oalloc(&o->dW, (size_t)o->maxE * 18); if (rcw == RUMI_OK) rcw = oalloc(&o->dColOf, (size_t)o->maxE); if (rcw != RUMI_OK) return rcw; }
         if ((size_t)n * 8 > 16 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, n * 8));
@@ -2215,7 +2228,6 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     if (useLds && ldsSolve > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
     const int nSlices = 64;
-    hipStream_t st = nullptr;
     // the eight scalars of o->dScal -> o->hScal, without a runtime synchronisation (see k_ba_publish); falls back to one if the stream has
     // drained without the number arriving (a failed launch)
     auto fetch_scalars = [&]() -> int {
@@ -2226,7 +2238,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         for (unsigned spin = 0; *flag != seq; spin++) {
             if ((spin & 0xFFFF) == 0xFFFF && hipStreamQuery(st) != hipErrorNotReady) {
                 HIP_TRY(hipStreamSynchronize(st));
-                if (*flag != seq) { HIP_TRY(hipMemcpy(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost)); break; }
+                if (*flag != seq) { HIP_TRY(hipMemcpyAsync(o->hScal, o->dScal, 8 * sizeof(double), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); break; }
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -2381,7 +2393,8 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     HIP_TRY(hipMemcpyAsync(o->dBaOut + rT, o->dT[cur], (size_t)nKF * 64, hipMemcpyDeviceToDevice, st));
     if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rX, o->dX[cur], (size_t)nMP * 24, hipMemcpyDeviceToDevice, st));
     if (nE > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rE, o->dErase, (size_t)nE, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpy(o->hBa, o->dBaOut, dnBytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(o->hBa, o->dBaOut, dnBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     const double *T1 = reinterpret_cast<const double *>(o->hBa + rT), *X1 = reinterpret_cast<const double *>(o->hBa + rX);
     if (nE > 0) std::memcpy(erase_out, o->hBa + rE, (size_t)nE);
     HIP_TRY(hipEventElapsedTime(&o->stageMs[5], o->ev[0], o->ev[1]));
@@ -2400,6 +2413,36 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
                              int32_t nE, const int32_t *e_mp, const int32_t *e_kf, const float *e_obs, const float *e_inv_sigma2,
                              const float *K4, const volatile uint8_t *stop_flag, uint8_t *erase_out, int32_t *stats) {
     return ba_run(o, 0, nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats);
+}
+
+// R independent local windows (the only multi-window form local BA has: a window does not shard).  n_workers host threads, each
+// with a child handle of its own (own stream, own arenas, created on first use and kept), take the windows from a shared counter: while one
+// window's host thread waits for the eight scalars of an LM trial, the kernels of the others fill the device.
+extern "C" int rumi_local_ba_batch(RumiOptimizer *o, int32_t n_windows, RumiBaWindow *win, int32_t n_workers) {
+    if (!o || n_windows < 0 || (n_windows > 0 && !win) || n_workers < 1) return RUMI_E_INVALID;
+    n_workers = std::min(std::min(n_workers, n_windows), 16);
+    if (n_windows == 0) return RUMI_OK;
+    while ((int)o->workers.size() < n_workers) {
+        RumiOptimizer *c = nullptr;
+        const int rc = rumi_opt_create(o->maxPoseEdges, 1, o->maxKF, o->maxMP, o->maxE, o->device, &c);
+        if (rc != RUMI_OK) return rc;
+        o->workers.push_back(c);
+    }
+    std::atomic<int> next{0};
+    auto work = [&](RumiOptimizer *c) {
+        for (int i = next.fetch_add(1); i < n_windows; i = next.fetch_add(1)) {
+            RumiBaWindow &W = win[i];
+            W.status = ba_run(c, 0, W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3, W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2, W.K4, W.stop_flag,
+                              W.erase_out, W.stats);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_workers; k++) th.emplace_back(work, o->workers[k]);
+    work(o->workers[0]);
+    for (auto &t : th) t.join();
+    int worst = RUMI_OK;
+    for (int i = 0; i < n_windows; i++) if (win[i].status != RUMI_OK) worst = win[i].status;
+    return worst;
 }
 
 extern "C" int rumi_bundle_adjustment(RumiOptimizer *o, int32_t nKF, float *kf_pose7, const uint8_t *kf_fixed, int32_t nMP, float *mp_pos3,

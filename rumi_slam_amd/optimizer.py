@@ -28,6 +28,7 @@ def _lib():
     L.rumi_pose_optimization.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.rumi_pose_optimization_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rumi_local_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rumi_local_ba_batch.argtypes = [vp, i32, vp, i32]
     L.rumi_bundle_adjustment.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.rumi_sim3_inliers.argtypes = [vp, i32] + [vp] * 17
     L.rumi_merge_ba.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -38,6 +39,12 @@ def _lib():
     L.rumi_optimize_sim3.argtypes = [vp, i32, vp, i32] + [vp] * 12 + [C.c_float, i32, i32, vp, vp, vp]
     L._opt_ready = True
     return L
+
+
+class RumiBaWindow(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("kf_pose7", C.c_void_p), ("kf_fixed", C.c_void_p), ("n_mp", C.c_int32), ("mp_pos3", C.c_void_p),
+                ("n_edges", C.c_int32), ("e_mp", C.c_void_p), ("e_kf", C.c_void_p), ("e_obs", C.c_void_p), ("e_inv_sigma2", C.c_void_p),
+                ("K4", C.c_void_p), ("stop_flag", C.c_void_p), ("erase_out", C.c_void_p), ("stats", C.c_int32 * 4), ("status", C.c_int32)]
 
 
 class Optimizer:
@@ -89,6 +96,24 @@ class Optimizer:
         capi.check(fn(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
                       capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
         return stats, kp, mp, erase[:len(em)]
+
+    def LocalBundleAdjustmentBatch(self, windows, n_workers=4):
+        """rumi_local_ba_batch: `windows` = list of (kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4) tuples; returns one
+        (stats[4], kf_pose, mp_pos, erase[nE]) per window, as LocalBundleAdjustment does."""
+        arr = (RumiBaWindow * len(windows))()
+        keep = []
+        for W, w in zip(arr, windows):
+            kp = np.ascontiguousarray(w[0], np.float32).copy(); kfix = np.ascontiguousarray(w[1], np.uint8)
+            mp = np.ascontiguousarray(w[2], np.float32).copy(); em = np.ascontiguousarray(w[3], np.int32)
+            ek = np.ascontiguousarray(w[4], np.int32); eo = np.ascontiguousarray(w[5], np.float32)
+            ew = np.ascontiguousarray(w[6], np.float32); K4 = np.ascontiguousarray(w[7], np.float32)
+            erase = np.zeros(max(len(em), 1), np.uint8)
+            keep.append((kp, kfix, mp, em, ek, eo, ew, K4, erase))
+            W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3 = len(kfix), kp.ctypes.data, kfix.ctypes.data, len(mp), mp.ctypes.data
+            W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2 = len(em), em.ctypes.data, ek.ctypes.data, eo.ctypes.data, ew.ctypes.data
+            W.K4, W.stop_flag, W.erase_out = K4.ctypes.data, None, erase.ctypes.data
+        capi.check(self._lib.rumi_local_ba_batch(self._h, len(windows), C.cast(arr, C.c_void_p), int(n_workers)))
+        return [(np.array(W.stats, np.int32), k[0], k[2], k[8][:len(k[3])]) for W, k in zip(arr, keep)]
 
     def BundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, n_iterations=5, robust=True, stop_flag=None):
         """Optimizer::BundleAdjustment (global BA): returns (stats[4], kf_pose, mp_pos)."""

@@ -330,3 +330,19 @@ def test_error_conventions_of_the_new_entry_points(opt):
     b2 = ba_problem(seed=9, n_opt=4, n_fixed=1, n_points=100)
     stats, _, _ = small.BundleAdjustment(b2["kf_pose"], b2["kf_fixed"], b2["mp_pos"], b2["e_mp"], b2["e_kf"], b2["e_obs"], b2["e_w"], b2["K"], n_iterations=3, robust=True)
     assert stats[2] == 4
+
+
+def test_local_ba_batch_equals_single_calls(opt):
+    """rumi_local_ba_batch: R independent windows over worker threads with their own child handles and streams; every window's result must be
+    the single-call result (same LM iterations, same erase flags; values to 1e-6: the accumulations are f64 atomics, their order is not
+    fixed), whatever the number of workers."""
+    cfgs = [dict(seed=20 + i, n_opt=6 + 3 * (i % 4), n_fixed=2, n_points=300 + 100 * (i % 3), outlier_frac=0.05 * (i % 2)) for i in range(10)]
+    probs = [ba_problem(**c) for c in cfgs]
+    wins = [(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"]) for b in probs]
+    single = [opt.LocalBundleAdjustment(*w) for w in wins]
+    for workers in (1, 3, 4):
+        got = opt.LocalBundleAdjustmentBatch(wins, workers)
+        for i, (s, g) in enumerate(zip(single, got)):
+            assert np.array_equal(s[0], g[0]), f"window {i}, {workers} workers: stats {g[0]} vs {s[0]}"
+            assert np.array_equal(s[3], g[3]), f"window {i}, {workers} workers: erase flags"
+            assert np.allclose(s[1], g[1], rtol=1e-6, atol=1e-7) and np.allclose(s[2], g[2], rtol=1e-6, atol=1e-7), f"window {i}, {workers} workers"
