@@ -19,7 +19,9 @@ extern "C" {
 typedef struct RumiTracker RumiTracker;
 
 /* The map points the frame can be matched against, as one table: those the last frame observes (last_mp indexes this table) and
- * mvpLocalMapPoints (local[j] != 0).  Same per-point data as rumi_search_by_projection_frame / rumi_search_local_points take. */
+ * mvpLocalMapPoints (local[j] != 0).  The local search visits the table in index order, as SearchByProjection visits mvpLocalMapPoints: list those
+ * first and in their order (who gets a contested feature depends on it).  Same per-point data as rumi_search_by_projection_frame /
+ * rumi_search_local_points take. */
 typedef struct RumiTrackPoints {
     int32_t n;
     const float *pos;        /* [n][3] GetWorldPos() */

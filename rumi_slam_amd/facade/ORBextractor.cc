@@ -33,6 +33,10 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 
 ORBextractor::~ORBextractor() { rumi_orb_destroy(handle_); }
 
+RumiOrbConfig ORBextractor::rumiConfig(int width, int height) const {
+    return RumiOrbConfig{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1, -1, 0, RUMI_FACADE_BLUR_VARIANT};
+}
+
 void ORBextractor::ensureHandle(int width, int height) {
     if (handle_ && width <= capW_ && height <= capH_) return;
     rumi_orb_destroy(handle_);

@@ -34,6 +34,9 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
+    // facade-only: the constructor arguments as the C ABI takes them (rumi_facade::TrackFrame creates its tracker from the frame's extractor)
+    RumiOrbConfig rumiConfig(int width, int height) const;
+
     // Filled after every call when keepPyramid is true (stereo matching reads it, Frame.cc:834,918-932); each level is a
     // view with the reference's 19-px BORDER_REFLECT_101 frame around it.  Mono tracking never reads it: set false there.
     std::vector<cv::Mat> mvImagePyramid;

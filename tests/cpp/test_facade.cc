@@ -16,6 +16,7 @@
 #include "rumi_status.h"
 #include "Optimizer.h"
 #include "FrameFrustum.h"
+#include "TrackingStep.h"
 #include "orb_oracle.h"
 
 extern "C" {
@@ -57,8 +58,9 @@ struct MapPoint {
     void AddObservation(KeyFrame *k, int idx) { if (!obs.count(k)) nObs++; obs[k] = std::make_tuple(idx, -1); }
     void Replace(MapPoint *other);                     // defined after KeyFrame
     bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
-    long mnLastFrameSeen = -1; int nVisible = 0;
+    long mnLastFrameSeen = -1; int nVisible = 0, nFound = 0;
     void IncreaseVisible() { nVisible++; }
+    void IncreaseFound() { nFound++; }
 };
 std::mutex MapPoint::mGlobalMutex;
 struct Frame {
@@ -71,13 +73,18 @@ struct Frame {
     std::map<unsigned, std::vector<unsigned>> mFeatVec;
     SE3f GetPose() const { return pose; }
     void SetPoseFromQuatTrans(const float *T7) { std::memcpy(pose.T, T7, 28); }
-    void PoseMatrices(float *R, float *t, float *Ow) const {          // mRcw, mtcw, mOw = -Rcw^T tcw
+    void PoseMatrices(float *R, float *t, float *Ow) const {          // Frame::UpdatePoseMatrices in Eigen's / Sophus' float arithmetic (as the device does it)
         const float x = pose.T[0], y = pose.T[1], z = pose.T[2], w = pose.T[3];
-        const float r[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+        const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        const float r[9] = {1.f - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.f - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.f - (txx + tyy)};
         for (int i = 0; i < 9; i++) R[i] = r[i];
         for (int i = 0; i < 3; i++) t[i] = pose.T[4 + i];
-        for (int i = 0; i < 3; i++) Ow[i] = -(r[i] * t[0] + r[3 + i] * t[1] + r[6 + i] * t[2]);
+        const float qx = -x, qy = -y, qz = -z, v0 = t[0] * -1.f, v1 = t[1] * -1.f, v2 = t[2] * -1.f;     // Ow = conj(q) * (-tcw)
+        float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+        u0 += u0; u1 += u1; u2 += u2;
+        const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+        Ow[0] = (v0 + w * u0) + c0; Ow[1] = (v1 + w * u1) + c1; Ow[2] = (v2 + w * u2) + c2;
     }
 };
 struct KeyFrame : Frame {
@@ -432,6 +439,65 @@ int main(int argc, char **argv) {
         const int nm = big.SearchByProjection(F, vpMany, 3.f);
         CHECK(nm > fr[1].N / 2 && ORB_SLAM3::ORBmatcher::arena_scale() > before && rumi_facade::last_status() == RUMI_OK, "matcher arena grows past 32768 queries instead of failing");
         std::printf("arena growth: %d matches of %d in-view points, arena scale %d -> %d\n", nm, fr[1].N, before, ORB_SLAM3::ORBmatcher::arena_scale());
+    }
+    // ---- rumi_facade::TrackFrame (one device-resident call) == the same Tracking step through the separate facade members ----
+    {
+        for (auto &m : mps) { m.bad = false; m.mnLastFrameSeen = -1; m.mbTrackInView = false; m.normal = V3f{{0, 0, 1}}; }
+        for (size_t i = 0; i < mps.size(); i += 41) mps[i].bad = true;
+        std::vector<MapPoint *> localPts;
+        for (auto &m : mps) localPts.push_back(&m);
+        cv::Mat image1(480, 640, CV_8U, im[1].data(), 640), mask1;
+        Frame A;
+        A.mnId = 21;
+        ext(image1, mask1, A.mvKeysUn, A.mDescriptors, lap);
+        A.N = (int)A.mvKeysUn.size();
+        A.mvScaleFactors = ext.GetScaleFactors(); A.mvInvLevelSigma2 = ext.GetInverseScaleSigmaSquares();
+        A.mvpMapPoints.assign(A.N, nullptr); A.mvbOutlier.assign(A.N, false); A.mvuRight.assign(A.N, -1.f);
+        std::memcpy(A.pose.T, T7, 28);
+        ORB_SLAM3::ORBmatcher m9(0.9f, true);
+        int thUsed = 15;
+        int nmA = m9.SearchByProjection(A, fr[0], 15.f, true);
+        if (nmA < 20) { A.mvpMapPoints.assign(A.N, nullptr); nmA = m9.SearchByProjection(A, fr[0], 30.f, true); thUsed = 30; }
+        const int g1 = ORB_SLAM3::Optimizer::PoseOptimization(&A);
+        float TmotionA[7]; std::memcpy(TmotionA, A.pose.T, 28);
+        int nmatchesMap = 0;
+        for (int i = 0; i < A.N; i++) if (A.mvpMapPoints[i]) {                     // Tracking.cc:2489-2508
+            if (A.mvbOutlier[i]) { MapPoint *p = A.mvpMapPoints[i]; A.mvpMapPoints[i] = nullptr; A.mvbOutlier[i] = false; p->mbTrackInView = false; p->mnLastFrameSeen = A.mnId; }
+            else if (A.mvpMapPoints[i]->Observations() > 0) nmatchesMap++;
+        }
+        for (auto &p : A.mvpMapPoints) if (p) {                                     // :2998-3010
+            if (p->isBad()) p = nullptr; else { p->IncreaseVisible(); p->mnLastFrameSeen = A.mnId; p->mbTrackInView = false; }
+        }
+        int nto = 0;
+        const int nl = rumi_facade::SearchLocalPoints(A, localPts, 1.f, false, 50.f, 0.8f, &nto);
+        const int g2 = ORB_SLAM3::Optimizer::PoseOptimization(&A);
+        int inliersA = 0;
+        for (int i = 0; i < A.N; i++) if (A.mvpMapPoints[i] && !A.mvbOutlier[i] && A.mvpMapPoints[i]->Observations() > 0) inliersA++;
+        for (auto &m : mps) { m.nVisible = 0; m.nFound = 0; }
+        Frame B;
+        B.mnId = 22;
+        rumi_facade::TrackStep st;
+        const int monoB = rumi_facade::TrackFrame(B, image1, ext, T7, fr[0], localPts, 15.f, 1.f, false, 50.f, &st);
+        CHECK(monoB >= 0 && B.N == A.N && std::memcmp(B.mvKeysUn.data(), A.mvKeysUn.data(), (size_t)A.N * 28) == 0, "TrackFrame: the frame's features");
+        CHECK(st.thMotion == thUsed && st.nmatches == nmA && st.ngoodMotion == g1 && st.nmatchesMap == nmatchesMap && st.nToMatch == nto && st.nmatchesLocal == nl &&
+              st.ngoodLocal == g2 && st.mnMatchesInliers == inliersA, "TrackFrame: the numbers TrackWithMotionModel / TrackLocalMap decide on");
+        bool same = B.mvpMapPoints.size() == A.mvpMapPoints.size();
+        for (int i = 0; same && i < A.N; i++) same = B.mvpMapPoints[i] == A.mvpMapPoints[i] && (!A.mvpMapPoints[i] || B.mvbOutlier[i] == A.mvbOutlier[i]);
+        CHECK(same, "TrackFrame: mvpMapPoints / mvbOutlier");
+        double dM = 0, dF = 0;
+        for (int c = 0; c < 7; c++) { dM = std::fmax(dM, std::fabs(st.TcwMotion[c] - TmotionA[c])); dF = std::fmax(dF, std::fabs(B.pose.T[c] - A.pose.T[c])); }
+        CHECK(dM < 1e-5 && dF < 1e-5, "TrackFrame: poses");
+        if (!same || !(dM < 1e-5 && dF < 1e-5)) {
+            int dmp = 0, dout = 0;
+            for (int i = 0; i < A.N; i++) { dmp += B.mvpMapPoints[i] != A.mvpMapPoints[i]; dout += A.mvpMapPoints[i] && B.mvbOutlier[i] != A.mvbOutlier[i]; }
+            std::printf("TrackFrame diff: map points %d, outlier flags %d, dM %.3e dF %.3e\n", dmp, dout, dM, dF);
+            for (int i = 0, shown = 0; i < A.N && shown < 8; i++) if (B.mvpMapPoints[i] != A.mvpMapPoints[i]) { shown++; std::printf("  feature %d: A %ld B %ld\n", i, A.mvpMapPoints[i] ? (long)(A.mvpMapPoints[i] - mps.data()) : -1L, B.mvpMapPoints[i] ? (long)(B.mvpMapPoints[i] - mps.data()) : -1L); }
+        }
+        int vis = 0, found = 0;
+        for (auto &m : mps) { vis += m.nVisible; found += m.nFound; }
+        CHECK(nl > 20 && nmA >= 20 && vis > 0 && found == g2, "TrackFrame: the scene tracks; IncreaseFound once per inlier");
+        std::printf("TrackFrame: motion matches %d (th %d), inliers %d, nmatchesMap %d, in view %d, local matches %d, inliers %d / %d\n", st.nmatches, st.thMotion, st.ngoodMotion,
+                    st.nmatchesMap, st.nToMatch, st.nmatchesLocal, st.ngoodLocal, st.mnMatchesInliers);
     }
     std::printf("facade test: %d failure(s); matches %d, pose inliers %d, LBA edges %d (erased %d) dK %.2e dP %.2e\n", fails, ngpu, good, nEdges, erasedRef, dK, dP);
     (void)erased;
