@@ -173,6 +173,31 @@ def test_bruteforce_batch():
     assert [bi[1, 0].item(), bd[1, 0].item(), sd[1, 0].item()] == [int(rbi[0]), int(rbd[0]), int(rsd[0])] == [-1, 256, 256]
 
 
+def test_bruteforce_on_extractor_records():
+    """The bench path: consecutive frames extracted into per-frame records on the device and matched in place through the strided entry
+    (descriptors of real key-points: many near-duplicates and ties, unlike random bytes)."""
+    import torch
+    from rumi_slam_amd import rumination as R
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.matcher import bruteforce_batch
+    from rumi_slam_amd.synth import synth_frame, warp_frame
+    img0 = synth_frame(77)
+    frames = [img0] + [warp_frame(img0, 100 + i)[0] for i in range(3)]
+    ext = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=4)
+    cap = ext.cap if hasattr(ext, "cap") else 1000 + 4 * 8 + 64
+    rec = ext.extract_batch_records(torch.from_numpy(np.stack(frames)).cuda(), cap=cap)
+    ext.sync()
+    kp, desc, counts = R.record_views(rec, cap)
+    bi, bd, sd = bruteforce_batch(desc[1:], counts[1:], desc[:-1], counts[:-1])
+    torch.cuda.synchronize()
+    d, c = desc.cpu().numpy(), counts.cpu().numpy()
+    for b in range(3):
+        nq, nt = int(c[b + 1, 0]), int(c[b, 0])
+        rbi, rbd, rsd = O.bruteforce_match(np.ascontiguousarray(d[b + 1, :nq]), np.ascontiguousarray(d[b, :nt]))
+        assert np.array_equal(bi[b, :nq].cpu().numpy(), rbi) and np.array_equal(bd[b, :nq].cpu().numpy(), rbd) and np.array_equal(sd[b, :nq].cpu().numpy(), rsd), b
+        assert (rbd < 40).sum() > 300, "consecutive warped frames are supposed to share most features"
+
+
 @pytest.mark.parametrize("seed,nn", [(0, 0.75), (2, 0.9)])
 def test_search_by_bow_keyframe_keyframe(matcher, seed, nn):
     from rumi_slam_amd.matcher import FrameView, SearchByBoW_KF
