@@ -191,10 +191,20 @@ def main():
         return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
                 bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
 
+    match_stream = torch.cuda.Stream(dev)
+
     def step():
         if world == 1:
             kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
-            return kp, desc, counts, match(desc, counts)
+            # the matching of step i runs on a stream of its own behind the extraction of step i: the wide Hamming kernel shares the device with
+            # the latency-bound stretches (quadtree, compaction, upper pyramid levels) of step i + 1 instead of waiting in line before it
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(match_stream):
+                match_stream.wait_event(ev)
+                m = match(desc, counts)
+            desc.record_stream(match_stream); counts.record_stream(match_stream)
+            return kp, desc, counts, m
         # N > 1: per-frame records written in place, then the path's one exchange step: every GPU ends up with all records.
         # The all-gather is launched here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of
         # step i overlaps the extraction of step i + 1; drain() joins the last one inside the timed region.
