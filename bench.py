@@ -211,7 +211,12 @@ def main():
         rec = torch.zeros((per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev)
         ext.extract_batch_records(frames, (0, 1000), cap=cap, wait=False, out=rec)
         kp, desc, counts = rumination.record_views(rec[:B], cap)
-        m = match(desc, counts)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(match_stream):                  # matching and exchange both wait for the extraction only
+            match_stream.wait_event(ev)
+            m = match(desc, counts)
+        rec.record_stream(match_stream)
         prev, pending[0] = pending[0], rumination.all_gather_records_async(rec, n_queue)
         if prev is not None:
             prev.wait()
