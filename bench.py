@@ -90,8 +90,17 @@ def side_legs(args):
                            "hpp_us_per_trial": round(det["hpp"] * 1e3 / trials, 2),
                            "hpp_mfma_util": round(hpp_flops / (det["hpp"] * 1e-3 / trials) / 1e12 / F64_MFMA_PEAK_TFLOPS, 5) if det["hpp"] > 0 else None,
                            "solve_us": round(det["solve"] * 1e3 / trials, 2)}
+        lba["roofline"]["note"] = "per-kernel times are HIP-event brackets on the library's stream: each carries about 6.5 us of bracket overhead (an empty kernel measures 6.4-6.8 us); the rocprofv3 durations are in profiles/"
     except Exception as e:                                               # older library without the per-kernel slots
         lba["roofline"] = {"error": str(e)}
+    # R independent windows (the only multi-window form local BA has): worker threads with child handles and streams of their own
+    try:
+        R, workers = 16, 8
+        opt.LocalBundleAdjustmentBatch([a] * R, workers)
+        t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([a] * R, workers); bt = time.perf_counter() - t0
+        lba["batch"] = {"windows": R, "workers": workers, "ms_per_window": round(bt / R * 1e3, 3)}
+    except Exception as e:
+        lba["batch"] = {"error": str(e)}
     probs = [pose_problem(100 + i, 300, 0.1) for i in range(256)]
     start = np.cumsum([0] + [len(p["inv_sigma2"]) for p in probs]).astype(np.int32)
     pa = (start, np.concatenate([p["Xw"] for p in probs]), np.concatenate([p["obs"] for p in probs]),
@@ -104,7 +113,14 @@ def side_legs(args):
     cp = (time.perf_counter() - t0) / 64
     pose = {"workload": "PoseOptimization: 256 frames x 300 correspondences, one launch (host arrays in, PCIe included)",
             "gpu_us_per_frame": round(gp / 256 * 1e6, 2), "cpu_us_per_frame": round(cp * 1e6, 2), "speedup": round(cp / (gp / 256), 1)}
-    return {"lba": lba, "pose_opt": pose}
+    # one Tracking-thread frame (BASELINE.json configs[0]'s path on a synthetic plane scene): the fused device-resident entry next to the separate ones
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import track_probe
+        track = track_probe.measure(40)
+    except Exception as e:
+        track = {"error": str(e)}
+    return {"lba": lba, "pose_opt": pose, "tracking_frame": track}
 
 
 def spawn_ranks(args):

@@ -13,56 +13,63 @@ from scene import K_TUM3
 from test_tracking_loop_gpu import PLANE_D, _homography, _pose_gt
 from test_track_frame_gpu import _pose_matrices
 
-W, H = 640, 480
-ext, m9, m8, opt = ORBextractor(1000, 1.2, 8, 20, 7), ORBmatcher(0.9, True), ORBmatcher(0.8, True), Optimizer()
-trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
-sf, inv_sigma2 = ext.GetScaleFactors(), ext.GetInverseScaleSigmaSquares()
-img0 = synth_frame(4242)
-fx, fy, cx, cy = K_TUM3.astype(np.float64)
-_, keys0, desc0 = ext(img0)
-n0 = len(keys0)
-pos = np.stack([(keys0["x"] - cx) / fx * PLANE_D, (keys0["y"] - cy) / fy * PLANE_D, np.full(n0, PLANE_D)], 1).astype(np.float32)
-dist0 = np.linalg.norm(pos, axis=1).astype(np.float32)
-lvl = keys0["octave"]
-pts = dict(pos=pos, normal=(pos / dist0[:, None]).astype(np.float32), max_dist=(dist0 * sf[lvl]).astype(np.float32),
-           min_dist=(dist0 * sf[lvl] / sf[7]).astype(np.float32), desc=desc0.copy(), obs=np.ones(n0, np.int32), bad=np.zeros(n0, np.uint8),
-           local=np.ones(n0, np.uint8))
-rng = np.random.default_rng(7)
-known = rng.random(n0) < 0.5
-last = dict(keys=keys0, mp=np.where(known, np.arange(n0), -1).astype(np.int32), outlier=np.zeros(n0, np.uint8))
-T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
-img = warp_homography(img0, _homography(*_pose_gt(1)))
-log_sf = float(np.log(np.float32(1.2)))
+def measure(reps=60):
+    W, H = 640, 480
+    ext, m9, m8, opt = ORBextractor(1000, 1.2, 8, 20, 7), ORBmatcher(0.9, True), ORBmatcher(0.8, True), Optimizer()
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    sf, inv_sigma2 = ext.GetScaleFactors(), ext.GetInverseScaleSigmaSquares()
+    img0 = synth_frame(4242)
+    fx, fy, cx, cy = K_TUM3.astype(np.float64)
+    _, keys0, desc0 = ext(img0)
+    n0 = len(keys0)
+    pos = np.stack([(keys0["x"] - cx) / fx * PLANE_D, (keys0["y"] - cy) / fy * PLANE_D, np.full(n0, PLANE_D)], 1).astype(np.float32)
+    dist0 = np.linalg.norm(pos, axis=1).astype(np.float32)
+    lvl = keys0["octave"]
+    pts = dict(pos=pos, normal=(pos / dist0[:, None]).astype(np.float32), max_dist=(dist0 * sf[lvl]).astype(np.float32),
+               min_dist=(dist0 * sf[lvl] / sf[7]).astype(np.float32), desc=desc0.copy(), obs=np.ones(n0, np.int32), bad=np.zeros(n0, np.uint8),
+               local=np.ones(n0, np.uint8))
+    rng = np.random.default_rng(7)
+    known = rng.random(n0) < 0.5
+    last = dict(keys=keys0, mp=np.where(known, np.arange(n0), -1).astype(np.int32), outlier=np.zeros(n0, np.uint8))
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    img = warp_homography(img0, _homography(*_pose_gt(1)))
+    log_sf = float(np.log(np.float32(1.2)))
 
 
-def separate():
-    mono, keys, desc = ext(img)
-    F = FrameView(keys, desc, W, H, sf)
-    nm, cur = m9.SearchByProjection_Frame(F, T, K_TUM3, last["keys"], last["mp"], last["outlier"], pts["pos"], pts["desc"], pts["obs"], np.full(F.n, -1, np.int32), 15.0)
-    idx = np.nonzero(cur >= 0)[0]
-    ng, T1, out = opt.PoseOptimization(pts["pos"][cur[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T)
-    seen = np.zeros(n0, np.uint8); seen[cur[idx]] = 1
-    cur[idx[out != 0]] = -1
-    R, t, Ow = _pose_matrices(T1)
-    nto, nml, cur2, _ = m8.SearchLocalPoints(F, R, t, Ow, K_TUM3, log_sf, 8, dict(pts, skip=seen), cur, 1.0)
-    idx2 = np.nonzero(cur2 >= 0)[0]
-    ng2, T2, out2 = opt.PoseOptimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)
-    return ng2, T2
+    def separate():
+        mono, keys, desc = ext(img)
+        F = FrameView(keys, desc, W, H, sf)
+        nm, cur = m9.SearchByProjection_Frame(F, T, K_TUM3, last["keys"], last["mp"], last["outlier"], pts["pos"], pts["desc"], pts["obs"], np.full(F.n, -1, np.int32), 15.0)
+        idx = np.nonzero(cur >= 0)[0]
+        ng, T1, out = opt.PoseOptimization(pts["pos"][cur[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T)
+        seen = np.zeros(n0, np.uint8); seen[cur[idx]] = 1
+        cur[idx[out != 0]] = -1
+        R, t, Ow = _pose_matrices(T1)
+        nto, nml, cur2, _ = m8.SearchLocalPoints(F, R, t, Ow, K_TUM3, log_sf, 8, dict(pts, skip=seen), cur, 1.0)
+        idx2 = np.nonzero(cur2 >= 0)[0]
+        ng2, T2, out2 = opt.PoseOptimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)
+        return ng2, T2
 
 
-def fused():
-    r = trk.track(img, K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts, 15.0, 1.0)
-    return r["ngood_local"], r["Tcw"]
+    def fused():
+        r = trk.track(img, K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts, 15.0, 1.0)
+        return r["ngood_local"], r["Tcw"]
 
 
-def med(f, reps=60):
-    for _ in range(5): f()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
-    return float(np.median(ts)) * 1e3
+    def med(f, reps):
+        for _ in range(5): f()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
 
 
-a, b = separate(), fused()
-assert a[0] == b[0] and np.allclose(a[1], b[1], atol=1e-5), (a, b)
-print("one Tracking-thread frame (640x480, 1000 features, %d map points, inliers %d): separate entries %.3f ms, rumi_track_frame %.3f ms" % (n0, b[0], med(separate), med(fused)))
+    a, b = separate(), fused()
+    assert a[0] == b[0] and np.allclose(a[1], b[1], atol=1e-5), (a, b)
+    return dict(workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
+                inliers=int(b[0]), separate_entries_ms=round(med(separate, reps), 3), rumi_track_frame_ms=round(med(fused, reps), 3))
+
+
+if __name__ == "__main__":
+    r = measure()
+    print("%s: separate entries %.3f ms, rumi_track_frame %.3f ms (inliers %d)" % (r["workload"], r["separate_entries_ms"], r["rumi_track_frame_ms"], r["inliers"]))
