@@ -36,7 +36,7 @@ enum Op {
     OR_B32, SUB_U32, LSHLREV, LSHRREV, ASHRREV, MOV_B32, NOT_B32, MUL_F32, MAX_F32, MIN_F32, MAX_U32, MIN_U32, MAX_I32, MIN_U16, SUB_U16, MUL_U32_U24, FMAC_F32,
     BFE_U32, AND_OR_B32, OR3_B32, LSHL_ADD_U32, XAD_U32, BFI_B32, MED3_I32, MAX3_U32, MUL_HI_U32, CVT_F32_I32, CNDMASK_S, CMP_GT_U32_S, CMP_GT_F32,
     SDWA_SUB_U32_BYTES, SDWA_ADD_U32_W1, SDWA_AND_BYTE, SDWA_MIN_U16_BYTES, SDWA_MAX_I32_WORDS, SDWA_SUB_F32, SDWA_CVT_UBYTE, SDWA_MOV_W1, SDWA_CMP_BYTES, DPP_MOV_SHR1, DPP_ADD_SHR1, DPP_MOV_BCAST, READLANE,
-    DS_READ_U8, DS_READ_U8_D16_HI, DS_READ_B32, DS_READ_B64, NOPS
+    DS_READ_U8, DS_READ_U8_D16_HI, DS_READ_B32, DS_READ_B64, DS_READ_B32_MIS1, DS_READ_B64_MIS1, DS_READ_B64_MIS4, DS_READ_B32_STRIDE5, DS_READ_B64_STRIDE7, NOPS
 };
 
 template <int OP> __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *ticks, unsigned seed, int iters) {
@@ -45,7 +45,11 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned *out, unsign
     unsigned long long A = a | (unsigned long long)b << 32, B = c | (unsigned long long)d << 32, C = e, D = f, E = 0x3f8000003f800000ull, F = 0x3a8000003a800000ull;
     if (OP >= DS_READ_U8 && OP < NOPS) {
         for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = i * seed;
-        e = (threadIdx.x & 63) * (OP == DS_READ_B64 ? 8 : 4);   // conflict-free: consecutive (d)words
+        e = (threadIdx.x & 63) * ((OP == DS_READ_B64 || OP == DS_READ_B64_MIS1 || OP == DS_READ_B64_MIS4) ? 8 : 4);   // conflict-free: consecutive (d)words
+        if (OP == DS_READ_B32_MIS1 || OP == DS_READ_B64_MIS1) e += 1;      // every lane's access straddles a dword boundary
+        if (OP == DS_READ_B64_MIS4) e += 4;                                 // 8-byte reads on odd dword boundaries
+        if (OP == DS_READ_B32_STRIDE5) e = (threadIdx.x & 63) * 5;          // byte-granular gather: 4-byte reads at 5-byte steps
+        if (OP == DS_READ_B64_STRIDE7) e = (threadIdx.x & 63) * 7;          // 8-byte reads at 7-byte steps
         __syncthreads();
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -139,7 +143,8 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned *out, unsign
             if (OP == DS_READ_U8) LDS4("ds_read_u8")
             if (OP == DS_READ_U8_D16_HI) LDS4("ds_read_u8_d16_hi")
             if (OP == DS_READ_B32) LDS4("ds_read_b32")
-            if (OP == DS_READ_B64) LDS4_64("ds_read_b64")
+            if (OP == DS_READ_B64 || OP == DS_READ_B64_MIS1 || OP == DS_READ_B64_MIS4 || OP == DS_READ_B64_STRIDE7) LDS4_64("ds_read_b64")
+            if (OP == DS_READ_B32_MIS1 || OP == DS_READ_B32_STRIDE5) LDS4("ds_read_b32")
         }
         if (OP >= DS_READ_U8 && OP < NOPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -206,5 +211,7 @@ int main() {
     run<DPP_MOV_SHR1>("mov_b32 dpp row_shr"); run<DPP_ADD_SHR1>("add_u32 dpp row_shr"); run<DPP_MOV_BCAST>("mov_b32 dpp wave_shr"); run<READLANE>("v_readlane_b32");
     std::printf("# -- LDS issue (conflict-free, 4 in flight, drained every 64) --\n");
     run<DS_READ_U8>("ds_read_u8"); run<DS_READ_U8_D16_HI>("ds_read_u8_d16_hi"); run<DS_READ_B32>("ds_read_b32"); run<DS_READ_B64>("ds_read_b64");
+    std::printf("# -- LDS reads at addresses that are not multiples of their size (unaligned-ds-access) --\n");
+    run<DS_READ_B32_MIS1>("b32 at 4 l + 1"); run<DS_READ_B64_MIS1>("b64 at 8 l + 1"); run<DS_READ_B64_MIS4>("b64 at 8 l + 4"); run<DS_READ_B32_STRIDE5>("b32 at 5 l"); run<DS_READ_B64_STRIDE7>("b64 at 7 l");
     return 0;
 }
