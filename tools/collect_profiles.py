@@ -13,6 +13,19 @@ def newest(pattern):
 shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_kernel_stats.csv"))
 shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_serial_kernel_stats.csv"))
 shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, "r02_lba_20kf_3000mp_kernel_stats.csv"))
+# second pass (tools/measure_more.sh): latency paths
+for src, dst in (("prof_track/*/*kernel_stats.csv", "r02_track_frame_kernel_stats.csv"),):
+    try:
+        shutil.copy(newest(src), os.path.join(P, dst))
+    except ValueError:
+        print("missing", src)
+for src, dst in (("track_probe.log", "r02_track_frame_probe.txt"), ("lba_probe.log", "r02_lba_probe.txt"), ("bow_batch.log", "r02_bow_batch_probe.txt"),
+                 ("pose_probe.log", "r02_pose_probe.txt"), ("rsq_probe.log", "r02_rsq_rcp_accuracy.txt"), ("bench_matrix.json", "r02_bench_matrix.json")):
+    if os.path.exists(os.path.join(G, src)):
+        txt = open(os.path.join(G, src)).read()
+        open(os.path.join(P, dst), "w").write("\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l) + "\n")
+    else:
+        print("missing", src)
 for d, tmp in (("pmc_fetch", "/tmp/_pf"), ("pmc_write", "/tmp/_pw")):
     shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/x")
     shutil.copy(newest(d + "/*/*counter_collection.csv"), tmp + "/x/")
