@@ -977,11 +977,27 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
         }
     }
     __syncthreads();
+    // One tile of the rank-16 trailing update of panel p: C(I, J)^T -= L(J, p) L(I, p)^T on the matrix cores
+    auto update_tile = [&](int I, int J, int p) {
+        const double *LJ = T + tile_at(J, p), *LI = T + tile_at(I, p);
+        double *C = T + tile_at(I, J);
+        v4f64 acc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = C[64 * q + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[64 * s + lane], LI[64 * s + lane], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) C[64 * q + lane] = acc[q];
+    };
+    // Panels with look-ahead.  Per panel p: [rows of the panel into registers] barrier [the owning waves factor it | the OTHER waves finish the
+    // trailing update of panel p - 1 on the columns right of p] barrier [all waves: panel p applied to tile column p + 1 only] barrier.  The
+    // factorisation (a dependent chain of ~270 cycles per pivot on a few waves) thus runs beside the bulk of the previous panel's update instead
+    // of after it; only one tile column per panel is on the critical path.
+    // Wave u < kSolveWaves - 1 owns the diagonal rows (lanes 0..15) and rows p*16 + 16 + 48 u + (lane - 16) below the block.  The last wave runs
+    // the same instructions on the diagonal rows and, in lanes 16..31, on the rows of the identity: "solving" e_c^T against L_pp^T leaves
+    // column c of L_pp^-1 in lane 16 + c - the inverse the backward substitution wants, for free.
     for (int p = 0; p < PT; p++) {
         const int w = min(16, n - p * 16);
-        // ---- panel.  Wave u < kSolveWaves - 1 owns the diagonal rows (lanes 0..15) and rows p*16 + 16 + 48 u + (lane - 16) below the block.  The last wave runs the
-        // same instructions on the diagonal rows and, in lanes 16..31, on the rows of the identity: "solving" e_c^T against L_pp^T leaves
-        // column c of L_pp^-1 in lane 16 + c - the inverse the backward substitution wants, for free.
         const int rowsBelow = NT * 16 - (p + 1) * 16;
         const bool inv = wave == kSolveWaves - 1;
         const bool mine = inv || wave == 0 || wave * 48 < rowsBelow;
@@ -990,10 +1006,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
         const bool live = mine && (lane < 16 || (!inv && Ip < NT));
         double *src = T + tile_at(live ? Ip : p, p) + (rrel & 15);
         double a[16];
+        if (mine) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = src[c * 16];       // unconditional (the address is always inside the tile array): 16 reads in flight
+            for (int c = 0; c < 16; c++) a[c] = src[c * 16];   // unconditional (the address is always inside the tile array): 16 reads in flight
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = live ? a[c] : (inv && lane == 16 + c ? 1.0 : 0.0);
+            for (int c = 0; c < 16; c++) a[c] = live ? a[c] : (inv && lane == 16 + c ? 1.0 : 0.0);
+        }
         __syncthreads();                                      // every wave holds the diagonal rows before the tile is overwritten
         if (mine) {
             const bool bad = panel_factor(a, w, lane, sBuf[wave]);
@@ -1014,23 +1032,26 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
             }
             if (wave == 0 && bad && lane == 0) sFail = 1;
         }
+        int freeIdx = 0, nFree = 0;
+        for (int u = 1; u < kSolveWaves - 1; u++) {
+            const bool owns = u * 48 < rowsBelow;
+            if (!owns) { if (u < wave) freeIdx++; nFree++; }
+        }
+        if (nFree == 0) { freeIdx = wave; nFree = kSolveWaves; }      // (cannot happen up to 11 tile rows: at most three waves own rows below the block)
+        if (p > 0 && (!mine || nFree == kSolveWaves)) {
+            // the rest of panel p - 1's update: tiles (I, J), p < J <= I < NT, shared among the waves that own no row of panel p
+            const int m1 = NT - 1 - p, nTiles = m1 * (m1 + 1) / 2;
+            for (int t = freeIdx; t < nTiles; t += nFree) {
+                int Ir = 0, r = t;
+                while (r > Ir) { r -= Ir + 1; Ir++; }
+                update_tile(p + 1 + Ir, p + 1 + r, p - 1);
+            }
+        }
         __syncthreads();
         if (sFail) break;
-        // ---- trailing tiles (I, J), p < J <= I < NT
-        const int m1 = NT - 1 - p, nTiles = m1 * (m1 + 1) / 2;
-        for (int t = wave; t < nTiles; t += kSolveWaves) {
-            int Ir = 0, r = t;
-            while (r > Ir) { r -= Ir + 1; Ir++; }
-            const int I = p + 1 + Ir, J = p + 1 + r;
-            const double *LJ = T + tile_at(J, p), *LI = T + tile_at(I, p);
-            double *C = T + tile_at(I, J);
-            v4f64 acc;
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = C[64 * q + lane];
-#pragma unroll
-            for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[64 * s + lane], LI[64 * s + lane], acc, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) C[64 * q + lane] = acc[q];
+        // panel p applied to tile column p + 1 (the next panel): tiles (I, p + 1), p < I < NT
+        if (p + 1 < PT) {
+            for (int I = p + 1 + wave; I < NT; I += kSolveWaves) update_tile(I, p + 1, p);
         }
         __syncthreads();
     }
