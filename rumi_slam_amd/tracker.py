@@ -50,7 +50,8 @@ class Tracker:
             self._h = C.c_void_p()
 
     def track(self, img, K4, Tcw_pred7, last_keys, last_mp, last_outlier, points, th_motion=15.0, th_local=1.0, far_points=False, th_far_points=50.0):
-        img = np.ascontiguousarray(img, np.uint8)
+        img = np.asarray(img, np.uint8)                      # rows may be strided (a view into a wider buffer); pixels of a row are contiguous
+        assert img.ndim == 2 and img.strides[1] == 1
         h, w = img.shape
         K4 = np.ascontiguousarray(K4, np.float32); T = np.ascontiguousarray(Tcw_pred7, np.float32)
         lk = np.ascontiguousarray(last_keys, KP_DTYPE); lm = np.ascontiguousarray(last_mp, np.int32); lo = np.ascontiguousarray(last_outlier, np.uint8)
