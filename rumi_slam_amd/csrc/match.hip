@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -388,35 +389,13 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int PASS> __device__ __forceinline__ int offsets_of(const int32_t *offsets, int qi, int listCap) { return PASS == 2 ? qi * listCap : offsets[qi]; }
+
+// The candidates of one query, walked by one wave: FILL = false counts them, FILL = true computes their Hamming distances and stores them (into the
+// wave's LDS sort arrays when they fit, else straight to `out`).  Returns the count.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Query *__restrict__ q, FrameDev F,
-                                                    const uint8_t *__restrict__ qDesc, const uint32_t *__restrict__ fvIdx,
-                                                    int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
-                                                    uint32_t *__restrict__ lists, int listCap, int32_t *__restrict__ overflow) {
-    __shared__ uint32_t sKey[FILL ? 4 * kSortMax : 1], sVal[FILL ? 4 * kSortMax : 1];
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return;
-    if (FILL && offsets[nq] > listCap) {                 // the arena cannot hold this call's lists: report the need, write nothing
-        if (qi == 0 && lane == 0) *overflow = offsets[nq];
-        return;
-    }
-    const Query Q = q[qi];
-    if (!Q.valid) {
-        if (!FILL && lane == 0) counts[qi] = 0;
-        return;
-    }
-    const int total = FILL ? counts[qi] : 0;
-    const bool sorted = FILL && total <= kSortMax;
-    uint32_t *key = sKey + (threadIdx.x >> 6) * kSortMax, *val = sVal + (threadIdx.x >> 6) * kSortMax;
-    uint32_t qd[8];
-    if (FILL) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(qDesc + (size_t)Q.descId * 32);
-        const uint32_t mine = src[lane & 7];
-#pragma unroll
-        for (int k = 0; k < 8; k++) qd[k] = __shfl(mine, k);
-    }
-    uint32_t *out = FILL ? lists + offsets[qi] : nullptr;
+__device__ __forceinline__ int candidates_walk(int mode, const Query &Q, const FrameDev &F, const uint32_t (&qd)[8], const uint32_t *__restrict__ fvIdx, bool sorted,
+                                               uint32_t *out, uint32_t *key, uint32_t *val, int lane) {
     int count = 0;
     if (mode == MODE_BOW || mode == MODE_BOW_KF) {
         for (int p = Q.c0 + lane; p - lane < Q.c1; p += 64) {
@@ -429,53 +408,99 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
                 else out[p - Q.c0] = e;
             }
         }
-        count = Q.c1 - Q.c0;
-    } else {
-        // Frame::GetFeaturesInArea (Frame.cc:695-750)
-        const int nMinCellX = max(0, (int)floorf((Q.u - F.minX - Q.r) * F.wInv));
-        const int nMaxCellX = min(kGridCols - 1, (int)ceilf((Q.u - F.minX + Q.r) * F.wInv));
-        const int nMinCellY = max(0, (int)floorf((Q.v - F.minY - Q.r) * F.hInv));
-        const int nMaxCellY = min(kGridRows - 1, (int)ceilf((Q.v - F.minY + Q.r) * F.hInv));
-        if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0) {
-            const bool checkLevels = Q.minLevel > 0 || Q.maxLevel >= 0;
-            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-                const int p0 = F.cellStart[ix * kGridRows + nMinCellY], p1 = F.cellStart[ix * kGridRows + nMaxCellY + 1];
-                for (int base = p0; base < p1; base += 64) {
-                    const int p = base + lane;
-                    bool pass = false;
-                    int idx = 0, oct = 0;
-                    if (p < p1) {
-                        idx = F.sortedIdx[p];
-                        const RumiKeyPoint kp = F.keys[idx];
-                        oct = kp.octave;
-                        pass = true;
-                        if (checkLevels) {
-                            if (oct < Q.minLevel) pass = false;
-                            if (Q.maxLevel >= 0 && oct > Q.maxLevel) pass = false;
-                        }
-                        const float dx = kp.x - Q.u, dy = kp.y - Q.v;
-                        if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) pass = false;
-                        if (mode == MODE_FUSE && Q.c0 && pass) {                        // mono reprojection gate, ORBmatcher.cc:1138-1145
-                            const float ex = Q.u - kp.x, ey = Q.v - kp.y;
-                            const float e2 = ex * ex + ey * ey;
-                            const float s2 = F.scale[oct] * F.scale[oct];              // mvLevelSigma2; mvInvLevelSigma2 = 1.0f / it
-                            if ((double)(e2 * (1.0f / s2)) > 5.99) pass = false;
-                        }
+        return Q.c1 - Q.c0;
+    }
+    // Frame::GetFeaturesInArea (Frame.cc:695-750)
+    const int nMinCellX = max(0, (int)floorf((Q.u - F.minX - Q.r) * F.wInv));
+    const int nMaxCellX = min(kGridCols - 1, (int)ceilf((Q.u - F.minX + Q.r) * F.wInv));
+    const int nMinCellY = max(0, (int)floorf((Q.v - F.minY - Q.r) * F.hInv));
+    const int nMaxCellY = min(kGridRows - 1, (int)ceilf((Q.v - F.minY + Q.r) * F.hInv));
+    if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0) {
+        const bool checkLevels = Q.minLevel > 0 || Q.maxLevel >= 0;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+            const int p0 = F.cellStart[ix * kGridRows + nMinCellY], p1 = F.cellStart[ix * kGridRows + nMaxCellY + 1];
+            for (int base = p0; base < p1; base += 64) {
+                const int p = base + lane;
+                bool pass = false;
+                int idx = 0, oct = 0;
+                if (p < p1) {
+                    idx = F.sortedIdx[p];
+                    const RumiKeyPoint kp = F.keys[idx];
+                    oct = kp.octave;
+                    pass = true;
+                    if (checkLevels) {
+                        if (oct < Q.minLevel) pass = false;
+                        if (Q.maxLevel >= 0 && oct > Q.maxLevel) pass = false;
                     }
-                    const unsigned long long b = __ballot(pass);
-                    if (FILL && pass) {
-                        const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
-                        const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
-                        const uint32_t e = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
-                        if (sorted) { key[pos] = ((uint32_t)d << 10) | (uint32_t)pos; val[pos] = e; }
-                        else out[pos] = e;
+                    const float dx = kp.x - Q.u, dy = kp.y - Q.v;
+                    if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) pass = false;
+                    if (mode == MODE_FUSE && Q.c0 && pass) {                        // mono reprojection gate, ORBmatcher.cc:1138-1145
+                        const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                        const float e2 = ex * ex + ey * ey;
+                        const float s2 = F.scale[oct] * F.scale[oct];              // mvLevelSigma2; mvInvLevelSigma2 = 1.0f / it
+                        if ((double)(e2 * (1.0f / s2)) > 5.99) pass = false;
                     }
-                    count += __popcll(b);
                 }
+                const unsigned long long b = __ballot(pass);
+                if (FILL && pass) {
+                    const int d = hamming256(qd, reinterpret_cast<const uint32_t *>(F.desc + (size_t)idx * 32));
+                    const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+                    const uint32_t e = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
+                    if (sorted) { key[pos] = ((uint32_t)d << 10) | (uint32_t)pos; val[pos] = e; }
+                    else out[pos] = e;
+                }
+                count += __popcll(b);
             }
         }
     }
-    if (!FILL && lane == 0) counts[qi] = count;
+    return count;
+}
+
+// PASS 0: count pass (counts[q]).  PASS 1: fill pass at the offsets a scan of the counts produced.  PASS 2: both in one launch, every query's list
+// in a fixed slot of `listCap` entries (offsets[q] = q * listCap written here): two dispatches (~4.5 us each) less per search; a query with more
+// candidates than a slot raises kFusedOverflow and the host repeats the search with passes 0 / scan / 1.
+constexpr int kFusedOverflow = -0x40000000;
+template <int PASS>
+__global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Query *__restrict__ q, FrameDev F,
+                                                    const uint8_t *__restrict__ qDesc, const uint32_t *__restrict__ fvIdx,
+                                                    int32_t *__restrict__ counts, int32_t *__restrict__ offsets,
+                                                    uint32_t *__restrict__ lists, int listCap, int32_t *__restrict__ overflow) {
+    constexpr bool FILL = PASS != 0;
+    __shared__ uint32_t sKey[FILL ? 4 * kSortMax : 1], sVal[FILL ? 4 * kSortMax : 1];
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    if (PASS == 1 && offsets[nq] > listCap) {            // the arena cannot hold this call's lists: report the need, write nothing
+        if (qi == 0 && lane == 0) *overflow = offsets[nq];
+        return;
+    }
+    const Query Q = q[qi];
+    if (PASS == 2 && lane == 0) offsets[qi] = qi * listCap;
+    if (!Q.valid) {
+        if (PASS != 1 && lane == 0) counts[qi] = 0;
+        return;
+    }
+    uint32_t *key = sKey + (threadIdx.x >> 6) * kSortMax, *val = sVal + (threadIdx.x >> 6) * kSortMax;
+    uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int total = 0;
+    if (PASS == 0 || PASS == 2) {
+        total = candidates_walk<false>(mode, Q, F, qd, fvIdx, false, nullptr, key, val, lane);
+        if (lane == 0) counts[qi] = total;
+        if (PASS == 0) return;
+        if (total > listCap) {
+            if (lane == 0) atomicExch(overflow, kFusedOverflow);
+            return;
+        }
+    } else total = counts[qi];
+    const bool sorted = total <= kSortMax;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(qDesc + (size_t)Q.descId * 32);
+        const uint32_t mine = src[lane & 7];
+#pragma unroll
+        for (int k = 0; k < 8; k++) qd[k] = __shfl(mine, k);
+    }
+    uint32_t *out = lists + offsets_of<PASS>(offsets, qi, listCap);
+    candidates_walk<true>(mode, Q, F, qd, fvIdx, sorted, out, key, val, lane);
     if (sorted && total > 0) {
         int m = 1;
         while (m < total) m <<= 1;
@@ -1198,14 +1223,19 @@ static int upload_frame(RumiMatcher *m, const RumiFrameFeatures *F, FrameDev *fd
 
 // count pass, scan, fill pass.  The fill pass refuses to write past the list arena and raises the overflow word instead; the
 // caller sees it in the result block, grows the arena and repeats the call (run_search) — no mid-pipeline read-back.
-static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, bool retry) {
+static int build_lists(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, bool retry, bool fused) {
     FLUSH(m);
     if (retry) HIP_TRY(hipMemsetAsync(m->dOut, 0, 4 * sizeof(int32_t), nullptr));   // the first attempt's header was cleared with the frame upload
-    if (nq > 0) {
-        hipLaunchKernelGGL(k_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
+    if (nq > 0 && fused) {
+        // one launch: every query's list in a fixed slot of the arena (k_candidates<2>)
+        const int slot = (int)std::min<size_t>(m->listCap / (size_t)nq, 0x7FFFFFFF / (size_t)nq);
+        hipLaunchKernelGGL(k_candidates<2>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
+                           m->dCounts, m->dOffsets, m->dLists, slot, m->dOverflow);
+    } else if (nq > 0) {
+        hipLaunchKernelGGL(k_candidates<0>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists, 0, m->dOverflow);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, nullptr, nq, m->dCounts, m->dOffsets);
-        hipLaunchKernelGGL(k_candidates<true>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
+        hipLaunchKernelGGL(k_candidates<1>, dim3((nq + 3) / 4), dim3(256), 0, nullptr, mode, nq, m->dQ, fd, dQueryDesc, m->dFvIdx,
                            m->dCounts, m->dOffsets, m->dLists, (int)std::min<size_t>(m->listCap, 0x7FFFFFFF), m->dOverflow);
     }
     return RUMI_OK;
@@ -1229,8 +1259,12 @@ static int grow_lists(RumiMatcher *m, size_t need) {
 static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, const uint8_t *dQueryDesc, const int32_t *dMpObs,
                       float nnratio, int checkOri, int32_t *hostFeatMp, int32_t *nmatchesOut, const uint8_t *dBlocked0 = nullptr,
                       float thrF = 0.f, int thrI = 0, int32_t *hostAssign = nullptr) {
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const int rcl = build_lists(m, mode, nq, fd, dQueryDesc, attempt > 0);
+    // first with every query's list in a fixed slot (one candidate launch); a query that does not fit falls back to count / scan / fill, which
+    // sizes the lists exactly and grows the arena when needed
+    static const bool noFused = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    bool fused = !noFused && nq > 0 && m->listCap / (size_t)nq >= 64;
+    for (int attempt = 0, grown = 0; attempt < 4; attempt++) {
+        const int rcl = build_lists(m, mode, nq, fd, dQueryDesc, attempt > 0, fused);
         if (rcl != RUMI_OK) return rcl;
         ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, dMpObs, m->dFeatMp, m->dAssign, m->dNmatches,
                       nnratio, checkOri, dBlocked0, thrF, thrI, m->dOverflow};
@@ -1239,10 +1273,12 @@ static int run_search(RumiMatcher *m, int mode, int nq, const FrameDev &fd, cons
         const int rcf = fetch_results(m, fd.n, nq, hostAssign != nullptr);
         if (rcf != RUMI_OK) return rcf;
         if (m->hOut[1] == 0) break;
+        if (m->hOut[1] == kFusedOverflow) { fused = false; continue; }      // the resolve did not run; repeat with exact list sizes
         // list arena too small: the resolve did not run and the frame's map-point vector is untouched
-        if (attempt == 1) { g_lastError = "candidate list arena overflow after growing"; return RUMI_E_CAPACITY; }
+        if (grown) { g_lastError = "candidate list arena overflow after growing"; return RUMI_E_CAPACITY; }
         const int rcg = grow_lists(m, (size_t)m->hOut[1]);
         if (rcg != RUMI_OK) return rcg;
+        grown = 1;
     }
     *nmatchesOut = m->hOut[0];
     if (fd.n > 0 && hostFeatMp) std::memcpy(hostFeatMp, m->hOut + 4, (size_t)fd.n * sizeof(int32_t));
@@ -1638,7 +1674,7 @@ extern "C" int rumi_search_for_initialization(RumiMatcher *m, const RumiFrameFea
     FLUSH(m);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, nullptr, n1, m->dQKeys, m->dF[0], (float)window_size, m->dQ);
     for (int attempt = 0; attempt < 2; attempt++) {
-        rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc, attempt > 0);
+        rc = build_lists(m, MODE_INIT, n1, fd, m->dQDesc, attempt > 0, false);
         if (rc != RUMI_OK) return rc;
         InitArgs A{n1, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dAssign, m->dF[0], m->dNmatches, nnratio, check_orientation,
                    m->dOverflow};

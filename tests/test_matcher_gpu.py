@@ -35,6 +35,25 @@ def test_search_by_projection_frame(matcher, seed, th):
         assert np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} features differ"
 
 
+def test_candidate_lists_larger_than_a_slot():
+    """The one-launch candidate pass gives every query a fixed slot of the list arena; a radius that makes most of the frame a candidate of every
+    query does not fit, and the search must fall back to count / scan / fill (and grow the arena) with the same result."""
+    from rumi_slam_amd.matcher import FrameView, ORBmatcher
+    s = TrackingScene(3)
+    cur = FrameView(s.cur_keys, s.cur_desc, s.w, s.h, s.sf)
+    cur_mp0 = np.full(cur.n, -1, np.int32)
+    th = 400.0
+    n_ref, ref = O.search_by_projection_frame(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos,
+                                              s.mp_desc, s.mp_obs, cur_mp0, th, True)
+    m = ORBmatcher(0.9, True, max_features=2048, max_queries=2048)
+    n_gpu, got = m.SearchByProjection_Frame(cur, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos, s.mp_desc, s.mp_obs, cur_mp0, th)
+    assert n_gpu == n_ref and np.array_equal(got, ref), f"{np.count_nonzero(got != ref)} features differ"
+    n_gpu, got = m.SearchByProjection_Frame(cur, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos, s.mp_desc, s.mp_obs, cur_mp0, 15.0)
+    n_ref, ref = O.search_by_projection_frame(s.cur_keys, s.cur_desc, s.w, s.h, s.sf, s.Tcw7, K_TUM3, s.last_keys, s.last_mp, s.last_outlier, s.mp_pos,
+                                              s.mp_desc, s.mp_obs, cur_mp0, 15.0, True)
+    assert n_gpu == n_ref and np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("seed,th", [(0, 1.0), (1, 3.0), (2, 5.0), (4, 15.0)])
 def test_search_by_projection_mappoints(matcher, seed, th):
     from rumi_slam_amd.matcher import FrameView
