@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 rm -rf $O/prof_track $O/prof_lba
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_track -- python3 $R/tools/_track_loop.py > $O/track_loop.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_track -- python3 $R/tools/track_loop.py > $O/track_loop.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lba -- python3 $R/tools/prof_lba.py > $O/prof_lba.log 2>&1
 cd $R
 python tools/track_probe.py > $O/track_probe.log 2>&1
