@@ -92,7 +92,7 @@ struct RumiOrb {
     static constexpr int kFeedSlots = 4, kFeedFrames = 64;
     uint8_t *hFeed[kFeedSlots] = {nullptr}; size_t hFeedBytes = 0;
     hipEvent_t evFeed[kFeedSlots] = {nullptr};
-    hipStream_t copyStream = nullptr;
+    hipStream_t copyStream = nullptr, copyStream2 = nullptr;     // host -> device transfers of rumi_orb_extract_batch_host, groups alternating (two DMA engines)
     std::function<int(int, hipStream_t)> feed;
     bool pending = false;            // an asynchronous call has been enqueued and not yet waited for
     hipStream_t pendingStream = nullptr;
@@ -230,6 +230,7 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     for (auto &p : h->hFeed) if (p) (void)hipHostFree(p);
     for (auto &e : h->evFeed) if (e) (void)hipEventDestroy(e);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+    if (h->copyStream2) (void)hipStreamDestroy(h->copyStream2);
     if (h->hIn) (void)hipHostFree(h->hIn);
     if (h->hOut1) (void)hipHostFree(h->hOut1);
     if (h->dOut1) (void)hipFree(h->dOut1);
@@ -559,6 +560,7 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
     }
     if (!h->copyStream) {
         HIP_TRY(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->copyStream2, hipStreamNonBlocking));
         for (auto &e : h->evFeed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // is the source pinned?  (one answer for the whole queue: the frames of a queue come from one allocator)
@@ -573,17 +575,19 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
     }
     hipStream_t st = (hipStream_t)hip_stream;
     int fed = 0, group = 0;                                    // frames already on their way, groups enqueued
+    static const bool twoCopyStreams = std::getenv("RUMI_ONE_COPY_STREAM") == nullptr;
     h->feed = [&](int upto, hipStream_t s) -> int {
         while (fed < upto) {
             const int n = std::min(G, nframes - fed), slot = group % S;
+            hipStream_t cs = (twoCopyStreams && (group & 1)) ? h->copyStream2 : h->copyStream;
             if (group >= S) HIP_TRY(hipEventSynchronize(h->evFeed[slot]));       // the slot's previous group has left the pinned buffer / its event is free again
             bool dense = pinned && stride == wp;                               // one buffer, frames back to back: one transfer per group
             for (int f = 1; dense && f < n; f++) dense = imgs[fed + f] == imgs[fed] + (size_t)f * frameBytes;
             if (dense) {
-                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, imgs[fed], frameBytes * n, hipMemcpyHostToDevice, h->copyStream));
+                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, imgs[fed], frameBytes * n, hipMemcpyHostToDevice, cs));
             } else if (pinned) {
                 for (int f = 0; f < n; f++)
-                    HIP_TRY(hipMemcpy2DAsync(h->dHostIn + (size_t)(fed + f) * frameBytes, wp, imgs[fed + f], stride, w, hgt, hipMemcpyHostToDevice, h->copyStream));
+                    HIP_TRY(hipMemcpy2DAsync(h->dHostIn + (size_t)(fed + f) * frameBytes, wp, imgs[fed + f], stride, w, hgt, hipMemcpyHostToDevice, cs));
             } else {
                 uint8_t *dst = h->hFeed[slot];
                 const int nt = std::max(1, std::min(h->hostThreads, n));
@@ -595,13 +599,14 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
                 for (int t = 1; t < nt; t++) th.emplace_back(work, t);
                 work(0);
                 for (auto &x : th) x.join();
-                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, dst, frameBytes * n, hipMemcpyHostToDevice, h->copyStream));
+                HIP_TRY(hipMemcpyAsync(h->dHostIn + (size_t)fed * frameBytes, dst, frameBytes * n, hipMemcpyHostToDevice, cs));
             }
-            HIP_TRY(hipEventRecord(h->evFeed[slot], h->copyStream));
+            HIP_TRY(hipEventRecord(h->evFeed[slot], cs));
             fed += n; group++;
         }
-        // copies complete in order on the copy stream: waiting for the newest group covers every frame below `upto`
+        // copies complete in order on each copy stream: waiting for the newest group of each covers every frame below `upto`
         HIP_TRY(hipStreamWaitEvent(s, h->evFeed[(group - 1) % S], 0));
+        if (twoCopyStreams && group >= 2) HIP_TRY(hipStreamWaitEvent(s, h->evFeed[(group - 2) % S], 0));
         return RUMI_OK;
     };
     rc = rumi_orb_extract_batch_device_async(h, h->dHostIn, nframes, w, hgt, wp, (int64_t)frameBytes, lap0, lap1, d_kp, d_desc, d_counts, cap, hip_stream);
