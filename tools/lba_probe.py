@@ -28,5 +28,7 @@ w = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"],
 for workers in (1, 2, 4, 8):
     R = 16
     opt.LocalBundleAdjustmentBatch([w] * R, workers)
-    t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([w] * R, workers); dt = time.perf_counter() - t0
-    print("batch of %d windows (20 + 5 key-frames x 3000 points), %d workers: %.3f ms per window" % (R, workers, dt * 1e3 / R))
+    dts = []
+    for _ in range(5):                                   # worker threads spin on their trial scalars: host scheduling shows, the best of five is the device's rate
+        t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([w] * R, workers); dts.append(time.perf_counter() - t0)
+    print("batch of %d windows (20 + 5 key-frames x 3000 points), %d workers: %.3f ms per window (best of 5; median %.3f)" % (R, workers, min(dts) * 1e3 / R, float(np.median(dts)) * 1e3 / R))
