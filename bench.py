@@ -49,6 +49,20 @@ def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
                 per_kp=1369 + 749 + 60, total=px[0] + (total - px[0]) + total + 2 * total + n_kp * (1369 + 749 + 60))
 
 
+def whole_path_valu_issue(fps):
+    """The step against the vector-issue ceiling: VALU wave-instructions per 256-frame pass summed over the path's kernels (committed SQ counters,
+    k_resize runs seven times) over SIMD-cycles available at the measured rate, for the two instruction classes of gfx950 (profiles/r02_valu_issue_rates.txt)."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")))["kernels"]
+        insts = sum(v.get("SQ_INSTS_VALU", 0) * (7 if k == "k_resize" else 1) for k, v in sq.items())
+        simd_cycles = 1024 * 2.4e9 * (256.0 / fps)
+        return {"valu_wave_insts_per_256_frames": int(insts), "frac_of_ceiling_at_4.2_cycles": round(insts * 4.2 / simd_cycles, 3),
+                "frac_of_ceiling_at_2.4_cycles": round(insts * 2.4 / simd_cycles, 3),
+                "source": "committed profile profiles/r02_pmc_sq_counters.json (separate --pmc passes), rate of this run"}
+    except Exception:
+        return None
+
+
 def side_legs(args):
     """BASELINE.json configs[3] (local BA) and PoseOptimization, GPU next to the CPU oracle (rank 0, N = 1)."""
     import numpy as np
@@ -327,6 +341,7 @@ def main():
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
                          "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu,
                          "valu_source": "committed profile profiles/r02_pmc_sq_counters.json, not this run" if valu else None},
+            "valu_issue": whole_path_valu_issue(fps),
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
             "stage_ms_note": "one extra profiled step: every kernel alone on ONE stream (RUMI_SERIAL-equivalent: the blur too), launches of up to 256 frames, summed over the step's launches",
         }
