@@ -144,3 +144,47 @@ def test_local_ba_cost_against_scipy_huber():
     sol = sopt.least_squares(fun, x1, method="trf", xtol=1e-12, ftol=1e-12, max_nfev=100)
     c_scipy = 2 * sol.cost
     assert c_scipy <= c_oracle * (1 + 1e-9) and c_oracle <= c_scipy * 1.02, (c_start, c_oracle, c_scipy)
+
+
+def _fast_bruteforce(img, threshold):
+    """FAST-9/16 straight from its definition (Rosten & Drummond; the contract of cv::FAST with nonmaxSuppression = true), written without looking at
+    how the oracle or the kernel evaluate it: p is a corner at t iff 9 CONTIGUOUS pixels of the 16-pixel Bresenham circle are all brighter than
+    I(p) + t or all darker than I(p) - t; its score is the largest t for which it still is one; a corner survives iff its score is strictly
+    greater than the scores of its 8 neighbours; a 3-pixel margin is never examined."""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    I = img.astype(np.int32)
+    score = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = np.array([I[y + dy, x + dx] - I[y, x] for dx, dy in ring])
+            best = -1
+            for sign in (1, -1):
+                e = sign * d                                    # contrast on this side
+                for s in range(16):
+                    arc = min(e[(s + k) % 16] for k in range(9))
+                    best = max(best, arc - 1)                    # all nine exceed t  <=>  t <= arc - 1
+            if best >= threshold:
+                score[y, x] = best
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s > 0 and all(s > score[y + j, x + i] for j in (-1, 0, 1) for i in (-1, 0, 1) if (i, j) != (0, 0)):
+                out.append((x, y, s))
+    return out
+
+
+@pytest.mark.parametrize("seed,threshold", [(0, 20), (1, 7), (2, 20), (3, 12)])
+def test_fast_against_the_definition(seed, threshold):
+    """The oracle's cv::FAST restatement (oracle/orb_oracle.cc, which the GPU kernel is held bit-exact to) against a brute-force evaluation of the
+    published definition on random textured patches: same corners, same scores, same non-maximum suppression, same order (row-major)."""
+    rng = np.random.default_rng(seed)
+    h, w = 34, 41
+    base = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2)).astype(np.float64)
+    img = np.kron(base, np.ones((4, 4)))[:h, :w] + rng.normal(0, 12, (h, w))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    got = O.fast_cell(img, threshold)
+    ref = _fast_bruteforce(img, threshold)
+    assert len(ref) > 5, "the patch is supposed to have corners"
+    assert [(int(k["x"]), int(k["y"]), int(k["response"])) for k in got] == ref
