@@ -226,7 +226,7 @@ def main():
     match_stream = torch.cuda.Stream(dev)
 
     def step():
-        if world == 1:
+        if world == 1 and not os.environ.get("RUMI_BENCH_FORCE_RECORDS"):     # (the env switch runs the N > 1 code path on one GPU: its exchange degenerates to a no-op)
             kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
             # the matching of step i runs on a stream of its own behind the extraction of step i: the wide Hamming kernel shares the device with
             # the latency-bound stretches (quadtree, compaction, upper pyramid levels) of step i + 1 instead of waiting in line before it
