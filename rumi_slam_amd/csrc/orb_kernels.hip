@@ -749,7 +749,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 constexpr int kDiscP = 36, kPatchP = 40;       // LDS row pitches: 31 (+3 alignment slack) and 37 (+3) bytes as whole dwords
 constexpr int kKpPerWg = 8;
 
-__global__ __launch_bounds__(256) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
+__global__ __launch_bounds__(256, 6) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
