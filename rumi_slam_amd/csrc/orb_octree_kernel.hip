@@ -508,7 +508,7 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
 // latency of one (frame, level) is what counts — small batches); !REGS: 69 VGPRs, three workgroups per CU hide each other's L2
 // round trips (large batches).  launch_octree picks by the number of workgroups.
 template <bool REGS>
-__global__ __launch_bounds__(kOctThreads) void k_octree(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
+__global__ __launch_bounds__(kOctThreads, REGS ? 1 : 8) void k_octree(const DevParams *__restrict__ P, const uint32_t *__restrict__ cand,
                                                         const int32_t *__restrict__ levelStart, uint16_t *__restrict__ owner,
                                                         uint32_t *__restrict__ selLevel, int32_t *__restrict__ selLevelCnt,
                                                         int selLevelCap, int32_t *__restrict__ errFlag) {
