@@ -186,7 +186,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // the "4 consecutive" rule is 23 ANDs / ORs of those words per polarity.
 // Ring entries = tile offset of the pixel | polarity << 15; a pixel's darker entry always precedes its brighter one.
 constexpr int kRingCap = 640;        // linear: < 128 entries wait between steps, a step appends up to 512 (64 lanes x 4 pixels x 2 polarities)
-constexpr int kScoredCap = 512;
+constexpr int kScoredCap = 448;          // with 448 the four waves of a workgroup take 27 072 B of LDS at the 640x480 geometry: six workgroups per CU instead of five
 constexpr uint32_t kF16Bias = 0x4100u;   // contrasts d in [-255, 255] travel as 0x4100 + d: positive normal f16 bit patterns of one exponent, ordered like the integers
 
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
