@@ -149,3 +149,20 @@ def test_divide_free_indexing_is_exact():
     for d in range(1, 99):
         for idx in range(0, 98 * d + d):
             assert H.rumi_hook_magic_div(idx, d) == idx // d, (idx, d)
+
+
+def test_sim3solver_decl_is_minimal():
+    """tests/cpp/ref_decls/Sim3Solver.h is a test stand-in, not upstream's header: it may declare only names that
+    facade/shells/Sim3Solver.cc defines or touches (no reference text under tests/)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    decl = open(os.path.join(root, "tests", "cpp", "ref_decls", "Sim3Solver.h")).read()
+    shell = open(os.path.join(root, "rumi_slam_amd", "facade", "shells", "Sim3Solver.cc")).read()
+    body = decl[decl.index("protected:"):]
+    body = re.sub(r"//[^\n]*", "", body)
+    members = set(re.findall(r"\b(m[A-Z][A-Za-z0-9]*|mv[A-Za-z0-9]+|mn[A-Za-z0-9]+|mp[A-Za-z0-9]+|ms12i|mt12i|mbFixScale|pCamera[12]|N)\b", body))
+    assert len(members) >= 30
+    missing = [m for m in sorted(members) if not re.search(r"\b" + re.escape(m) + r"\b", shell)]
+    assert not missing, f"declared but never used by the shell: {missing}"
+    for helper in ("ComputeCentroid", "ComputeSim3", "CheckInliers", "FromCameraToImage", "mT21i", "mSigma2", "mTh"):
+        assert helper not in body
