@@ -161,7 +161,7 @@ __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b)
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 // One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
-// sub-image as aligned dwords, scores 64 pixels per step, and emits in index order with a running offset.  LDS per wave is
+// sub-image as dwords, tests 256 pixels per step, and emits in index order with a running offset.  LDS per wave is
 // sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
 struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
 
@@ -171,23 +171,26 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- quick test and exact score, second formulation (round 2) -------------------------------------------------------------------
+// ---- quick test and exact score, third formulation (round 3) --------------------------------------------------------------------
 // Instruction classes on gfx950 (tools/valu_rate.hip, profiles/r02_valu_issue_rates.txt): plain add / sub / and / or / xor / right shift /
 // mov issue in ~2.4 cycles per wave once two waves share a SIMD; every min / max, three-operand, packed, SDWA and DPP form takes ~4.2.
-// So the quick test makes its decisions with SUBTRACTIONS and LOGIC instead of packed min / max, and the exact score, which cannot avoid
-// min / max, uses the packed three-input forms gfx950 adds (v_pk_minimum3_f16 / v_pk_maximum3_f16) on two entries per lane.
+//
+// Tile.  Column c of the LDS tile is image column iniX - 1 + c: the detection region (cv::FAST's 3-px margin inside the sub-image)
+// ALWAYS starts at tile column 4, i.e. on a dword, whatever iniX is (the staging loads are unaligned 4-byte global loads).  A row of the
+// region then is ceil(dw / 4) aligned 4-pixel groups with no partial first group (round 2 staged aligned dwords and lost up to one
+// group per row to the shift).
 //
 // Quick test (necessary condition, per polarity): every arc of 9 contains 4 consecutive of the 8 EVEN circle positions, so a pixel can
-// reach contrast thr on the darker-ring side only if 4 consecutive even positions all have v - p_k >= thr (brighter ring: p_k - v >= thr).
-// A lane takes 4 horizontally adjacent pixels of one ALIGNED tile dword; its operands come from 11 aligned dword reads of LDS (the
-// centre row and rows +-2 with their left / right neighbours, rows +-3) instead of 36 byte reads.  The pixels (0, 2) and (1, 3) travel as
-// 16-bit halves of two registers ("even" / "odd" pair); with V + (0x8000 - thr) in each half, ONE 32-bit subtraction of the packed ring
-// pixels leaves "v - p >= thr" in bit 15 / 31 (the halves never borrow from each other: every half stays within 0x8000 +- 511), and
-// the "4 consecutive" rule is 23 ANDs / ORs of those words per polarity.
+// reach contrast T on the darker-ring side only if 4 consecutive even positions all have v - p_k >= T (brighter ring: p_k - v >= T).
+// A lane takes the 4 pixels of one group; its operands come from 11 aligned dword reads of LDS.  Pixels (0, 2) and (1, 3) travel as
+// 16-bit halves of two registers ("even" / "odd" pair).  Adding 2^b - T to the centre before ONE 32-bit subtraction of the packed ring
+// pixels leaves "contrast >= T" in bit b of each half (the halves never borrow from each other: every half stays within 2^b +- 511).
+// The four families (pair x polarity) use b = 12..15, one v_bfi_b32 each merges them into ONE word per circle position, and the
+// "4 consecutive" rule (23 ANDs / ORs) runs once for all eight (pixel, polarity) combinations of the lane instead of four times.
 // Ring entries = tile offset of the pixel | polarity << 15; a pixel's darker entry always precedes its brighter one.
 constexpr int kRingCap = 640;        // linear: < 128 entries wait between steps, a step appends up to 512 (64 lanes x 4 pixels x 2 polarities)
-constexpr int kScoredCap = 448;          // with 448 the four waves of a workgroup take 27 072 B of LDS at the 640x480 geometry: six workgroups per CU instead of five
-constexpr uint32_t kF16Bias = 0x4100u;   // contrasts d in [-255, 255] travel as 0x4100 + d: positive normal f16 bit patterns of one exponent, ordered like the integers
+constexpr int kScoredCap = 448;
+constexpr uint32_t kF16Bias = 0x4100u;   // ring pixels q in [0, 255] travel as 0x4100 + q: positive normal f16 bit patterns of one exponent, ordered like the integers
 
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -197,11 +200,6 @@ __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t
 __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) {       // per 16-bit half: a * b + c
-    uint32_t r;
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 // inclusive prefix sum over the wave's 64 lanes: four row shifts and two row broadcasts (v_add_u32 with a DPP operand each)
@@ -215,7 +213,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// bit 15 / 31 of the result: 4 consecutive of the 8 flag words have theirs set (circular)
+// every bit position on its own: 4 consecutive of the 8 words have the bit set (circular)
 __device__ __forceinline__ uint32_t four_consecutive(const uint32_t (&f)[8]) {
     uint32_t c[8];
 #pragma unroll
@@ -225,39 +223,86 @@ __device__ __forceinline__ uint32_t four_consecutive(const uint32_t (&f)[8]) {
     for (int k = 1; k < 8; k++) any |= c[k] & c[(k + 2) & 7];
     return any;
 }
+// (a & mask) | (b & ~mask) as ONE instruction.  Inline asm on purpose: written in C the compiler sees that only the masked bits are ever
+// used, distributes the masks through the AND / OR network below and ends up with the four separate networks again.
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
 
-// exact scores of up to 128 ring entries, two per lane.
-// Per entry: the 16 circle contrasts of ITS polarity as 0x4100 + d in a 16-bit half (v_pk_mad_i16 by -1 / +1), then
-// max over the 16 arcs of 9 of the minimum: 16 + 16 packed three-input minima and 8 maxima for both entries together.
-// Darker entries store their score; after a wave fence brighter entries keep the maximum (their darker twin sits earlier in the ring).
-// Every entry whose score reaches tlow is appended to the cell's SCORED LIST sl (tile offsets, ascending because the ring is filled in
-// pixel order; a pixel scored for both polarities appears twice in a row): NMS and emission then walk a few hundred listed pixels
-// instead of the whole score map.  nScored counts all appends; entries beyond kScoredCap are dropped and the caller scans the map.
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __forceinline__ uint32_t lds_addr(const uint8_t *p) { return (uint32_t)(uintptr_t)(lds_cu8 *)p; }
+
+// The 16 circle pixels and the centre of ring entry 0 (7 x 7 neighbourhood with top-left corner t0) in the LOW halves of 17 registers, and
+// those of entry 1 (t1) in the HIGH halves of 17 others: ds_read_u8 and ds_read_u8_d16_hi with immediate offsets (compile-time tile
+// pitch).  The d16_hi form puts the byte where the packed arithmetic wants it, so that no shift is spent on packing -- but on a part
+// with SRAM ECC (gfx950) a d16 load ZEROES the other half of its destination instead of keeping it, so the two entries cannot share a
+// register at load time; one three-input bit operation per circle position merges them (and applies the polarity mask, see below).
+// Each asm block carries its own s_waitcnt: the compiler does not track the LDS counter of inline asm, so no result may leave a block
+// before it has arrived.
 template <int CTP>
-__device__ __forceinline__ void fast_score_batch2(const uint8_t *tile, uint8_t *sc, uint16_t *sl, int &nScored, const uint16_t *ring, int n, int tp, int scDelta,
-                                                  int tlow, int lane) {
+__device__ __forceinline__ void fast_ring_load(const uint8_t *t0, const uint8_t *t1, int tp, uint32_t (&lo)[17], uint32_t (&hi)[17]) {
+    if constexpr (CTP != 0) {
+        const uint32_t A0 = lds_addr(t0), A1 = lds_addr(t1);
+#define RUMI_LD(reg, dx, dy) " %" #reg ", %17 offset:%18*(3+(" #dy "))+3+(" #dx ")\n\t"
+#define RUMI_LD17(op)                                                                                              \
+        op RUMI_LD(0, 0, 3)    op RUMI_LD(1, 1, 3)    op RUMI_LD(2, 2, 2)     op RUMI_LD(3, 3, 1)                      \
+        op RUMI_LD(4, 3, 0)    op RUMI_LD(5, 3, -1)   op RUMI_LD(6, 2, -2)    op RUMI_LD(7, 1, -3)                     \
+        op RUMI_LD(8, 0, -3)   op RUMI_LD(9, -1, -3)  op RUMI_LD(10, -2, -2)  op RUMI_LD(11, -3, -1)                   \
+        op RUMI_LD(12, -3, 0)  op RUMI_LD(13, -3, 1)  op RUMI_LD(14, -2, 2)   op RUMI_LD(15, -1, 3)                    \
+        op RUMI_LD(16, 0, 0)   "s_waitcnt lgkmcnt(0)"
+        asm volatile(RUMI_LD17("ds_read_u8")
+                     : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]), "=&v"(lo[8]),
+                       "=&v"(lo[9]), "=&v"(lo[10]), "=&v"(lo[11]), "=&v"(lo[12]), "=&v"(lo[13]), "=&v"(lo[14]), "=&v"(lo[15]), "=&v"(lo[16])
+                     : "v"(A0), "n"(CTP)
+                     : "memory");
+        asm volatile(RUMI_LD17("ds_read_u8_d16_hi")
+                     : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7]), "=&v"(hi[8]),
+                       "=&v"(hi[9]), "=&v"(hi[10]), "=&v"(hi[11]), "=&v"(hi[12]), "=&v"(hi[13]), "=&v"(hi[14]), "=&v"(hi[15]), "=&v"(hi[16])
+                     : "v"(A1), "n"(CTP)
+                     : "memory");
+#undef RUMI_LD17
+#undef RUMI_LD
+    } else {
+#define RUMI_RING(k, dx, dy) lo[k] = t0[(3 + (dy)) * tp + 3 + (dx)]; hi[k] = (uint32_t)t1[(3 + (dy)) * tp + 3 + (dx)] << 16;
+        RUMI_RING(0, 0, 3)    RUMI_RING(1, 1, 3)    RUMI_RING(2, 2, 2)     RUMI_RING(3, 3, 1)
+        RUMI_RING(4, 3, 0)    RUMI_RING(5, 3, -1)   RUMI_RING(6, 2, -2)    RUMI_RING(7, 1, -3)
+        RUMI_RING(8, 0, -3)   RUMI_RING(9, -1, -3)  RUMI_RING(10, -2, -2)  RUMI_RING(11, -3, -1)
+        RUMI_RING(12, -3, 0)  RUMI_RING(13, -3, 1)  RUMI_RING(14, -2, 2)   RUMI_RING(15, -1, 3)
+        RUMI_RING(16, 0, 0)
+#undef RUMI_RING
+    }
+}
+
+// exact scores of up to 128 ring entries, two per lane (entries `lane` and `lane + 64` of the batch: one LDS instruction then serves 64
+// CONSECUTIVE entries, which lie within a few tile rows).
+// A darker-ring entry is scored on COMPLEMENTED pixels (255 - p, 255 - v): its contrasts v - p_k are then the brighter-ring contrasts
+// q_k - vq of the complemented data, so one network serves both polarities and the two entries of a lane may differ in polarity.  Per
+// entry, with q_k = p_k ^ x (x = 0xFF darker, 0 brighter) and vq = v ^ x:  score = max over the 16 arcs of 9 of min q_k  -  vq  -  1.
+// The XOR also sets the f16 exponent (0x4100) and rides on the instruction that merges the two entries' bytes; then 16 + 16 packed
+// three-input minima and 8 maxima for both entries.
+// A pixel cannot reach a positive score in both polarities (two arcs of 9 on a circle of 16 share two positions), so a hit stores its
+// score byte unconditionally and is appended to the cell's SCORED LIST sl (tile offsets, ascending because the ring is filled in pixel
+// order): NMS and emission then walk a few hundred listed pixels instead of the whole score map.  nScored counts all appends; once it
+// passes kScoredCap the list is abandoned and the caller scans the map.
+template <int CTP>
+__device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *sc, uint16_t *sl, int &nScored, const uint16_t *ring, int n, int tp, int scDelta,
+                                                 int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
-    // lane takes entries `lane` and `lane + 64` of the batch: one LDS instruction then serves 64 CONSECUTIVE entries, which lie within a few
-    // tile rows (fewer bank conflicts than 64 entries spread over the whole batch)
     const bool act0 = lane < n, act1 = lane + 64 < n;
     const uint32_t e0 = ring[lane], e1 = ring[lane + 64];
     const int a0 = act0 ? (int)(e0 & 0x7FFFu) : 3 * TP + 4, a1 = act1 ? (int)(e1 & 0x7FFFu) : 3 * TP + 4;
-    const uint32_t b0 = e0 >> 15, b1 = e1 >> 15;                     // 1 = brighter-ring polarity
-    const uint8_t *t0 = tile + a0 - 3 * TP - 3, *t1 = tile + a1 - 3 * TP - 3;   // top-left corner of the 7 x 7 neighbourhood: every offset below is >= 0
-    // multiplier -1 (darker ring: v - p) or +1 (brighter ring: p - v) per half, and the matching constant 0x4100 +- v
-    const uint32_t S = (b0 ? 1u : 0xFFFFu) | ((b1 ? 1u : 0xFFFFu) << 16);
-    const uint32_t v0 = t0[3 * TP + 3], v1 = t1[3 * TP + 3];
-    const uint32_t C = ((b0 ? kF16Bias - v0 : kF16Bias + v0) & 0xFFFFu) | ((b1 ? kF16Bias - v1 : kF16Bias + v1) << 16);
-    uint32_t d[16];
-#define RUMI_RING(k, dx, dy) d[k] = pk_mad_i16((uint32_t)t0[(3 + (dy)) * TP + 3 + (dx)] | ((uint32_t)t1[(3 + (dy)) * TP + 3 + (dx)] << 16), S, C);
-    RUMI_RING(0, 0, 3)    RUMI_RING(1, 1, 3)    RUMI_RING(2, 2, 2)     RUMI_RING(3, 3, 1)
-    RUMI_RING(4, 3, 0)    RUMI_RING(5, 3, -1)   RUMI_RING(6, 2, -2)    RUMI_RING(7, 1, -3)
-    RUMI_RING(8, 0, -3)   RUMI_RING(9, -1, -3)  RUMI_RING(10, -2, -2)  RUMI_RING(11, -3, -1)
-    RUMI_RING(12, -3, 0)  RUMI_RING(13, -3, 1)  RUMI_RING(14, -2, 2)   RUMI_RING(15, -1, 3)
-#undef RUMI_RING
+    // per half: 0x41FF for a darker-ring entry, 0x4100 for a brighter-ring one
+    const uint32_t X = 0x41FF41FFu - ((e0 >> 15) | ((e1 >> 15) << 16)) * 0xFFu;
+    uint32_t lo[17], hi[17], q[16];
+    fast_ring_load<CTP>(tile + a0 - 3 * TP - 3, tile + a1 - 3 * TP - 3, TP, lo, hi);     // top-left corners of the 7 x 7 neighbourhoods: every offset is >= 0
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = (lo[k] | hi[k]) ^ X;                              // one v_bitop3_b32 each
+    const uint32_t vc = lo[16] | hi[16];
     uint32_t lo3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) lo3[k] = pk_min3_f16(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) lo3[k] = pk_min3_f16(q[k], q[(k + 1) & 15], q[(k + 2) & 15]);
     uint32_t arc[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) arc[k] = pk_min3_f16(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
@@ -265,43 +310,47 @@ __device__ __forceinline__ void fast_score_batch2(const uint8_t *tile, uint8_t *
 #pragma unroll
     for (int k = 3; k < 15; k += 2) A = pk_max3_f16(A, arc[k], arc[k + 1]);
     A = pk_max3_f16(A, arc[15], arc[15]);
-    const int s0 = (int)(A & 0xFFFFu) - (int)kF16Bias - 1, s1 = (int)(A >> 16) - (int)kF16Bias - 1;
-    const bool hit0 = act0 && s0 >= tlow, hit1 = act1 && s1 >= tlow;
-    uint8_t *dst0 = &sc[a0 + scDelta], *dst1 = &sc[a1 + scDelta];
-    if (hit0 && !b0) *dst0 = (uint8_t)s0;
-    if (hit1 && !b1) *dst1 = (uint8_t)s1;
+    // per half: A = 0x4100 + max-min q, vq' = 0x4100 + vq; hit <=> A - vq' - 1 >= tlow.  D = (A | 0x8000) - (vq' + tlow + 1) stays within
+    // 0x7E01 .. 0x80FE per half (no borrow between the halves) and carries the decision in bits 15 / 31; for a hit the low byte of
+    // D + tlow is the score.
+    const uint32_t D = (A | 0x80008000u) - ((vc ^ X) + (uint32_t)(tlow + 1) * 0x10001u);
+    const uint32_t Sb = D + (uint32_t)tlow * 0x10001u;
+    const bool hit0 = act0 && (D & 0x8000u) != 0, hit1 = act1 && (int32_t)D < 0;
+    if (hit0) sc[a0 + scDelta] = (uint8_t)Sb;
+    if (hit1) sc[a1 + scDelta] = (uint8_t)(Sb >> 16);
     const unsigned long long h0 = __ballot(hit0), h1 = __ballot(hit1);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int pos0 = nScored + __popcll(h0 & below), pos1 = nScored + __popcll(h0) + __popcll(h1 & below);   // ring order: entries 0..63, then 64..127
-    if (hit0 && pos0 < kScoredCap) sl[pos0] = (uint16_t)a0;
-    if (hit1 && pos1 < kScoredCap) sl[pos1] = (uint16_t)a1;
-    nScored += __popcll(h0) + __popcll(h1);
-    wave_lds_fence();
-    if (hit0 && b0 && s0 > (int)*dst0) *dst0 = (uint8_t)s0;
-    if (hit1 && b1 && s1 > (int)*dst1) *dst1 = (uint8_t)s1;
+    const int c0 = __popcll(h0), total = nScored + c0 + __popcll(h1);
+    if (total <= kScoredCap) {                                       // wave-uniform: once the list has overflowed its content is never read
+        const int pos0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(h0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h0, nScored));
+        const int pos1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(h1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h1, nScored + c0));   // ring order: entries 0..63, then 64..127
+        if (hit0) sl[pos0] = (uint16_t)a0;
+        if (hit1) sl[pos1] = (uint16_t)a1;
+    }
+    nScored = total;
 }
 
 // score map of one cell (CTP != 0: compile-time tile pitch; the score map shares the tile's pitch, so a pixel's score byte sits at
 // its tile offset + scDelta).  Returns the number of scored-list appends.
 template <int CTP>
-__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int shx, int dw, int dh,
-                                               int tlow, int lane) {
+__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int dw, int dh, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
-    const int c0 = 3 + shx, c1 = c0 + dw;                 // tile columns of the detection region
-    const int g0 = c0 >> 2, ng = ((c1 + 3) >> 2) - g0;    // aligned 4-pixel groups per row that touch it
+    const int ng = (dw + 3) >> 2;                         // aligned 4-pixel groups per row; the first starts at tile column 4
     const int nItems = ng * dh;
     const unsigned Mng = magic_of(ng);
-    const int scDelta = -2 * TP - 2 - shx;                // tile offset (py + 3) * TP + px + 3 + shx  ->  score byte (py + 1) * TP + px + 1
-    // entry masks (2 bits per pixel) of the first / last group of a row: pixels left of c0 / from c1 on lie outside the region
-    const uint32_t mFirst = (0xFFu << (2 * (c0 & 3))) & 0xFFu, mLast = 0xFFu >> (2 * (3 - ((c1 - 1) & 3)));
-    const uint32_t T2 = (uint32_t)(tlow + 1) * 0x10001u, kD = 0x80008000u - T2;
+    const int scDelta = -2 * TP - 3;                      // tile offset (py + 3) * TP + px + 4  ->  score byte (py + 1) * TP + px + 1
+    // entry mask (2 bits per pixel) of a row's last group: pixels from column dw on lie outside the region
+    const uint32_t mLast = 0xFFu >> (2 * (4 * ng - dw));
+    const uint32_t T2 = (uint32_t)(tlow + 1);             // the contrast a circle pixel needs
+    // flag bit of each (pair, polarity) family: even-pair darker 12, even-pair brighter 13, odd-pair darker 14, odd-pair brighter 15 -- bit
+    // 2 i + polarity of (any >> 12) then belongs to pixel i of the group (pixel order 0, 1, 2, 3 = even.lo, odd.lo, even.hi, odd.hi)
+    const uint32_t kDe = (0x1000u - T2) * 0x10001u, kBe = (0x2000u - T2) * 0x10001u, kDo = (0x4000u - T2) * 0x10001u, kBo = (0x8000u - T2) * 0x10001u;
     uint32_t *cl32 = reinterpret_cast<uint32_t *>(cl);
     int pending = 0, nScored = 0;
     for (int base = 0; base < nItems; base += 64) {
         const int ip = base + lane;
         const bool live = ip < nItems;
         const int row = live ? magic_div(ip, Mng) : 0, gi = live ? ip - mul24(row, ng) : 0;
-        const int A = mul24(row + 3, TP) + 4 * (gi + g0);                     // tile offset of the group's first pixel
+        const int A = mul24(row + 3, TP) + 4 * (gi + 1);                      // tile offset of the group's first pixel
         const uint8_t *t = tile + A;
 #define RUMI_DW(off) (*reinterpret_cast<const uint32_t *>(t + (off)))
         const uint32_t cM3 = RUMI_DW(-3 * TP), cP3 = RUMI_DW(3 * TP);
@@ -322,24 +371,14 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         pe[6] = __builtin_amdgcn_perm(cc, l0, 0x0c030c01u);      po[6] = __builtin_amdgcn_perm(cc, l0, 0x0c040c02u);
         pe[7] = __builtin_amdgcn_perm(cP2, lP2, 0x0c040c02u);    po[7] = __builtin_amdgcn_perm(cP2, lP2, 0x0c050c03u);
         const uint32_t ve = cc & 0x00FF00FFu, vo = (cc >> 8) & 0x00FF00FFu;
+        const uint32_t cDe = ve + kDe, cBe = kBe - ve, cDo = vo + kDo, cBo = kBo - vo;
         uint32_t f[8];
-        const uint32_t vde = ve + kD, vdo = vo + kD, kbe = kD - ve, kbo = kD - vo;
 #pragma unroll
-        for (int k = 0; k < 8; k++) f[k] = vde - pe[k];          // bit 15 / 31: v - p >= thr
-        const uint32_t aDe = four_consecutive(f);
-#pragma unroll
-        for (int k = 0; k < 8; k++) f[k] = pe[k] + kbe;          // bit 15 / 31: p - v >= thr
-        const uint32_t aBe = four_consecutive(f);
-#pragma unroll
-        for (int k = 0; k < 8; k++) f[k] = vdo - po[k];
-        const uint32_t aDo = four_consecutive(f);
-#pragma unroll
-        for (int k = 0; k < 8; k++) f[k] = po[k] + kbo;
-        const uint32_t aBo = four_consecutive(f);
-        // entry mask: bit 2 i + polarity for pixel i of the group (pixel order 0, 1, 2, 3 = even.lo, odd.lo, even.hi, odd.hi)
-        const uint32_t u = ((aDe & 0x80008000u) >> 15) | ((aBe & 0x80008000u) >> 14) | ((aDo & 0x80008000u) >> 13) | ((aBo & 0x80008000u) >> 12);
-        uint32_t m = (u | (u >> 12)) & 0xFFu;
-        if (gi == 0) m &= mFirst;
+        for (int k = 0; k < 8; k++)
+            f[k] = bfi(0x10001000u, cDe - pe[k], bfi(0x20002000u, pe[k] + cBe, bfi(0x40004000u, cDo - po[k], po[k] + cBo)));
+        const uint32_t any = four_consecutive(f);
+        // entry mask: bit 2 i + polarity for pixel i of the group
+        uint32_t m = ((any >> 12) & 0xFu) | ((any >> 24) & 0xF0u);
         if (gi == ng - 1) m &= mLast;
         if (!live) m = 0;
         if (__ballot(m != 0) != 0) {
@@ -358,7 +397,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
             int head = 0;
             while (pending >= 128) {                       // a full batch: score it exactly
                 wave_lds_fence();
-                fast_score_batch2<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
+                fast_score_batch<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
                 head += 128;
                 pending -= 128;
             }
@@ -371,15 +410,15 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         }
     }
     wave_lds_fence();
-    if (pending) fast_score_batch2<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
+    if (pending) fast_score_batch<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
     return nScored;
 }
 
 // One cell's place in its frame.
 struct FastCell {
-    const uint8_t *img;              // first staged byte: row iniY, column iniX rounded down to a dword
+    const uint8_t *img;              // first staged byte: row iniY, column iniX - 1 (any alignment)
     long long cellIdx;
-    int pitch, rows, cols, shx, nd;  // image pitch; sub-image size; iniX & 3; dwords per staged row
+    int pitch, rows, cols, nd;       // image pitch; sub-image size; dwords per staged row
     int ox, oy;                      // cell origin relative to (16, 16): ci_j * wCell, ci_i * hCell
     bool live;
 };
@@ -402,36 +441,40 @@ __device__ __forceinline__ FastCell fast_cell_geom(const DevParams *__restrict__
         if (lane == 0) cellCnt[g.cellIdx] = 0;
         return g;
     }
-    g.shx = iniX & 3;
-    g.img = level_base(src, P, level, frame, &g.pitch) + (long long)iniY * g.pitch + (iniX - g.shx);
-    g.nd = (g.shx + g.cols + 3) >> 2;
+    // tile column c = image column iniX - 1 + c (iniX >= 16): the detection region starts at tile column 4.  A staged row is
+    // ceil((cols - 6) / 4) + 2 dwords; its last byte is at most image column maxX + 3 <= width - 13, inside the row.
+    g.img = level_base(src, P, level, frame, &g.pitch) + (long long)iniY * g.pitch + (iniX - 1);
+    g.nd = ((g.cols - 6 + 3) >> 2) + 2;
     g.ox = ci_j * L.wCell; g.oy = ci_i * L.hCell;
     g.live = true;
     return g;
 }
-// The first 512 dwords of a sub-image (all of it for cells up to ~44 x 44), eight per lane, all in flight together
-__device__ __forceinline__ void fast_cell_load(const FastCell &g, uint32_t (&v)[8], int lane) {
-    const int total = g.rows * g.nd;
-    const unsigned Mnd = magic_of(g.nd);
+struct __attribute__((packed)) U32 { uint32_t v; };      // possibly unaligned 4-byte global access
+// Staging.  A lane owns ONE dword column c of the tile and one row r0 of every block of rps rows (rps = 64 / dword columns of the tile
+// pitch): its offset into the sub-image and its LDS address are computed once, a block adds a wave-uniform row offset to both.  The
+// last block is moved up so that it ends with the sub-image's last row (it re-loads a few rows of its predecessor): every lane of a
+// block then is in range and no per-lane row test is needed.  The first kStageDepth blocks are in flight together (one memory round
+// trip per cell for sub-images of up to kStageDepth x rps rows); lanes of columns beyond the cell's own width idle.  The loads are
+// unaligned 4-byte GLOBAL accesses (the tile's column 0 is image column iniX - 1; buffer loads would drop the two low address bits).
+constexpr int kStageDepth = 10;
+template <int TPC>
+__device__ __forceinline__ void fast_cell_stage(const FastCell &g, uint8_t *tile, int tp, int lane) {
+    const int TP = TPC ? TPC : tp;
+    const int ndT = TP >> 2, rps = min(64 / ndT, 7);           // a sub-image has at least 7 rows
+    const int r0 = lane / ndT, c = lane - r0 * ndT;
+    if (r0 < rps && c < g.nd) {
+        const uint8_t *src = g.img + r0 * g.pitch + 4 * c;
+        uint8_t *dst = tile + r0 * TP + 4 * c;
+        const int nb = (g.rows + rps - 1) / rps, lastRow = g.rows - rps;
+        uint32_t v[kStageDepth];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int idx = min(j * 64 + lane, total - 1);
-        const int r = magic_div(idx, Mnd), c = idx - mul24(r, g.nd);
-        v[j] = *reinterpret_cast<const uint32_t *>(g.img + mul24(r, g.pitch) + 4 * c);
-    }
-}
-__device__ __forceinline__ void fast_cell_store(const FastCell &g, uint8_t *tile, const int TP, const uint32_t (&v)[8], int lane) {
-    const int total = g.rows * g.nd;
-    const unsigned Mnd = magic_of(g.nd);
+        for (int j = 0; j < kStageDepth; j++)
+            if (j < nb) v[j] = reinterpret_cast<const U32 *>(src + (long long)min(j * rps, lastRow) * g.pitch)->v;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int idx = j * 64 + lane;
-        const int r = magic_div(min(idx, total - 1), Mnd), c = min(idx, total - 1) - mul24(r, g.nd);
-        if (idx < total) *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = v[j];
-    }
-    for (int idx = 512 + lane; idx < total; idx += 64) {         // larger sub-images: the rest, one round trip per 64 dwords
-        const int r = magic_div(idx, Mnd), c = idx - mul24(r, g.nd);
-        *reinterpret_cast<uint32_t *>(&tile[mul24(r, TP) + 4 * c]) = *reinterpret_cast<const uint32_t *>(g.img + mul24(r, g.pitch) + 4 * c);
+        for (int j = 0; j < kStageDepth; j++)
+            if (j < nb) *reinterpret_cast<uint32_t *>(dst + min(j * rps, lastRow) * TP) = v[j];
+        for (int j = kStageDepth; j < nb; j++)                    // taller sub-images: the rest, one round trip per block of rows
+            *reinterpret_cast<uint32_t *>(dst + min(j * rps, lastRow) * TP) = reinterpret_cast<const U32 *>(src + (long long)min(j * rps, lastRow) * g.pitch)->v;
     }
 }
 
@@ -440,13 +483,12 @@ template <int TPC>
 __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ P, const FastLds &F, const FastCell &g, uint8_t *tile, uint8_t *sc,
                                                   uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt, int lane) {
     const int TP = TPC ? TPC : F.tp;
-    const int shx = g.shx;
     const int dw = g.cols - 6, dh = g.rows - 6;
     const unsigned Mdw = magic_of(dw), Mtp = magic_of(TP);
-    for (int idx = lane * 4; idx < (dh + 2) * TP; idx += 256) *reinterpret_cast<uint32_t *>(&sc[idx]) = 0;
+    for (int idx = lane * 16; idx < (dh + 2) * TP; idx += 1024) *reinterpret_cast<uint4 *>(&sc[idx]) = make_uint4(0, 0, 0, 0);   // (scBytes is a multiple of 16)
     wave_lds_fence();
     const int npx = dw * dh;
-    const int scDelta = -2 * TP - 2 - shx;                           // tile offset of a detection pixel -> its byte in the score map
+    const int scDelta = -2 * TP - 3;                                 // tile offset of a detection pixel -> its byte in the score map
     uint16_t *cl = reinterpret_cast<uint16_t *>(sc + F.scBytes);
     uint16_t *sl = cl + kRingCap;
     unsigned long long *balI = reinterpret_cast<unsigned long long *>(cl);      // NMS ballots: the ring is dead once the scores are final
@@ -459,10 +501,10 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
     bool listed;
 #pragma nounroll
     for (int pass = 0;; pass++) {
-        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, shx, dw, dh, thr, lane);
+        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, dw, dh, thr, lane);
         wave_lds_fence();
-        // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in); a cell with more than
-        // kScoredCap scored pixels scans its whole score map instead
+        // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in; every pixel at most once); a cell with more
+        // than kScoredCap scored pixels scans its whole score map instead
         listed = nScored <= kScoredCap;
         nItems = listed ? nScored : npx;
         iters = (nItems + 63) >> 6;
@@ -472,17 +514,15 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
             bool isMax = false;
             if (k < nItems) {
                 int si;                                                          // score-map offset of the pixel
-                bool dup = false;
                 if (listed) {
                     si = (int)sl[k] + scDelta;
-                    dup = k > 0 && sl[k - 1] == sl[k];                           // second entry of a pixel scored for both polarities
                 } else {
                     const int py = magic_div(k, Mdw);
                     si = mul24(py + 1, TP) + (k - mul24(py, dw)) + 1;
                 }
                 const uint8_t *s = &sc[si];
                 const int v = s[0];
-                isMax = !dup && v > 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
+                isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
                         v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
             }
             const unsigned long long bi = __ballot(isMax);
@@ -511,16 +551,14 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
     }
 }
 
-// One WAVE per two consecutive cells of a frame, eight cells per 256-thread workgroup, no workgroup barrier anywhere.  The second cell's
-// sub-image is loaded into registers BEFORE the first cell is processed, so its memory round trip runs under the first cell's arithmetic
-// (a wave's loads were the quarter of the kernel no other wave could cover: every wave starts with them).
 // TPC: tile pitch (= score-map pitch) as a compile-time constant: the circle offsets and the NMS neighbours then are immediate LDS
 // offsets instead of one address add each; 0 = run-time
 template <int TPC>
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
                                                     uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: everything that depends only on the cell (geometry, magic numbers, LDS bases) then runs on the scalar unit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int cell = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
     uint8_t *tile = fl + (size_t)wave * F.perWave;
@@ -528,9 +566,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     const int TP = TPC ? TPC : F.tp;
     const FastCell gA = fast_cell_geom(P, src, cell, frame, cellCnt, lane);
     if (!gA.live) return;
-    uint32_t v[8];
-    fast_cell_load(gA, v, lane);
-    fast_cell_store(gA, tile, TP, v, lane);
+    fast_cell_stage<TPC>(gA, tile, TP, lane);
     fast_cell_process<TPC>(P, F, gA, tile, sc, cellBuf, cellCnt, lane);
 }
 
@@ -869,7 +905,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
     FastLds F;
-    F.tp = (wMax + 6 + 3 + 3) & ~3;                       // sub-image + alignment shift (<= 3), in whole dwords
+    F.tp = 4 * (((wMax + 3) >> 2) + 2);                   // the detection region's 4-pixel groups + one dword of margin on either side (tile column 4 = first detection column)
     F.sp = F.tp;                                          // the score map shares the tile's pitch (a pixel's score byte sits at its tile offset + a constant)
     F.tileBytes = (hMax + 6) * F.tp;
     F.scBytes = ((hMax + 2) * F.sp + 15) & ~15;
@@ -878,8 +914,8 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     // tile | score map | ring of (pixel, polarity) entries that passed the quick test (linear, kRingCap x uint16; the NMS ballots reuse it) |
     // list of scored pixels (kScoredCap x uint16)
     F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
-    // tile pitches of the common image sizes as compile-time constants (640x480 / 752x480 / 1241x376 / 1024x768 / 1280x720: 52;
-    // 1920x1080: 48; 848x480: 56; 600x350: 60); anything else takes the run-time instantiation
+    // tile pitches of the common image sizes as compile-time constants (cells up to 36 / 40 / 44 / 48 pixels wide: 44 / 48 / 52 / 56);
+    // anything else takes the run-time instantiation
     const dim3 grid((hP.totalCells + 3) / 4, nframes);
     const size_t lds = (size_t)4 * F.perWave;
 #define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt); return; }
