@@ -163,7 +163,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
 // sub-image as dwords, tests 256 pixels per step, and emits in index order with a running offset.  LDS per wave is
 // sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
-struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
+struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave, dbg; };
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -242,9 +242,10 @@ __device__ __forceinline__ uint32_t lds_addr(const uint8_t *p) { return (uint32_
 // Each asm block carries its own s_waitcnt: the compiler does not track the LDS counter of inline asm, so no result may leave a block
 // before it has arrived.
 template <int CTP>
-__device__ __forceinline__ void fast_ring_load(const uint8_t *t0, const uint8_t *t1, int tp, uint32_t (&lo)[17], uint32_t (&hi)[17]) {
+__device__ __forceinline__ void fast_ring_load(const uint8_t *t0g, const uint8_t *t1, int tp, uint32_t (&lo)[17], uint32_t (&hi)[17]) {
     if constexpr (CTP != 0) {
-        const uint32_t A0 = lds_addr(t0), A1 = lds_addr(t1);
+        lds_cu8 *t0 = (lds_cu8 *)t0g;
+        const uint32_t A1 = lds_addr(t1);
 #define RUMI_LD(reg, dx, dy) " %" #reg ", %17 offset:%18*(3+(" #dy "))+3+(" #dx ")\n\t"
 #define RUMI_LD17(op)                                                                                              \
         op RUMI_LD(0, 0, 3)    op RUMI_LD(1, 1, 3)    op RUMI_LD(2, 2, 2)     op RUMI_LD(3, 3, 1)                      \
@@ -252,11 +253,16 @@ __device__ __forceinline__ void fast_ring_load(const uint8_t *t0, const uint8_t 
         op RUMI_LD(8, 0, -3)   op RUMI_LD(9, -1, -3)  op RUMI_LD(10, -2, -2)  op RUMI_LD(11, -3, -1)                   \
         op RUMI_LD(12, -3, 0)  op RUMI_LD(13, -3, 1)  op RUMI_LD(14, -2, 2)   op RUMI_LD(15, -1, 3)                    \
         op RUMI_LD(16, 0, 0)   "s_waitcnt lgkmcnt(0)"
-        asm volatile(RUMI_LD17("ds_read_u8")
-                     : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]), "=&v"(lo[8]),
-                       "=&v"(lo[9]), "=&v"(lo[10]), "=&v"(lo[11]), "=&v"(lo[12]), "=&v"(lo[13]), "=&v"(lo[14]), "=&v"(lo[15]), "=&v"(lo[16])
-                     : "v"(A0), "n"(CTP)
-                     : "memory");
+        // entry 0: plain byte loads the compiler issues and tracks itself; they are queued BEFORE the asm block below (a volatile asm with a
+        // memory clobber is not crossed), whose single s_waitcnt lgkmcnt(0) therefore covers all 34 loads in one LDS round trip
+        asm("" : "+v"(t0));            // the base as one opaque register: all 17 offsets then are non-negative immediates of the load instruction
+#define RUMI_LO(k, dx, dy) lo[k] = t0[(3 + (dy)) * CTP + 3 + (dx)];
+        RUMI_LO(0, 0, 3)    RUMI_LO(1, 1, 3)    RUMI_LO(2, 2, 2)     RUMI_LO(3, 3, 1)
+        RUMI_LO(4, 3, 0)    RUMI_LO(5, 3, -1)   RUMI_LO(6, 2, -2)    RUMI_LO(7, 1, -3)
+        RUMI_LO(8, 0, -3)   RUMI_LO(9, -1, -3)  RUMI_LO(10, -2, -2)  RUMI_LO(11, -3, -1)
+        RUMI_LO(12, -3, 0)  RUMI_LO(13, -3, 1)  RUMI_LO(14, -2, 2)   RUMI_LO(15, -1, 3)
+        RUMI_LO(16, 0, 0)
+#undef RUMI_LO
         asm volatile(RUMI_LD17("ds_read_u8_d16_hi")
                      : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7]), "=&v"(hi[8]),
                        "=&v"(hi[9]), "=&v"(hi[10]), "=&v"(hi[11]), "=&v"(hi[12]), "=&v"(hi[13]), "=&v"(hi[14]), "=&v"(hi[15]), "=&v"(hi[16])
@@ -265,7 +271,7 @@ __device__ __forceinline__ void fast_ring_load(const uint8_t *t0, const uint8_t 
 #undef RUMI_LD17
 #undef RUMI_LD
     } else {
-#define RUMI_RING(k, dx, dy) lo[k] = t0[(3 + (dy)) * tp + 3 + (dx)]; hi[k] = (uint32_t)t1[(3 + (dy)) * tp + 3 + (dx)] << 16;
+#define RUMI_RING(k, dx, dy) lo[k] = t0g[(3 + (dy)) * tp + 3 + (dx)]; hi[k] = (uint32_t)t1[(3 + (dy)) * tp + 3 + (dx)] << 16;
         RUMI_RING(0, 0, 3)    RUMI_RING(1, 1, 3)    RUMI_RING(2, 2, 2)     RUMI_RING(3, 3, 1)
         RUMI_RING(4, 3, 0)    RUMI_RING(5, 3, -1)   RUMI_RING(6, 2, -2)    RUMI_RING(7, 1, -3)
         RUMI_RING(8, 0, -3)   RUMI_RING(9, -1, -3)  RUMI_RING(10, -2, -2)  RUMI_RING(11, -3, -1)
@@ -332,7 +338,7 @@ __device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *s
 // score map of one cell (CTP != 0: compile-time tile pitch; the score map shares the tile's pitch, so a pixel's score byte sits at
 // its tile offset + scDelta).  Returns the number of scored-list appends.
 template <int CTP>
-__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int dw, int dh, int tlow, int lane) {
+__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int dw, int dh, int tlow, int lane, int dbg = 0) {
     const int TP = CTP ? CTP : tp;
     const int ng = (dw + 3) >> 2;                         // aligned 4-pixel groups per row; the first starts at tile column 4
     const int nItems = ng * dh;
@@ -381,6 +387,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         uint32_t m = ((any >> 12) & 0xFu) | ((any >> 24) & 0xF0u);
         if (gi == ng - 1) m &= mLast;
         if (!live) m = 0;
+        if (dbg & 2) m = 0;
         if (__ballot(m != 0) != 0) {
             // ring positions: entries of lower lanes first; within a lane pixel by pixel, darker before brighter
             const int cnt = __popc(m);
@@ -397,7 +404,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
             int head = 0;
             while (pending >= 128) {                       // a full batch: score it exactly
                 wave_lds_fence();
-                fast_score_batch<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
+                if (!(dbg & 1)) fast_score_batch<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
                 head += 128;
                 pending -= 128;
             }
@@ -410,7 +417,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         }
     }
     wave_lds_fence();
-    if (pending) fast_score_batch<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
+    if (pending && !(dbg & 1)) fast_score_batch<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
     return nScored;
 }
 
@@ -491,64 +498,65 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
     const int scDelta = -2 * TP - 3;                                 // tile offset of a detection pixel -> its byte in the score map
     uint16_t *cl = reinterpret_cast<uint16_t *>(sc + F.scBytes);
     uint16_t *sl = cl + kRingCap;
-    unsigned long long *balI = reinterpret_cast<unsigned long long *>(cl);      // NMS ballots: the ring is dead once the scores are final
     // Two passes, as upstream calls cv::FAST (:771-785): threshold iniThFAST first, and minThFAST only when the cell yields no key-point (after
     // NMS) at iniThFAST.  A pixel below the pass's threshold can neither be emitted nor suppress a neighbour (cv::FAST's score rows hold 0
     // for it, and NMS needs a strictly larger neighbour), so each pass scores only what reaches ITS threshold: at iniThFAST the quick test
     // passes a fraction of the pixels it passes at minThFAST, and textured cells never run the second pass.
     int thr = max(1, P->iniTh);
-    int nScored, nItems, iters, found;
-    bool listed;
+    uint32_t *out = cellBuf + g.cellIdx * P->maxCellCand;
+    int found;
 #pragma nounroll
     for (int pass = 0;; pass++) {
-        nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, dw, dh, thr, lane);
+        const int nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, dw, dh, thr, lane, F.dbg);
         wave_lds_fence();
-        // NMS over the scored list (ascending pixel order = the row-major order cv::FAST emits in; every pixel at most once); a cell with more
-        // than kScoredCap scored pixels scans its whole score map instead
-        listed = nScored <= kScoredCap;
-        nItems = listed ? nScored : npx;
-        iters = (nItems + 63) >> 6;
+        // NMS + emission in one sweep over the scored list (ascending pixel order = the row-major order cv::FAST emits in; every pixel at
+        // most once); a cell with more than kScoredCap scored pixels scans its whole score map instead.  Two items per lane and sweep, all
+        // their LDS reads issued together and the eight comparisons evaluated without short-circuit: a sweep costs two LDS round trips, not
+        // ten.  Survivors go straight to the cell's output slots (a pass that finds nothing has written nothing).
+        const bool listed = nScored <= kScoredCap;
+        const int nItems = (F.dbg & 4) ? 0 : listed ? nScored : npx;
         found = 0;
-        for (int it = 0; it < iters; it++) {
-            const int k = it * 64 + lane;
-            bool isMax = false;
-            if (k < nItems) {
-                int si;                                                          // score-map offset of the pixel
+        for (int base = 0; base < nItems; base += 128) {
+            int si[2];
+            bool in[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = base + 64 * h + lane;
+                in[h] = k < nItems;
                 if (listed) {
-                    si = (int)sl[k] + scDelta;
+                    si[h] = (int)sl[in[h] ? k : 0] + scDelta;                     // score-map offset of the pixel
                 } else {
-                    const int py = magic_div(k, Mdw);
-                    si = mul24(py + 1, TP) + (k - mul24(py, dw)) + 1;
+                    const int kk = in[h] ? k : 0, py = magic_div(kk, Mdw);
+                    si[h] = mul24(py + 1, TP) + (kk - mul24(py, dw)) + 1;
                 }
-                const uint8_t *s = &sc[si];
-                const int v = s[0];
-                isMax = v > 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
-                        v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
             }
-            const unsigned long long bi = __ballot(isMax);
-            found += __popcll(bi);
-            if (lane == 0) balI[it] = bi;
+            int v[2];
+            bool isMax[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint8_t *s = &sc[si[h]];
+                v[h] = s[0];
+                const int n0 = s[-TP - 1], n1 = s[-TP], n2 = s[-TP + 1], n3 = s[-1], n4 = s[1], n5 = s[TP - 1], n6 = s[TP], n7 = s[TP + 1];
+                isMax[h] = in[h] & (v[h] > 0) & (v[h] > n0) & (v[h] > n1) & (v[h] > n2) & (v[h] > n3) & (v[h] > n4) & (v[h] > n5) & (v[h] > n6) & (v[h] > n7);
+            }
+            const unsigned long long b0 = __ballot(isMax[0]), b1 = __ballot(isMax[1]);
+            const int c0 = __popcll(b0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (isMax[h]) {
+                    const unsigned long long b = h ? b1 : b0;
+                    const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, found + (h ? c0 : 0)));
+                    const int py1 = magic_div(si[h], Mtp), px1 = si[h] - mul24(py1, TP);     // score-map row / column = detection row / column + 1
+                    const uint32_t x = (uint32_t)(px1 + 2 + g.ox), y = (uint32_t)(py1 + 2 + g.oy);
+                    out[slot] = x | (y << 12) | ((uint32_t)v[h] << 24);
+                }
+            }
+            found += c0 + __popcll(b1);
         }
-        wave_lds_fence();
-        if (found > 0 || pass == 1) break;                        // retry with minThFAST only if the first call found nothing (:783)
+        if (found > 0 || pass == 1 || F.dbg) break;               // retry with minThFAST only if the first call found nothing (:783)
         thr = max(1, P->minTh);                                      // scores of the first pass that are still in the map are rewritten with the same values
     }
     if (lane == 0) cellCnt[g.cellIdx] = found;
-    uint32_t *out = cellBuf + g.cellIdx * P->maxCellCand;
-    int run = 0;
-    for (int it = 0; it < iters; it++) {
-        const unsigned long long b = balI[it];
-        if ((b >> lane) & 1ull) {
-            const int k = it * 64 + lane;
-            int si;
-            if (listed) si = (int)sl[k] + scDelta;
-            else { const int py = magic_div(k, Mdw); si = mul24(py + 1, TP) + (k - mul24(py, dw)) + 1; }
-            const int py1 = magic_div(si, Mtp), px1 = si - mul24(py1, TP);       // score-map row / column = detection row / column + 1
-            const uint32_t x = (uint32_t)(px1 + 2 + g.ox), y = (uint32_t)(py1 + 2 + g.oy);
-            out[run + __popcll(b & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)sc[si] << 24);
-        }
-        run += __popcll(b);
-    }
 }
 
 // TPC: tile pitch (= score-map pitch) as a compile-time constant: the circle offsets and the NMS neighbours then are immediate LDS
@@ -560,7 +568,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     // the wave index as a scalar: everything that depends only on the cell (geometry, magic numbers, LDS bases) then runs on the scalar unit
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int cell = (wg % gridDim.x) * 4 + wave, frame = wg / gridDim.x;
+    const int wpg = blockDim.x >> 6;
+    const int cell = (wg % gridDim.x) * wpg + wave, frame = wg / gridDim.x;
     uint8_t *tile = fl + (size_t)wave * F.perWave;
     uint8_t *sc = tile + F.tileBytes;
     const int TP = TPC ? TPC : F.tp;
@@ -905,6 +914,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
     FastLds F;
+    F.dbg = getenv("RUMI_FAST_DBG") ? atoi(getenv("RUMI_FAST_DBG")) : 0;
     F.tp = 4 * (((wMax + 3) >> 2) + 2);                   // the detection region's 4-pixel groups + one dword of margin on either side (tile column 4 = first detection column)
     F.sp = F.tp;                                          // the score map shares the tile's pitch (a pixel's score byte sits at its tile offset + a constant)
     F.tileBytes = (hMax + 6) * F.tp;
@@ -916,12 +926,13 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
     // tile pitches of the common image sizes as compile-time constants (cells up to 36 / 40 / 44 / 48 pixels wide: 44 / 48 / 52 / 56);
     // anything else takes the run-time instantiation
-    const dim3 grid((hP.totalCells + 3) / 4, nframes);
-    const size_t lds = (size_t)4 * F.perWave;
-#define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt); return; }
+    const int wpg = getenv("RUMI_FAST_WPG") ? atoi(getenv("RUMI_FAST_WPG")) : 4;
+    const dim3 grid((hP.totalCells + wpg - 1) / wpg, nframes);
+    const size_t lds = (size_t)wpg * F.perWave;
+#define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(64 * wpg), lds, st, dP, src, F, cellBuf, cellCnt); return; }
     RUMI_FAST_CASE(48) RUMI_FAST_CASE(44) RUMI_FAST_CASE(52) RUMI_FAST_CASE(56)
 #undef RUMI_FAST_CASE
-    hipLaunchKernelGGL((k_fast_cells<0>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt);
+    hipLaunchKernelGGL((k_fast_cells<0>), grid, dim3(64 * wpg), lds, st, dP, src, F, cellBuf, cellCnt);
 }
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st) {
