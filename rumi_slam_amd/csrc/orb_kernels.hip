@@ -163,7 +163,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // One WAVE per (frame, cell), four cells per 256-thread workgroup, no workgroup barrier anywhere: the wave stages its
 // sub-image as dwords, tests 256 pixels per step, and emits in index order with a running offset.  LDS per wave is
 // sized by the host from the largest cell of the current geometry (FastLds), so occupancy is not limited by LDS.
-struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave, dbg; };
+struct FastLds { int tp, sp, tileBytes, scBytes, maxIters, perWave; };
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -190,7 +190,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Ring entries = tile offset of the pixel | polarity << 15; a pixel's darker entry always precedes its brighter one.
 constexpr int kRingCap = 640;        // linear: < 128 entries wait between steps, a step appends up to 512 (64 lanes x 4 pixels x 2 polarities)
 constexpr int kScoredCap = 448;
-constexpr uint32_t kF16Bias = 0x4100u;   // ring pixels q in [0, 255] travel as 0x4100 + q: positive normal f16 bit patterns of one exponent, ordered like the integers
+// (ring pixels q in [0, 255] travel as 0x4100 + q: positive normal f16 bit patterns of one exponent, ordered like the integers)
 
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void fast_score_batch(const uint8_t *tile, uint8_t *s
 // score map of one cell (CTP != 0: compile-time tile pitch; the score map shares the tile's pitch, so a pixel's score byte sits at
 // its tile offset + scDelta).  Returns the number of scored-list appends.
 template <int CTP>
-__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int dw, int dh, int tlow, int lane, int dbg = 0) {
+__device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc, uint16_t *cl, uint16_t *sl, int tp, int dw, int dh, int tlow, int lane) {
     const int TP = CTP ? CTP : tp;
     const int ng = (dw + 3) >> 2;                         // aligned 4-pixel groups per row; the first starts at tile column 4
     const int nItems = ng * dh;
@@ -387,7 +387,6 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         uint32_t m = ((any >> 12) & 0xFu) | ((any >> 24) & 0xF0u);
         if (gi == ng - 1) m &= mLast;
         if (!live) m = 0;
-        if (dbg & 2) m = 0;
         if (__ballot(m != 0) != 0) {
             // ring positions: entries of lower lanes first; within a lane pixel by pixel, darker before brighter
             const int cnt = __popc(m);
@@ -404,7 +403,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
             int head = 0;
             while (pending >= 128) {                       // a full batch: score it exactly
                 wave_lds_fence();
-                if (!(dbg & 1)) fast_score_batch<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
+                fast_score_batch<CTP>(tile, sc, sl, nScored, cl + head, 128, tp, scDelta, tlow, lane);
                 head += 128;
                 pending -= 128;
             }
@@ -417,7 +416,7 @@ __device__ __forceinline__ int fast_score_cell(const uint8_t *tile, uint8_t *sc,
         }
     }
     wave_lds_fence();
-    if (pending && !(dbg & 1)) fast_score_batch<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
+    if (pending) fast_score_batch<CTP>(tile, sc, sl, nScored, cl, pending, tp, scDelta, tlow, lane);
     return nScored;
 }
 
@@ -507,14 +506,14 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
     int found;
 #pragma nounroll
     for (int pass = 0;; pass++) {
-        const int nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, dw, dh, thr, lane, F.dbg);
+        const int nScored = fast_score_cell<TPC>(tile, sc, cl, sl, TP, dw, dh, thr, lane);
         wave_lds_fence();
         // NMS + emission in one sweep over the scored list (ascending pixel order = the row-major order cv::FAST emits in; every pixel at
         // most once); a cell with more than kScoredCap scored pixels scans its whole score map instead.  Two items per lane and sweep, all
         // their LDS reads issued together and the eight comparisons evaluated without short-circuit: a sweep costs two LDS round trips, not
         // ten.  Survivors go straight to the cell's output slots (a pass that finds nothing has written nothing).
         const bool listed = nScored <= kScoredCap;
-        const int nItems = (F.dbg & 4) ? 0 : listed ? nScored : npx;
+        const int nItems = listed ? nScored : npx;
         found = 0;
         for (int base = 0; base < nItems; base += 128) {
             int si[2];
@@ -553,7 +552,7 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
             }
             found += c0 + __popcll(b1);
         }
-        if (found > 0 || pass == 1 || F.dbg) break;               // retry with minThFAST only if the first call found nothing (:783)
+        if (found > 0 || pass == 1) break;               // retry with minThFAST only if the first call found nothing (:783)
         thr = max(1, P->minTh);                                      // scores of the first pass that are still in the map are rewritten with the same values
     }
     if (lane == 0) cellCnt[g.cellIdx] = found;
@@ -914,7 +913,6 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
     FastLds F;
-    F.dbg = getenv("RUMI_FAST_DBG") ? atoi(getenv("RUMI_FAST_DBG")) : 0;
     F.tp = 4 * (((wMax + 3) >> 2) + 2);                   // the detection region's 4-pixel groups + one dword of margin on either side (tile column 4 = first detection column)
     F.sp = F.tp;                                          // the score map shares the tile's pitch (a pixel's score byte sits at its tile offset + a constant)
     F.tileBytes = (hMax + 6) * F.tp;
@@ -926,7 +924,7 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
     // tile pitches of the common image sizes as compile-time constants (cells up to 36 / 40 / 44 / 48 pixels wide: 44 / 48 / 52 / 56);
     // anything else takes the run-time instantiation
-    const int wpg = getenv("RUMI_FAST_WPG") ? atoi(getenv("RUMI_FAST_WPG")) : 4;
+    const int wpg = 4;                                    // cells (= waves) per workgroup
     const dim3 grid((hP.totalCells + wpg - 1) / wpg, nframes);
     const size_t lds = (size_t)wpg * F.perWave;
 #define RUMI_FAST_CASE(T) if (F.tp == T) { hipLaunchKernelGGL((k_fast_cells<T>), grid, dim3(64 * wpg), lds, st, dP, src, F, cellBuf, cellCnt); return; }
