@@ -215,63 +215,90 @@ def main():
     ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
     cap = args.nfeatures + 4 * 8 + 64
 
-    pending = [None]
+    match_stream, xchg_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ext.set_resident_queue(True)          # the queue sits in HBM before the timed region: no call waits for the stream it is issued on (include/rumi_orb.h)
 
-    def match(desc, counts):
-        # frame i against frame i+1 (the last one against the first): B independent 1000 x 1000 problems
+    def match_pairs(desc, counts):
+        # frame i against frame i+1 (the last one against the first): independent 1000 x 1000 problems
         # (views of the extractor's output: the successor of frame i is the same buffer one record further, no copy; the last pair wraps)
-        return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if B > 1 else None,
+        return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if desc.shape[0] > 1 else None,
                 bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
 
-    match_stream = torch.cuda.Stream(dev)
+    class Step:
+        """One step over `fr` frames.  Outputs live in FOUR preallocated buffer sets used in turn (nothing is allocated or cleared inside the
+        timed region); a set is handed to the extractor again only behind the event that marks the end of its previous consumers (matching,
+        exchange): rumi_orb_wait_event.  records=True is the N > 1 code path: per-frame records written in place + the queue's one all-gather."""
 
-    def step():
-        if world == 1 and not os.environ.get("RUMI_BENCH_FORCE_RECORDS"):     # (the env switch runs the N > 1 code path on one GPU: its exchange degenerates to a no-op)
-            kp, desc, counts = ext.extract_batch(frames, (0, 1000), cap=cap, wait=False)    # enqueue only: the host queues step i + 1 while step i runs
+        def __init__(self, fr, records, n_queue_=None, per_=None):
+            self.fr, self.records, self.i, self.nbuf = fr, records, 0, 4      # four sets: as many calls in flight as the extractor has slots
+            n = fr.shape[0]
+            self.n_queue = n_queue_ if n_queue_ is not None else n
+            if records:
+                self.per = per_ if per_ is not None else n
+                self.rec = [torch.zeros((self.per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev) for _ in range(self.nbuf)]
+                self.views = [rumination.record_views(r[:n], cap) for r in self.rec]
+            else:
+                self.out = [(torch.empty((n, cap, 7), dtype=torch.float32, device=dev), torch.empty((n, cap, 32), dtype=torch.uint8, device=dev),
+                             torch.zeros((n, 2), dtype=torch.int32, device=dev)) for _ in range(self.nbuf)]
+            self.consumed = [None] * self.nbuf
+            self.gather = [None] * self.nbuf
+            torch.cuda.synchronize()
+
+        def __call__(self):
+            k = self.i % self.nbuf
+            self.i += 1
+            if self.gather[k] is not None:                       # the exchange that still reads this set: its end and the matching's, as ONE event
+                with torch.cuda.stream(xchg_stream):             # (a stream that carries nothing else: no false dependency on later steps)
+                    self.gather[k].wait()
+                    xchg_stream.wait_event(self.consumed[k])
+                    self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(xchg_stream)
+                self.gather[k] = None
+            if self.consumed[k] is not None:
+                ext.wait_event(self.consumed[k])
+            if self.records:
+                ext.extract_batch_records(self.fr, (0, 1000), cap=cap, wait=False, out=self.rec[k])
+                kp, desc, counts = self.views[k]
+            else:
+                kp, desc, counts = ext.extract_batch(self.fr, (0, 1000), cap=cap, wait=False, out=self.out[k])   # enqueue only
             # the matching of step i runs on a stream of its own behind the extraction of step i: the wide Hamming kernel shares the device with
             # the latency-bound stretches (quadtree, compaction, upper pyramid levels) of step i + 1 instead of waiting in line before it
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(match_stream):
                 match_stream.wait_event(ev)
-                m = match(desc, counts)
-            desc.record_stream(match_stream); counts.record_stream(match_stream)
+                if self.records:
+                    # the path's one exchange step: every GPU ends up with all records (SURVEY.md §8e).  Launched behind the extraction only
+                    # (RCCL runs on its own stream) and joined when its buffer set comes round again, so it overlaps the next steps' kernels
+                    self.gather[k] = rumination.all_gather_records_async(self.rec[k], self.n_queue)
+                m = match_pairs(desc, counts)
+                self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(match_stream)
             return kp, desc, counts, m
-        # N > 1: per-frame records written in place, then the path's one exchange step: every GPU ends up with all records.
-        # The all-gather is launched here and joined after the NEXT step's kernels are queued (RCCL runs on its own stream), so the exchange of
-        # step i overlaps the extraction of step i + 1; drain() joins the last one inside the timed region.
-        rec = torch.zeros((per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev)
-        ext.extract_batch_records(frames, (0, 1000), cap=cap, wait=False, out=rec)
-        kp, desc, counts = rumination.record_views(rec[:B], cap)
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(match_stream):                  # matching and exchange both wait for the extraction only
-            match_stream.wait_event(ev)
-            m = match(desc, counts)
-        rec.record_stream(match_stream)
-        prev, pending[0] = pending[0], rumination.all_gather_records_async(rec, n_queue)
-        if prev is not None:
-            prev.wait()
-        return kp, desc, counts, m
+
+        def drain(self):
+            for k in range(self.nbuf):
+                if self.gather[k] is not None:
+                    self.gather[k].wait()
+                    self.gather[k] = None
+            torch.cuda.current_stream().wait_stream(match_stream)
+
+    use_records = world > 1 or bool(os.environ.get("RUMI_BENCH_FORCE_RECORDS"))   # (the env switch runs the N > 1 code path on one GPU: its exchange degenerates to a no-op)
+    step = Step(frames, use_records, n_queue, per)
 
     def drain():
-        if pending[0] is not None:
-            g = pending[0].wait()
-            pending[0] = None
-            return g
-        return None
+        step.drain()
 
     def timed(fn, steps, warmup):
+        drain_ = fn.drain if hasattr(fn, "drain") else (lambda: None)
         for _ in range(warmup):
             out = fn()
-        drain(); ext.sync(); torch.cuda.synchronize()
+        drain_(); ext.sync(); torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             out = fn()
-        drain()
+        drain_()
         ext.sync()                                # waits for the last step and raises on any device-side capacity condition of the steps
         torch.cuda.synchronize()
         if world > 1:
@@ -288,11 +315,13 @@ def main():
 
     # per-stage device time of one more (untimed) pass with every kernel ALONE on one stream in launches of up to 256 frames
     # (rumi_orb_set_profiling: HIP events recorded by the library on the stream the kernels run on)
+    ext.set_resident_queue(False)
     ext.set_profiling(True)
     ext.extract_batch(frames, (0, 1000), cap=cap)
     torch.cuda.synchronize()
     stage = {k: float(v) for k, v in ext.stage_ms().items()}
     ext.set_profiling(False)
+    ext.set_resident_queue(True)
 
     if rank == 0:
         fps = n_queue * args.steps / dt
@@ -327,7 +356,7 @@ def main():
         line = {
             "metric": "frames/sec ORB extract+match", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "n/a", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (32 seeded frames per rank x cyclic shifts: every frame of a step distinct)",
             "config": {"workload": "ORB extract (640x480, 8-level pyramid, %d features/frame) + brute-force 256-bit Hamming match of consecutive frames (BASELINE.json configs[1]+[2]%s)" % (args.nfeatures, "; queue sharded as configs[4]" if world > 1 else ""),
                        "frames_per_step": n_queue, "frames_per_step_per_gpu": B, "scaling": args.scaling if world > 1 else "n/a (one GPU)",
@@ -351,7 +380,7 @@ def main():
 
             def step_h2d():
                 kp, desc, counts = ext.extract_batch_host(hostq, (0, 1000), cap=cap)
-                return kp, desc, counts, match(desc, counts)
+                return kp, desc, counts, match_pairs(desc, counts)
             dth, _ = timed(step_h2d, max(3, args.steps // 2), 1)
             line["value_h2d_inclusive"] = round(B * max(3, args.steps // 2) / dth, 1)
             line["h2d_note"] = "%d x 307 200 B per step from pinned host memory, 64-frame groups on a copy stream under the kernels (rumi_orb_extract_batch_host)" % B
@@ -365,21 +394,37 @@ def main():
                 ext1(host[i % len(host)], None, (0, 1000))
             line["single_frame_host_api_fps"] = round(200 / (time.perf_counter() - t0), 1)
             ext1.close()
-            # ---- frames per call: device-resident extract + match ----
-            sweep = {}
-            for nb in (64, 256, 1024):
+            # ---- frames per call: device-resident extract + match, the step above at other queue lengths (a rank's share of configs[4] is 128) ----
+            sweep, recs = {}, {}
+            for nb in (64, 128, 256, 1024):
                 if nb > B:
                     continue
-                sub = frames[:nb]
-
-                def step_n():
-                    kp, desc, counts = ext.extract_batch(sub, (0, 1000), cap=cap, wait=False)
-                    return kp, desc, counts, (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]),
-                                              bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
-                reps = max(4, 2048 // nb)
-                dts, _ = timed(step_n, reps, 2)
+                reps = max(12, 16384 // nb)
+                dts, _ = timed(Step(frames[:nb], False), reps, 6)
                 sweep[str(nb)] = round(nb * reps / dts, 1)
+                if nb in (128, 1024):
+                    dts, _ = timed(Step(frames[:nb], True), reps, 6)        # the N > 1 step on this one GPU (its all-gather degenerates to a no-op)
+                    recs[str(nb)] = round(nb * reps / dts, 1)
             line["batch_sweep_fps"] = sweep
+            line["records_path_fps"] = recs
+            line["records_path_note"] = "the step of the N > 1 code path (per-frame records written in place, exchange launched and joined) run on ONE GPU, where the all-gather moves nothing: what a rank of configs[4] does between collectives"
+            # ---- other inputs of SURVEY.md section 8d through the same step (256 frames): the headline frames are far denser in corners than images ----
+            from rumi_slam_amd.synth import synth_frame
+            inputs = {"sparse (40 rectangles: the corner density of natural images)": dict(n_rect=40),
+                      "low texture (60 rectangles of contrast 8-19: most cells take the minThFAST retry)": dict(n_rect=60, contrast=(8, 19))}
+            isweep = {}
+            for name, kw in inputs.items():
+                hs = np.stack([synth_frame(5000 + i, **kw) for i in range(16)])
+                bs = torch.from_numpy(hs).to(dev)
+                fr = torch.empty((256, H, W), dtype=torch.uint8, device=dev)
+                for k in range(256):
+                    fr[k] = torch.roll(bs[k % 16], shifts=(7 * (k // 16), 11 * (k // 16)), dims=(0, 1)) if k >= 16 else bs[k]
+                st_ = Step(fr, False)
+                dts, o = timed(st_, 12, 3)
+                isweep[name] = {"fps": round(256 * 12 / dts, 1), "mean_keypoints": round(float(o[2][:, 0].float().mean().item()), 1)}
+            dts, _ = timed(Step(frames[:256], False), 12, 3)
+            isweep["headline frames (400 rectangles), same 256-frame step"] = {"fps": round(256 * 12 / dts, 1)}
+            line["input_sweep_fps"] = isweep
             # ---- CPU baseline ----
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib                      # the checker, timed as the CPU baseline (kind "port")

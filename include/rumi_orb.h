@@ -100,6 +100,20 @@ int rumi_orb_extract_batch_device_async(RumiOrb *h, const void *d_imgs, int32_t 
                                         int32_t stride, int64_t frame_stride, int32_t lap0, int32_t lap1,
                                         void *d_kp, void *d_desc, void *d_counts, int32_t cap, void *hip_stream);
 int rumi_orb_sync(RumiOrb *h);
+/* Declares the frames of the following batched calls RESIDENT: they do not depend on work pending on `hip_stream` when a call is made (the
+ * rumination queue sits in device memory long before it is processed, CloudImageSampler.cc:148-170).  Sub-chunks then never wait for the
+ * caller's stream, so back-to-back asynchronous calls overlap like the sub-chunks of one large call -- what a rank's share of a sharded
+ * queue (64-128 frames per call) needs to run at the rate of a long one.  The caller's stream still waits for each call's results.
+ * The output buffers must be free too (no initialisation queued on `hip_stream`, no reader of their previous contents still running:
+ * see rumi_orb_wait_event).  The handle grows its device arenas to four slots of min(64, max_batch) frames.  With a resident queue the
+ * arenas keep the pyramid of a call's LAST sub-chunk only (rumi_orb_pyramid_level refuses other frames).  Off by default; switching waits
+ * for pending calls. */
+int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on);
+/* With a resident queue nothing orders a call's kernels behind the caller's stream, so what the call reads AND what it overwrites must be
+ * free when it is made.  When an output buffer is being reused, hand over the event (a hipEvent_t) that marks its previous consumer's end:
+ * the sub-chunks of the NEXT batched call start behind it.  One event per call; NULL clears.  (Without a resident queue the caller's stream
+ * waits for the event instead.) */
+int rumi_orb_wait_event(RumiOrb *h, void *hip_event);
 
 /* The same work with ONE fixed-capacity record per frame as output,
  *   { int32 n; int32 monoIndex; RumiKeyPoint kp[cap]; uint8 desc[cap][32]; }  = 8 + 60 * cap bytes (record_bytes >= that, multiple of 4),

@@ -119,6 +119,16 @@ struct RumiOrb {
     // a chunk's frames are split over the caller's stream and these, see Stage B
     static constexpr int kMaxParts = 8;
     hipStream_t partStream[kMaxParts - 1] = {nullptr}, partSide[kMaxParts - 1] = {nullptr};   // partSide: the part's blur when the pyramid is split too
+    // rumi_orb_set_resident_queue: the frames of a call do not depend on work pending on the caller's stream, so sub-chunk 0 gets a stream of
+    // its own too (with its blur stream) and no sub-chunk waits for the caller's stream: back-to-back calls then overlap like the sub-chunks of
+    // one large call, only the caller's stream waits for each call's results
+    bool residentQueue = false;
+    int scratchFrames = 0, arenaFrames = 0;   // frames the scratch arrays / the pyramid and blur arenas hold
+    int rot = 0;                     // slot of the next sub-chunk
+    hipEvent_t userReady = nullptr;  // rumi_orb_wait_event: the sub-chunks of the next resident-queue call start behind it
+    bool lastResident = false;       // the previous batched call ran in the resident-queue arrangement
+    hipStream_t part0Stream = nullptr, part0Side = nullptr;
+    hipEvent_t evPart0Join = nullptr, evSide0Fork = nullptr, evSide0Join = nullptr;
     hipEvent_t evPartFork = nullptr, evPartJoin[kMaxParts - 1] = {nullptr}, evSideFork[kMaxParts - 1] = {nullptr}, evSideJoin[kMaxParts - 1] = {nullptr};
     hipEvent_t evFork = nullptr, evJoin = nullptr, evB0 = nullptr, evB1 = nullptr;
 };
@@ -226,6 +236,9 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     for (auto &e : h->evSideFork) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->evSideJoin) if (e) (void)hipEventDestroy(e);
     if (h->evPartFork) (void)hipEventDestroy(h->evPartFork);
+    if (h->part0Stream) (void)hipStreamDestroy(h->part0Stream);
+    if (h->part0Side) (void)hipStreamDestroy(h->part0Side);
+    for (hipEvent_t e : {h->evPart0Join, h->evSide0Fork, h->evSide0Join}) if (e) (void)hipEventDestroy(e);
     if (h->dHostIn) (void)hipFree(h->dHostIn);
     for (auto &p : h->hFeed) if (p) (void)hipHostFree(p);
     for (auto &e : h->evFeed) if (e) (void)hipEventDestroy(e);
@@ -235,6 +248,33 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (h->hOut1) (void)hipHostFree(h->hOut1);
     if (h->dOut1) (void)hipFree(h->dOut1);
     delete h;
+}
+
+// The per-frame device arrays: candidate / quadtree scratch for `scratch` frames, pyramid and blurred levels for `arena` frames.  Called by
+// rumi_orb_create and again by rumi_orb_set_resident_queue when four 64-frame slots need more than the handle was created with.
+static int alloc_frame_arenas(RumiOrb *h, size_t scratch, size_t arena) {
+    void *old[] = {h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dOwner, h->dSelLevel, h->dSelLevelCnt};
+    for (void *p : old) if (p) (void)hipFree(p);
+    h->dPyr = h->dBlur = nullptr; h->dCellBuf = nullptr; h->dCellCnt = nullptr; h->dCand = nullptr; h->dLevelStart = nullptr; h->dSelPacked = h->dSelMeta = nullptr;
+    h->dSelCount = nullptr; h->dOwner = nullptr; h->dSelLevel = nullptr; h->dSelLevelCnt = nullptr;
+    const size_t C = scratch;
+    int rc;
+#define TRY_A(x) if ((rc = (x)) != RUMI_OK) return rc;
+    TRY_A(dev_alloc(&h->dPyr, (size_t)h->capArena * arena));
+    TRY_A(dev_alloc(&h->dBlur, (size_t)h->capArena * arena));
+    TRY_A(dev_alloc(&h->dCellBuf, C * h->capCells * h->capCellCand));
+    TRY_A(dev_alloc(&h->dCellCnt, C * h->capCells));
+    TRY_A(dev_alloc(&h->dCand, C * h->capCand));
+    TRY_A(dev_alloc(&h->dLevelStart, C * (kMaxLevels + 1)));
+    TRY_A(dev_alloc(&h->dSelPacked, C * h->capSel));
+    TRY_A(dev_alloc(&h->dSelMeta, C * h->capSel));
+    TRY_A(dev_alloc(&h->dSelCount, C));
+    TRY_A(dev_alloc(&h->dOwner, C * h->capCand));
+    TRY_A(dev_alloc(&h->dSelLevel, C * h->cfg.nlevels * h->selLevelCap));
+    TRY_A(dev_alloc(&h->dSelLevelCnt, C * h->cfg.nlevels));
+#undef TRY_A
+    h->scratchFrames = (int)scratch; h->arenaFrames = (int)arena;
+    return RUMI_OK;
 }
 
 extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
@@ -276,6 +316,9 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     h->capRowTab = 0;
     for (int l = 1; l < cfg->nlevels; l++) h->capRowTab += g[l].h + 8;
     h->capSel = cfg->nfeatures + 4 * cfg->nlevels + 64;   // the quadtree may return a few more than N per level
+    int maxN = 0;
+    for (int l = 0; l < cfg->nlevels; l++) maxN = std::max(maxN, h->tab.featuresPerLevel[l]);
+    h->selLevelCap = maxN + 4 * 16 + 8;
     // scratch arenas: frames of one pass, rounded up to a multiple of 12 so that 2, 3 or 4 equal slots hold ceil(frames / parts) each
     const size_t B = (size_t)cfg->max_batch, C = (size_t)scratch_frames(cfg->max_batch);
     int rc = RUMI_OK;
@@ -284,15 +327,7 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     TRY_ALLOC(dev_alloc(&h->dCoef, (size_t)h->capCoef));
     TRY_ALLOC(dev_alloc(&h->dRowTab, (size_t)std::max(h->capRowTab, 1)));
     TRY_ALLOC(dev_alloc(&h->dIn, (size_t)((cfg->max_width + 3) & ~3) * cfg->max_height));
-    TRY_ALLOC(dev_alloc(&h->dPyr, (size_t)h->capArena * B));
-    TRY_ALLOC(dev_alloc(&h->dBlur, (size_t)h->capArena * B));
-    TRY_ALLOC(dev_alloc(&h->dCellBuf, C * h->capCells * h->capCellCand));
-    TRY_ALLOC(dev_alloc(&h->dCellCnt, C * h->capCells));
-    TRY_ALLOC(dev_alloc(&h->dCand, C * h->capCand));
-    TRY_ALLOC(dev_alloc(&h->dLevelStart, C * (kMaxLevels + 1)));
-    TRY_ALLOC(dev_alloc(&h->dSelPacked, C * h->capSel));
-    TRY_ALLOC(dev_alloc(&h->dSelMeta, C * h->capSel));
-    TRY_ALLOC(dev_alloc(&h->dSelCount, C));
+    TRY_ALLOC(alloc_frame_arenas(h, C, B));
     TRY_ALLOC(dev_alloc(&h->dKp, (size_t)h->capSel));
     TRY_ALLOC(dev_alloc(&h->dDesc, (size_t)h->capSel * 32));
     TRY_ALLOC(dev_alloc(&h->dCounts, 2));
@@ -301,12 +336,6 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
         hipHostMalloc((void **)&h->hOut1, (size_t)16 + (size_t)h->capSel * 60, hipHostMallocDefault) != hipSuccess) {
         rumi_orb_destroy(h); g_lastError = "pinned staging"; return RUMI_E_NO_DEVICE;
     }
-    int maxN = 0;
-    for (int l = 0; l < cfg->nlevels; l++) maxN = std::max(maxN, h->tab.featuresPerLevel[l]);
-    h->selLevelCap = maxN + 4 * 16 + 8;
-    TRY_ALLOC(dev_alloc(&h->dOwner, C * h->capCand));
-    TRY_ALLOC(dev_alloc(&h->dSelLevel, C * cfg->nlevels * h->selLevelCap));
-    TRY_ALLOC(dev_alloc(&h->dSelLevelCnt, C * cfg->nlevels));
     TRY_ALLOC(dev_alloc(&h->dErr, 1));
     TRY_ALLOC(pin_alloc(&h->hErr, 1));
 #undef TRY_ALLOC
@@ -317,6 +346,9 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
             hipEventCreateWithFlags(&h->evSideFork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evSideJoin[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->evPartJoin[i], hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part stream"; return RUMI_E_NO_DEVICE; }
     if (hipEventCreateWithFlags(&h->evPartFork, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part event"; return RUMI_E_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&h->part0Stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->part0Side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evPart0Join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evSide0Fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evSide0Join, hipEventDisableTiming) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "part stream 0"; return RUMI_E_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&h->evB0) != hipSuccess ||
@@ -328,6 +360,28 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
 extern "C" int rumi_orb_set_profiling(RumiOrb *h, int32_t on) {
     if (!h) return RUMI_E_INVALID;
     h->profiling = on != 0;
+    return RUMI_OK;
+}
+extern "C" int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on) {
+    if (!h) return RUMI_E_INVALID;
+    if (h->pending) { const int rc = rumi_orb_sync(h); if (rc != RUMI_OK) return rc; }
+    if (on) {
+        // four slots of up to 64 frames each: their scratch ranges and their ranges of the pyramid / blur arenas
+        const int need = (4 * std::min(64, h->cfg.max_batch) + 11) / 12 * 12;
+        if (h->scratchFrames < need || h->arenaFrames < need) {
+            HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipDeviceSynchronize());
+            const int rc = alloc_frame_arenas(h, (size_t)std::max(h->scratchFrames, need), (size_t)std::max(h->arenaFrames, need));
+            if (rc != RUMI_OK) { g_lastError = "resident queue: device arenas"; return rc; }
+            h->lastFrames = 0; h->tapValid = false;
+        }
+    }
+    h->residentQueue = on != 0;
+    return RUMI_OK;
+}
+extern "C" int rumi_orb_wait_event(RumiOrb *h, void *hip_event) {
+    if (!h) return RUMI_E_INVALID;
+    h->userReady = (hipEvent_t)hip_event;
     return RUMI_OK;
 }
 extern "C" int rumi_orb_stage_ms(RumiOrb *h, float ms[8]) {
@@ -405,35 +459,45 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 4;
     const int parts = (!prof && !serial) ? std::min(std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts), std::max(nframes / 32, 1)) : 1;
     if (!h->pending) HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
-    auto stage_a = [&](const ImgSrc &ps, int n, hipStream_t s, int side) -> int {
+    if (h->userReady && !(h->residentQueue && !prof && !serial && !h->feed)) { HIP_TRY(hipStreamWaitEvent(st, h->userReady, 0)); h->userReady = nullptr; }
+    // the streams and events of one sub-chunk slot: main stream, blur stream, fork / join of the blur
+    struct Lane { hipStream_t s, bs; hipEvent_t fork, join; };
+    const bool resident = h->residentQueue && !prof && !serial && !h->feed;
+    auto lane_of = [&](int slot) -> Lane {
+        if (slot) return {h->partStream[slot - 1], serial ? h->partStream[slot - 1] : h->partSide[slot - 1], h->evSideFork[slot - 1], h->evSideJoin[slot - 1]};
+        if (resident) return {h->part0Stream, h->part0Side, h->evSide0Fork, h->evSide0Join};      // (no slot runs on the caller's stream)
+        return {st, serial ? st : h->sideStream, h->evFork, h->evJoin};
+    };
+    auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
+        hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
         if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
-        hipStream_t bs = serial ? s : (side ? h->partSide[side - 1] : h->sideStream);
-        hipEvent_t fork = side ? h->evSideFork[side - 1] : h->evFork, join = side ? h->evSideJoin[side - 1] : h->evJoin;
-        HIP_TRY(hipEventRecord(fork, s));
-        HIP_TRY(hipStreamWaitEvent(bs, fork, 0));
-        if (prof) HIP_TRY(hipEventRecord(h->evB0, bs));
-        launch_blur(h->dP, P, ps, n, h->cfg.blur_variant, bs);
-        if (prof) HIP_TRY(hipEventRecord(h->evB1, bs));
-        HIP_TRY(hipEventRecord(join, bs));
+        HIP_TRY(hipEventRecord(L.fork, s));
+        HIP_TRY(hipStreamWaitEvent(L.bs, L.fork, 0));
+        if (prof) HIP_TRY(hipEventRecord(h->evB0, L.bs));
+        launch_blur(h->dP, P, ps, n, h->cfg.blur_variant, L.bs);
+        if (prof) HIP_TRY(hipEventRecord(h->evB1, L.bs));
+        HIP_TRY(hipEventRecord(L.join, L.bs));
         HIP_TRY(hipGetLastError());
         return RUMI_OK;
     };
-    if (parts == 1) {
+    if (parts == 1 && !resident) {
         if (h->feed && (rc = h->feed(nframes, st)) != RUMI_OK) return rc;
-        rc = stage_a(src, nframes, st, 0);
+        rc = stage_a(src, nframes, lane_of(0));
         if (rc != RUMI_OK) return rc;
     }
 
     // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [frame0, frame0 + n) of the batch on stream s, in the scratch
     // arenas from frame slot scr0 on (every scratch array is indexed by frame slot, so disjoint slot ranges can run on different streams)
-    auto run_part = [&](int frame0, int n, int scr0, hipStream_t s, bool timed, int side, bool withStageA) -> int {
+    // (arena0 >= 0: the sub-chunk's pyramid / blurred levels live at frame position arena0 of the arenas instead of at frame0)
+    auto run_part = [&](int frame0, int n, int scr0, const Lane &L, bool timed, bool withStageA, int arena0) -> int {
+        hipStream_t s = L.s;
         ImgSrc ps = src;
         ps.l0 = src.l0 + (long long)frame0 * frame_stride;
-        ps.pyr = src.pyr + (long long)frame0 * P.arenaStride;
-        ps.blur = src.blur + (long long)frame0 * P.arenaStride;
-        if (withStageA) { const int ra = stage_a(ps, n, s, side); if (ra != RUMI_OK) return ra; }
+        ps.pyr = src.pyr + (long long)(arena0 >= 0 ? arena0 : frame0) * P.arenaStride;
+        ps.blur = src.blur + (long long)(arena0 >= 0 ? arena0 : frame0) * P.arenaStride;
+        if (withStageA) { const int ra = stage_a(ps, n, L); if (ra != RUMI_OK) return ra; }
         uint32_t *cellBuf = h->dCellBuf + (size_t)scr0 * P.totalCells * P.maxCellCand;
         int32_t *cellCnt = h->dCellCnt + (size_t)scr0 * P.totalCells;
         uint32_t *candp = h->dCand + (size_t)scr0 * P.totalCand;
@@ -450,25 +514,59 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
                         (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
-        HIP_TRY(hipStreamWaitEvent(s, side ? h->evSideJoin[side - 1] : h->evJoin, 0));   // join: rBRIEF reads the blurred levels
+        HIP_TRY(hipStreamWaitEvent(s, L.join, 0));   // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
                            (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
                            (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
         return RUMI_OK;
     };
-    if (parts > 1) {
+    if (resident) {
+        // Resident queue: FOUR fixed slots (stream, blur stream, scratch range, pyramid / blur arena range), sub-chunks of at most 64 frames
+        // dealt to the slots round-robin ACROSS calls (a 64-frame call takes one slot, the next call the next one).  Everything a sub-chunk
+        // touches on the device belongs to its slot, so stream order alone keeps consecutive users of a slot apart: no sub-chunk waits for
+        // the caller's stream or for another slot -- except after a rumi_orb_sync, whose reset of the error word is queued on `st`.
+        constexpr int kSlots = 4;
+        const int slotFrames = h->scratchFrames / kSlots;
+        const int cap64 = std::min(64, slotFrames);
+        const int nsub = (nframes + cap64 - 1) / cap64, sub = (nframes + nsub - 1) / nsub;
+        const bool fork = !h->pending || !h->lastResident;
+        if (fork) HIP_TRY(hipEventRecord(h->evPartFork, st));
+        bool touched[kSlots] = {false, false, false, false};
+        for (int j = 0, base = 0; base < nframes; j++, base += sub) {
+            const int n = std::min(sub, nframes - base), slot = (h->rot + j) % kSlots;
+            const Lane L = lane_of(slot);
+            if (fork && !touched[slot]) HIP_TRY(hipStreamWaitEvent(L.s, h->evPartFork, 0));
+            if (h->userReady && !touched[slot]) HIP_TRY(hipStreamWaitEvent(L.s, h->userReady, 0));
+            touched[slot] = true;
+            rc = run_part(base, n, slot * slotFrames, L, false, true, slot * slotFrames);
+            if (rc != RUMI_OK) return rc;
+            h->lastChunkBase = base; h->lastChunkFrames = n; h->lastChunkSlot = slot * slotFrames;
+        }
+        h->rot = (h->rot + nsub) % kSlots;
+        h->userReady = nullptr;
+        // Join: the caller's stream waits for the results of every sub-chunk (an event per slot, taken after the slot's last sub-chunk)
+        for (int p = 0; p < kSlots; p++)
+            if (touched[p]) {
+                hipEvent_t e = p ? h->evPartJoin[p - 1] : h->evPart0Join;
+                HIP_TRY(hipEventRecord(e, lane_of(p).s));
+                HIP_TRY(hipStreamWaitEvent(st, e, 0));
+            }
+        HIP_TRY(hipGetLastError());
+    } else if (parts > 1) {
         // equal sub-chunks: rounds of `parts` sub-chunks, as few rounds as the slots allow, no short tail
-        const int slotFrames = scratch_frames(h->cfg.max_batch) / parts;
-        const int rounds = (nframes + parts * slotFrames - 1) / (parts * slotFrames), sub = (nframes + parts * rounds - 1) / (parts * rounds);
+        const int slotFrames = h->scratchFrames / parts;
+        static const int envSub = std::getenv("RUMI_SUBMAX") ? std::atoi(std::getenv("RUMI_SUBMAX")) : 1 << 30;
+        const int subMax = std::max(1, std::min(slotFrames, envSub));
+        const int rounds = (nframes + parts * subMax - 1) / (parts * subMax), sub = (nframes + parts * rounds - 1) / (parts * rounds);
         HIP_TRY(hipEventRecord(h->evPartFork, st));
         int used = 0;
         for (int j = 0, base = 0; base < nframes; j++, base += sub) {
             const int n = std::min(sub, nframes - base), slot = j % parts;
-            hipStream_t s = slot ? h->partStream[slot - 1] : st;
-            if (j < parts && slot) HIP_TRY(hipStreamWaitEvent(s, h->evPartFork, 0));
-            if (h->feed && (rc = h->feed(base + n, s)) != RUMI_OK) return rc;
-            rc = run_part(base, n, slot * slotFrames, s, false, slot, true);
+            const Lane L = lane_of(slot);
+            if (j < parts && slot) HIP_TRY(hipStreamWaitEvent(L.s, h->evPartFork, 0));
+            if (h->feed && (rc = h->feed(base + n, L.s)) != RUMI_OK) return rc;
+            rc = run_part(base, n, slot * slotFrames, L, false, true, -1);
             if (rc != RUMI_OK) return rc;
             used = std::max(used, slot + 1);
             h->lastChunkBase = base; h->lastChunkFrames = n; h->lastChunkSlot = slot * slotFrames;
@@ -482,7 +580,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         // one stream: chunks of kChunk frames reuse the scratch arenas in stream order
         for (int base = 0; base < nframes; base += kChunk) {
             const int nf = std::min(kChunk, nframes - base);
-            rc = run_part(base, nf, 0, st, prof, 0, false);
+            rc = run_part(base, nf, 0, lane_of(0), prof, false, -1);
             if (rc != RUMI_OK) return rc;
             HIP_TRY(hipGetLastError());
             if (prof) {
@@ -510,6 +608,11 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         for (int i = 0; i < 8; i++) h->stageMs[i] = acc[i];
     }
     h->lastSrc = src; h->lastFrames = nframes;
+    h->lastResident = resident;
+    if (resident) {      // the arenas hold the pyramids of the last sub-chunk of each slot only; the taps serve the call's last sub-chunk
+        h->lastSrc.pyr = src.pyr + ((long long)h->lastChunkSlot - h->lastChunkBase) * P.arenaStride;
+        h->lastSrc.blur = src.blur + ((long long)h->lastChunkSlot - h->lastChunkBase) * P.arenaStride;
+    }
     h->lastKp = (RumiKeyPoint *)d_kp; h->lastKpStride = out.kpStride; h->lastOutCap = cap;
     h->lastCounts = (int32_t *)d_counts;
     return RUMI_OK;
@@ -654,6 +757,10 @@ extern "C" int rumi_orb_pyramid_level(RumiOrb *h, int32_t frame, int32_t level, 
                                       uint8_t *out, int32_t out_stride, int32_t *w_out, int32_t *h_out) {
     if (!h || h->lastFrames == 0 || frame < 0 || frame >= h->lastFrames || level < 0 || level >= h->hP.nlevels || border < 0)
         return RUMI_E_INVALID;
+    if (h->lastResident && (frame < h->lastChunkBase || frame >= h->lastChunkBase + h->lastChunkFrames)) {
+        g_lastError = "with a resident queue the arenas keep the pyramid of the call's last sub-chunk only";
+        return RUMI_E_INVALID;
+    }
     const DevLevel &L = h->hP.lv[level];
     if (w_out) *w_out = L.w;
     if (h_out) *h_out = L.h;

@@ -16,6 +16,7 @@ class ORBextractor:
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width=640, max_height=480,
                  max_batch=1, device=-1, blur_variant=0):
         self._lib = capi.lib()
+        self._resident = False
         self.cfg = RumiOrbConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
                                  max_batch, device, 0, blur_variant)
         self._h = C.c_void_p()
@@ -68,18 +69,27 @@ class ORBextractor:
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
     # ---- batched, device-resident form (torch tensors on the handle's GPU) ----
-    def extract_batch(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, wait=True):
+    def extract_batch(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, wait=True, out=None):
         """frames: torch.uint8 CUDA tensor [B,H,W] (dense rows, any row pitch).  Returns (kp [B,cap,7] f32 view of the
         28-byte records, desc [B,cap,32] u8, counts [B,2] i32 = (n, monoIndex)) as CUDA tensors.
         wait=False only enqueues (rumi_orb_extract_batch_device_async): the outputs are valid in stream order, device-side
-        conditions are reported by the next ``sync()``; `frames` must stay alive until then."""
+        conditions are reported by the next ``sync()``; `frames` must stay alive until then.
+        out=(kp, desc, counts): tensors of those shapes to write into -- REQUIRED with a resident queue, where nothing orders the kernels behind
+        the caller's stream: buffers allocated (let alone zeroed) on that stream at call time are not safe to write to."""
         import torch
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
         B, H, W = frames.shape
         cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
-        kp = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
-        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
-        counts = torch.zeros((B, 2), dtype=torch.int32, device=frames.device)
+        if out is not None:
+            kp, desc, counts = out
+            assert kp.shape == (B, cap, 7) and kp.dtype == torch.float32 and kp.is_contiguous() and desc.shape == (B, cap, 32) and desc.dtype == torch.uint8
+            assert desc.is_contiguous() and counts.shape == (B, 2) and counts.dtype == torch.int32 and counts.is_contiguous()
+        else:
+            if self._resident:
+                raise ValueError("resident queue: pass preallocated out=(kp, desc, counts) buffers (see the docstring)")
+            kp = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
+            desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
+            counts = torch.zeros((B, 2), dtype=torch.int32, device=frames.device)
         st = stream if stream is not None else torch.cuda.current_stream(frames.device)
         fn = self._lib.rumi_orb_extract_batch_device if wait else self._lib.rumi_orb_extract_batch_device_async
         capi.check(fn(
@@ -97,6 +107,8 @@ class ORBextractor:
         B, H, W = frames.shape
         cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
         rb = rumination.record_bytes(cap)
+        if out is None and self._resident:
+            raise ValueError("resident queue: pass a preallocated out= record buffer")
         rec = out if out is not None else torch.zeros((B, rb), dtype=torch.uint8, device=frames.device)
         assert rec.is_cuda and rec.dtype == torch.uint8 and rec.shape[0] >= B and rec.shape[1] == rb and rec.is_contiguous()
         st = stream if stream is not None else torch.cuda.current_stream(frames.device)
@@ -159,6 +171,17 @@ class ORBextractor:
         out = np.zeros(max(n.value, 1), KP_DTYPE)
         capi.check(self._lib.rumi_orb_stage_keypoints(self._h, frame, level, stage, capi.ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    def set_resident_queue(self, on=True):
+        """The frames of the following batched calls do not depend on work pending on the caller's stream (a queue that sits in device memory):
+        back-to-back asynchronous calls then overlap like the sub-chunks of one large call (include/rumi_orb.h)."""
+        capi.check(self._lib.rumi_orb_set_resident_queue(self._h, int(on)))
+        self._resident = bool(on)
+
+    def wait_event(self, event):
+        """The next batched call starts behind `event` (a recorded torch.cuda.Event): the end of whoever still reads the buffers the call is
+        about to overwrite (rumi_orb_wait_event)."""
+        capi.check(self._lib.rumi_orb_wait_event(self._h, event.cuda_event if event is not None else None))
 
     def set_profiling(self, on=True):
         capi.check(self._lib.rumi_orb_set_profiling(self._h, int(on)))

@@ -157,6 +157,59 @@ def test_async_batches_match_blocking_calls():
             assert k[f, :n].tobytes() == ref[i][0][f, :n].tobytes(), f"batch {i} frame {f}: key-points"
             assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"batch {i} frame {f}: descriptors"
 
+@pytest.mark.gpu
+def test_resident_queue_calls_overlap_and_match_blocking_calls():
+    """rumi_orb_set_resident_queue: sub-chunks never wait for the caller's stream, consecutive calls rotate through four slots and run side by
+    side.  Calls of different sizes (one, two and four sub-chunks, an odd size, a single frame) enqueued back to back, one sync at the end:
+    every call must equal what the ordinary blocking call gives; the taps serve the last sub-chunk."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    B = 200
+    g, _ = _pair(batch=B)
+    sizes = [64, 64, 128, 64, 200, 37, 1, 64, 128]
+    batches = [torch.from_numpy(synth_batch(n, seed0=7000 + 50 * i)).cuda() for i, n in enumerate(sizes)]
+    ref = []
+    for fr in batches:
+        kp, desc, counts = g.extract_batch(fr)
+        ref.append((kp.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()))
+    g.set_resident_queue(True)
+    cap = 1000 + 4 * 8 + 64
+    def bufs(n):
+        return (torch.empty((n, cap, 7), dtype=torch.float32, device="cuda"), torch.empty((n, cap, 32), dtype=torch.uint8, device="cuda"),
+                torch.empty((n, 2), dtype=torch.int32, device="cuda"))
+    outs = [bufs(n) for n in sizes]                             # preallocated: a resident-queue call may not depend on the caller's stream
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        g.extract_batch(batches[0], wait=False)                 # the wrapper refuses to allocate outputs at call time
+    for rep in range(2):                                        # second round: the slots are in use when the calls arrive, the buffers are reused
+        if rep == 1:
+            for o in outs:
+                for t in o: t.zero_()
+            done = torch.cuda.Event(); done.record()
+            g.wait_event(done)                                  # the first call of the round starts behind the clearing of ALL buffers
+        for fr, o in zip(batches, outs):
+            g.extract_batch(fr, wait=False, out=o)
+        g.sync()
+        torch.cuda.synchronize()
+        for i, (kp, desc, counts) in enumerate(outs):
+            c = counts.cpu().numpy()
+            assert np.array_equal(c, ref[i][2]), f"round {rep} call {i}: counts"
+            k, d = kp.cpu().numpy(), desc.cpu().numpy()
+            for f in range(sizes[i]):
+                n = c[f, 0]
+                assert k[f, :n].tobytes() == ref[i][0][f, :n].tobytes(), f"round {rep} call {i} frame {f}: key-points"
+                assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"round {rep} call {i} frame {f}: descriptors"
+    # taps: the last call had two sub-chunks of 64; frame 127 is in the last one, frame 0 is not
+    lvl = g.pyramid_level(3, frame=127)
+    g.set_resident_queue(False)
+    g.extract_batch(batches[-1])
+    assert np.array_equal(lvl, g.pyramid_level(3, frame=127))
+    g.set_resident_queue(True)
+    g.extract_batch(batches[-1], out=outs[-1])
+    with pytest.raises(Exception):
+        g.pyramid_level(3, frame=0)
+
+
 
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_batch_bit_exact_300_frames(pinned):
