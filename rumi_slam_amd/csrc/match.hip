@@ -1449,7 +1449,16 @@ extern "C" int rumi_search_by_bow_batch(RumiMatcher *m, int32_t K, const RumiFra
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(m->hBowOut, dOut, outInts * 4, hipMemcpyDeviceToHost));
     const int32_t *ho = reinterpret_cast<const int32_t *>(m->hBowOut);
-    if (ho[(size_t)K * nf + K] & 1) { g_lastError = "SearchByBoW batch: a FeatureVector node of the frame holds more than 512 features"; return RUMI_E_CAPACITY; }
+    if (ho[(size_t)K * nf + K] & 1) {
+        // a FeatureVector node of the frame holds more than 512 features (k_bow_batch_match keeps a node's "taken" flags in one 32-bit mask per
+        // lane of a 16-lane group): shallow vocabularies or levelsup near L.  The results must still be those of K single searches, so run them.
+        for (int k = 0; k < K; k++) {
+            const int rc1 = rumi_search_by_bow(m, &KFs[k], &kf_fvs[k], kf_mp[k], nmp[k], mp_bad[k], F, f_fv, nnratio, check_orientation,
+                                               matches + (size_t)k * nf, &nmatches_out[k]);
+            if (rc1 != RUMI_OK) return rc1;
+        }
+        return RUMI_OK;
+    }
     std::memcpy(matches, ho, (size_t)K * nf * 4);
     std::memcpy(nmatches_out, ho + (size_t)K * nf, (size_t)K * 4);
     return RUMI_OK;

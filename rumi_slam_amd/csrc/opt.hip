@@ -2235,7 +2235,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         HIP_TRY(hipStreamSynchronize(st));                 // blk / pairs are temporaries
         if (!o->dW) { int rcw = oalloc(&o->dW, (size_t)o->maxE * 18); if (rcw == RUMI_OK) rcw = oalloc(&o->dColOf, (size_t)o->maxE); if (rcw != RUMI_OK) return rcw; }
         if ((size_t)n * 8 > 16 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, n * 8));
+            HIP_TRY(raise_lds_limit(reinterpret_cast<const void *>(k_chol_backsub), (size_t)n * 8));
     }
     const size_t ldsSolve = ((size_t)(n + 1) * (n + 1) + (size_t)n) * sizeof(double);
     const int useLds = !big && ldsSolve <= 158 * 1024;
@@ -2244,10 +2244,11 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     const size_t ldsTiles = ((size_t)(NT * (NT + 1) / 2) * 256 + (size_t)NT * 16) * sizeof(double);
     const int useTiles = !big && n > 0 && NT <= kSolveTilesMax && !forcePanel8;
     if (useTiles && ldsTiles > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTiles));
-    // more than 64 KiB of dynamic LDS needs the opt-in, sized to what this problem uses
+        HIP_TRY(raise_lds_limit(reinterpret_cast<const void *>(k_ba_solve_tiles), ldsTiles));
+    // more than 64 KiB of dynamic LDS needs the opt-in; the limit is process state and only grows (rumi_common.h: raise_lds_limit), so that the
+    // worker threads of rumi_local_ba_batch and the facade's per-thread arenas cannot lower it under each other
     if (useLds && ldsSolve > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+        HIP_TRY(raise_lds_limit(reinterpret_cast<const void *>(k_ba_solve<true>), ldsSolve));
     const int nSlices = 64;
     // the eight scalars of o->dScal -> o->hScal, without a runtime synchronisation (see k_ba_publish); falls back to one if the stream has
     // drained without the number arriving (a failed launch)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "orb_device.h"
+#include "rumi_common.h"
 #include "orb_octree.h"
 
 namespace rumi {
@@ -602,7 +603,7 @@ int launch_sort_hook(uint32_t *keys, uint16_t *ids, int n) {
     OctEntry *d = nullptr;
     if (hipMalloc((void **)&d, n * sizeof(OctEntry)) != hipSuccess) return -2;
     const size_t ldsBytes = (size_t)n * 20 + 8 + 2 * (size_t)(n / 16 + 2) * sizeof(SortSeg) + 64;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_hook), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    (void)raise_lds_limit(reinterpret_cast<const void *>(k_sort_hook), ldsBytes);
     bool ok = hipMemcpy(d, h.data(), n * sizeof(OctEntry), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_sort_hook, dim3(1), dim3(kOctThreads), ldsBytes, nullptr, d, n);
@@ -617,12 +618,9 @@ int launch_sort_hook(uint32_t *keys, uint16_t *ids, int n) {
 void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *cand, const int32_t *levelStart,
                    uint16_t *owner, uint32_t *selLevel, int32_t *selLevelCnt, int selLevelCap, int32_t *errFlag,
                    int nframes, size_t ldsBytes, hipStream_t st) {
-    static size_t attrSet = 0;
-    if (ldsBytes > attrSet) {   // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        attrSet = ldsBytes;
-    }
+    // > 64 KiB of dynamic LDS needs the opt-in (process state that only grows: rumi_common.h)
+    (void)raise_lds_limit(reinterpret_cast<const void *>(k_octree<true>), ldsBytes);
+    (void)raise_lds_limit(reinterpret_cast<const void *>(k_octree<false>), ldsBytes);
     static const int forced = [] { const char *e = getenv("RUMI_OCT_REGS"); return e ? atoi(e) : -1; }();
     const bool regs = forced >= 0 ? forced != 0 : hP.nlevels * nframes <= 256;   // at most one workgroup per CU
     hipLaunchKernelGGL(regs ? k_octree<true> : k_octree<false>, dim3(hP.nlevels, nframes), dim3(kOctThreads), ldsBytes, st, dP, cand, levelStart, owner, selLevel,

@@ -88,10 +88,11 @@ def test_search_by_bow(matcher, seed, nn):
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("K,nodes", [(10, 600), (4, 60), (1, 25)])
+@pytest.mark.parametrize("K,nodes", [(10, 600), (4, 60), (1, 25), (3, 1)])
 def test_search_by_bow_batch_matches_single_calls(matcher, K, nodes):
     """rumi_search_by_bow_batch: K candidate key-frames against one frame in one launch == K single SearchByBoW calls == the oracle, per
-    candidate; `nodes` small puts dozens of features into every FeatureVector node (long sequential chains inside a node)."""
+    candidate; `nodes` small puts dozens of features into every FeatureVector node (long sequential chains inside a node); nodes = 1 puts ALL
+    of the frame's features into one node -- more than the 512 the batch kernel holds per node, so the entry answers with K single searches."""
     from rumi_slam_amd.matcher import FrameView, SearchByBoW_batch
     scenes = [TrackingScene(40 + k) for k in range(K)]
     base = scenes[0]

@@ -346,3 +346,23 @@ def test_local_ba_batch_equals_single_calls(opt):
             assert np.array_equal(s[0], g[0]), f"window {i}, {workers} workers: stats {g[0]} vs {s[0]}"
             assert np.array_equal(s[3], g[3]), f"window {i}, {workers} workers: erase flags"
             assert np.allclose(s[1], g[1], rtol=1e-6, atol=1e-7) and np.allclose(s[2], g[2], rtol=1e-6, atol=1e-7), f"window {i}, {workers} workers"
+
+
+def test_local_ba_batch_windows_of_very_different_size(opt):
+    """Windows of 6 to 29 optimised key-frames in ONE rumi_local_ba_batch call over several workers: the solve kernels of the larger windows need
+    74-135 KB of dynamic LDS, which is an opt-in kept per FUNCTION, i.e. shared by all worker threads.  A worker with a small window must not
+    lower the limit under a worker about to launch a large one (the limit only grows: rumi_common.h raise_lds_limit); repeated so that the
+    workers meet in different orders."""
+    sizes = [29, 6, 22, 8, 16, 27, 7, 19, 6, 24, 9, 17]
+    cfgs = [dict(seed=300 + i, n_opt=k, n_fixed=2, n_points=400 + 50 * (i % 4), outlier_frac=0.03) for i, k in enumerate(sizes)]
+    probs = [ba_problem(**c) for c in cfgs]
+    wins = [(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"]) for b in probs]
+    single = [opt.LocalBundleAdjustment(*w) for w in wins]
+    for rep in range(3):
+        order = list(range(len(wins))) if rep == 0 else list(np.random.default_rng(rep).permutation(len(wins)))
+        got = opt.LocalBundleAdjustmentBatch([wins[i] for i in order], 4)
+        for j, i in enumerate(order):
+            s, g = single[i], got[j]
+            assert np.array_equal(s[0], g[0]), f"window {i} ({sizes[i]} key-frames), round {rep}: stats {g[0]} vs {s[0]}"
+            assert np.array_equal(s[3], g[3]), f"window {i}, round {rep}: erase flags"
+            assert np.allclose(s[1], g[1], rtol=1e-6, atol=1e-7) and np.allclose(s[2], g[2], rtol=1e-6, atol=1e-7), f"window {i}, round {rep}"
