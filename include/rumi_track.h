@@ -11,7 +11,9 @@
  */
 #ifndef RUMI_TRACK_H
 #define RUMI_TRACK_H
+#include "rumi_match.h"
 #include "rumi_orb.h"
+#include "rumi_voc.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -64,6 +66,52 @@ int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, int32_t h, i
                      const RumiKeyPoint *last_keys_un, int32_t nlast, const int32_t *last_mp, const uint8_t *last_outlier,
                      const RumiTrackPoints *pts, float th_motion, float th_local, int32_t far_points, float th_far_points,
                      RumiKeyPoint *keys_out, uint8_t *desc_out, int32_t cap, int32_t *frame_mp_motion, int32_t *frame_mp, uint8_t *outlier,
+                     uint8_t *in_view, RumiTrackResult *res);
+
+/* ---- step-wise entries -------------------------------------------------------------------------------------------------------------------
+ * The same stages ONE member function of Tracking at a time, for a host that keeps the reference's control flow: Tracking::Track decides
+ * between TrackWithMotionModel and TrackReferenceKeyFrame (Tracking.cc:1823-1843), UpdateLocalMap builds the local set from the matches those
+ * leave in mCurrentFrame.mvpMapPoints (:3092-3105) -- so it has to run BETWEEN them and TrackLocalMap, on the host -- and a failed
+ * TrackLocalMap is LOST, not a fall-back.  The frame extracted by rumi_track_extract stays resident on the device (key-points, descriptors,
+ * grid, and after rumi_track_reference_keyframe its FeatureVector) for every later call; each call takes the point table it needs and
+ * returns what its reference function leaves in the Frame.  rumi_track_frame above remains the fused form for a caller that supplies the
+ * local set itself. */
+
+/* Frame::ExtractORB(0, im, 0, 1000) (Frame.cc:473-479): host image in, key-points / descriptors out (keys_out, desc_out [cap >= nfeatures +
+ * 4 nlevels + 64]) and kept on the device. */
+int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride, RumiKeyPoint *keys_out, uint8_t *desc_out,
+                       int32_t cap, int32_t *n_out, int32_t *mono_out);
+
+/* Tracking::TrackWithMotionModel (Tracking.cc:2441-2518), monocular, no IMU, after UpdateLastFrame: SearchByProjection(Cur, Last, th) with
+ * the 2 th retry; with >= 20 matches PoseOptimization and the "discard outliers" loop.  pts: the table last_mp indexes (pos, desc, obs, bad
+ * are read).  Outputs: frame_mp [cap] = mCurrentFrame.mvpMapPoints as table indices when the function returns; discarded [cap] = the table
+ * index of the point whose match was discarded as an outlier at that feature (-1 elsewhere): the caller owes those points
+ * mbTrackInView = false and mnLastFrameSeen = mCurrentFrame.mnId.  res: n, mono_index, th_motion, nmatches_motion (< 20: the function
+ * returned false before optimising; frame_mp holds the search's result), ngood_motion, nmatches_map, Tcw_motion (= Tcw). */
+int rumi_track_motion(RumiTracker *t, const float *K4, const float *Tcw_pred7, const RumiKeyPoint *last_keys_un, int32_t nlast,
+                      const int32_t *last_mp, const uint8_t *last_outlier, const RumiTrackPoints *pts, float th_motion, int32_t *frame_mp,
+                      int32_t *discarded, RumiTrackResult *res);
+
+/* Tracking::TrackReferenceKeyFrame (Tracking.cc:2324-2375): Frame::ComputeBoW (Frame.cc:763-768: transform(..., levelsup = 4), tree descent and
+ * FeatureVector on the device), ORBmatcher(nnratio = 0.7, true).SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches); with >= 15
+ * matches SetPose(Tcw_init7 = mLastFrame.GetPose()), PoseOptimization and the "discard outliers" loop.
+ * KF / kf_fv / kf_mp: the reference key-frame's undistorted key-points + descriptors, its FeatureVector (CSR, rumi_match.h) and
+ * GetMapPointMatches() as indices into pts (-1 none); pts: that key-frame's map points (pos, desc unused, obs, bad).
+ * Outputs: word_id / word_weight / node_id [cap]: the per-feature transform, from which rumi_voc_assemble gives mBowVec and mFeatVec;
+ * frame_mp, discarded as rumi_track_motion; res->nmatches_motion = SearchByBoW's return value (< 15: the function returned false, frame_mp
+ * holds vpMapPointMatches, which the reference does not assign to the frame then), ngood_motion, nmatches_map, Tcw_motion. */
+int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc, int32_t levelsup, const float *K4, const float *Tcw_init7,
+                                  const RumiFrameFeatures *KF, const RumiFeatureVector *kf_fv, const int32_t *kf_mp, const RumiTrackPoints *pts,
+                                  float nnratio, int32_t check_orientation, uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                                  int32_t *frame_mp, int32_t *discarded, RumiTrackResult *res);
+
+/* Tracking::TrackLocalMap after UpdateLocalMap (Tracking.cc:2520-2607) = SearchLocalPoints (:2996-3055) + PoseOptimization + the statistics
+ * loop.  Tcw7 = mCurrentFrame.GetPose(); frame_mp_in [n] = mCurrentFrame.mvpMapPoints as indices into pts (the table: mvpLocalMapPoints first
+ * and in their order with local = 1, then any other point the frame holds); seen_in [pts->n] (may be NULL): points with mnLastFrameSeen ==
+ * mCurrentFrame.mnId already (the outliers the previous function discarded).  Outputs as rumi_track_frame: frame_mp / outlier [cap],
+ * in_view [pts->n]; res: n_to_match, nmatches_local, ngood_local, matches_inliers, Tcw, Rcw / tcw / Ow of Tcw7. */
+int rumi_track_local(RumiTracker *t, const float *K4, const float *Tcw7, const int32_t *frame_mp_in, const RumiTrackPoints *pts,
+                     const uint8_t *seen_in, float th_local, int32_t far_points, float th_far_points, int32_t *frame_mp, uint8_t *outlier,
                      uint8_t *in_view, RumiTrackResult *res);
 
 #ifdef __cplusplus

@@ -51,6 +51,12 @@ int rumi_voc_transform_batch_device(RumiVocabulary *v, const void *d_desc, const
 int rumi_voc_transform(RumiVocabulary *v, const uint8_t *desc, int32_t n, int32_t levelsup, uint32_t *bow_ids, double *bow_vals,
                        int32_t *n_words_out, uint32_t *fv_nodes, int32_t *fv_offsets, uint32_t *fv_indices, int32_t *n_nodes_out);
 
+/* The second half of rumi_voc_transform alone: BowVector and FeatureVector from the per-feature results (word_id, weight, node_id of
+ * rumi_voc_transform_features / rumi_track_reference_keyframe), assembled in feature order exactly as TemplatedVocabulary::transform's loop
+ * does (:1147-1190).  Host-only. */
+int rumi_voc_assemble(const RumiVocabulary *v, int32_t n, const uint32_t *word_id, const double *weight, const uint32_t *node_id, uint32_t *bow_ids,
+                      double *bow_vals, int32_t *n_words_out, uint32_t *fv_nodes, int32_t *fv_offsets, uint32_t *fv_indices, int32_t *n_nodes_out);
+
 #ifdef __cplusplus
 }
 #endif

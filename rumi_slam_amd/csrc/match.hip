@@ -180,9 +180,10 @@ __global__ void k_queries_frame(int nlast, const RumiKeyPoint *lastKeys, const i
 // SearchByBoW: one query per entry of the key-frame's FeatureVector, in (node, entry) order (ORBmatcher.cc:217-232)
 __global__ void k_queries_bow(int nnKF, const uint32_t *kfNodes, const int32_t *kfOff, const uint32_t *kfIdx,
                               const int32_t *kfMp, const uint8_t *mpBad, const RumiKeyPoint *kfKeys, int nnF,
-                              const uint32_t *fNodes, const int32_t *fOff, Query *q) {
+                              const uint32_t *fNodes, const int32_t *fOff, Query *q, const int32_t *nnFdev = nullptr) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nnKF) return;
+    if (nnFdev) nnF = *nnFdev;                              // the frame's FeatureVector was built on the device (k_fv_build)
     // the merge-walk of the two ordered maps visits exactly the node ids present in both
     int lo = 0, hi = nnF;
     const uint32_t id = kfNodes[a];
@@ -1873,6 +1874,95 @@ __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint
     if (tid == 0) { start[0] = 0; start[1] = sBase; }
 }
 
+// Frame::UpdatePoseMatrices (Frame.cc:522-528) in Sophus' / Eigen's float arithmetic: Rcw = q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw)
+// (quaternion _transformVector), as [Rcw9 | tcw3 | Ow3 | K4] for the frustum test.
+__device__ __forceinline__ void pose_matrices19(const float *Tcw7, const float *K4, float *pose19) {
+    const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    pose19[0] = 1.f - (tyy + tzz); pose19[1] = txy - twz; pose19[2] = txz + twy;
+    pose19[3] = txy + twz; pose19[4] = 1.f - (txx + tzz); pose19[5] = tyz - twx;
+    pose19[6] = txz - twy; pose19[7] = tyz + twx; pose19[8] = 1.f - (txx + tyy);
+    const float t0 = Tcw7[4], t1 = Tcw7[5], t2 = Tcw7[6];
+    pose19[9] = t0; pose19[10] = t1; pose19[11] = t2;
+    const float qx = -x, qy = -y, qz = -z, v0 = t0 * -1.f, v1 = t1 * -1.f, v2 = t2 * -1.f;
+    float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+    u0 += u0; u1 += u1; u2 += u2;
+    const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
+    pose19[12] = (v0 + w * u0) + c0; pose19[13] = (v1 + w * u1) + c1; pose19[14] = (v2 + w * u2) + c2;
+    pose19[15] = K4[0]; pose19[16] = K4[1]; pose19[17] = K4[2]; pose19[18] = K4[3];
+}
+
+// "Discard outliers" of TrackWithMotionModel / TrackReferenceKeyFrame alone (Tracking.cc:2489-2508, 2349-2369): the outliers of the optimisation
+// leave the frame, the others count towards nmatchesMap when their point has observations.  (The step-wise entries: SearchLocalPoints' own
+// loops belong to rumi_track_local.)
+__global__ void k_track_discard(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, TrackBlock *blk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= blk->start[1]) return;
+    const int i = idx[c], mp = featMp[i];
+    if (outlierC[c]) { featMp[i] = -1; return; }
+    if (mpObs[mp] > 0) atomicAdd(&blk->counters[0], 1);
+}
+
+// rumi_track_local: the pose the stage starts from and its UpdatePoseMatrices, cleared outputs and counters (the frame's map-point vector and
+// the seen flags arrive with the stage's upload)
+__global__ void k_track_local_init(int n, const float *Tcw7, const float *K4, uint8_t *outF, int32_t *mpOut, int32_t *searchHeader, TrackBlock *blk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { outF[i] = 0; mpOut[i] = -1; }
+    if (i < 4) searchHeader[i] = 0;
+    if (i == 0) {
+        for (int k = 0; k < 7; k++) { blk->Tout[k] = Tcw7[k]; blk->Tout[7 + k] = Tcw7[k]; }
+        pose_matrices19(Tcw7, K4, blk->pose19);
+        blk->nGood[0] = blk->nGood[1] = 0; blk->counters[0] = blk->counters[1] = 0; blk->start[0] = blk->start[1] = 0;
+    }
+}
+
+// The frame's DBoW2::FeatureVector on the device (TemplatedVocabulary.h:1147-1190, FeatureVector.cpp:31-45): the features with a positive word
+// weight grouped by their node id, nodes ascending, feature indices ascending inside a node, in the CSR form the BoW search reads.
+// ONE workgroup: 64-bit keys node << 32 | feature in LDS, bitonic sort, then the group boundaries by an ordered compaction.
+constexpr int kFvThreads = 1024;
+__global__ __launch_bounds__(kFvThreads) void k_fv_build(int n, int npad, const uint32_t *__restrict__ node, const double *__restrict__ weight,
+                                                         uint32_t *fvNodes, int32_t *fvOff, uint32_t *fvIdx, int32_t *nnOut) {
+    extern __shared__ unsigned long long fvKey[];          // npad keys (a power of two >= n)
+    __shared__ int sCnt[kFvThreads / 64], sBase, sValid;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npad; i += kFvThreads)
+        fvKey[i] = (i < n && weight[i] > 0.0) ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;       // stopped words and padding sort last
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += kFvThreads) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = fvKey[i], b = fvKey[l];
+                    if ((a > b) == ((i & k) == 0)) { fvKey[i] = b; fvKey[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) { sBase = 0; sValid = 0; }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; c0 < npad; c0 += kFvThreads) {
+        const int i = c0 + tid;
+        const unsigned long long key = i < npad ? fvKey[i] : ~0ull;
+        const bool valid = key != ~0ull;
+        const bool first = valid && (i == 0 || (uint32_t)(fvKey[i - 1] >> 32) != (uint32_t)(key >> 32));
+        if (valid) fvIdx[i] = (uint32_t)key;
+        const unsigned long long b = __ballot(first);
+        if (lane == 0) sCnt[wave] = __popcll(b);
+        if (valid) atomicMax(&sValid, i + 1);
+        __syncthreads();
+        int off = sBase;
+        for (int k = 0; k < wave; k++) off += sCnt[k];
+        if (first) { const int a = off + __popcll(b & ((1ull << lane) - 1)); fvNodes[a] = (uint32_t)(key >> 32); fvOff[a] = i; }
+        __syncthreads();
+        if (tid == 0) { int t = sBase; for (int k = 0; k < kFvThreads / 64; k++) t += sCnt[k]; sBase = t; }
+        __syncthreads();
+    }
+    if (tid == 0) { fvOff[sBase] = sValid; *nnOut = sBase; }
+}
+
 // After the first PoseOptimization (Tracking.cc:2489-2508) and the first loop of SearchLocalPoints (:2998-3010): every point the motion search
 // matched has been seen in this frame (inliers by SearchLocalPoints, outliers by the discard loop); outliers and bad points leave the frame.
 // Thread 0 also derives Frame::UpdatePoseMatrices (Frame.cc:522-528) of the optimised pose in Sophus' / Eigen's float arithmetic: Rcw =
@@ -1880,24 +1970,7 @@ __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint
 __global__ void k_track_after_motion(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, const uint8_t *mpBad, uint8_t *seen,
                                      const float *K4, TrackBlock *blk) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) {
-        const float *Tcw7 = blk->Tout;
-        float *pose19 = blk->pose19;
-        const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
-        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
-        const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-        pose19[0] = 1.f - (tyy + tzz); pose19[1] = txy - twz; pose19[2] = txz + twy;
-        pose19[3] = txy + twz; pose19[4] = 1.f - (txx + tzz); pose19[5] = tyz - twx;
-        pose19[6] = txz - twy; pose19[7] = tyz + twx; pose19[8] = 1.f - (txx + tyy);
-        const float t0 = Tcw7[4], t1 = Tcw7[5], t2 = Tcw7[6];
-        pose19[9] = t0; pose19[10] = t1; pose19[11] = t2;
-        const float qx = -x, qy = -y, qz = -z, v0 = t0 * -1.f, v1 = t1 * -1.f, v2 = t2 * -1.f;
-        float u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
-        u0 += u0; u1 += u1; u2 += u2;
-        const float c0 = qy * u2 - qz * u1, c1 = qz * u0 - qx * u2, c2 = qx * u1 - qy * u0;
-        pose19[12] = (v0 + w * u0) + c0; pose19[13] = (v1 + w * u1) + c1; pose19[14] = (v2 + w * u2) + c2;
-        pose19[15] = K4[0]; pose19[16] = K4[1]; pose19[17] = K4[2]; pose19[18] = K4[3];
-    }
+    if (c == 0) pose_matrices19(blk->Tout, K4, blk->pose19);
     if (c >= blk->start[1]) return;
     const int i = idx[c], mp = featMp[i];
     seen[mp] = 1;
@@ -1967,6 +2040,7 @@ __global__ void k_track_finish(const int32_t *idx, const uint8_t *outlierC, cons
 #include "rumi_internal.h"
 #include "rumi_orb.h"
 #include "rumi_track.h"
+#include "rumi_voc.h"
 
 struct RumiTracker {
     int device = 0, cap = 0, maxPts = 0, nlevels = 0;
@@ -1981,6 +2055,9 @@ struct RumiTracker {
     uint8_t *dOutC = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr;
     double *dChi = nullptr;
     float scale[64] = {0};
+    // the step-wise entries (rumi_track_extract / _motion / _reference_keyframe / _local): the frame that is resident, and its BoW transform
+    int curN = -1, curW = 0, curH = 0, curMono = -1;
+    uint32_t *dWord = nullptr, *dNode = nullptr; double *dWeight = nullptr; int32_t *dNN = nullptr;
 };
 
 extern "C" void rumi_track_destroy(RumiTracker *t) {
@@ -1988,7 +2065,7 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     (void)hipSetDevice(t->device);
     rumi_orb_destroy(t->ext);
     rumi_match_destroy(t->m);
-    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi};
+    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN};
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
     delete t;
@@ -2016,6 +2093,7 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
     TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dBlk, t->blkBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
     TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dIdx, C));
     TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C));
+    TRYA(dalloc(&t->dWord, C)); TRYA(dalloc(&t->dNode, C)); TRYA(dalloc(&t->dWeight, C)); TRYA(dalloc(&t->dNN, 4));
 #undef TRYA
     if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
     float inv2[64] = {0};
@@ -2142,5 +2220,274 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     }
     res->n_to_match = nTo;
     if (n > 0) std::memcpy(frame_mp_motion, localRan ? t->hBlk + t->oMpM : t->hBlk + t->oMp, (size_t)n * 4);
+    return RUMI_OK;
+}
+
+// ==================================================================================================================
+// The same stages one member function of Tracking at a time (include/rumi_track.h, "step-wise entries"): the frame extracted by
+// rumi_track_extract stays on the device -- key-points, descriptors, grid, FeatureVector -- while the host runs the reference's own control
+// flow between the calls (the decisions of TrackWithMotionModel / TrackReferenceKeyFrame, UpdateLocalMap).
+// ==================================================================================================================
+namespace {
+// the resident frame as the matcher's kernels address it (upload_frame of an empty frame queues the scale table and the cleared result header)
+int track_frame_dev(RumiTracker *t, FrameDev *fd) {
+    RumiMatcher *m = t->m;
+    RumiFrameFeatures F{};
+    F.n = 0; F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)t->curW; F.max_y = (float)t->curH;
+    const int rc = upload_frame(m, &F, fd);
+    if (rc != RUMI_OK) return rc;
+    const uint8_t *dRecord = t->dBlk + t->oRec;
+    fd->n = t->curN;
+    fd->keys = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
+    fd->desc = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
+    m->gridN = t->curN; m->gridKeys = fd->keys;
+    return RUMI_OK;
+}
+int track_check_points(const RumiTrackPoints *pts, bool needFrustum) {
+    if (!pts || pts->n < 0) return RUMI_E_INVALID;
+    if (pts->n > 0 && (!pts->pos || !pts->desc || !pts->obs || !pts->bad)) return RUMI_E_INVALID;
+    if (pts->n > 0 && needFrustum && (!pts->normal || !pts->min_dist || !pts->max_dist || !pts->local)) return RUMI_E_INVALID;
+    return RUMI_OK;
+}
+}  // namespace
+
+extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride, RumiKeyPoint *keys_out, uint8_t *desc_out,
+                                  int32_t cap, int32_t *n_out, int32_t *mono_out) {
+    if (!t || !img || !keys_out || !desc_out || !n_out || !mono_out || stride < w) return RUMI_E_INVALID;
+    *n_out = 0; *mono_out = -1;
+    if (w <= 0 || h <= 0) return RUMI_E_EMPTY;
+    if (w > t->cfg.max_width || h > t->cfg.max_height || cap < t->cap) { g_lastError = "rumi_track_extract: image larger than the tracker was created for, or cap too small"; return RUMI_E_CAPACITY; }
+    HIP_TRY(hipSetDevice(t->device));
+    t->curN = -1;
+    uint8_t *dRecord = t->dBlk + t->oRec;
+    const int wp = (w + 3) & ~3;
+    HIP_TRY(hipMemcpy2DAsync(t->dImage, wp, img, stride, w, h, hipMemcpyHostToDevice, nullptr));
+    int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
+    if (rc != RUMI_OK) return rc;
+    int32_t counts[2] = {0, -1};
+    HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
+    if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
+    const int n = counts[0];
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(t->hBlk + t->oRec + 8, dRecord + 8, (size_t)n * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpy(t->hBlk + t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), (size_t)n * 32, hipMemcpyDeviceToHost));
+        std::memcpy(keys_out, t->hBlk + t->oRec + 8, (size_t)n * sizeof(RumiKeyPoint));
+        std::memcpy(desc_out, t->hBlk + t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), (size_t)n * 32);
+    }
+    t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];
+    *n_out = n; *mono_out = counts[1];
+    return RUMI_OK;
+}
+
+extern "C" int rumi_track_motion(RumiTracker *t, const float *K4, const float *Tcw_pred7, const RumiKeyPoint *last_keys_un, int32_t nlast,
+                                 const int32_t *last_mp, const uint8_t *last_outlier, const RumiTrackPoints *pts, float th_motion, int32_t *frame_mp,
+                                 int32_t *discarded, RumiTrackResult *res) {
+    if (!t || !K4 || !Tcw_pred7 || !res || !frame_mp || !discarded || nlast < 0 || (nlast > 0 && (!last_keys_un || !last_mp || !last_outlier)) ||
+        track_check_points(pts, false) != RUMI_OK)
+        return RUMI_E_INVALID;
+    if (t->curN < 0) { g_lastError = "rumi_track_motion: no frame is resident (rumi_track_extract first)"; return RUMI_E_INVALID; }
+    RumiMatcher *m = t->m;
+    const int n = t->curN, nmp = pts->n;
+    if (nlast > m->maxQ || nmp > t->maxPts) { g_lastError = "rumi_track_motion: more points / features than the tracker was created for"; return RUMI_E_CAPACITY; }
+    for (int i = 0; i < nlast; i++) if (last_mp[i] >= nmp) { g_lastError = "rumi_track_motion: last_mp index outside the point table"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    std::memset(res, 0, sizeof(*res));
+    res->n = n; res->mono_index = t->curMono; res->th_motion = (int32_t)th_motion;
+    std::memcpy(res->Tcw_motion, Tcw_pred7, 28); std::memcpy(res->Tcw, Tcw_pred7, 28);
+    for (int i = 0; i < n; i++) { frame_mp[i] = -1; discarded[i] = -1; }
+    TrackBlock *dB = reinterpret_cast<TrackBlock *>(t->dBlk);
+    int32_t *dMpOut = reinterpret_cast<int32_t *>(t->dBlk + t->oMp);
+    uint8_t *dOutF = t->dBlk + t->oOut;
+    FrameDev fd;
+    int rc = track_frame_dev(t, &fd);
+    if (rc != RUMI_OK) return rc;
+    float pose[11];
+    std::memcpy(pose, Tcw_pred7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
+    H2D(m->dPose, pose, 11);
+    if (nmp > 0) { H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); }
+    if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
+    FLUSH(m);
+    const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
+    hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+    int nm = 0;
+    std::vector<int32_t> searched((size_t)std::max(n, 1), -1);
+    for (int attempt = 0; attempt < 2 && n > 0 && nlast > 0 && nmp > 0; attempt++) {      // Tracking.cc:2466-2474
+        const float th = attempt == 0 ? th_motion : 2 * th_motion;
+        if (attempt == 1) hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 0, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
+                           m->dPose + 7, m->dScale, th, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+        if ((rc = run_search(m, MODE_FRAME, nlast, fd, m->dQDesc, m->dI[1], 0.f, 1, searched.data(), &nm)) != RUMI_OK) return rc;
+        res->th_motion = (int32_t)th;
+        if (nm >= 20) break;
+    }
+    res->nmatches_motion = nm;
+    if (n > 0) std::memcpy(frame_mp, searched.data(), (size_t)n * 4);
+    if (nm < 20) return RUMI_OK;                                  // TrackWithMotionModel returns false here (:2476-2483): nothing else has happened to the frame
+    const bool small = n <= kTrackLdsEdges;
+    hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+    if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+    hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->hBlk + t->oMp, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, sizeof(TrackBlock), hipMemcpyDeviceToHost));
+    const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
+    std::memcpy(res->Tcw_motion, hB->Tout, 28); std::memcpy(res->Tcw, hB->Tout, 28);
+    res->ngood_motion = hB->nGood[0]; res->nmatches_map = hB->counters[0];
+    const int32_t *after = reinterpret_cast<const int32_t *>(t->hBlk + t->oMp);
+    for (int i = 0; i < n; i++) { if (searched[i] >= 0 && after[i] < 0) discarded[i] = searched[i]; frame_mp[i] = after[i]; }
+    return RUMI_OK;
+}
+
+extern "C" int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc, int32_t levelsup, const float *K4, const float *Tcw_init7,
+                                             const RumiFrameFeatures *KF, const RumiFeatureVector *kf_fv, const int32_t *kf_mp,
+                                             const RumiTrackPoints *pts, float nnratio, int32_t check_orientation, uint32_t *word_id, double *word_weight,
+                                             uint32_t *node_id, int32_t *frame_mp, int32_t *discarded, RumiTrackResult *res) {
+    if (!t || !voc || !K4 || !Tcw_init7 || !KF || !kf_fv || !res || !frame_mp || !discarded || !word_id || !word_weight || !node_id || KF->n < 0 ||
+        kf_fv->n_nodes < 0 || (KF->n > 0 && (!kf_mp || !KF->keys_un || !KF->desc)) || track_check_points(pts, false) != RUMI_OK)
+        return RUMI_E_INVALID;
+    if (t->curN < 0) { g_lastError = "rumi_track_reference_keyframe: no frame is resident (rumi_track_extract first)"; return RUMI_E_INVALID; }
+    RumiMatcher *m = t->m;
+    const int n = t->curN, nmp = pts->n;
+    const int nqe = kf_fv->n_nodes > 0 ? kf_fv->offsets[kf_fv->n_nodes] : 0;
+    if (KF->n > m->maxQ || nqe > m->maxQ || nmp > t->maxPts || nmp > m->maxQ || kf_fv->n_nodes > m->maxQ) {
+        g_lastError = "rumi_track_reference_keyframe: sizes exceed the tracker's capacities"; return RUMI_E_CAPACITY;
+    }
+    for (int i = 0; i < KF->n; i++) if (kf_mp[i] >= nmp) { g_lastError = "rumi_track_reference_keyframe: kf_mp index outside the point table"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    std::memset(res, 0, sizeof(*res));
+    res->n = n; res->mono_index = t->curMono;
+    std::memcpy(res->Tcw_motion, Tcw_init7, 28); std::memcpy(res->Tcw, Tcw_init7, 28);
+    for (int i = 0; i < n; i++) { frame_mp[i] = -1; discarded[i] = -1; }
+    if (n == 0) return RUMI_OK;
+    TrackBlock *dB = reinterpret_cast<TrackBlock *>(t->dBlk);
+    int32_t *dMpOut = reinterpret_cast<int32_t *>(t->dBlk + t->oMp);
+    uint8_t *dOutF = t->dBlk + t->oOut;
+    const uint8_t *dRecord = t->dBlk + t->oRec;
+    // ---- Frame::ComputeBoW (Frame.cc:763-768): the tree descent of every descriptor, then the FeatureVector, both on the device
+    int rc = rumi_voc_transform_batch_device(voc, dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), dRecord, 1, t->cap, levelsup, t->dWord, t->dWeight, t->dNode, nullptr);
+    if (rc != RUMI_OK) return rc;
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    const size_t fvLds = (size_t)npad * sizeof(unsigned long long);
+    if (fvLds > 64 * 1024) HIP_TRY(raise_lds_limit(reinterpret_cast<const void *>(k_fv_build), fvLds));
+    hipLaunchKernelGGL(k_fv_build, dim3(1), dim3(kFvThreads), fvLds, nullptr, n, npad, t->dNode, t->dWeight, m->dNodesB, m->dOffB, m->dFvIdx, t->dNN);
+    // ---- SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:198-370): the key-frame side comes from the host, the frame side is resident
+    FrameDev fd;
+    if ((rc = track_frame_dev(t, &fd)) != RUMI_OK) return rc;
+    float pose[11];
+    std::memcpy(pose, Tcw_init7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
+    H2D(m->dPose, pose, 11);
+    if (KF->n > 0) { H2D(m->dQKeys, KF->keys_un, KF->n); H2D(m->dQDesc, KF->desc, (size_t)KF->n * 32); H2D(m->dI[0], kf_mp, KF->n); }
+    if (nmp > 0) { H2D(m->dU8a, pts->bad, nmp); H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dI[1], pts->obs, nmp); }
+    if (kf_fv->n_nodes > 0) { H2D(m->dNodesA, kf_fv->node_ids, kf_fv->n_nodes); H2D(m->dOffA, kf_fv->offsets, kf_fv->n_nodes + 1); }
+    if (nqe > 0) H2D(m->dIdxA, kf_fv->indices, nqe);
+    m->gridPending = false;                                 // candidates come from the FeatureVectors: the spatial grid is not read
+    FLUSH(m);
+    const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
+    hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+    if (kf_fv->n_nodes > 0)
+        hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
+                           m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, 0, m->dNodesB, m->dOffB, m->dQ, t->dNN);
+    int nm = 0;
+    std::vector<int32_t> searched((size_t)n, -1);
+    if ((rc = run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, searched.data(), &nm)) != RUMI_OK) return rc;
+    res->nmatches_motion = nm;
+    std::memcpy(frame_mp, searched.data(), (size_t)n * 4);
+    // the per-feature transform for the host's mBowVec / mFeatVec (assembled there in feature order: rumi_voc_assemble)
+    HIP_TRY(hipMemcpyAsync(word_id, t->dWord, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(node_id, t->dNode, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(word_weight, t->dWeight, (size_t)n * 8, hipMemcpyDeviceToHost, nullptr));
+    if (nm < 15) { HIP_TRY(hipStreamSynchronize(nullptr)); return RUMI_OK; }     // TrackReferenceKeyFrame returns false here (:2335-2338)
+    const bool small = n <= kTrackLdsEdges;
+    hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+    if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+    hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->hBlk + t->oMp, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, sizeof(TrackBlock), hipMemcpyDeviceToHost));
+    const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
+    std::memcpy(res->Tcw_motion, hB->Tout, 28); std::memcpy(res->Tcw, hB->Tout, 28);
+    res->ngood_motion = hB->nGood[0]; res->nmatches_map = hB->counters[0];
+    const int32_t *after = reinterpret_cast<const int32_t *>(t->hBlk + t->oMp);
+    for (int i = 0; i < n; i++) { if (searched[i] >= 0 && after[i] < 0) discarded[i] = searched[i]; frame_mp[i] = after[i]; }
+    return RUMI_OK;
+}
+
+extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tcw7, const int32_t *frame_mp_in, const RumiTrackPoints *pts,
+                                const uint8_t *seen_in, float th_local, int32_t far_points, float th_far_points, int32_t *frame_mp, uint8_t *outlier,
+                                uint8_t *in_view, RumiTrackResult *res) {
+    if (!t || !K4 || !Tcw7 || !res || !frame_mp || !outlier || !frame_mp_in || track_check_points(pts, true) != RUMI_OK || (pts->n > 0 && !in_view))
+        return RUMI_E_INVALID;
+    if (t->curN < 0) { g_lastError = "rumi_track_local: no frame is resident (rumi_track_extract first)"; return RUMI_E_INVALID; }
+    RumiMatcher *m = t->m;
+    const int n = t->curN, nmp = pts->n;
+    if (nmp > t->maxPts) { g_lastError = "rumi_track_local: more points than the tracker was created for"; return RUMI_E_CAPACITY; }
+    for (int i = 0; i < n; i++) if (frame_mp_in[i] >= nmp) { g_lastError = "rumi_track_local: frame_mp_in index outside the point table"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    std::memset(res, 0, sizeof(*res));
+    res->n = n; res->mono_index = t->curMono;
+    std::memcpy(res->Tcw_motion, Tcw7, 28); std::memcpy(res->Tcw, Tcw7, 28);
+    // SearchLocalPoints, first loop (Tracking.cc:2998-3010), on the host while the arrays are being staged: a bad point leaves the frame, the
+    // others are "seen in this frame"; seen_in carries the points the caller's discard loop has marked (mnLastFrameSeen == mCurrentFrame.mnId)
+    std::vector<int32_t> mpIn((size_t)std::max(n, 1), -1);
+    std::vector<uint8_t> seen((size_t)std::max(nmp, 1), 0);
+    if (seen_in && nmp > 0) std::memcpy(seen.data(), seen_in, (size_t)nmp);
+    for (int i = 0; i < n; i++) {
+        const int mp = frame_mp_in[i];
+        if (mp < 0) continue;
+        if (pts->bad[mp]) continue;
+        mpIn[i] = mp; seen[mp] = 1;
+    }
+    TrackBlock *dB = reinterpret_cast<TrackBlock *>(t->dBlk);
+    int32_t *dMpOut = reinterpret_cast<int32_t *>(t->dBlk + t->oMp), *dMpMotion = reinterpret_cast<int32_t *>(t->dBlk + t->oMpM);
+    uint8_t *dOutF = t->dBlk + t->oOut, *dView = t->dBlk + t->oView;
+    FrameDev fd;
+    int rc = track_frame_dev(t, &fd);
+    if (rc != RUMI_OK) return rc;
+    float pose[11];
+    std::memcpy(pose, Tcw7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
+    H2D(m->dPose, pose, 11);
+    if (n > 0) H2D(m->dFeatMp, mpIn.data(), n);
+    if (nmp > 0) {
+        H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dF[1], pts->normal, (size_t)nmp * 3); H2D(m->dF[2], pts->min_dist, nmp); H2D(m->dF[3], pts->max_dist, nmp);
+        H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
+        H2D(t->dSeen, seen.data(), nmp);
+    }
+    FLUSH(m);
+    const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
+    hipLaunchKernelGGL(k_track_local_init, dim3(gI), dim3(256), 0, nullptr, n, m->dPose, m->dPose + 7, dOutF, dMpOut, m->dOut, dB);
+    int nmLocal = 0;
+    std::vector<int32_t> tmpMp((size_t)std::max(n, 1));
+    if (nmp > 0 && n > 0) {
+        const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+        if (n16 * 21 > m->stageCap) { g_lastError = "rumi_track_local: point table exceeds the staging block"; return RUMI_E_CAPACITY; }
+        uint8_t *dSkip = m->dU8b;
+        float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
+        int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
+        const float logSf = std::log(t->cfg.scale_factor);
+        hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
+        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
+                           far_points, th_far_points, m->dQ);
+        if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
+    }
+    res->nmatches_local = nmLocal;
+    const bool small = n <= kTrackLdsEdges;
+    hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+    if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+    hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec, hipMemcpyDeviceToHost));       // header, mvpMapPoints, mvbOutlier, mbTrackInView
+    const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
+    std::memcpy(res->Tcw, hB->Tout + 7, 28);
+    std::memcpy(res->Rcw, hB->pose19, 36); std::memcpy(res->tcw, hB->pose19 + 9, 12); std::memcpy(res->Ow, hB->pose19 + 12, 12);
+    res->ngood_local = hB->nGood[1]; res->matches_inliers = hB->counters[1];
+    if (n > 0) { std::memcpy(frame_mp, t->hBlk + t->oMp, (size_t)n * 4); std::memcpy(outlier, t->hBlk + t->oOut, (size_t)n); }
+    int nTo = 0;
+    if (nmp > 0) {
+        if (n > 0) std::memcpy(in_view, t->hBlk + t->oView, (size_t)nmp); else std::memset(in_view, 0, (size_t)nmp);
+        for (int j = 0; j < nmp; j++) nTo += in_view[j];
+    }
+    res->n_to_match = nTo;
     return RUMI_OK;
 }

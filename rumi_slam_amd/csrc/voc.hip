@@ -225,6 +225,15 @@ extern "C" int rumi_voc_transform(RumiVocabulary *v, const uint8_t *desc, int32_
     std::vector<double> w(n);
     const int rc = rumi_voc_transform_features(v, desc, n, levelsup, word.data(), w.data(), node.data());
     if (rc != RUMI_OK) return rc;
+    return rumi_voc_assemble(v, n, word.data(), w.data(), node.data(), bow_ids, bow_vals, n_words_out, fv_nodes, fv_offsets, fv_indices, n_nodes_out);
+}
+
+extern "C" int rumi_voc_assemble(const RumiVocabulary *v, int32_t n, const uint32_t *word, const double *w, const uint32_t *node, uint32_t *bow_ids,
+                                 double *bow_vals, int32_t *n_words_out, uint32_t *fv_nodes, int32_t *fv_offsets, uint32_t *fv_indices, int32_t *n_nodes_out) {
+    if (!v || n < 0 || !n_words_out || !n_nodes_out || !fv_offsets) return RUMI_E_INVALID;
+    *n_words_out = 0; *n_nodes_out = 0; fv_offsets[0] = 0;
+    if (n == 0) return RUMI_OK;
+    if (!word || !w || !node || !bow_ids || !bow_vals || !fv_nodes || !fv_indices) return RUMI_E_INVALID;
     // the two ordered maps, filled in feature order (TemplatedVocabulary.h:1147-1190)
     std::map<uint32_t, double> bow;
     std::map<uint32_t, std::vector<uint32_t>> fv;

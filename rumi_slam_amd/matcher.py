@@ -89,6 +89,15 @@ class FeatureVector:
         self.indices = np.array(idx, np.uint32)
         self.c = RumiFeatureVector(len(nodes), capi.ptr(self.node_ids), capi.ptr(self.offsets), capi.ptr(self.indices))
 
+    @classmethod
+    def from_csr(cls, node_ids, offsets, indices):
+        """From the CSR arrays ``ORBVocabulary.transform`` / ``assemble`` return."""
+        fv = cls.__new__(cls)
+        fv.node_ids = np.ascontiguousarray(node_ids, np.uint32); fv.offsets = np.ascontiguousarray(offsets, np.int32)
+        fv.indices = np.ascontiguousarray(indices, np.uint32)
+        fv.c = RumiFeatureVector(len(fv.node_ids), capi.ptr(fv.node_ids), capi.ptr(fv.offsets), capi.ptr(fv.indices))
+        return fv
+
 
 def DescriptorDistance(a, b):
     a = np.ascontiguousarray(a, np.uint8)

@@ -29,6 +29,11 @@ def _bind(L):
     L.rumi_track_destroy.restype = None
     L.rumi_track_frame.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, C.POINTER(RumiTrackPoints), f32, f32, i32, f32,
                                    vp, vp, i32, vp, vp, vp, vp, C.POINTER(RumiTrackResult)]
+    L.rumi_track_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.rumi_track_motion.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.POINTER(RumiTrackPoints), f32, vp, vp, C.POINTER(RumiTrackResult)]
+    L.rumi_track_reference_keyframe.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, C.POINTER(RumiTrackPoints), f32, i32, vp, vp, vp, vp, vp,
+                                                C.POINTER(RumiTrackResult)]
+    L.rumi_track_local.argtypes = [vp, vp, vp, vp, C.POINTER(RumiTrackPoints), vp, f32, i32, f32, vp, vp, vp, C.POINTER(RumiTrackResult)]
     L._track_ready = True
     return L
 
@@ -76,4 +81,78 @@ class Tracker:
             out[f] = np.array(getattr(res, f), np.float32)
         out.update(keys=keys[:k].copy(), desc=desc[:k].copy(), frame_mp_motion=mp_motion[:k].copy(), frame_mp=mp[:k].copy(), outlier=outl[:k].copy(),
                    in_view=in_view[:n].copy())
+        return out
+
+    # ---- step-wise entries: one member function of Tracking per call, the frame resident in between (include/rumi_track.h) ----
+    @staticmethod
+    def _points(points, need_frustum):
+        n = len(points["obs"])
+        z3, z1 = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+        a = dict(pos=np.ascontiguousarray(points["pos"], np.float32), normal=np.ascontiguousarray(points.get("normal", z3), np.float32),
+                 mn=np.ascontiguousarray(points.get("min_dist", z1), np.float32), mx=np.ascontiguousarray(points.get("max_dist", z1), np.float32),
+                 desc=np.ascontiguousarray(points["desc"], np.uint8), obs=np.ascontiguousarray(points["obs"], np.int32),
+                 bad=np.ascontiguousarray(points["bad"], np.uint8), local=np.ascontiguousarray(points.get("local", np.zeros(n, np.uint8)), np.uint8))
+        return n, a, RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")))
+
+    @staticmethod
+    def _result(res, fields):
+        out = {f: getattr(res, f) for f in fields if f not in ("Tcw_motion", "Tcw", "Rcw", "tcw", "Ow")}
+        for f in ("Tcw_motion", "Tcw", "Rcw", "tcw", "Ow"):
+            if f in fields:
+                out[f] = np.array(getattr(res, f), np.float32)
+        return out
+
+    def extract(self, img):
+        """rumi_track_extract: Frame::ExtractORB; returns (monoIndex, keys, desc) and keeps the frame on the device."""
+        img = np.asarray(img, np.uint8)
+        assert img.ndim == 2 and img.strides[1] == 1
+        h, w = img.shape
+        keys = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int32(), C.c_int32()
+        capi.check(self._lib.rumi_track_extract(self._h, capi.ptr(img), w, h, img.strides[0], capi.ptr(keys), capi.ptr(desc), self.cap, C.byref(n), C.byref(mono)))
+        self._n = n.value
+        return mono.value, keys[:n.value].copy(), desc[:n.value].copy()
+
+    def motion(self, K4, Tcw_pred7, last_keys, last_mp, last_outlier, points, th_motion=15.0):
+        """rumi_track_motion: Tracking::TrackWithMotionModel on the resident frame."""
+        K4 = np.ascontiguousarray(K4, np.float32); T = np.ascontiguousarray(Tcw_pred7, np.float32)
+        lk = np.ascontiguousarray(last_keys, KP_DTYPE); lm = np.ascontiguousarray(last_mp, np.int32); lo = np.ascontiguousarray(last_outlier, np.uint8)
+        _, keep, P = self._points(points, False)
+        mp = np.full(self.cap, -1, np.int32); dis = np.full(self.cap, -1, np.int32)
+        res = RumiTrackResult()
+        capi.check(self._lib.rumi_track_motion(self._h, capi.ptr(K4), capi.ptr(T), capi.ptr(lk), len(lk), capi.ptr(lm), capi.ptr(lo), C.byref(P), float(th_motion),
+                                               capi.ptr(mp), capi.ptr(dis), C.byref(res)))
+        out = self._result(res, ("n", "mono_index", "th_motion", "nmatches_motion", "ngood_motion", "nmatches_map", "Tcw_motion"))
+        out.update(frame_mp=mp[:res.n].copy(), discarded=dis[:res.n].copy())
+        return out
+
+    def reference_keyframe(self, voc, K4, Tcw_init7, kf_view, kf_fv, kf_mp, points, levelsup=4, nnratio=0.7, check_orientation=True):
+        """rumi_track_reference_keyframe: Tracking::TrackReferenceKeyFrame on the resident frame.  voc: rumi_slam_amd.vocabulary.Vocabulary;
+        kf_view: matcher.FrameView of the key-frame; kf_fv: matcher.FeatureVectorView (CSR); kf_mp: indices into `points`."""
+        K4 = np.ascontiguousarray(K4, np.float32); T = np.ascontiguousarray(Tcw_init7, np.float32)
+        km = np.ascontiguousarray(kf_mp, np.int32)
+        _, keep, P = self._points(points, False)
+        mp = np.full(self.cap, -1, np.int32); dis = np.full(self.cap, -1, np.int32)
+        word = np.zeros(self.cap, np.uint32); node = np.zeros(self.cap, np.uint32); wgt = np.zeros(self.cap, np.float64)
+        res = RumiTrackResult()
+        capi.check(self._lib.rumi_track_reference_keyframe(self._h, voc._h, int(levelsup), capi.ptr(K4), capi.ptr(T), C.byref(kf_view.c), C.byref(kf_fv.c),
+                                                           capi.ptr(km), C.byref(P), float(nnratio), int(check_orientation), capi.ptr(word), capi.ptr(wgt),
+                                                           capi.ptr(node), capi.ptr(mp), capi.ptr(dis), C.byref(res)))
+        out = self._result(res, ("n", "mono_index", "nmatches_motion", "ngood_motion", "nmatches_map", "Tcw_motion"))
+        k = res.n
+        out.update(frame_mp=mp[:k].copy(), discarded=dis[:k].copy(), word_id=word[:k].copy(), word_weight=wgt[:k].copy(), node_id=node[:k].copy())
+        return out
+
+    def local(self, K4, Tcw7, frame_mp_in, points, seen_in=None, th_local=1.0, far_points=False, th_far_points=50.0):
+        """rumi_track_local: Tracking::TrackLocalMap after UpdateLocalMap on the resident frame."""
+        K4 = np.ascontiguousarray(K4, np.float32); T = np.ascontiguousarray(Tcw7, np.float32)
+        fin = np.ascontiguousarray(frame_mp_in, np.int32)
+        n, keep, P = self._points(points, True)
+        si = np.ascontiguousarray(seen_in, np.uint8) if seen_in is not None else None
+        mp = np.full(self.cap, -1, np.int32); outl = np.zeros(self.cap, np.uint8); in_view = np.zeros(max(n, 1), np.uint8)
+        res = RumiTrackResult()
+        capi.check(self._lib.rumi_track_local(self._h, capi.ptr(K4), capi.ptr(T), capi.ptr(fin), C.byref(P), capi.ptr(si) if si is not None else None,
+                                              float(th_local), int(far_points), float(th_far_points), capi.ptr(mp), capi.ptr(outl), capi.ptr(in_view), C.byref(res)))
+        out = self._result(res, ("n", "n_to_match", "nmatches_local", "ngood_local", "matches_inliers", "Tcw", "Rcw", "tcw", "Ow"))
+        out.update(frame_mp=mp[:res.n].copy(), outlier=outl[:res.n].copy(), in_view=in_view[:n].copy())
         return out

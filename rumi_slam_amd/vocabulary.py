@@ -6,7 +6,7 @@ import numpy as np
 from . import capi
 
 VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_set_levels", "rumi_voc_transform_features",
-               "rumi_voc_transform_batch_device", "rumi_voc_transform"]
+               "rumi_voc_transform_batch_device", "rumi_voc_transform", "rumi_voc_assemble"]
 TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
 L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = range(6)
 
@@ -26,6 +26,7 @@ def _lib():
     L.rumi_voc_transform_features.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.rumi_voc_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.rumi_voc_transform.argtypes = [vp, vp, i32, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
+    L.rumi_voc_assemble.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
     L._voc_ready = True
     return L
 
@@ -88,3 +89,14 @@ class ORBVocabulary:
         capi.check(self._lib.rumi_voc_transform_batch_device(self._h, desc.data_ptr(), counts.data_ptr(), B, cap, int(levelsup), word.data_ptr(),
                                                              w.data_ptr(), node.data_ptr(), st))
         return word, w, node
+
+    def assemble(self, word_id, weight, node_id):
+        """BowVector and FeatureVector from the per-feature transform (rumi_voc_assemble): ((bow_ids, bow_vals), (fv_nodes, fv_offsets, fv_indices))."""
+        w = np.ascontiguousarray(word_id, np.uint32); v = np.ascontiguousarray(weight, np.float64); nd = np.ascontiguousarray(node_id, np.uint32)
+        n = len(w)
+        bi, bv = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fn, fo, fi = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int32(), C.c_int32()
+        capi.check(self._lib.rumi_voc_assemble(self._h, n, capi.ptr(w), capi.ptr(v), capi.ptr(nd), capi.ptr(bi), capi.ptr(bv), C.byref(nw), capi.ptr(fn),
+                                               capi.ptr(fo), capi.ptr(fi), C.byref(nn)))
+        return (bi[:nw.value].copy(), bv[:nw.value].copy()), (fn[:nn.value].copy(), fo[:nn.value + 1].copy(), fi[:fo[nn.value]].copy())

@@ -1,0 +1,199 @@
+"""The step-wise entries of include/rumi_track.h -- rumi_track_extract, rumi_track_motion, rumi_track_reference_keyframe, rumi_track_local: one
+member function of Tracking per call, the frame resident on the device in between -- against the ORACLE chain of the same functions
+(R/lib_src/Tracking.cc:2441-2518, 2324-2375, 2520-2607, 2996-3055), and against the fused rumi_track_frame where the two must agree.
+Match indices, flags and counts identical; poses within 1e-4 relative."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from rumi_slam_amd.synth import synth_frame, warp_homography
+from scene import K_TUM3
+from test_track_frame_gpu import H, W, _oracle_step, _pose_close, _pose_matrices, _scene
+from test_tracking_loop_gpu import _homography, _pose_gt
+from voc_scene import synthetic_vocabulary
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_motion(keys, desc, sf, inv_sigma2, T_pred, last, pts):
+    """Tracking::TrackWithMotionModel alone: the frame's vector when the function returns (bad points still in it: their removal is
+    SearchLocalPoints' first loop), the discarded outliers, the counts."""
+    n = len(keys)
+    cur0 = np.full(n, -1, np.int32)
+    a = (keys, desc, W, H, sf, T_pred, K_TUM3, last["keys"], last["mp"], last["outlier"], pts["pos"], pts["desc"], pts["obs"], cur0)
+    th = 15.0
+    nm, cur = O.search_by_projection_frame(*a, th, True)
+    if nm < 20:
+        th = 30.0
+        nm, cur = O.search_by_projection_frame(*a, th, True)
+    r = dict(th_motion=int(th), nmatches_motion=nm, frame_mp=cur.copy(), discarded=np.full(n, -1, np.int32), ngood_motion=0, nmatches_map=0, Tcw_motion=T_pred)
+    if nm < 20:
+        return r
+    idx = np.nonzero(cur >= 0)[0]
+    ng, T1, out = O.pose_optimization(pts["pos"][cur[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T_pred)
+    inl = idx[out == 0]
+    r["discarded"][idx[out != 0]] = cur[idx[out != 0]]
+    r.update(ngood_motion=ng, Tcw_motion=T1, nmatches_map=int((pts["obs"][cur[inl]] > 0).sum()))
+    cur[idx[out != 0]] = -1
+    r["frame_mp"] = cur
+    return r
+
+
+def _oracle_local(keys, desc, sf, inv_sigma2, T1, frame_mp_in, seen_in, pts, th_local):
+    """Tracking::TrackLocalMap after UpdateLocalMap: SearchLocalPoints' two loops, the search, PoseOptimization, the statistics loop."""
+    n, nmp = len(keys), len(pts["obs"])
+    cur = frame_mp_in.copy()
+    seen = seen_in.copy()
+    for i in range(n):
+        if cur[i] >= 0:
+            if pts["bad"][cur[i]]:
+                cur[i] = -1
+            else:
+                seen[cur[i]] = 1
+    R, t, Ow = _pose_matrices(T1)
+    skip = ((pts["local"] == 0) | (seen != 0) | (pts["bad"] != 0)).astype(np.uint8)
+    fr = O.is_in_frustum(R, t, Ow, K_TUM3, W, H, float(np.log(np.float32(1.2))), 8, 0.5, pts)
+    for k in fr:
+        fr[k] = np.where(skip != 0, np.array(-1 if k in ("proj_x", "proj_y") else 0, fr[k].dtype), fr[k])
+    nml, cur2 = O.search_by_projection_mappoints(keys, desc, W, H, sf, dict(fr, is_bad=skip, desc=pts["desc"], obs=pts["obs"]), cur, th_local, False, 0.0, 0.8)
+    idx2 = np.nonzero(cur2 >= 0)[0]
+    ng2, T2, out2 = O.pose_optimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)
+    outl = np.zeros(n, np.uint8)
+    outl[idx2] = out2
+    return dict(in_view=fr["track_in_view"], n_to_match=int(fr["track_in_view"].sum()), nmatches_local=nml, frame_mp=cur2, ngood_local=ng2, Tcw=T2, outlier=outl,
+                matches_inliers=int(((out2 == 0) & (pts["obs"][cur2[idx2]] > 0)).sum()), Rcw=R, tcw=t, Ow=Ow)
+
+
+def _seen_from(discarded, nmp):
+    s = np.zeros(nmp, np.uint8)
+    s[discarded[discarded >= 0]] = 1
+    return s
+
+
+@pytest.mark.parametrize("th_local", [1.0, 3.0])
+def test_motion_then_local_equal_the_oracle_chain_and_the_fused_call(th_local):
+    from rumi_slam_amd.tracker import Tracker
+    fused, steps = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096), Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    orc = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img0, sf, inv_sigma2, pts, last = _scene(n_keep=0.5)
+    rng = np.random.default_rng(7)
+    n0 = len(pts["obs"])
+    pts["obs"] = np.where(rng.random(n0) < 0.05, 0, 1).astype(np.int32)
+    pts["bad"] = (rng.random(n0) < 0.03).astype(np.uint8)
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    for t in range(1, 5):
+        q_gt, t_gt = _pose_gt(t)
+        img = warp_homography(img0, _homography(q_gt, t_gt))
+        mono, keys, desc = steps.extract(img)
+        omono, okeys, odesc = orc.extract(img)
+        assert mono == omono and keys.tobytes() == okeys.tobytes() and np.array_equal(desc, odesc), f"frame {t}: extraction"
+        # --- TrackWithMotionModel
+        rm = _oracle_motion(okeys, odesc, sf, inv_sigma2, T, last, pts)
+        gm = steps.motion(K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts)
+        for k in ("th_motion", "nmatches_motion", "ngood_motion", "nmatches_map"):
+            assert gm[k] == rm[k], f"frame {t} motion: {k} {gm[k]} vs {rm[k]}"
+        assert np.array_equal(gm["frame_mp"], rm["frame_mp"]) and np.array_equal(gm["discarded"], rm["discarded"]), f"frame {t} motion: vectors"
+        assert (rm["discarded"] >= 0).sum() > 0 or t > 1
+        _pose_close(gm["Tcw_motion"], rm["Tcw_motion"], f"frame {t} pose after the motion model")
+        # --- (the host's UpdateLocalMap would run here) --- TrackLocalMap
+        seen = _seen_from(gm["discarded"], n0)
+        rl = _oracle_local(okeys, odesc, sf, inv_sigma2, gm["Tcw_motion"], gm["frame_mp"], seen, pts, th_local)
+        gl = steps.local(K_TUM3, gm["Tcw_motion"], gm["frame_mp"], pts, seen, th_local)
+        for k in ("n_to_match", "nmatches_local", "ngood_local", "matches_inliers"):
+            assert gl[k] == rl[k], f"frame {t} local: {k} {gl[k]} vs {rl[k]}"
+        for k in ("frame_mp", "outlier", "in_view", "Rcw", "tcw", "Ow"):
+            assert np.array_equal(gl[k], rl[k]), f"frame {t} local: {k}"
+        _pose_close(gl["Tcw"], rl["Tcw"], f"frame {t} pose after the local map")
+        # --- the fused call on the same inputs ends in the same frame (same table, the discarded points marked seen)
+        gf = fused.track(img, K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts, 15.0, th_local)
+        for k in ("frame_mp", "outlier", "in_view"):
+            assert np.array_equal(gf[k], gl[k]), f"frame {t}: fused vs step-wise {k}"
+        assert gf["matches_inliers"] == gl["matches_inliers"] and gf["nmatches_local"] == gl["nmatches_local"]
+        assert np.array_equal(gf["Tcw"], gl["Tcw"]), "same kernels on the same inputs: the same pose, bit for bit"
+        last = dict(keys=keys, mp=gl["frame_mp"], outlier=gl["outlier"])
+        T = gl["Tcw"]
+
+
+def test_motion_model_gives_up_then_reference_keyframe_takes_over():
+    """A hopeless prediction: TrackWithMotionModel finds fewer than 20 matches and returns before optimising (the frame's vector then holds the
+    search's result and NOTHING else has happened: no discard list).  Tracking::Track falls back to TrackReferenceKeyFrame on the SAME
+    resident frame: BoW transform and FeatureVector on the device, SearchByBoW against the key-frame, PoseOptimization, discard."""
+    from rumi_slam_amd.matcher import FeatureVector, FrameView
+    from rumi_slam_amd.tracker import Tracker
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    orc = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img0, sf, inv_sigma2, pts, last = _scene(n_keep=0.9)
+    n0 = len(pts["obs"])
+    rng = np.random.default_rng(5)
+    pts["obs"] = np.where(rng.random(n0) < 0.1, 0, 2).astype(np.int32)
+    pts["bad"] = (rng.random(n0) < 0.04).astype(np.uint8)
+    voc_nodes = synthetic_vocabulary(21, 10, 3)
+    # a vocabulary whose words are the scene's own descriptors makes true correspondences share words, as a trained one does
+    parent, leaf, vdesc, weight = (a.copy() for a in voc_nodes)
+    leaves = np.nonzero(leaf)[0]
+    take = rng.choice(n0, len(leaves), replace=len(leaves) > n0)
+    vdesc[leaves] = pts["desc"][take]
+    g, o = ORBVocabulary(parent, leaf, vdesc, weight), O.OracleVocabulary(parent, leaf, vdesc, weight)
+    q_gt, t_gt = _pose_gt(2)
+    img = warp_homography(img0, _homography(q_gt, t_gt))
+    mono, keys, desc = trk.extract(img)
+    T_bad = np.array([0, 0, 0, 1, 9.0, 0, 0], np.float32)
+    rm = _oracle_motion(keys, desc, sf, inv_sigma2, T_bad, last, pts)
+    gm = trk.motion(K_TUM3, T_bad, last["keys"], last["mp"], last["outlier"], pts)
+    assert rm["nmatches_motion"] < 20 and gm["nmatches_motion"] == rm["nmatches_motion"] and gm["th_motion"] == 30
+    assert gm["ngood_motion"] == 0 and (gm["discarded"] == -1).all() and np.array_equal(gm["frame_mp"], rm["frame_mp"]) and np.array_equal(gm["Tcw_motion"], T_bad)
+    # --- TrackReferenceKeyFrame: the key-frame is frame 0 (the last frame's features with their map points)
+    levelsup = 2
+    kf_keys, kf_desc, kf_mp = last["keys"], pts["desc"], last["mp"]       # frame-0 descriptors are the map points' descriptors in this scene
+    (_, _), (kn, ko, ki) = o.transform(kf_desc, levelsup)
+    wq, vq, nq = o.transform_features(desc, levelsup)
+    (_, _), (fn, fo, fi) = o.transform(desc, levelsup)
+    nm_ref, vp = O.search_by_bow(kf_keys, kf_desc, kf_mp, pts["bad"], (kn, ko, ki), keys, desc, (fn, fo, fi), 0.7, True)
+    T_init = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)                   # mLastFrame.GetPose()
+    got = trk.reference_keyframe(g, K_TUM3, T_init, FrameView(kf_keys, kf_desc, W, H, sf), FeatureVector.from_csr(kn, ko, ki), kf_mp, pts, levelsup, 0.7, True)
+    assert np.array_equal(got["word_id"], wq) and np.array_equal(got["node_id"], nq) and np.array_equal(got["word_weight"], vq), "Frame::ComputeBoW per feature"
+    (bi, bv), (an, ao, ai) = g.assemble(got["word_id"], got["word_weight"], got["node_id"])
+    (bi2, bv2), _ = o.transform(desc, levelsup)
+    assert np.array_equal(bi, bi2) and bv.tobytes() == bv2.tobytes() and np.array_equal(an, fn) and np.array_equal(ao, fo) and np.array_equal(ai, fi)
+    assert nm_ref >= 15, f"the scene must give the BoW search enough matches ({nm_ref})"
+    assert got["nmatches_motion"] == nm_ref
+    idx = np.nonzero(vp >= 0)[0]
+    ng, T1, out = O.pose_optimization(pts["pos"][vp[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T_init)
+    exp_mp, exp_dis = vp.copy(), np.full(len(keys), -1, np.int32)
+    exp_dis[idx[out != 0]] = vp[idx[out != 0]]
+    exp_mp[idx[out != 0]] = -1
+    inl = idx[out == 0]
+    assert got["ngood_motion"] == ng and got["nmatches_map"] == int((pts["obs"][vp[inl]] > 0).sum())
+    assert np.array_equal(got["frame_mp"], exp_mp) and np.array_equal(got["discarded"], exp_dis)
+    _pose_close(got["Tcw_motion"], T1, "pose after TrackReferenceKeyFrame")
+    # --- and TrackLocalMap on top of it, still the same resident frame
+    seen = _seen_from(got["discarded"], n0)
+    rl = _oracle_local(keys, desc, sf, inv_sigma2, got["Tcw_motion"], got["frame_mp"], seen, pts, 1.0)
+    gl = trk.local(K_TUM3, got["Tcw_motion"], got["frame_mp"], pts, seen, 1.0)
+    for k in ("n_to_match", "nmatches_local", "ngood_local", "matches_inliers"):
+        assert gl[k] == rl[k], f"local after the reference key-frame: {k} {gl[k]} vs {rl[k]}"
+    for k in ("frame_mp", "outlier", "in_view"):
+        assert np.array_equal(gl[k], rl[k]), f"local after the reference key-frame: {k}"
+    _pose_close(gl["Tcw"], rl["Tcw"], "pose after the local map")
+
+
+def test_reference_keyframe_with_too_few_matches_and_stage_order_errors():
+    from rumi_slam_amd.capi import RumiError
+    from rumi_slam_amd.matcher import FeatureVector, FrameView
+    from rumi_slam_amd.tracker import Tracker
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    img0, sf, inv_sigma2, pts, last = _scene(n_keep=0.9)
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    with pytest.raises(RumiError):
+        trk.motion(K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts)            # no frame is resident yet
+    voc = synthetic_vocabulary(3, 8, 3)
+    g, o = ORBVocabulary(*voc), O.OracleVocabulary(*voc)
+    mono, keys, desc = trk.extract(synth_frame(777))                                  # an unrelated image: the BoW search finds (almost) nothing
+    (_, _), (kn, ko, ki) = o.transform(pts["desc"], 2)
+    (_, _), (fn, fo, fi) = o.transform(desc, 2)
+    nm_ref, vp = O.search_by_bow(last["keys"], pts["desc"], last["mp"], pts["bad"], (kn, ko, ki), keys, desc, (fn, fo, fi), 0.7, True)
+    got = trk.reference_keyframe(g, K_TUM3, T, FrameView(last["keys"], pts["desc"], W, H, sf), FeatureVector.from_csr(kn, ko, ki), last["mp"], pts, 2, 0.7, True)
+    assert nm_ref < 15 and got["nmatches_motion"] == nm_ref and np.array_equal(got["frame_mp"], vp)
+    assert got["ngood_motion"] == 0 and (got["discarded"] == -1).all() and np.array_equal(got["Tcw_motion"], T)
