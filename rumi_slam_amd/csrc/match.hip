@@ -2114,6 +2114,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         return RUMI_E_INVALID;
     if (w <= 0 || h <= 0) return RUMI_E_EMPTY;
     if (w > t->cfg.max_width || h > t->cfg.max_height) { g_lastError = "rumi_track_frame: image larger than the tracker was created for"; return RUMI_E_CAPACITY; }
+    t->curN = -1;
     RumiMatcher *m = t->m;
     const int nmp = pts->n;
     if (nlast > m->maxQ || nmp > t->maxPts || cap < t->cap) { g_lastError = "rumi_track_frame: more points / features than the tracker was created for, or cap too small"; return RUMI_E_CAPACITY; }
@@ -2135,6 +2136,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
     const int n = counts[0];
     res->n = n; res->mono_index = counts[1];
+    t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];      // the frame is resident for the step-wise entries too
     const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
     const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
 

@@ -499,6 +499,106 @@ int main(int argc, char **argv) {
         std::printf("TrackFrame: motion matches %d (th %d), inliers %d, nmatchesMap %d, in view %d, local matches %d, inliers %d / %d\n", st.nmatches, st.thMotion, st.ngoodMotion,
                     st.nmatchesMap, st.nToMatch, st.nmatchesLocal, st.ngoodLocal, st.mnMatchesInliers);
     }
+    // ---- the step-wise members (one Tracking member function per call, the frame resident in between) ----
+    {
+        for (auto &m : mps) { m.bad = false; m.mnLastFrameSeen = -1; m.mbTrackInView = false; m.normal = V3f{{0, 0, 1}}; m.nVisible = 0; m.nFound = 0; }
+        for (size_t i = 0; i < mps.size(); i += 41) mps[i].bad = true;
+        std::vector<MapPoint *> localPts;
+        for (auto &m : mps) localPts.push_back(&m);
+        cv::Mat image1(480, 640, CV_8U, im[1].data(), 640), mask1;
+        // (a) the same frame through ExtractFrame -> TrackWithMotionModel -> [host: UpdateLocalMap] -> TrackLocalMap == the fused TrackFrame
+        Frame F1; F1.mnId = 31;
+        rumi_facade::TrackStep sf;
+        const int monoF = rumi_facade::TrackFrame(F1, image1, ext, T7, fr[0], localPts, 15.f, 1.f, false, 50.f, &sf);
+        std::vector<int> visF(mps.size()), foundF(mps.size());
+        for (size_t i = 0; i < mps.size(); i++) { visF[i] = mps[i].nVisible; foundF[i] = mps[i].nFound; mps[i].nVisible = 0; mps[i].nFound = 0; mps[i].mnLastFrameSeen = -1; mps[i].mbTrackInView = false; }
+        Frame F2; F2.mnId = 32;
+        rumi_facade::TrackStep ss;
+        const int monoS = rumi_facade::ExtractFrame(F2, image1, ext, (int)mps.size());
+        const bool okM = rumi_facade::TrackWithMotionModel(F2, fr[0], T7, 15.f, &ss);
+        int heldAfterMotion = 0, seenAfterMotion = 0;
+        for (int i = 0; i < F2.N; i++) heldAfterMotion += F2.mvpMapPoints[i] != nullptr;
+        for (auto &m : mps) seenAfterMotion += m.mnLastFrameSeen == F2.mnId;
+        int visAfterMotion = 0;
+        for (auto &m : mps) visAfterMotion += m.nVisible;
+        const int inl = rumi_facade::TrackLocalMap(F2, localPts, 1.f, false, 50.f, &ss);
+        CHECK(monoF >= 0 && monoS == monoF && F2.N == F1.N && sf.okMotion && okM && ss.okMotion, "step-wise: extraction and the motion model's verdict");
+        CHECK(ss.nmatches == sf.nmatches && ss.thMotion == sf.thMotion && ss.ngoodMotion == sf.ngoodMotion && ss.nmatchesMap == sf.nmatchesMap, "step-wise: TrackWithMotionModel's numbers");
+        // (nmatches counts assignments, also those a later query overwrote -- the reference's own count -- so it bounds the discarded points from above)
+        CHECK(visAfterMotion == 0 && seenAfterMotion > 0 && seenAfterMotion <= ss.nmatches - heldAfterMotion, "step-wise: TrackWithMotionModel touches MapPoints only in its discard loop");
+        CHECK(inl == sf.mnMatchesInliers && ss.nToMatch == sf.nToMatch && ss.nmatchesLocal == sf.nmatchesLocal && ss.ngoodLocal == sf.ngoodLocal, "step-wise: TrackLocalMap's numbers");
+        bool sameS = true;
+        for (int i = 0; sameS && i < F1.N; i++) sameS = F1.mvpMapPoints[i] == F2.mvpMapPoints[i] && F1.mvbOutlier[i] == F2.mvbOutlier[i];
+        bool sameStats = true;
+        for (size_t i = 0; sameStats && i < mps.size(); i++) sameStats = mps[i].nVisible == visF[i] && mps[i].nFound == foundF[i];
+        CHECK(sameS && std::memcmp(F1.pose.T, F2.pose.T, 28) == 0, "step-wise: the frame after TrackLocalMap equals the fused call's");
+        CHECK(sameStats, "step-wise: IncreaseVisible / IncreaseFound per point as in the fused call");
+        // (b) a hopeless prediction: the fused call reports okMotion = false, has replayed NOTHING of TrackLocalMap, and the frame is in
+        // TrackWithMotionModel's failure state; TrackReferenceKeyFrame takes over on the resident frame
+        for (auto &m : mps) { m.nVisible = 0; m.nFound = 0; m.mnLastFrameSeen = -1; m.mbTrackInView = false; }
+        const float Tbad[7] = {0, 0, 0, 1, 9.f, 0, 0};
+        Frame F3; F3.mnId = 33;
+        rumi_facade::TrackStep sb;
+        rumi_facade::TrackFrame(F3, image1, ext, Tbad, fr[0], localPts, 15.f, 1.f, false, 50.f, &sb);
+        int touched = 0;
+        for (auto &m : mps) touched += m.nVisible + m.nFound + (m.mnLastFrameSeen == F3.mnId);
+        CHECK(!sb.okMotion && !sb.ranLocal && sb.nmatches < 20 && sb.thMotion == 30 && touched == 0 && F3.N == F1.N, "fused call, motion model fails: nothing of TrackLocalMap replayed");
+        // the reference key-frame: frame 0 with its map points, FeatureVectors from a vocabulary whose words are the scene's descriptors
+        const char *vocPath = "/tmp/rumi_facade_voc.txt";
+        {
+            FILE *vf = std::fopen(vocPath, "w");
+            const int k = 12, L = 2;
+            std::fprintf(vf, "%d %d 0 0\n", k, L);
+            std::mt19937 vr(5);
+            std::vector<int> inner;
+            int id = 0;
+            auto put = [&](int parent, int leaf, const uint8_t *d) { std::fprintf(vf, "%d %d", parent, leaf); for (int b = 0; b < 32; b++) std::fprintf(vf, " %d", (int)d[b]); std::fprintf(vf, " %.17g\n", leaf ? 1.0 + (id % 7) * 0.25 : 0.0); id++; };
+            for (int a = 0; a < k; a++) { put(0, 0, fr[0].mDescriptors.ptr((int)(vr() % fr[0].N))); inner.push_back(id); }
+            for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) put(inner[a], 1, fr[0].mDescriptors.ptr((int)(vr() % fr[0].N)));
+            std::fclose(vf);
+        }
+        rumi_facade::ORBVocabulary voc;
+        CHECK(voc.loadFromTextFile(vocPath) && voc.size() == 144, "vocabulary text file");
+        KeyFrame kref; static_cast<Frame &>(kref) = fr[0];
+        {
+            std::vector<cv::Mat> dd;
+            for (int i = 0; i < kref.N; i++) dd.push_back(cv::Mat(1, 32, CV_8U, kref.mDescriptors.ptr(i), 32));
+            std::map<unsigned, double> bow;
+            voc.transform(dd, bow, kref.mFeatVec, 1);
+        }
+        Frame lastF = fr[0];
+        const float Tid[7] = {0, 0, 0, 1, 0, 0, 0};
+        std::memcpy(lastF.pose.T, Tid, 28);
+        const bool okR = rumi_facade::TrackReferenceKeyFrame(F3, &kref, lastF, voc, &sb, 1);
+        // the same through the separate facade members: transform -> SearchByBoW -> PoseOptimization -> discard
+        Frame G = F3;
+        G.mvpMapPoints.assign(G.N, nullptr); G.mvbOutlier.assign(G.N, false);
+        G.mvScaleFactors = ext.GetScaleFactors(); G.mvInvLevelSigma2 = ext.GetInverseScaleSigmaSquares(); G.mvuRight.assign(G.N, -1.f);
+        {
+            std::vector<cv::Mat> dd;
+            for (int i = 0; i < G.N; i++) dd.push_back(cv::Mat(1, 32, CV_8U, G.mDescriptors.ptr(i), 32));
+            std::map<unsigned, double> bow;
+            G.mFeatVec.clear();
+            voc.transform(dd, bow, G.mFeatVec, 1);
+        }
+        CHECK(G.mFeatVec == F3.mFeatVec && !F3.mFeatVec.empty(), "TrackReferenceKeyFrame: mFeatVec of the frame = ORBVocabulary::transform");
+        std::vector<MapPoint *> vpm;
+        ORB_SLAM3::ORBmatcher m7(0.7f, true);
+        const int nbow = m7.SearchByBoW(&kref, G, vpm);
+        CHECK(nbow == sb.nmatchesBoW && nbow >= 15, "TrackReferenceKeyFrame: SearchByBoW's count");
+        G.mvpMapPoints = vpm;
+        std::memcpy(G.pose.T, Tid, 28);
+        const int gR = ORB_SLAM3::Optimizer::PoseOptimization(&G);
+        int mapR = 0;
+        for (int i = 0; i < G.N; i++) if (G.mvpMapPoints[i]) { if (G.mvbOutlier[i]) { G.mvpMapPoints[i] = nullptr; G.mvbOutlier[i] = false; } else if (G.mvpMapPoints[i]->Observations() > 0) mapR++; }
+        bool sameR = true;
+        for (int i = 0; sameR && i < G.N; i++) sameR = G.mvpMapPoints[i] == F3.mvpMapPoints[i];
+        double dR = 0;
+        for (int c = 0; c < 7; c++) dR = std::fmax(dR, std::fabs(G.pose.T[c] - F3.pose.T[c]));
+        CHECK(sb.ngoodMotion == gR && sb.nmatchesMap == mapR && okR == (mapR >= 10) && sameR && dR < 1e-5, "TrackReferenceKeyFrame == transform + SearchByBoW + PoseOptimization + discard");
+        std::printf("step-wise: motion %d matches (%d map), local inliers %d; fall-back: motion %d matches at th %d -> BoW %d matches, %d inliers, %d map matches\n", ss.nmatches, ss.nmatchesMap, inl,
+                    sb.nmatches, sb.thMotion, sb.nmatchesBoW, sb.ngoodMotion, sb.nmatchesMap);
+    }
     std::printf("facade test: %d failure(s); matches %d, pose inliers %d, LBA edges %d (erased %d) dK %.2e dP %.2e\n", fails, ngpu, good, nEdges, erasedRef, dK, dP);
     (void)erased;
     return fails ? 1 : 0;
