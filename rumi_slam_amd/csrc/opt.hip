@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <sys/prctl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -312,6 +313,23 @@ struct BADev {
     int robust;                                // Huber kernel on the edges (off in the merge BA second pass)
 };
 
+// Device-side control of g2o's Levenberg-Marquardt loop (optimization_algorithm_levenberg.cpp:61-169) for the local windows.  The host enqueues
+// one SLOT per LM trial -- [build the system if the previous trial was accepted] -> reduced system -> solve -> update -> chi2 -> decide -- ahead
+// of the device; k_lm_decide takes the accept / reject decision, updates lambda and the iteration bookkeeping here, and every kernel of a slot
+// reads this block to know what to do (nothing once `done`; which of the two state buffers is the estimate; the damping).  No host round
+// trip inside the loop: the host only watches `trialsDone` / `done` in the pinned mirror to keep one slot queued ahead, and forwards the
+// reference's stop flag (pbStopFlag, plain host memory) into `stopWord`.
+struct LmState {
+    double lambda, ni, currentChi, iniChi;
+    double *T[2], *X[2];                 // the two state buffers; `cur` is the estimate, cur ^ 1 the trial
+    int32_t cur, needBuild, done, nBad, qmax, it, maxIt, trials, iters, nUnknowns;
+};
+struct LmMirror {                        // fine-grained pinned host memory, written by k_lm_decide / k_lm_begin
+    volatile int32_t trialsDone, done, cur, iters, trials, pad;
+    volatile unsigned long long seq;
+};
+__device__ __forceinline__ bool lm_skip(const LmState *S, bool buildOnly) { return S && (S->done || (buildOnly && !S->needBuild)); }
+
 __device__ __forceinline__ DSE3 load_pose(const double *T, int k) {
     const double *p = T + (size_t)k * 8;
     return DSE3{{p[0], p[1], p[2], p[3]}, {p[4], p[5], p[6]}};
@@ -321,8 +339,9 @@ __device__ __forceinline__ void store_pose(double *T, int k, const DSE3 &P) {
     p[0] = P.r.x; p[1] = P.r.y; p[2] = P.r.z; p[3] = P.r.w; p[4] = P.t.x; p[5] = P.t.y; p[6] = P.t.z; p[7] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_ba_chi2(BADev B, const double *T, const double *X) {
+__global__ __launch_bounds__(256) void k_ba_chi2(BADev B, const double *T, const double *X, const LmState *S = nullptr, int trial = 0) {
     __shared__ double red[4];
+    if (S) { if (S->done) return; T = S->T[S->cur ^ trial]; X = S->X[S->cur ^ trial]; }
     const int e = blockIdx.x * 256 + threadIdx.x;
     double acc[1] = {0};
     if (e < B.nE) {
@@ -357,7 +376,8 @@ __device__ __forceinline__ void seg_reduce_atomic(double v, int p, bool head, do
     if (head && p >= 0) atomicAdd(dst, v);
 }
 
-__global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, const double *X) {
+__global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, const double *X, const LmState *S = nullptr) {
+    if (S) { if (lm_skip(S, true)) return; T = S->T[S->cur]; X = S->X[S->cur]; }
     const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const bool liveEdge = t < B.nE;
     const int e = liveEdge ? B.ptEdge[t] : 0;
@@ -443,7 +463,8 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
 // grid (nOpt, kHppSlices): every wave owns an interleaved subset of the 4-row chunks (4 loads in flight per wave); the
 // slices of one key-frame are combined with f64 atomics into the zeroed H_pp / b_p.
 constexpr int kHppSlices = 16;
-__global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
+__global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B, const LmState *S = nullptr) {
+    if (lm_skip(S, true)) return;
     const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = B.kfRowStart[kf], r1 = B.kfRowStart[kf + 1];
     const int col = lane & 15, sub = lane >> 4;
@@ -480,7 +501,8 @@ __global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B) {
 
 // one launch instead of a memset per array
 struct ZeroList { double *p[4]; int n[4]; };
-__global__ void k_ba_zero(ZeroList Z) {
+__global__ void k_ba_zero(ZeroList Z, const LmState *S = nullptr) {
+    if (lm_skip(S, true)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int s = 0; s < 4; s++) if (i < Z.n[s]) Z.p[s][i] = 0.0;
@@ -558,7 +580,8 @@ __device__ __forceinline__ void dinv_factor(const double *Hll, double lambda, do
     const double l11 = sqrt(I[4] - l10 * l10), l21 = (I[7] - l20 * l10) / l11, l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
     L[0] = l00; L[1] = l10; L[2] = l20; L[3] = l11; L[4] = l21; L[5] = l22;
 }
-__global__ __launch_bounds__(256) void k_ba_dinv_yfill(BADev B, double lambda, double *Yt, int NP, double *Lp) {
+__global__ __launch_bounds__(256) void k_ba_dinv_yfill(BADev B, double lambda, double *Yt, int NP, double *Lp, const LmState *S = nullptr) {
+    if (S) { if (S->done) return; lambda = S->lambda; }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < B.nMP) {
         const int p = t;
@@ -594,7 +617,8 @@ __global__ __launch_bounds__(256) void k_ba_dinv_yfill(BADev B, double lambda, d
 // G += Yt^T Yt over a K-slice; one wave per (upper 16x16 tile, slice); grid tiles x slices/4, 256 threads.  A wave's 36-odd MFMAs take 2.3 k
 // cycles, one round trip to L2 / HBM about as long: the slice is walked in chunks of 64 rows (16 operand pairs per lane) with the loads of two
 // chunks in flight before the first MFMA, so the kernel pays the memory latency once per wave, not once per 16 rows.
-__global__ __launch_bounds__(256) void k_ba_syrk_mfma(const double *__restrict__ Yt, int K, int NP, int nSlices, double *G) {
+__global__ __launch_bounds__(256) void k_ba_syrk_mfma(const double *__restrict__ Yt, int K, int NP, int nSlices, double *G, const LmState *S = nullptr) {
+    if (lm_skip(S, false)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NT = NP / 16;
     // 1-D grid of tiles x slice groups.  Workgroups go round-robin over the 8 XCDs, each with its own L2: the mapping below gives every XCD
@@ -676,6 +700,56 @@ __global__ void k_ba_publish(const double *__restrict__ scal, volatile double *h
     __threadfence_system();
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(const_cast<double *>(hostScal + 8)), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// First slot only, after chi2(estimate), the first buildSystem and k_ba_maxdiag: currentChi, and computeLambdaInit = tau * max |H_jj|
+__global__ void k_lm_begin(const double *__restrict__ scal, LmState *S) {
+    if (threadIdx.x != 0 || S->done) return;
+    S->currentChi = scal[0]; S->iniChi = scal[0];
+    S->lambda = 1e-5 * scal[2]; S->ni = 2; S->nBad = 0;
+}
+// The end of one LM trial (levenberg.cpp:102-166): rho from the trial's chi2 (scal[0]), the gain denominator (scal[1]) and the solver's verdict
+// (scal[3]); accept -> the trial buffer becomes the estimate and the next slot rebuilds the system; reject -> larger damping, same system.
+// Iteration bookkeeping as the host loop had it: at most 10 trials per iteration, stop after `maxIt` iterations, on rho == 0, or after three
+// iterations in a row that gain less than a thousandth; the stop flag is looked at where the host loop looked at it.
+__global__ void k_lm_decide(const double *__restrict__ scal, LmState *S, LmMirror *mirror, const volatile int32_t *stopWord, unsigned long long seq) {
+    if (threadIdx.x != 0) return;
+    if (!S->done) {
+        const bool ok2 = S->nUnknowns == 0 || scal[3] != 0.0;
+        const double tempChi = ok2 ? scal[0] : DBL_MAX;
+        double rho = S->currentChi - tempChi;
+        rho /= scal[1] + 1e-3;
+        if (rho > 0 && isfinite(tempChi)) {
+            const double tr = 2 * rho - 1;
+            double alpha = 1. - tr * tr * tr;
+            alpha = fmin(alpha, 2. / 3.);
+            S->lambda *= fmax(1. / 3., alpha);
+            S->ni = 2;
+            S->currentChi = tempChi;
+            S->cur ^= 1;                                   // discardTop(): the trial state becomes the estimate
+        } else {
+            S->lambda *= S->ni;
+            S->ni *= 2;                                    // pop(): keep the current state
+        }
+        S->qmax++; S->trials++;
+        const bool stop = __hip_atomic_load(const_cast<const int32_t *>(stopWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        if (rho < 0 && S->qmax < 10 && !stop) {
+            S->needBuild = 0;                              // another trial on the same system
+        } else {
+            S->iters++;
+            bool term = S->qmax == 10 || rho == 0;
+            if (!term) {
+                if ((S->iniChi - S->currentChi) * 1e3 < S->iniChi) S->nBad++; else S->nBad = 0;
+                term = S->nBad >= 3;
+            }
+            S->it++;
+            if (term || S->it >= S->maxIt || stop) S->done = 1;
+            else { S->needBuild = 1; S->qmax = 0; S->iniChi = S->currentChi; }
+        }
+    }
+    mirror->cur = S->cur; mirror->iters = S->iters; mirror->trials = S->trials; mirror->done = S->done; mirror->trialsDone = S->trials;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<unsigned long long *>(&mirror->seq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <bool USE_LDS>
@@ -918,7 +992,8 @@ __device__ __forceinline__ bool panel_factor(double (&a)[16], int w, int lane, d
     return bad;
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, double *__restrict__ G, int NP) {
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, double *__restrict__ G, int NP, const LmState *S = nullptr) {
+    if (S) { if (S->done) return; lambda = S->lambda; }
     extern __shared__ double T[];                             // tiles | y[NT*16]
     __shared__ int sFail;
     __shared__ double sBuf[kSolveWaves][16];                           // per wave: the scaled pivot column of the panel step in flight
@@ -1411,8 +1486,9 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *A, int ld, 
 // gain-ratio denominator.  Eight lanes share a landmark (its ~15 edges are two rounds instead of fifteen dependent ones); the
 // first nKF * 8 lanes past the landmarks carry the poses (one per group of eight).
 constexpr int kLmLanes = 8;
-__global__ __launch_bounds__(256) void k_ba_update(BADev B, double lambda, const double *T, const double *X, double *Tt, double *Xt) {
+__global__ __launch_bounds__(256) void k_ba_update(BADev B, double lambda, const double *T, const double *X, double *Tt, double *Xt, const LmState *S = nullptr) {
     __shared__ double red[4];
+    if (S) { if (S->done) return; lambda = S->lambda; T = S->T[S->cur]; X = S->X[S->cur]; Tt = S->T[S->cur ^ 1]; Xt = S->X[S->cur ^ 1]; }
     const int gi = (blockIdx.x * 256 + threadIdx.x) / kLmLanes, sub = threadIdx.x & (kLmLanes - 1);
     double acc[1] = {0};
     if (gi < B.nMP) {
@@ -1905,6 +1981,12 @@ struct RumiOptimizer {
     int32_t *dPairs = nullptr; size_t pairCap = 0, pairOff = 0;   // Schur block descriptors + observation pairs of the large-window path
     double *hScal = nullptr;         // fine-grained pinned: [0..7] the trial's scalars, [8] sequence number of the last publication (k_ba_publish)
     double *dhScal = nullptr;        // the same memory as the device sees it
+    // device-side LM control (LmState on the device; its mirror and the forwarded stop flag in fine-grained pinned memory)
+    rumi::LmState *dLm = nullptr;
+    rumi::LmMirror *hLm = nullptr, *dhLm = nullptr;
+    int32_t *hStop = nullptr, *dhStop = nullptr;
+    rumi::LmState *hLmInit = nullptr;    // pinned staging of the initial state
+    unsigned long long lmSeq = 0;
     unsigned long long pubSeq = 0;
     hipStream_t stream = nullptr;    // bundle adjustments of this handle (created non-blocking)
     std::vector<RumiOptimizer *> workers;   // rumi_local_ba_batch: one child handle per worker thread, created on first use
@@ -1939,6 +2021,10 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->dPairs) (void)hipFree(o->dPairs);
     if (o->hScal) (void)hipHostFree(o->hScal);
+    if (o->hLm) (void)hipHostFree(o->hLm);
+    if (o->hStop) (void)hipHostFree(o->hStop);
+    if (o->hLmInit) (void)hipHostFree(o->hLmInit);
+    if (o->dLm) (void)hipFree(o->dLm);
     if (o->hPose) (void)hipHostFree(o->hPose);
     if (o->hBa) (void)hipHostFree(o->hBa);
     if (o->dBa) (void)hipFree(o->dBa);
@@ -1977,6 +2063,13 @@ extern "C" int rumi_opt_create(int32_t max_pose_edges, int32_t max_pose_batch, i
     if (hipHostMalloc((void **)&o->hScal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&o->dhScal, o->hScal, 0) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
     std::memset(o->hScal, 0, 16 * sizeof(double));
+    if (hipHostMalloc((void **)&o->hLm, sizeof(rumi::LmMirror), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&o->dhLm, o->hLm, 0) != hipSuccess ||
+        hipHostMalloc((void **)&o->hStop, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&o->dhStop, o->hStop, 0) != hipSuccess ||
+        hipHostMalloc((void **)&o->hLmInit, sizeof(rumi::LmState), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&o->dLm, sizeof(rumi::LmState)) != hipSuccess) { rumi_opt_destroy(o); return RUMI_E_NO_DEVICE; }
+    std::memset((void *)o->hLm, 0, sizeof(rumi::LmMirror)); *o->hStop = 0;
     o->baStageCap = E * 48 + M * 32 + K * 80 + 1024;
     if (hipHostMalloc((void **)&o->hBa, o->baStageCap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&o->dBa, o->baStageCap) != hipSuccess ||
         hipMalloc((void **)&o->dBaOut, o->baStageCap) != hipSuccess) {
@@ -2397,15 +2490,96 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     }
     return RUMI_OK;
     };
+    // The same loop with the decisions taken on the device (LmState / k_lm_decide above): slots of one LM trial each are enqueued one ahead of the
+    // device, no kernel waits for the host.  For the windows the tile solver handles (up to 29 optimised key-frames); the large problems of
+    // global BA, the panel solvers and the profiled path keep the host loop.  RUMI_BA_HOST_LM=1 forces the host loop (A/B measurements).
+    static const bool forceHostLm = std::getenv("RUMI_BA_HOST_LM") != nullptr;
+    const bool deviceLm = !big && useTiles && !prof && !forceHostLm && nE > 0;
+    auto lm_device = [&](int maxIt) -> int {
+        if (stop_flag && *stop_flag) return RUMI_OK;                       // the host loop's condition before its first iteration
+        LmState &init = *o->hLmInit;                                       // (pinned; the previous run's copy has long completed)
+        init = LmState{};
+        init.T[0] = o->dT[0]; init.T[1] = o->dT[1]; init.X[0] = o->dX[0]; init.X[1] = o->dX[1];
+        init.cur = cur; init.needBuild = 1; init.maxIt = maxIt; init.nUnknowns = n; init.ni = 2; init.lambda = -1;
+        *o->hStop = 0;
+        // slots of an earlier run may still be queued (they exit at once, but their k_lm_decide still reports): only reports carrying a sequence
+        // number of THIS run count
+        const unsigned long long firstSeq = o->lmSeq + 1;
+        auto report = [&](int32_t *trialsDone, int32_t *done) {
+            const unsigned long long q = __atomic_load_n(const_cast<const unsigned long long *>(&o->hLm->seq), __ATOMIC_ACQUIRE);
+            if (q < firstSeq) { *trialsDone = 0; *done = 0; return; }
+            *trialsDone = o->hLm->trialsDone; *done = o->hLm->done;
+        };
+        HIP_TRY(hipMemcpyAsync(o->dLm, &init, sizeof init, hipMemcpyHostToDevice, st));
+        const LmState *S = o->dLm;
+        // prologue of the first iteration: chi2 of the estimate, clean accumulators, buildSystem, computeLambdaInit
+        {
+            const ZeroList Z0{{o->dG, o->dScal, nullptr, nullptr}, {gClean ? 0 : NP * NP, 3, 0, 0}};
+            hipLaunchKernelGGL(k_ba_zero, dim3(((gClean ? 3 : NP * NP) + 255) / 256), dim3(256), 0, st, Z0, (const LmState *)nullptr);
+            gClean = true;
+            hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], S, 0);
+            ranChi2 = true;
+        }
+        const ZeroList Zb{{o->dHll, o->dBl, o->dHpp, o->dBp}, {nMP * 9, nMP * 3, nOpt * 36, n}};
+        const int zmax = std::max(std::max(nMP * 9, nOpt * 36), 1);
+        auto enqueue_slot = [&](bool first) {
+            hipLaunchKernelGGL(k_ba_zero, dim3((zmax + 255) / 256), dim3(256), 0, st, Zb, S);
+            hipLaunchKernelGGL(k_ba_build, dim3(gE), dim3(256), 0, st, B, o->dT[0], o->dX[0], S);
+            if (nOpt > 0) hipLaunchKernelGGL(k_ba_hpp_mfma, dim3(nOpt, kHppSlices), dim3(256), 0, st, B, S);
+            if (first) {
+                const int nd = nOpt * 6 + nMP * 3;
+                hipLaunchKernelGGL(k_ba_maxdiag, dim3((nd + 255) / 256), dim3(256), 0, st, B);
+                hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(64), 0, st, o->dScal, o->dLm);
+            }
+            if (nMP > 0) hipLaunchKernelGGL(k_ba_dinv_yfill, dim3((nMP + nE + 255) / 256), dim3(256), 0, st, B, 0.0, o->dYt, NP, o->dLp, S);
+            if (nMP > 0 && n > 0) hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(NT * (NT + 1) / 2 * (nSlices / 4)), dim3(256), 0, st, o->dYt, K3, NP, nSlices, o->dG, S);
+            hipLaunchKernelGGL(k_ba_solve_tiles, dim3(1), dim3(kSolveThreads), ldsTiles, st, B, 0.0, o->dG, NP, S);
+            hipLaunchKernelGGL(k_ba_update, dim3(((nMP + nKF) * kLmLanes + 255) / 256), dim3(256), 0, st, B, 0.0, o->dT[0], o->dX[0], o->dT[1], o->dX[1], S);
+            hipLaunchKernelGGL(k_ba_chi2, dim3(gE), dim3(256), 0, st, B, o->dT[0], o->dX[0], S, 1);
+            hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, st, o->dScal, o->dLm, o->dhLm, o->dhStop, ++o->lmSeq);
+        };
+        // one slot queued ahead of the one that is running.  While it waits the host thread SLEEPS in short naps (a slot lasts ~100 us; the
+        // thread's timer slack is set to 1 us so that a 30 us nap is not rounded up to the default 50 us slack): the workers of
+        // rumi_local_ba_batch no longer burn a core each (hipEventSynchronize spins on this runtime whatever the event's flags; measured).
+        // The reference's stop flag is forwarded once per nap.
+        static thread_local bool slackSet = false;
+        if (!slackSet) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slackSet = true; }
+        const int maxSlots = maxIt * 10;
+        int enq = 0, naps = 0;
+        for (;;) {
+            int32_t tdone = 0, done = 0;
+            report(&tdone, &done);
+            if (done) break;
+            if (stop_flag && *stop_flag) *o->hStop = 1;
+            if (enq < maxSlots && enq <= tdone + 1) {
+                enqueue_slot(enq == 0);
+                HIP_TRY(hipGetLastError());
+                enq++;
+                naps = 0;
+                continue;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(30));
+            if ((++naps & 0xFF) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+                // the stream has drained: either the last report is about to be seen, or a launch failed
+                HIP_TRY(hipStreamSynchronize(st));
+                report(&tdone, &done);
+                if (!done && (enq >= maxSlots || enq > tdone + 1)) { g_lastError = "local BA: the device-side LM loop stalled"; return RUMI_E_NO_DEVICE; }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        cur = o->hLm->cur; iters += o->hLm->iters; trials += o->hLm->trials;
+        return RUMI_OK;
+    };
+    auto lm_any = [&](int maxIt) -> int { return deviceLm ? lm_device(maxIt) : lm(maxIt); };
     int itersFirst = 0;
     const double tE = now();
-    if ((rc = lm(mode == 0 ? 10 : mode == 1 ? 5 : gbaIterations)) != RUMI_OK) return rc;
+    if ((rc = lm_any(mode == 0 ? 10 : mode == 1 ? 5 : gbaIterations)) != RUMI_OK) return rc;
     const double tF = now();
     itersFirst = iters;
     if (mode == 1 && !(stop_flag && *stop_flag)) {          // bDoMore
         if (nE > 0 && ranChi2) hipLaunchKernelGGL(k_ba_mark, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], o->dEOff);
         B.robust = 0;
-        if ((rc = lm(10)) != RUMI_OK) return rc;
+        if ((rc = lm_any(10)) != RUMI_OK) return rc;
     }
     if (nE > 0) hipLaunchKernelGGL(k_ba_finalize, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dErase);
     HIP_TRY(hipEventRecord(o->ev[1], st));

@@ -28,7 +28,8 @@ w = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"],
 for workers in (1, 2, 4, 8):
     R = 16
     opt.LocalBundleAdjustmentBatch([w] * R, workers)
-    dts = []
-    for _ in range(5):                                   # worker threads spin on their trial scalars: host scheduling shows, the best of five is the device's rate
-        t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([w] * R, workers); dts.append(time.perf_counter() - t0)
-    print("batch of %d windows (20 + 5 key-frames x 3000 points), %d workers: %.3f ms per window (best of 5; median %.3f)" % (R, workers, min(dts) * 1e3 / R, float(np.median(dts)) * 1e3 / R))
+    dts, cpu = [], []
+    for _ in range(5):
+        c0, t0 = time.process_time(), time.perf_counter(); opt.LocalBundleAdjustmentBatch([w] * R, workers); dts.append(time.perf_counter() - t0); cpu.append(time.process_time() - c0)
+    print("batch of %d windows (20 + 5 key-frames x 3000 points), %d workers: %.3f ms per window (best of 5; median %.3f); host cores busy %.2f (process CPU time / wall time, LM loop %s)" % (
+        R, workers, min(dts) * 1e3 / R, float(np.median(dts)) * 1e3 / R, float(np.median(cpu)) / float(np.median(dts)), "on the HOST (RUMI_BA_HOST_LM)" if os.environ.get("RUMI_BA_HOST_LM") else "on the device"))

@@ -64,12 +64,45 @@ def measure(reps=60):
         return float(np.median(ts)) * 1e3
 
 
+    # ---- the step-wise entries on one resident frame: extract | motion | local, and extract | reference key-frame (BoW) | local
+    from rumi_slam_amd.matcher import FeatureVector
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    from voc_scene import synthetic_vocabulary
+    parent, leaf, vdesc, weight = (x.copy() for x in synthetic_vocabulary(21, 10, 3))
+    leaves = np.nonzero(leaf)[0]
+    vdesc[leaves] = desc0[rng.choice(n0, len(leaves), replace=len(leaves) > n0)]
+    voc = ORBVocabulary(parent, leaf, vdesc, weight)
+    (_, _), (kn, ko, ki) = voc.transform(desc0, 2)
+    kfv, kview = FeatureVector.from_csr(kn, ko, ki), FrameView(keys0, desc0, W, H, sf)
+    kf_mp = np.arange(n0, dtype=np.int32)
+    stage = {}
+
+    def steps_motion():
+        t0 = time.perf_counter(); trk.extract(img); t1 = time.perf_counter()
+        m = trk.motion(K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts); t2 = time.perf_counter()
+        seen = np.zeros(n0, np.uint8); seen[m["discarded"][m["discarded"] >= 0]] = 1
+        l = trk.local(K_TUM3, m["Tcw_motion"], m["frame_mp"], pts, seen, 1.0); t3 = time.perf_counter()
+        stage.setdefault("extract", []).append(t1 - t0); stage.setdefault("motion", []).append(t2 - t1); stage.setdefault("local", []).append(t3 - t2)
+        return l["ngood_local"], l["Tcw"]
+
+    def steps_refkf():
+        trk.extract(img); t1 = time.perf_counter()
+        m = trk.reference_keyframe(voc, K_TUM3, T, kview, kfv, kf_mp, pts, 2, 0.7, True); t2 = time.perf_counter()
+        stage.setdefault("reference_keyframe", []).append(t2 - t1)
+        return m["ngood_motion"], m["Tcw_motion"]
+
     a, b = separate(), fused()
     assert a[0] == b[0] and np.allclose(a[1], b[1], atol=1e-5), (a, b)
-    return dict(workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
+    c = steps_motion()
+    assert c[0] == b[0] and np.allclose(c[1], b[1], atol=1e-5), (c, b)
+    step_ms, ref_ms = med(steps_motion, reps), med(steps_refkf, reps)
+    per = {k: round(float(np.median(v[5:])) * 1e3, 3) for k, v in stage.items()}
+    return dict(step_wise_ms=round(step_ms, 3), extract_plus_reference_keyframe_ms=round(ref_ms, 3), stage_ms=per, workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
                 inliers=int(b[0]), separate_entries_ms=round(med(separate, reps), 3), rumi_track_frame_ms=round(med(fused, reps), 3))
 
 
 if __name__ == "__main__":
     r = measure()
     print("%s: separate entries %.3f ms, rumi_track_frame %.3f ms (inliers %d)" % (r["workload"], r["separate_entries_ms"], r["rumi_track_frame_ms"], r["inliers"]))
+    print("step-wise entries on the resident frame: extract + motion + local %.3f ms; extract + reference key-frame %.3f ms; per call (ms): %s" %
+          (r["step_wise_ms"], r["extract_plus_reference_keyframe_ms"], r["stage_ms"]))
