@@ -50,15 +50,18 @@ def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
 
 
 def whole_path_valu_issue(fps):
-    """The step against the vector-issue ceiling: VALU wave-instructions per 256-frame pass summed over the path's kernels (committed SQ counters,
-    k_resize runs seven times) over SIMD-cycles available at the measured rate, for the two instruction classes of gfx950 (profiles/r02_valu_issue_rates.txt)."""
+    """The step against the vector-issue ceiling, as ONE number: every kernel's VALU wave-instructions per 256-frame pass (committed SQ counters)
+    priced with the measured issue cost of ITS OWN instruction mix -- each opcode of the disassembled hot loops in the 2.4-, 4.2- or 8.2-cycle
+    class of profiles/r02_valu_issue_rates.txt, loops weighted by their trip counts (tools/valu_mix.py -> profiles/r03_valu_mix.json) -- over the
+    SIMD-cycles available at the rate measured in THIS run."""
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")))["kernels"]
-        insts = sum(v.get("SQ_INSTS_VALU", 0) * (7 if k == "k_resize" else 1) for k, v in sq.items())
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))
         simd_cycles = 1024 * 2.4e9 * (256.0 / fps)
-        return {"valu_wave_insts_per_256_frames": int(insts), "frac_of_ceiling_at_4.2_cycles": round(insts * 4.2 / simd_cycles, 3),
-                "frac_of_ceiling_at_2.4_cycles": round(insts * 2.4 / simd_cycles, 3),
-                "source": "committed profile profiles/r02_pmc_sq_counters.json (separate --pmc passes), rate of this run"}
+        return {"valu_wave_insts_per_256_frames": mix["valu_wave_insts_per_256_frames"], "weighted_cycles": mix["weighted_cycles_per_256_frames"],
+                "avg_cycles_per_inst": mix["avg_cycles_per_inst"], "frac_of_weighted_ceiling": round(mix["weighted_cycles_per_256_frames"] / simd_cycles, 4),
+                "per_kernel_mix": {k: {"M_insts": round(v["valu_wave_insts_per_256_frames"] / 1e6, 1), "fast": v["fast_frac"], "slow": v["slow_frac"], "v8": v["v8_frac"],
+                                       "avg_cycles": v["avg_cycles_per_inst"]} for k, v in mix["kernels"].items()},
+                "source": "instruction counts and mix: committed profile profiles/r03_valu_mix.json (separate --pmc passes + disassembly), not this run; rate: this run"}
     except Exception:
         return None
 
@@ -327,7 +330,8 @@ def main():
         fps = n_queue * args.steps / dt
         ab = algorithmic_bytes_per_frame(n_kp)
         # dominant kernel by device time; algorithmic bytes of that kernel per launch
-        kern_bytes = {"fast": ab["fast_read"], "pyramid": ab["read_l0"] + 1.44 * ab["write_levels"] + ab["write_levels"],
+        # (pyramid: SURVEY.md section 8d's figure -- level 0 read once, levels 1-7 written once; the re-reads of levels 1-6 as sources are traffic, not algorithm)
+        kern_bytes = {"fast": ab["fast_read"], "pyramid": ab["read_l0"] + ab["write_levels"],
                       "blur": ab["blur_rw"], "orient_desc": n_kp * ab["per_kp"], "quadtree": 0.0}
         kern_ms = {k: stage[k] for k in kern_bytes}
         dom = max(kern_ms, key=kern_ms.get)
@@ -336,17 +340,17 @@ def main():
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         kname = {"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot wrap this process from inside, so these two numbers are the committed
-        # results of separate --pmc passes of this command line (profiles/r02_pmc_*.json); `*_source` says so, and they are used only when
+        # results of separate --pmc passes of this command line (profiles/r03_pmc_*.json); `*_source` says so, and they are used only when
         # taken at the same frames-per-launch.
         traffic, valu = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             if pm.get("frames_per_launch") == per_launch and kname in pm["kernels"]:
                 traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")))["kernels"][kname]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_counters.json")))["kernels"][kname]
             if per_launch == 256:
                 valu = {"wave_insts_per_launch": int(sq["SQ_INSTS_VALU"]), "lds_insts_per_launch": int(sq.get("SQ_INSTS_LDS", 0)),
                         "lds_bank_conflict_cycles": int(sq.get("SQ_LDS_BANK_CONFLICT", 0)),
@@ -364,12 +368,12 @@ def main():
                        "exchange": "one all_gather_into_tensor of %d-byte per-frame records over RCCL, overlapped with the next step" % rumination.record_bytes(cap) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "committed profile profiles/r02_pmc_traffic.json (separate --pmc passes), not this run" if traffic else None,
+                         "traffic_source": "committed profile profiles/r03_pmc_traffic.json (separate --pmc passes), not this run" if traffic else None,
                          "algorithmic_bytes_per_launch": int(kern_bytes[dom] * per_launch), "frames_per_launch": per_launch,
                          "launch_ms": round(kern_ms[dom] / n_launch, 4),
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
                          "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu,
-                         "valu_source": "committed profile profiles/r02_pmc_sq_counters.json, not this run" if valu else None},
+                         "valu_source": "committed profile profiles/r03_pmc_sq_counters.json, not this run" if valu else None},
             "valu_issue": whole_path_valu_issue(fps),
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
             "stage_ms_note": "one extra profiled step: every kernel alone on ONE stream (RUMI_SERIAL-equivalent: the blur too), launches of up to 256 frames, summed over the step's launches",

@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
-"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag r02) and prints a summary.
+"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag: first argument, default r03) and prints a summary.
 Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r02.json, stage_serial.log, host_batch.log, r02_valu_issue_rates.txt."""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def newest(pattern):
     return max(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
 
 
-shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_kernel_stats.csv"))
-shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, "r02_extract_match_serial_kernel_stats.csv"))
-shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, "r02_lba_20kf_3000mp_kernel_stats.csv"))
+shutil.copy(newest("prof_default/*/*kernel_stats.csv"), os.path.join(P, TAG + "_extract_match_kernel_stats.csv"))
+shutil.copy(newest("prof_serial/*/*kernel_stats.csv"), os.path.join(P, TAG + "_extract_match_serial_kernel_stats.csv"))
+try:
+    shutil.copy(newest("prof_serial128/*/*kernel_stats.csv"), os.path.join(P, TAG + "_extract_match_serial_128frames_kernel_stats.csv"))
+    shutil.copy(os.path.join(G, "bench_%s_records.json" % TAG), os.path.join(P, TAG + "_bench_line_records_path.json"))
+except (ValueError, OSError):
+    print("missing the 128-frame serial pass / the records-path bench line")
+shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, TAG + "_lba_20kf_3000mp_kernel_stats.csv"))
 # second pass (tools/measure_more.sh): latency paths
-for src, dst in (("prof_track/*/*kernel_stats.csv", "r02_track_frame_kernel_stats.csv"),):
+for src, dst in (("prof_track/*/*kernel_stats.csv", TAG + "_track_frame_kernel_stats.csv"),):
     try:
         shutil.copy(newest(src), os.path.join(P, dst))
     except ValueError:
         print("missing", src)
-for src, dst in (("track_probe.log", "r02_track_frame_probe.txt"), ("lba_probe.log", "r02_lba_probe.txt"), ("bow_batch.log", "r02_bow_batch_probe.txt"),
-                 ("pose_probe.log", "r02_pose_probe.txt"), ("rsq_probe.log", "r02_rsq_rcp_accuracy.txt"), ("bench_matrix.json", "r02_bench_matrix.json")):
+for src, dst in (("track_probe.log", TAG + "_track_frame_probe.txt"), ("lba_probe.log", TAG + "_lba_probe.txt"), ("bow_batch.log", TAG + "_bow_batch_probe.txt"),
+                 ("pose_probe.log", TAG + "_pose_probe.txt"), ("rsq_probe.log", TAG + "_rsq_rcp_accuracy.txt"), ("bench_matrix.json", TAG + "_bench_matrix.json")):
     if os.path.exists(os.path.join(G, src)):
         txt = open(os.path.join(G, src)).read()
         open(os.path.join(P, dst), "w").write("\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l) + "\n")
@@ -29,7 +35,7 @@ for src, dst in (("track_probe.log", "r02_track_frame_probe.txt"), ("lba_probe.l
 for d, tmp in (("pmc_fetch", "/tmp/_pf"), ("pmc_write", "/tmp/_pw")):
     shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/x")
     shutil.copy(newest(d + "/*/*counter_collection.csv"), tmp + "/x/")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "/tmp/_pf", "/tmp/_pw", os.path.join(P, "r02_pmc_traffic.json"), "256"],
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "/tmp/_pf", "/tmp/_pw", os.path.join(P, TAG + "_pmc_traffic.json"), "256"],
                       stdout=subprocess.DEVNULL)
 out = {"command": "RUMI_SERIAL=1 rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 bench.py --steps 2 --warmup 1 --batch 256 --no-cpu (two passes)",
        "unit": "counter value per launch (256 frames), averaged over the sampled launches", "kernels": {}}
@@ -41,17 +47,17 @@ for d in ("pmc_a", "pmc_b"):
             agg[n.replace("rumi::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for n, c in agg.items():
         out["kernels"].setdefault(n, {}).update({k: round(sum(v) / len(v)) for k, v in c.items()})
-json.dump(out, open(os.path.join(P, "r02_pmc_sq_counters.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "bench_r02.json"), os.path.join(P, "r02_bench_line.json"))
-shutil.copy(os.path.join(G, "host_batch.log"), os.path.join(P, "r02_host_batch_probe.txt"))
-shutil.copy(os.path.join(G, "r02_valu_issue_rates.txt"), os.path.join(P, "r02_valu_issue_rates.txt"))
-shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, "r02_stage_ms_standalone.txt"))
-for f in ("r02_extract_match_kernel_stats.csv", "r02_extract_match_serial_kernel_stats.csv", "r02_lba_20kf_3000mp_kernel_stats.csv"):
+json.dump(out, open(os.path.join(P, TAG + "_pmc_sq_counters.json"), "w"), indent=1)
+shutil.copy(os.path.join(G, "bench_%s.json" % TAG), os.path.join(P, TAG + "_bench_line.json"))
+shutil.copy(os.path.join(G, "host_batch.log"), os.path.join(P, TAG + "_host_batch_probe.txt"))
+shutil.copy(os.path.join(G, TAG + "_valu_issue_rates.txt"), os.path.join(P, TAG + "_valu_issue_rates.txt"))
+shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, TAG + "_stage_ms_standalone.txt"))
+for f in (TAG + "_extract_match_kernel_stats.csv", TAG + "_extract_match_serial_kernel_stats.csv", TAG + "_lba_20kf_3000mp_kernel_stats.csv"):
     print(f)
     for r in list(csv.DictReader(open(os.path.join(P, f))))[:12]:
         print("   ", r["Name"][:42].ljust(44), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us", r["Percentage"])
-t = json.load(open(os.path.join(P, "r02_pmc_traffic.json")))["kernels"]
+t = json.load(open(os.path.join(P, TAG + "_pmc_traffic.json")))["kernels"]
 for k, v in out["kernels"].items():
     print(k.ljust(16), "VALU", round(v.get("SQ_INSTS_VALU", 0) / 1e6, 1), "M  LDS", round(v.get("SQ_INSTS_LDS", 0) / 1e6, 1), "M  HBM", round(t.get(k, {}).get("hbm_bytes_per_launch", 0) / 1e6, 1), "MB")
-b = json.load(open(os.path.join(P, "r02_bench_line.json")))
+b = json.load(open(os.path.join(P, TAG + "_bench_line.json")))
 print({k: b.get(k) for k in ("value", "value_h2d_inclusive", "single_frame_host_api_fps", "batch_sweep_fps", "ms_per_step", "roofline", "stage_ms_per_step", "cpu_baseline", "lba", "pose_opt")})
