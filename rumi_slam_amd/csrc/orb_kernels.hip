@@ -189,7 +189,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // "4 consecutive" rule (23 ANDs / ORs) runs once for all eight (pixel, polarity) combinations of the lane instead of four times.
 // Ring entries = tile offset of the pixel | polarity << 15; a pixel's darker entry always precedes its brighter one.
 constexpr int kRingCap = 640;        // linear: < 128 entries wait between steps, a step appends up to 512 (64 lanes x 4 pixels x 2 polarities)
-constexpr int kScoredCap = 448;
+constexpr int kScoredCap = 640;
 // (ring pixels q in [0, 255] travel as 0x4100 + q: positive normal f16 bit patterns of one exponent, ordered like the integers)
 
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
