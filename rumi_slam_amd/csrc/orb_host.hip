@@ -466,7 +466,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     auto lane_of = [&](int slot) -> Lane {
         if (slot) return {h->partStream[slot - 1], serial ? h->partStream[slot - 1] : h->partSide[slot - 1], h->evSideFork[slot - 1], h->evSideJoin[slot - 1]};
         if (resident) return {h->part0Stream, h->part0Side, h->evSide0Fork, h->evSide0Join};      // (no slot runs on the caller's stream)
-        return {st, serial ? st : h->sideStream, h->evFork, h->evJoin};
+        return {st, serial || prof ? st : h->sideStream, h->evFork, h->evJoin};        // profiling: the blur on the call's stream too, so that every stage time is a stand-alone duration
     };
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
