@@ -177,28 +177,30 @@ __global__ void k_queries_frame(int nlast, const RumiKeyPoint *lastKeys, const i
     q[i] = o;
 }
 
-// SearchByBoW: one query per entry of the key-frame's FeatureVector, in (node, entry) order (ORBmatcher.cc:217-232)
+// SearchByBoW: one query per entry of the key-frame's FeatureVector, in (node, entry) order (ORBmatcher.cc:217-232).  One THREAD per entry
+// (it finds its node by bisection of the offsets, then the node's twin in the frame's vector by bisection of the ids): a vocabulary level with
+// few nodes -- levelsup near L, small trees -- used to leave the work to a handful of threads walking a hundred entries each (84 us at 10 nodes).
 __global__ void k_queries_bow(int nnKF, const uint32_t *kfNodes, const int32_t *kfOff, const uint32_t *kfIdx,
                               const int32_t *kfMp, const uint8_t *mpBad, const RumiKeyPoint *kfKeys, int nnF,
                               const uint32_t *fNodes, const int32_t *fOff, Query *q, const int32_t *nnFdev = nullptr) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= nnKF) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nnKF <= 0 || p >= kfOff[nnKF]) return;
     if (nnFdev) nnF = *nnFdev;                              // the frame's FeatureVector was built on the device (k_fv_build)
+    int a = 0, ahi = nnKF;                                  // the node that holds entry p: last a with kfOff[a] <= p
+    while (ahi - a > 1) { const int mid = (a + ahi) >> 1; if (kfOff[mid] <= p) a = mid; else ahi = mid; }
     // the merge-walk of the two ordered maps visits exactly the node ids present in both
     int lo = 0, hi = nnF;
     const uint32_t id = kfNodes[a];
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (fNodes[mid] < id) lo = mid + 1; else hi = mid; }
     const bool hit = lo < nnF && fNodes[lo] == id;
-    for (int p = kfOff[a]; p < kfOff[a + 1]; p++) {
-        Query o{};
-        const int feat = (int)kfIdx[p];
-        const int mp = kfMp[feat];
-        o.valid = hit && mp >= 0 && !mpBad[mp];
-        o.descId = feat; o.mpId = mp; o.blocks = 1;
-        if (o.valid) { o.c0 = fOff[lo]; o.c1 = fOff[lo + 1]; }
-        o.angle = kfKeys[feat].angle;
-        q[p] = o;
-    }
+    Query o{};
+    const int feat = (int)kfIdx[p];
+    const int mp = kfMp[feat];
+    o.valid = hit && mp >= 0 && !mpBad[mp];
+    o.descId = feat; o.mpId = mp; o.blocks = 1;
+    if (o.valid) { o.c0 = fOff[lo]; o.c1 = fOff[lo + 1]; }
+    o.angle = kfKeys[feat].angle;
+    q[p] = o;
 }
 
 // MapPoint::PredictScale (MapPoint.cc:538-570); log in double (oracle/match_oracle.cc explains the choice)
@@ -1360,7 +1362,7 @@ extern "C" int rumi_search_by_bow(RumiMatcher *m, const RumiFrameFeatures *KF, c
     m->gridPending = false;                                 // candidates come from the FeatureVectors: the spatial grid is not read
     FLUSH(m);
     if (kf_fv->n_nodes > 0)
-        hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
+        hipLaunchKernelGGL(k_queries_bow, dim3((std::max(nqe, 1) + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, f_fv->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     return run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, matches, nmatches_out);
 }
@@ -1492,7 +1494,7 @@ extern "C" int rumi_search_by_bow_kf(RumiMatcher *m, const RumiFrameFeatures *KF
     m->gridPending = false;
     FLUSH(m);
     if (fv1->n_nodes > 0)
-        hipLaunchKernelGGL(k_queries_bow, dim3((fv1->n_nodes + 255) / 256), dim3(256), 0, nullptr, fv1->n_nodes, m->dNodesA, m->dOffA, m->dIdxA,
+        hipLaunchKernelGGL(k_queries_bow, dim3((std::max(nqe, 1) + 255) / 256), dim3(256), 0, nullptr, fv1->n_nodes, m->dNodesA, m->dOffA, m->dIdxA,
                            m->dI[0], m->dU8a, m->dQKeys, fv2->n_nodes, m->dNodesB, m->dOffB, m->dQ);
     std::vector<int32_t> assign(std::max(nqe, 1), -1);
     rc = run_search(m, MODE_BOW_KF, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, nullptr, nmatches_out, m->dU8b, 0.f, 0, assign.data());
@@ -2388,7 +2390,7 @@ extern "C" int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc
     const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
     if (kf_fv->n_nodes > 0)
-        hipLaunchKernelGGL(k_queries_bow, dim3((kf_fv->n_nodes + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
+        hipLaunchKernelGGL(k_queries_bow, dim3((std::max(nqe, 1) + 255) / 256), dim3(256), 0, nullptr, kf_fv->n_nodes, m->dNodesA, m->dOffA,
                            m->dIdxA, m->dI[0], m->dU8a, m->dQKeys, 0, m->dNodesB, m->dOffB, m->dQ, t->dNN);
     int nm = 0;
     std::vector<int32_t> searched((size_t)n, -1);
