@@ -117,7 +117,7 @@ def side_legs(args):
         bts = []
         for _ in range(5):
             t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([a] * R, workers); bts.append(time.perf_counter() - t0)
-        lba["batch"] = {"windows": R, "workers": workers, "ms_per_window": round(min(bts) / R * 1e3, 3), "note": "best of 5 (the worker threads spin on their trial scalars: host scheduling shows)"}
+        lba["batch"] = {"windows": R, "workers": workers, "ms_per_window": round(min(bts) / R * 1e3, 3), "note": "best of 5; the LM decisions are taken on the device, the worker threads nap while a trial runs (tools/lba_probe.py prints the busy host cores)"}
     except Exception as e:
         lba["batch"] = {"error": str(e)}
     probs = [pose_problem(100 + i, 300, 0.1) for i in range(256)]
