@@ -2539,11 +2539,15 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
             hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, st, o->dScal, o->dLm, o->dhLm, o->dhStop, ++o->lmSeq);
         };
         // one slot queued ahead of the one that is running.  While it waits the host thread SLEEPS in short naps (a slot lasts ~100 us; the
-        // thread's timer slack is set to 1 us so that a 30 us nap is not rounded up to the default 50 us slack): the workers of
+        // thread's timer slack is 1 us meanwhile, so that a 30 us nap is not rounded up to the default 50 us slack): the workers of
         // rumi_local_ba_batch no longer burn a core each (hipEventSynchronize spins on this runtime whatever the event's flags; measured).
         // The reference's stop flag is forwarded once per nap.
-        static thread_local bool slackSet = false;
-        if (!slackSet) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slackSet = true; }
+        // (the calling thread's own slack is put back when the loop is over: it is the caller's thread)
+        struct SlackGuard {
+            long old;
+            SlackGuard() : old(prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL)) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
+            ~SlackGuard() { if (old > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0UL, 0UL, 0UL); }
+        } slackGuard;
         const int maxSlots = maxIt * 10;
         int enq = 0, naps = 0;
         for (;;) {
