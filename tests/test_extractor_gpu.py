@@ -301,6 +301,17 @@ def test_workgroup_sort_replays_std_sort():
     for n in [0, 1, 2, 15, 16, 17, 18, 31, 33, 64, 65, 100, 257, 700, 1000, 2189, 4096]:
         for hi in (2, 5, 40, 100000):
             cases.append(rng.integers(0, hi, n).astype(np.uint32))
+    for n in range(17, 65):                                                     # the one-wave form (entries in registers)
+        for hi in (3, 12, 1000):
+            cases.append(rng.integers(0, hi, n).astype(np.uint32))
+        cases.append(np.arange(n, dtype=np.uint32))
+        cases.append(np.arange(n, dtype=np.uint32)[::-1].copy())
+        cases.append(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.uint32))
+        kk = np.zeros(n, np.uint32); hh = n // 2                                # median-of-3 killer at this size
+        for i in range(hh):
+            kk[2 * i] = i + 1 if i % 2 == 0 else 0
+            kk[2 * i + 1] = hh + i + 1
+        cases.append(kk)
     cases.append(np.arange(3000, dtype=np.uint32))                              # sorted
     cases.append(np.arange(3000, dtype=np.uint32)[::-1].copy())                # reversed
     cases.append(np.concatenate([np.arange(1500), np.arange(1500)[::-1]]).astype(np.uint32))   # organ pipe
