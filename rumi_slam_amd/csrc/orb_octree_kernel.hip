@@ -27,9 +27,6 @@ __host__ __device__ inline int octree_pool_cap(int N, int nIni) { return 2 * (N 
 // Level d starts at a multiple of four entries, so the four counts of a cell are one aligned 8-byte LDS read.
 // D grows with the number of nodes wanted (the coarse passes stop near 4^depth = N), within 4096 cells of depth D.
 __host__ __device__ inline int oct_tab_depth(int nIni, int N) {
-#ifdef RUMI_OCT_FIXED_D
-    return nIni <= 4 ? 4 : 3;
-#endif
     int D = N <= 256 ? 4 : N <= 1024 ? 5 : N <= 1152 ? 6 : 5;   // (beyond that the node pool needs the LDS)
     while (D > 1 && (nIni << (2 * D)) > 4096) D--;
     return D;
@@ -185,22 +182,7 @@ __device__ void wg_sort_like_libstdcxx(OctEntry *a, int n, OctEntry *tmp, uint16
 // ---- the same replay for up to 64 entries, by ONE wave with the entries in registers (lane i = element i) ------------------------
 // The fine rounds of a 1000-feature frame sort ~60 entries: the workgroup version spends its time in barriers and dependent LDS round
 // trips (median, pivot, stop lists, swaps, segment lists: ~15 k cycles); here the stops of the two pointers are two ballots, the k-th stop
-// of one pointer meets the k-th stop of the other through a bit select, the swap is one ds_bpermute pair, and nothing waits on LDS.
-// k-th lowest set bit of mask (0-based, k < popcount); works on scalar and on per-lane operands alike
-__device__ __forceinline__ int kth_low_bit(unsigned long long mask, int k) {
-    const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
-    int c = __popc(lo), pos = 0;
-    uint32_t m = lo;
-    if (k >= c) { k -= c; pos = 32; m = hi; }
-#pragma unroll
-    for (int h = 16; h >= 1; h >>= 1) {
-        c = __popc(m & ((1u << h) - 1u));
-        if (k >= c) { k -= c; pos += h; m >>= h; }
-    }
-    return pos;
-}
-__device__ __forceinline__ int kth_high_bit(unsigned long long mask, int k) { return 63 - kth_low_bit(__brevll(mask), k); }
-
+// of one pointer meets the k-th stop of the other through two ds_permute rank tables, the swap is one ds_bpermute pair, and nothing is stored in LDS.
 // key / id: the lane's entry (lanes >= n: anything); sorted entries are written to out[0..n) (LDS); heapScratch: n entries of LDS
 __device__ __forceinline__ void wave_sort_like_libstdcxx(uint32_t key, uint32_t id, int n, OctEntry *out, OctEntry *heapScratch) {
     using namespace sortimpl;
@@ -245,21 +227,26 @@ __device__ __forceinline__ void wave_sort_like_libstdcxx(uint32_t key, uint32_t 
                 const int nF = __popcll(MF), nR = __popcll(MR);
                 const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~0ull << (lane + 1);
                 const bool isF = (MF >> lane) & 1, isR = (MR >> lane) & 1;
-                const int kF = __popcll(MF & below), kR = __popcll(MR & above);
-                const int rpos = kth_high_bit(MR, min(kF, nR - 1)), fpos = kth_low_bit(MF, min(kR, nF - 1));
+                const int fBelow = __popcll(MF & below), rBelow = __popcll(MR & below);
+                const int kF = fBelow, kR = __popcll(MR & above);
+                // tabF[k] / tabR[k] (in lane k) = position of the k-th stop of the left / right pointer: every lane sends its index to a slot
+                // of its own (stops first, by rank; the other lanes behind them), one ds_permute each
+                const int tabF = __builtin_amdgcn_ds_permute((isF ? kF : nF + lane - fBelow) << 2, lane);
+                const int tabR = __builtin_amdgcn_ds_permute((isR ? kR : nR + lane - rBelow) << 2, lane);
+                const int rpos = __builtin_amdgcn_ds_bpermute(kF << 2, tabR), fpos = __builtin_amdgcn_ds_bpermute(kR << 2, tabF);
                 const bool swF = isF && kF < nR && lane < rpos, swR = isR && kR < nF && fpos < lane;
                 const int swaps = __popcll(__ballot(swF));
                 {
                     const int partner = swF ? rpos : fpos;
-                    const uint32_t pk = (uint32_t)__shfl((int)key, partner), pid = (uint32_t)__shfl((int)id, partner);
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)key), pid = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)id);
                     if (swF || swR) { key = pk; id = pid; }
                 }
                 int cut;
                 if (swaps >= 1) {
-                    const int nextF = swaps < nF ? kth_low_bit(MF, swaps) : 0x7FFFFFFF;
-                    cut = min(nextF, kth_high_bit(MR, swaps - 1));
+                    const int nextF = swaps < nF ? __builtin_amdgcn_readlane(tabF, swaps) : 0x7FFFFFFF;
+                    cut = min(nextF, __builtin_amdgcn_readlane(tabR, swaps - 1));
                 } else {
-                    cut = kth_low_bit(MF, 0);
+                    cut = __builtin_amdgcn_readlane(tabF, 0);
                 }
                 if (last - cut > 16) {
                     if (lane == sp) stack = cut | last << 8 | depth << 16;
@@ -269,12 +256,19 @@ __device__ __forceinline__ void wave_sort_like_libstdcxx(uint32_t key, uint32_t 
             }
         }
     }
-    // __final_insertion_sort == stable sort inside each leaf of <= 16; elements outside an entry's leaf never count (left ones are <=, right ones >=)
+    // __final_insertion_sort == stable sort inside each leaf of <= 16 == stable rank over a +-15 window (elements of other leaves never
+    // count: left ones are <=, right ones >=).  The neighbours come by whole-wave DPP shifts, one lane further per step.
     int pos = lane;
-    for (int j = 0; j < n; j++) {
-        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-        pos += (j > lane && kj < key) ? 1 : 0;
-        pos -= (j < lane && kj > key) ? 1 : 0;
+    {
+        const uint32_t kk = lane < n ? key : 0xFFFFFFFFu;
+        int l = (int)kk, r = (int)kk;
+#pragma unroll
+        for (int d = 1; d <= 15; d++) {
+            l = __builtin_amdgcn_update_dpp(0, l, 0x138, 0xF, 0xF, false);             // wave_shr:1 -> key of lane - d (0 beyond lane 0)
+            r = __builtin_amdgcn_update_dpp(-1, r, 0x130, 0xF, 0xF, false);            // wave_shl:1 -> key of lane + d (max beyond lane 63)
+            pos -= (uint32_t)l > kk ? 1 : 0;
+            pos += (uint32_t)r < kk ? 1 : 0;
+        }
     }
     if (lane < n) out[pos] = OctEntry{key, (uint16_t)id, 0};
 }
@@ -344,49 +338,6 @@ __device__ __forceinline__ bool emit_children(const OctLds &S, int id, int g0, i
     }
     return deep;
 }
-
-#ifdef RUMI_OCT_EMIT_FIELDS
-// (experiment) the field-by-field form for the workgroup-wide passes: fewer live registers
-__device__ __forceinline__ bool emit_children_fields(const OctLds &S, int id, int g0, int o0, int K, int freeTop, uint16_t *newList,
-                                                     int *sNSplit, bool table) {
-    OctNode &p = S.nodes[id];
-    const int dc = node_depth(p) + 1, pc0 = node_path(p) * 4;
-    const int hx = (p.x1 - p.x0 + 1) >> 1, hy = (p.y1 - p.y0 + 1) >> 1;   // ceil(float(d)/2)
-    const int xs[3] = {p.x0, p.x0 + hx, p.x1}, ys[3] = {p.y0, p.y0 + hy, p.y1};
-    uint16_t cnt[4] = {p.cnt[0], p.cnt[1], p.cnt[2], p.cnt[3]};
-    bool deep = false;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int c = cnt[q];
-        uint16_t cid = kNil;
-        if (c != 0) {
-            cid = S.freeIds[freeTop - 1 - g0];
-            OctNode &ch = S.nodes[cid];
-            ch.x0 = (uint16_t)xs[q & 1]; ch.x1 = (uint16_t)xs[(q & 1) + 1];
-            ch.y0 = (uint16_t)ys[q >> 1]; ch.y1 = (uint16_t)ys[(q >> 1) + 1];
-            ch.n = (uint16_t)c; ch.noMore = c == 1; ch.split = 0;
-            node_depth(ch) = (uint16_t)dc; node_path(ch) = (uint16_t)(pc0 + q);
-            uint2 cc = make_uint2(0u, 0u);
-            if (table && c > 1) {
-                if (dc < S.D) cc = *reinterpret_cast<const uint2 *>(S.tab + oct_tab_off(dc + 1, S.nIni) + 4 * (pc0 + q));
-                else deep = true;
-            }
-            *reinterpret_cast<uint2 *>(&ch.cnt[0]) = cc;
-            ch.child[0] = ch.child[1] = ch.child[2] = ch.child[3] = kNil;
-            newList[K - 1 - g0] = cid;
-            if (c > 1) S.open[o0++] = OctEntry{((uint32_t)c << 16) | ch.x0, cid, 0};
-            g0++;
-        }
-        p.child[q] = cid;
-    }
-    p.split = 1;
-    S.splitIds[atomicAdd(sNSplit, 1)] = (uint16_t)id;
-    return deep;
-}
-#define EMIT_WG emit_children_fields
-#else
-#define EMIT_WG emit_children<false>
-#endif
 
 __device__ __forceinline__ int quadrants_nonempty(const OctNode &nd) { return (nd.cnt[0] != 0) + (nd.cnt[1] != 0) + (nd.cnt[2] != 0) + (nd.cnt[3] != 0); }
 __device__ __forceinline__ int quadrants_open(const OctNode &nd) { return (nd.cnt[0] > 1) + (nd.cnt[1] > 1) + (nd.cnt[2] > 1) + (nd.cnt[3] > 1); }
@@ -736,7 +687,7 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
                     const OctNode &nd = nodes[id];
                     if (!nd.noMore) {
                         const int kc = quadrants_nonempty(nd), ko = quadrants_open(nd);
-                        if (EMIT_WG(S, id, g, o, K, nFree, B, &sNSplit, table)) sDeep = 1;
+                        if (emit_children<false>(S, id, g, o, K, nFree, B, &sNSplit, table)) sDeep = 1;
                         g += kc; o += ko;
                     } else {
                         B[K + kb++] = (uint16_t)id;
@@ -797,7 +748,7 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
                     const int id = S.prev[nPrev - 1 - t].id;
                     const OctNode &nd = nodes[id];
                     const int kc = quadrants_nonempty(nd), ko = quadrants_open(nd);
-                    if (t < J) if (EMIT_WG(S, id, g, o, K, nFree, B, &sNSplit, table)) sDeep = 1;
+                    if (t < J) if (emit_children<false>(S, id, g, o, K, nFree, B, &sNSplit, table)) sDeep = 1;
                     g += kc; o += ko;
                 }
                 __syncthreads();

@@ -1,12 +1,10 @@
 #!/usr/bin/env python3
-"""Scratch probe: one-frame extraction with the octree kernel's cycle stamps (library built with -DRUMI_OCT_STAMP prints them)."""
+"""One-frame extraction with the quadtree kernel's in-kernel cycle stamps (a library built by tools/build_stamp_lib.sh prints them:
+   python tools/with_lib.py tools/bin/librumi_hip_stamp.so tools/oct_stamp.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-import rumi_slam_amd.capi as capi
-if os.environ.get('RUMI_STAMP_LIB'):
-    capi.LIB_PATH = os.environ['RUMI_STAMP_LIB']
 from rumi_slam_amd.extractor import ORBextractor
 from rumi_slam_amd.synth import synth_frame
 fr = torch.from_numpy(synth_frame(1234)).cuda()[None].contiguous()

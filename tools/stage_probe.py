@@ -4,9 +4,6 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-import rumi_slam_amd.capi as capi
-if os.environ.get('RUMI_STAMP_LIB'):   # a differently built library (experiments)
-    capi.LIB_PATH = os.environ['RUMI_STAMP_LIB']
 from rumi_slam_amd.extractor import ORBextractor
 from rumi_slam_amd.synth import synth_frame
 B = 256
