@@ -424,8 +424,9 @@ struct OctKeys {
             }
         }
     }
-    // f(i, valid, key, owner&): owner may be rewritten
-    template <class F>
+    // f(i, valid, key, owner&): owner may be rewritten.  OWN (keys in memory only): 0 = owners are read and written back when they change,
+    // 1 = no owner traffic at all (the visitor gets 0 and what it leaves is dropped), 2 = written, not read.
+    template <int OWN = 0, class F>
     __device__ __forceinline__ void for_each(F f) {
         if constexpr (REG) {
 #pragma unroll
@@ -444,7 +445,7 @@ struct OctKeys {
                 for (int u = 0; u < 4; u++) {
                     const int i = i0 + u * NT + (int)threadIdx.x;
                     k4[u] = i < n ? c[i] : 0u;
-                    o4[u] = i < n ? (int)own[i] : 0;
+                    o4[u] = OWN == 0 && i < n ? (int)own[i] : 0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -452,7 +453,7 @@ struct OctKeys {
                     const int i = i0 + u * NT + (int)threadIdx.x;
                     int o = o4[u];
                     f(i, i < n, k4[u], o);
-                    if (i < n && o != o4[u]) own[i] = (uint16_t)o;
+                    if (OWN != 1 && i < n && (OWN == 2 || o != o4[u])) own[i] = (uint16_t)o;
                 }
             }
         }
@@ -544,10 +545,11 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
     // The x comparisons of a path depend on x alone (the root is a function of x) and the y comparisons on y alone, so the two halves of
     // the path come from two small tables by coordinate.  A key keeps the path of its cell (its "owner" until the tree outgrows the
     // tables); T_D counts the keys of every cell.
-    keys.for_each([&](int, bool valid, uint32_t ck, int &o) {
+    auto cell_of = [&](uint32_t ck) { return (int)S.xbin[min(cand_x(ck), W)] | (int)S.ybin[min(cand_y(ck), Hh)]; };
+    keys.template for_each<1>([&](int, bool valid, uint32_t ck, int &o) {      // (keys in memory: the cell is looked up again when it is needed)
         int P = -1;
         if (valid) {
-            P = (int)S.xbin[min(cand_x(ck), W)] | (int)S.ybin[min(cand_y(ck), Hh)];
+            P = cell_of(ck);
             o = P;
         }
         wave_run_add(P, reinterpret_cast<unsigned int *>(S.tab + offD) + ((P < 0 ? 0 : P) >> 1), 1u << (16 * (P & 1)));
@@ -782,10 +784,10 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
             if (uni(sDeep)) {
                 fill_leaf(A, m2);
                 __syncthreads();
-                keys.for_each([&](int, bool valid, uint32_t ck, int &o) {
+                keys.template for_each<2>([&](int, bool valid, uint32_t ck, int &o) {
                     int key = -1, q = 0, id = 0;
                     if (valid) {
-                        id = S.leaf[o];
+                        id = S.leaf[REG ? o : cell_of(ck)];
                         o = id;
                         OctNode &nd = nodes[id];
                         if (!nd.noMore && node_depth(nd) == D) { q = oct_quadrant(nd, cand_x(ck), cand_y(ck)); key = id * 4 + q; }
@@ -828,8 +830,8 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
     __syncthreads();
     OCT_STAMP(9);
     if (table) {
-        keys.for_each([&](int i, bool valid, uint32_t ck, int &o) {
-            wave_run_max(nodes, valid ? (int)S.leaf[o] : 0, valid, ((uint32_t)cand_score(ck) << 16) | (uint32_t)(0xFFFF - i));
+        keys.template for_each<1>([&](int i, bool valid, uint32_t ck, int &o) {
+            wave_run_max(nodes, valid ? (int)S.leaf[REG ? o : cell_of(ck)] : 0, valid, ((uint32_t)cand_score(ck) << 16) | (uint32_t)(0xFFFF - i));
         });
     } else {
         keys.for_each([&](int i, bool valid, uint32_t ck, int &o) {
