@@ -15,9 +15,17 @@
 
 namespace rumi {
 
-__constant__ int8_t c_pattern[256 * 4] = {
+// the 256 rBRIEF test pairs (x0, y0, x1, y1) as floats: a lane fetches its pair with one 16-byte load and no conversions
+struct PatternF { float v[256 * 4]; };
+constexpr PatternF make_pattern_f() {
+    constexpr int8_t src[256 * 4] = {
 #include "orb_pattern.inc"
-};
+    };
+    PatternF p{};
+    for (int i = 0; i < 256 * 4; i++) p.v[i] = (float)src[i];
+    return p;
+}
+__constant__ PatternF c_patternF = make_pattern_f();
 
 // XCD-aware workgroup placement (cdna_hip_programming.md T1): the dispatcher deals consecutive workgroups round-robin over
 // the 8 XCDs, each with a private L2.  Remapping the linear workgroup id with this bijection gives every XCD one contiguous
@@ -790,114 +798,144 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-constexpr int kDiscP = 36, kPatchP = 40;       // LDS row pitches: 31 (+3 alignment slack) and 37 (+3) bytes as whole dwords
-constexpr int kKpPerWg = 8;
+constexpr int kDiscP = 48, kPatchP = 48;       // LDS row pitches: 36 and 40 staged bytes per row (31 / 37 + alignment slack), rows 16-byte aligned for b128 stores
+constexpr int kKpPerWg = 8;                    // half waves of a workgroup
+constexpr int kKpGroups = 4;                   // key-points a half wave handles one after the other (the next one's pixels are in flight meanwhile)
 
-__global__ __launch_bounds__(256, 6) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
+__global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
                                                      RumiKeyPoint *__restrict__ kpOut, long long kpStride, uint8_t *__restrict__ descOut,
                                                      long long descStride, int outCap) {
-    // per key-point: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged
-    // with aligned dword loads that are all in flight together (one memory latency instead of 24 dependent byte gathers)
+    // per key-point: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged by the half wave
+    // that owns the key-point and read by nobody else: no workgroup barrier anywhere past the pattern table's
     __shared__ __attribute__((aligned(16))) uint8_t sDisc[kKpPerWg][31 * kDiscP];
     __shared__ __attribute__((aligned(16))) uint8_t sPatch[kKpPerWg][37 * kPatchP];
+    __shared__ __attribute__((aligned(16))) float sPat[256 * 4];
+    reinterpret_cast<float4 *>(sPat)[threadIdx.x] = reinterpret_cast<const float4 *>(c_patternF.v)[threadIdx.x];
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;             // lane within the half wave, half-wave index 0..7
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // a frame's key-points share one L2
-    const int k = (wg % gridDim.x) * kKpPerWg + hw, frame = wg / gridDim.x;
-    const bool live = k < selCount[frame];
-    int level = 0, slot = 0, x = kEdge, y = kEdge, score = 0;
-    if (live) {
-        const uint32_t pk = selPacked[(long long)frame * selCap + k], meta = selMeta[(long long)frame * selCap + k];
-        level = meta & 0xFF; slot = (int)(meta >> 8);
-        x = (int)(pk & 0xFFF) + kBorder; y = (int)((pk >> 12) & 0xFFF) + kBorder; score = (int)(pk >> 24);
-    }
-    const DevLevel &L = P->lv[level];
-    const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;     // aligned first columns of the two staged windows
-    if (live) {
+    const int kb = (wg % gridDim.x) * (kKpPerWg * kKpGroups) + hw, frame = wg / gridDim.x;
+    const int cnt = selCount[frame];
+    __syncthreads();
+
+    struct __attribute__((packed, aligned(4))) Q16 { uint32_t x, y, z, w; };      // (dword-aligned wide loads)
+    struct __attribute__((packed, aligned(4))) Q8 { uint32_t x, y; };
+    auto ld16 = [](const uint8_t *q) { const Q16 t = *reinterpret_cast<const Q16 *>(q); return make_uint4(t.x, t.y, t.z, t.w); };
+    auto ld8 = [](const uint8_t *q) { const Q8 t = *reinterpret_cast<const Q8 *>(q); return make_uint2(t.x, t.y); };
+    struct Staged { uint4 d0, d1, p0, p1, q0, q1; uint2 p2, q2; uint32_t d2; };
+    const bool dRow = lane < 31, qRow = lane < 5;
+    // lane = row: a row's 36 / 40 bytes are two 16-byte loads and a 4- / 8-byte one (dword-aligned addresses; the 37 rows of the patch take a
+    // second, five-lane trip); no index arithmetic
+    auto fetch = [&](uint32_t pk, uint32_t meta, bool live, Staged &S) {
+        if (!live) return;
+        const int level = meta & 0xFF, x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder;
+        const DevLevel &L = P->lv[level];
+        const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;         // aligned first columns of the two staged windows
         int pitch;
         const uint8_t *c = level_base(src, P, level, frame, &pitch) + (long long)(y - kHalfPatch) * pitch + xd;
         const uint8_t *b = src.blur + (long long)frame * P->arenaStride + L.off + (long long)(y - 18) * L.pitch + xp;
-        uint32_t vd[9], vp[12];
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const int idx = lane + 32 * q, r = idx / 9, cc = idx - r * 9;
-            vd[q] = idx < 31 * 9 ? *reinterpret_cast<const uint32_t *>(c + (long long)r * pitch + 4 * cc) : 0;
+        const uint8_t *cr = c + (long long)lane * pitch, *br = b + (long long)lane * L.pitch, *br2 = br + 32LL * L.pitch;
+        if (dRow) { S.d0 = ld16(cr); S.d1 = ld16(cr + 16); S.d2 = *reinterpret_cast<const uint32_t *>(cr + 32); }
+        S.p0 = ld16(br); S.p1 = ld16(br + 16); S.p2 = ld8(br + 32);
+        if (qRow) { S.q0 = ld16(br2); S.q1 = ld16(br2 + 16); S.q2 = ld8(br2 + 32); }
+    };
+    auto stage = [&](bool live, const Staged &S) {
+        if (!live) return;
+        if (dRow) {
+            uint8_t *dst = &sDisc[hw][lane * kDiscP];
+            *reinterpret_cast<uint4 *>(dst) = S.d0; *reinterpret_cast<uint4 *>(dst + 16) = S.d1; *reinterpret_cast<uint32_t *>(dst + 32) = S.d2;
         }
-#pragma unroll
-        for (int q = 0; q < 12; q++) {
-            const int idx = lane + 32 * q, r = idx / 10, cc = idx - r * 10;
-            vp[q] = idx < 37 * 10 ? *reinterpret_cast<const uint32_t *>(b + (long long)r * L.pitch + 4 * cc) : 0;
+        {
+            uint8_t *dst = &sPatch[hw][lane * kPatchP];
+            *reinterpret_cast<uint4 *>(dst) = S.p0; *reinterpret_cast<uint4 *>(dst + 16) = S.p1; *reinterpret_cast<uint2 *>(dst + 32) = S.p2;
         }
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const int idx = lane + 32 * q, r = idx / 9, cc = idx - r * 9;
-            if (idx < 31 * 9) *reinterpret_cast<uint32_t *>(&sDisc[hw][r * kDiscP + 4 * cc]) = vd[q];
+        if (qRow) {
+            uint8_t *dst = &sPatch[hw][(lane + 32) * kPatchP];
+            *reinterpret_cast<uint4 *>(dst) = S.q0; *reinterpret_cast<uint4 *>(dst + 16) = S.q1; *reinterpret_cast<uint2 *>(dst + 32) = S.q2;
         }
+    };
+    auto compute = [&](uint32_t pk, uint32_t meta) {
+        const int level = meta & 0xFF, slot = (int)(meta >> 8);
+        const int x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder, score = (int)(pk >> 24);
+        const DevLevel &L = P->lv[level];
+        const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;
+        // IC_Angle (ORBextractor.cc:73-97): lane = column u of the disc; the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a
+        // lane's rows are |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
+        const uint8_t *dc = &sDisc[hw][kHalfPatch * kDiscP + (x - xd)];
+        const int u = lane - kHalfPatch;
+        const int vmaxU = lane < 31 ? P->umax[u < 0 ? -u : u] : -1;
+        int colSum = 0, m01 = 0;
 #pragma unroll
-        for (int q = 0; q < 12; q++) {
-            const int idx = lane + 32 * q, r = idx / 10, cc = idx - r * 10;
-            if (idx < 37 * 10) *reinterpret_cast<uint32_t *>(&sPatch[hw][r * kPatchP + 4 * cc]) = vp[q];
+        for (int i = 0; i < 31; i++) {
+            const int v = -kHalfPatch + i;
+            if (v <= vmaxU && -v <= vmaxU) {
+                const int val = dc[v * kDiscP + u];
+                colSum += val;
+                m01 += v * val;
+            }
         }
-    }
-    __syncthreads();
-    if (!live) return;
+        int m10 = u * colSum;
+        m10 = half_wave_sum(m10);
+        m01 = half_wave_sum(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // IC_Angle (ORBextractor.cc:73-97): lane = column u of the disc; the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a
-    // lane's rows are |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
-    const uint8_t *dc = &sDisc[hw][kHalfPatch * kDiscP + (x - xd)];
-    const int u = lane - kHalfPatch;
-    const int vmaxU = lane < 31 ? P->umax[u < 0 ? -u : u] : -1;
-    int colSum = 0, m01 = 0;
+        // computeOrbDescriptor (ORBextractor.cc:99-143) on the blurred level
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float ang = angle * factorPI;
+        const float a = cosf_glibc(ang), b = sinf_glibc(ang);
+        const uint8_t *bc = &sPatch[hw][18 * kPatchP + (x - xp)];
+        uint32_t w = 0;                                                   // lane j of the half wave ends up with descriptor word j
 #pragma unroll
-    for (int i = 0; i < 31; i++) {
-        const int v = -kHalfPatch + i;
-        if (v <= vmaxU && -v <= vmaxU) {
-            const int val = dc[v * kDiscP + u];
-            colSum += val;
-            m01 += v * val;
+        for (int j = 0; j < 8; j++) {
+            const float4 pt = reinterpret_cast<const float4 *>(sPat)[j * 32 + lane];
+            const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
+            const int r0 = cv_round_f(x0 * b + y0 * a), c0 = cv_round_f(x0 * a - y0 * b);
+            const int r1 = cv_round_f(x1 * b + y1 * a), c1 = cv_round_f(x1 * a - y1 * b);
+            const int t0 = bc[r0 * kPatchP + c0], t1 = bc[r1 * kPatchP + c1];
+            const unsigned long long bal = __ballot(t0 < t1);             // both key-points of the wave; lanes j and 32 + j keep their halves
+            const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+            // (v_writelane reads its scalar operand early: the compare that wrote it needs wait states the assembler does not add inside asm
+            //  blocks; without them lanes 32.. received the PREVIOUS ballot)
+            asm("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4" : "+v"(w) : "s"(lo), "s"(hi), "n"(j), "n"(32 + j));
         }
-    }
-    int m10 = u * colSum;
-    m10 = half_wave_sum(m10);
-    m01 = half_wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+        if (slot < outCap) {
+            if (lane < 8) reinterpret_cast<uint32_t *>(descOut + frame * descStride + (long long)slot * 32)[lane] = w;
+            if (lane == 0) {
+                RumiKeyPoint kp;
+                kp.x = (float)x; kp.y = (float)y;
+                if (level != 0) { kp.x = kp.x * L.scale; kp.y = kp.y * L.scale; }   // keypoint->pt *= scale (:1073-1075)
+                kp.size = L.patchSize;
+                kp.angle = angle;
+                kp.response = (float)score;
+                kp.octave = level;
+                kp.class_id = -1;
+                reinterpret_cast<RumiKeyPoint *>(reinterpret_cast<uint8_t *>(kpOut) + frame * kpStride)[slot] = kp;
+            }
+        }
+    };
 
-    // computeOrbDescriptor (ORBextractor.cc:99-143) on the blurred level
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float ang = angle * factorPI;
-    const float a = cosf_glibc(ang), b = sinf_glibc(ang);
-    const uint8_t *bc = &sPatch[hw][18 * kPatchP + (x - xp)];
-    uint32_t bits[8];
+    const uint32_t *selP = selPacked + (long long)frame * selCap, *selM = selMeta + (long long)frame * selCap;
+    bool liveC = kb < cnt, liveN = kb + kKpPerWg < cnt;
+    uint32_t pkC = 0, mtC = 0, pkN = 0, mtN = 0;
+    if (liveC) { pkC = selP[kb]; mtC = selM[kb]; }
+    if (liveN) { pkN = selP[kb + kKpPerWg]; mtN = selM[kb + kKpPerWg]; }
+    Staged S;
+    fetch(pkC, mtC, liveC, S);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int8_t *pt = &c_pattern[(j * 32 + lane) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int r0 = cv_round_f(x0 * b + y0 * a), c0 = cv_round_f(x0 * a - y0 * b);
-        const int r1 = cv_round_f(x1 * b + y1 * a), c1 = cv_round_f(x1 * a - y1 * b);
-        const int t0 = bc[r0 * kPatchP + c0], t1 = bc[r1 * kPatchP + c1];
-        const unsigned long long bal = __ballot(t0 < t1);                 // both key-points of the wave; mine is my half
-        bits[j] = (uint32_t)(bal >> (32 * (hw & 1)));
-    }
-    if (slot < outCap) {
-        if (lane < 8) {
-            uint32_t w = bits[0];
-#pragma unroll
-            for (int j = 1; j < 8; j++) if (lane == j) w = bits[j];
-            reinterpret_cast<uint32_t *>(descOut + frame * descStride + (long long)slot * 32)[lane] = w;
-        }
-        if (lane == 0) {
-            RumiKeyPoint kp;
-            kp.x = (float)x; kp.y = (float)y;
-            if (level != 0) { kp.x = kp.x * L.scale; kp.y = kp.y * L.scale; }   // keypoint->pt *= scale (:1073-1075)
-            kp.size = L.patchSize;
-            kp.angle = angle;
-            kp.response = (float)score;
-            kp.octave = level;
-            kp.class_id = -1;
-            reinterpret_cast<RumiKeyPoint *>(reinterpret_cast<uint8_t *>(kpOut) + frame * kpStride)[slot] = kp;
-        }
+    for (int g = 0; g < kKpGroups; g++) {
+        if (!__any(liveC)) break;                                         // (key-points of a half wave come in ascending k: nothing further)
+        stage(liveC, S);
+        // the key-point after this one: its pixels travel while this one is computed; the one after that: its record
+        const int k2 = kb + (g + 2) * kKpPerWg;
+        const bool liveNN = g + 2 < kKpGroups && k2 < cnt;
+        uint32_t pkNN = 0, mtNN = 0;
+        if (liveNN) { pkNN = selP[k2]; mtNN = selM[k2]; }
+        if (g + 1 < kKpGroups) fetch(pkN, mtN, liveN, S);
+        if (liveC) compute(pkC, mtC);
+        pkC = pkN; mtC = mtN; liveC = liveN;
+        pkN = pkNN; mtN = mtNN; liveN = liveNN;
     }
 }
 
@@ -966,7 +1004,7 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
                         long long descStride, int outCap, int nframes, hipStream_t st) {
     if (maxSel <= 0) return;
-    hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + kKpPerWg - 1) / kKpPerWg, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
+    hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + kKpPerWg * kKpGroups - 1) / (kKpPerWg * kKpGroups), nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
                        selCount, selCap, kpOut, kpStride, descOut, descStride, outCap);
 }
 
