@@ -787,10 +787,16 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
 //   rBRIEF:   lane l evaluates test pairs l, l+32, ... l+224; __ballot packs 32 bits per key-point at a time, which
 //             is exactly the descriptor's little-endian bit order (bit k of byte i = pair 8i+k).
 // ------------------------------------------------------------------------------------------------
+// sum over the 32 lanes of a half wave, returned in every lane of that half: DPP adds inside the rows of 16 (the row's total lands in its
+// lane 15), row_bcast:15 carries it into the next row, lanes 31 / 63 then hold the two totals (five ds_bpermute round trips otherwise)
 __device__ __forceinline__ int half_wave_sum(int v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);          // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);          // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);          // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);          // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);          // row_bcast:15 -> rows 1 and 3
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
@@ -813,12 +819,25 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
     __shared__ __attribute__((aligned(16))) uint8_t sDisc[kKpPerWg][31 * kDiscP];
     __shared__ __attribute__((aligned(16))) uint8_t sPatch[kKpPerWg][37 * kPatchP];
     __shared__ __attribute__((aligned(16))) float sPat[256 * 4];
+    __shared__ int4 sLv[kMaxLevels];              // per level: offset and pitch of the un-blurred image (level 0 = the caller's frame), of the blurred one
+    __shared__ float2 sLvF[kMaxLevels];           // scale, patch size
     reinterpret_cast<float4 *>(sPat)[threadIdx.x] = reinterpret_cast<const float4 *>(c_patternF.v)[threadIdx.x];
+    if (threadIdx.x < (unsigned)P->nlevels) {
+        const DevLevel &Lv = P->lv[threadIdx.x];
+        sLv[threadIdx.x] = threadIdx.x == 0 ? make_int4(0, src.l0Pitch, (int)Lv.off, Lv.pitch) : make_int4((int)Lv.off, Lv.pitch, (int)Lv.off, Lv.pitch);
+        sLvF[threadIdx.x] = make_float2(Lv.scale, Lv.patchSize);
+    }
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;             // lane within the half wave, half-wave index 0..7
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // a frame's key-points share one L2
     const int kb = (wg % gridDim.x) * (kKpPerWg * kKpGroups) + hw, frame = wg / gridDim.x;
     const int cnt = selCount[frame];
     __syncthreads();
+#ifdef RUMI_OD_STAMP
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stLast = clock64();
+#define OD_STAMP(k) do { const long long t_ = clock64(); st[k] += t_ - stLast; stLast = t_; } while (0)
+#else
+#define OD_STAMP(k) do { } while (0)
+#endif
 
     struct __attribute__((packed, aligned(4))) Q16 { uint32_t x, y, z, w; };      // (dword-aligned wide loads)
     struct __attribute__((packed, aligned(4))) Q8 { uint32_t x, y; };
@@ -826,17 +845,17 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
     auto ld8 = [](const uint8_t *q) { const Q8 t = *reinterpret_cast<const Q8 *>(q); return make_uint2(t.x, t.y); };
     struct Staged { uint4 d0, d1, p0, p1, q0, q1; uint2 p2, q2; uint32_t d2; };
     const bool dRow = lane < 31, qRow = lane < 5;
+    const uint8_t *frame0 = src.l0 + (long long)frame * src.l0FrameStride, *framePyr = src.pyr + (long long)frame * P->arenaStride,
+                  *frameBlur = src.blur + (long long)frame * P->arenaStride;
     // lane = row: a row's 36 / 40 bytes are two 16-byte loads and a 4- / 8-byte one (dword-aligned addresses; the 37 rows of the patch take a
     // second, five-lane trip); no index arithmetic
     auto fetch = [&](uint32_t pk, uint32_t meta, bool live, Staged &S) {
         if (!live) return;
         const int level = meta & 0xFF, x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder;
-        const DevLevel &L = P->lv[level];
+        const int4 lv = sLv[level];                                       // (a frame's arena is far below 2 GB: 32-bit offsets)
         const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;         // aligned first columns of the two staged windows
-        int pitch;
-        const uint8_t *c = level_base(src, P, level, frame, &pitch) + (long long)(y - kHalfPatch) * pitch + xd;
-        const uint8_t *b = src.blur + (long long)frame * P->arenaStride + L.off + (long long)(y - 18) * L.pitch + xp;
-        const uint8_t *cr = c + (long long)lane * pitch, *br = b + (long long)lane * L.pitch, *br2 = br + 32LL * L.pitch;
+        const uint8_t *cr = (level == 0 ? frame0 : framePyr) + (lv.x + (y - kHalfPatch + lane) * lv.y + xd);
+        const uint8_t *br = frameBlur + (lv.z + (y - 18 + lane) * lv.w + xp), *br2 = br + 32 * lv.w;
         if (dRow) { S.d0 = ld16(cr); S.d1 = ld16(cr + 16); S.d2 = *reinterpret_cast<const uint32_t *>(cr + 32); }
         S.p0 = ld16(br); S.p1 = ld16(br + 16); S.p2 = ld8(br + 32);
         if (qRow) { S.q0 = ld16(br2); S.q1 = ld16(br2 + 16); S.q2 = ld8(br2 + 32); }
@@ -859,26 +878,26 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
     auto compute = [&](uint32_t pk, uint32_t meta) {
         const int level = meta & 0xFF, slot = (int)(meta >> 8);
         const int x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder, score = (int)(pk >> 24);
-        const DevLevel &L = P->lv[level];
         const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;
         // IC_Angle (ORBextractor.cc:73-97): lane = column u of the disc; the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a
         // lane's rows are |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
         const uint8_t *dc = &sDisc[hw][kHalfPatch * kDiscP + (x - xd)];
         const int u = lane - kHalfPatch;
         const int vmaxU = lane < 31 ? P->umax[u < 0 ? -u : u] : -1;
-        int colSum = 0, m01 = 0;
+        // rows +v and -v share their bound: one compare masks both; every row of the staged disc exists, so the reads are unconditional
+        const int mid = dc[u];
+        int colSum = vmaxU >= 0 ? mid : 0, m01 = 0;
 #pragma unroll
-        for (int i = 0; i < 31; i++) {
-            const int v = -kHalfPatch + i;
-            if (v <= vmaxU && -v <= vmaxU) {
-                const int val = dc[v * kDiscP + u];
-                colSum += val;
-                m01 += v * val;
-            }
+        for (int v = 1; v <= kHalfPatch; v++) {
+            const int lo = dc[-v * kDiscP + u], hi = dc[v * kDiscP + u];
+            const bool in = v <= vmaxU;
+            colSum += in ? lo + hi : 0;
+            m01 += in ? v * (hi - lo) : 0;
         }
         int m10 = u * colSum;
         m10 = half_wave_sum(m10);
         m01 = half_wave_sum(m01);
+        OD_STAMP(4);
         const float angle = fast_atan2_deg((float)m01, (float)m10);
 
         // computeOrbDescriptor (ORBextractor.cc:99-143) on the blurred level
@@ -887,6 +906,7 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
         const float a = cosf_glibc(ang), b = sinf_glibc(ang);
         const uint8_t *bc = &sPatch[hw][18 * kPatchP + (x - xp)];
         uint32_t w = 0;                                                   // lane j of the half wave ends up with descriptor word j
+        OD_STAMP(5);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float4 pt = reinterpret_cast<const float4 *>(sPat)[j * 32 + lane];
@@ -900,13 +920,15 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
             //  blocks; without them lanes 32.. received the PREVIOUS ballot)
             asm("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4" : "+v"(w) : "s"(lo), "s"(hi), "n"(j), "n"(32 + j));
         }
+        OD_STAMP(6);
         if (slot < outCap) {
             if (lane < 8) reinterpret_cast<uint32_t *>(descOut + frame * descStride + (long long)slot * 32)[lane] = w;
             if (lane == 0) {
                 RumiKeyPoint kp;
                 kp.x = (float)x; kp.y = (float)y;
-                if (level != 0) { kp.x = kp.x * L.scale; kp.y = kp.y * L.scale; }   // keypoint->pt *= scale (:1073-1075)
-                kp.size = L.patchSize;
+                const float2 lf = sLvF[level];
+                if (level != 0) { kp.x = kp.x * lf.x; kp.y = kp.y * lf.x; }   // keypoint->pt *= scale (:1073-1075)
+                kp.size = lf.y;
                 kp.angle = angle;
                 kp.response = (float)score;
                 kp.octave = level;
@@ -926,17 +948,24 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
 #pragma unroll
     for (int g = 0; g < kKpGroups; g++) {
         if (!__any(liveC)) break;                                         // (key-points of a half wave come in ascending k: nothing further)
+        OD_STAMP(0);
         stage(liveC, S);
+        OD_STAMP(1);
         // the key-point after this one: its pixels travel while this one is computed; the one after that: its record
         const int k2 = kb + (g + 2) * kKpPerWg;
         const bool liveNN = g + 2 < kKpGroups && k2 < cnt;
         uint32_t pkNN = 0, mtNN = 0;
         if (liveNN) { pkNN = selP[k2]; mtNN = selM[k2]; }
         if (g + 1 < kKpGroups) fetch(pkN, mtN, liveN, S);
+        OD_STAMP(2);
         if (liveC) compute(pkC, mtC);
+        OD_STAMP(3);
         pkC = pkN; mtC = mtN; liveC = liveN;
         pkN = pkNN; mtN = mtNN; liveN = liveNN;
     }
+#ifdef RUMI_OD_STAMP
+    if (threadIdx.x == 0 && (blockIdx.x % 8) == 0 && blockIdx.y == 0) printf("od wg %d: loop-head %lld stage(wait loads) %lld issue-next %lld | IC_Angle %lld trig %lld rBRIEF %lld store %lld\n", (int)blockIdx.x, st[0], st[1], st[2], st[4], st[5], st[6], st[3]);
+#endif
 }
 
 // ---- launch wrappers (called from orb_host.hip) ----

@@ -1,9 +1,12 @@
 #!/bin/bash
-# The product library with the quadtree kernel's in-kernel cycle stamps compiled in (-DRUMI_OCT_STAMP: one printf per (frame 0, level)):
+# The product library with in-kernel cycle stamps compiled into k_octree (-DRUMI_OCT_STAMP: one printf per (frame 0, level)) and
+# k_orient_desc (-DRUMI_OD_STAMP: every eighth workgroup of frame 0):
 #   tools/build_stamp_lib.sh && python tools/with_lib.py tools/bin/librumi_hip_stamp.so tools/oct_stamp.py     (on the GPU box)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R/rumi_slam_amd/csrc
 make -j8 > /dev/null
 mkdir -p $R/tools/bin
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -I../../include -I. -DRUMI_OCT_STAMP -c orb_octree_kernel.hip -o /tmp/oct_stamp.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_stamp.so /tmp/oct_stamp.o $(ls *.o | grep -v orb_octree_kernel) -lpthread
+F="-O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -I../../include -I."
+/opt/rocm/bin/hipcc $F -DRUMI_OCT_STAMP -c orb_octree_kernel.hip -o /tmp/oct_stamp.o
+/opt/rocm/bin/hipcc $F -DRUMI_OD_STAMP -c orb_kernels.hip -o /tmp/orbk_stamp.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_stamp.so /tmp/oct_stamp.o /tmp/orbk_stamp.o $(ls *.o | grep -v -e orb_octree_kernel -e orb_kernels) -lpthread
