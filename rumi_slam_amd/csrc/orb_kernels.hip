@@ -806,8 +806,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 constexpr int kDiscP = 48, kPatchP = 48;       // LDS row pitches: 36 and 40 staged bytes per row (31 / 37 + alignment slack), rows 16-byte aligned for b128 stores
 constexpr int kKpPerWg = 8;                    // half waves of a workgroup
-constexpr int kKpGroups = 4;                   // key-points a half wave handles one after the other (the next one's pixels are in flight meanwhile)
+// kKpGroups: key-points a half wave handles one after the other (the next one's pixels are in flight meanwhile).  Two for batches: with four,
+// the workgroups resident on an XCD span five frames instead of two and a half, their pyramids no longer fit its L2 and the kernel fetches
+// 1.7x the bytes (FETCH_SIZE).  One for a handful of frames: there are not enough workgroups to fill the chip otherwise.
 
+template <int kKpGroups>
 __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
@@ -1033,8 +1036,13 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
                         long long descStride, int outCap, int nframes, hipStream_t st) {
     if (maxSel <= 0) return;
-    hipLaunchKernelGGL(k_orient_desc, dim3((maxSel + kKpPerWg * kKpGroups - 1) / (kKpPerWg * kKpGroups), nframes), dim3(256), 0, st, dP, src, selPacked, selMeta,
-                       selCount, selCap, kpOut, kpStride, descOut, descStride, outCap);
+    const int wg1 = (maxSel + kKpPerWg - 1) / kKpPerWg;
+    if ((long long)wg1 * nframes <= 2048)
+        hipLaunchKernelGGL(k_orient_desc<1>, dim3(wg1, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride, descOut,
+                           descStride, outCap);
+    else
+        hipLaunchKernelGGL(k_orient_desc<2>, dim3((wg1 + 1) / 2, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride,
+                           descOut, descStride, outCap);
 }
 
 }  // namespace rumi

@@ -214,7 +214,7 @@ def analyse(sq, fps=None):
         out[name] = dict(waves=waves, per_wave={"prologue": 1, "strip loop, 7 source rows per trip (fitted to VALU)": round(trips, 3)},
                          closure_lds=round(tot["lds"] / max(c.get("SQ_INSTS_LDS", 0) / waves, 1e-9), 3) if c.get("SQ_INSTS_LDS") else None, mix=tot)
     # ---- the rest: the static mix of the whole kernel (straight-line or fully unrolled hot code; the alternative paths have the same classes)
-    for name, f, needle in (("k_resize", "orb_kernels.hip", "k_resize"), ("k_orient_desc", "orb_kernels.hip", "k_orient_desc"), ("k_compact", "orb_kernels.hip", "k_compact"),
+    for name, f, needle in (("k_resize", "orb_kernels.hip", "k_resize"), ("k_orient_desc", "orb_kernels.hip", "k_orient_descILi2"), ("k_compact", "orb_kernels.hip", "k_compact"),
                             ("k_octree", "orb_octree_kernel.hip", "k_octreeILb0ELi256"), ("k_assemble", "orb_octree_kernel.hip", "k_assemble"), ("k_bruteforce", "match.hip", "k_bruteforce")):
         if name not in sq:
             continue
