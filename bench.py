@@ -202,7 +202,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from rumi_slam_amd.extractor import ORBextractor
-    from rumi_slam_amd.matcher import bruteforce_batch
+    from rumi_slam_amd.matcher import bruteforce_ring
     from rumi_slam_amd import rumination
 
     W, H = 640, 480
@@ -218,31 +218,35 @@ def main():
     ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
     cap = args.nfeatures + 4 * 8 + 64
 
-    match_stream, xchg_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    xchg_stream = torch.cuda.Stream(dev)
     ext.set_resident_queue(True)          # the queue sits in HBM before the timed region: no call waits for the stream it is issued on (include/rumi_orb.h)
 
-    def match_pairs(desc, counts):
-        # frame i against frame i+1 (the last one against the first): independent 1000 x 1000 problems
-        # (views of the extractor's output: the successor of frame i is the same buffer one record further, no copy; the last pair wraps)
-        return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]) if desc.shape[0] > 1 else None,
-                bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
+    def match_pairs(desc, counts, out=None):
+        # frame i against frame i+1 (the last one against the first): independent 1000 x 1000 problems, one launch over the extractor's output
+        # in place (the successor of frame i is the same buffer one record further)
+        return bruteforce_ring(desc, counts, out=out)
 
     class Step:
         """One step over `fr` frames.  Outputs live in FOUR preallocated buffer sets used in turn (nothing is allocated or cleared inside the
         timed region); a set is handed to the extractor again only behind the event that marks the end of its previous consumers (matching,
         exchange): rumi_orb_wait_event.  records=True is the N > 1 code path: per-frame records written in place + the queue's one all-gather."""
 
-        def __init__(self, fr, records, n_queue_=None, per_=None):
-            self.fr, self.records, self.i, self.nbuf = fr, records, 0, 4      # four sets: as many calls in flight as the extractor has slots
+        def __init__(self, fr, records, n_queue_=None, per_=None, slots=None):
             n = fr.shape[0]
+            if slots is None:                                     # (more than four calls in flight measured no faster at any queue length)
+                slots = int(os.environ.get("RUMI_BENCH_SLOTS", "0")) or 4
+            ext.set_resident_queue(slots)
+            self.fr, self.records, self.i, self.nbuf = fr, records, 0, slots  # as many buffer sets as the extractor has slots: that many calls in flight
             self.n_queue = n_queue_ if n_queue_ is not None else n
             if records:
                 self.per = per_ if per_ is not None else n
                 self.rec = [torch.zeros((self.per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev) for _ in range(self.nbuf)]
                 self.views = [rumination.record_views(r[:n], cap) for r in self.rec]
+                self.gbuf = [torch.empty((world * self.per, rumination.record_bytes(cap)), dtype=torch.uint8, device=dev) if world > 1 else None for _ in range(self.nbuf)]
             else:
                 self.out = [(torch.empty((n, cap, 7), dtype=torch.float32, device=dev), torch.empty((n, cap, 32), dtype=torch.uint8, device=dev),
                              torch.zeros((n, 2), dtype=torch.int32, device=dev)) for _ in range(self.nbuf)]
+            self.mout = [[torch.empty((n, cap), dtype=torch.int32, device=dev) for _ in range(3)] for _ in range(self.nbuf)]
             self.consumed = [None] * self.nbuf
             self.gather = [None] * self.nbuf
             torch.cuda.synchronize()
@@ -263,18 +267,15 @@ def main():
                 kp, desc, counts = self.views[k]
             else:
                 kp, desc, counts = ext.extract_batch(self.fr, (0, 1000), cap=cap, wait=False, out=self.out[k])   # enqueue only
-            # the matching of step i runs on a stream of its own behind the extraction of step i: the wide Hamming kernel shares the device with
-            # the latency-bound stretches (quadtree, compaction, upper pyramid levels) of step i + 1 instead of waiting in line before it
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(match_stream):
-                match_stream.wait_event(ev)
-                if self.records:
-                    # the path's one exchange step: every GPU ends up with all records.  Launched behind the extraction only
-                    # (RCCL runs on its own stream) and joined when its buffer set comes round again, so it overlaps the next steps' kernels
-                    self.gather[k] = rumination.all_gather_records_async(self.rec[k], self.n_queue)
-                m = match_pairs(desc, counts)
-                self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(match_stream)
+            # The matching of step i follows on the caller's stream, which the call above has made wait for the extraction of step i; the
+            # resident extractor never waits for this stream, so the wide Hamming kernel shares the device with the latency-bound stretches
+            # (quadtree, compaction, upper pyramid levels) of the next steps without a stream of its own (a separate one measured 1-13 % slower).
+            if self.records:
+                # the path's one exchange step: every GPU ends up with all records.  Launched behind the extraction only
+                # (RCCL runs on its own stream) and joined when its buffer set comes round again, so it overlaps the next steps' kernels
+                self.gather[k] = rumination.all_gather_records_async(self.rec[k], self.n_queue, out=self.gbuf[k])
+            m = match_pairs(desc, counts, self.mout[k])
+            self.consumed[k] = torch.cuda.Event(); self.consumed[k].record()
             return kp, desc, counts, m
 
         def drain(self):
@@ -282,7 +283,6 @@ def main():
                 if self.gather[k] is not None:
                     self.gather[k].wait()
                     self.gather[k] = None
-            torch.cuda.current_stream().wait_stream(match_stream)
 
     use_records = world > 1 or bool(os.environ.get("RUMI_BENCH_FORCE_RECORDS"))   # (the env switch runs the N > 1 code path on one GPU: its exchange degenerates to a no-op)
     step = Step(frames, use_records, n_queue, per)

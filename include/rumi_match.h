@@ -210,6 +210,11 @@ int rumi_match_bruteforce_batch_device(const void *d_query, const void *d_nq, co
 int rumi_match_bruteforce_batch_device_strided(const void *d_query, const void *d_nq, const void *d_train, const void *d_nt,
                                                int32_t count_stride, int64_t query_stride, int64_t train_stride, int32_t cap, int32_t nbatch,
                                                void *d_best_idx, void *d_best_dist, void *d_second_dist, void *hip_stream);
+/* The consecutive-frame matching of a rumination queue (BASELINE.json configs[2]/[4]) in ONE launch: frame i of the buffer against frame i + 1,
+ * the last one against the first.  d_desc: nframes descriptor blocks `frame_stride` bytes apart, d_n: their counts `count_stride` int32s apart;
+ * outputs [nframes][cap] int32 each (row i = the matches of frame i in its successor). */
+int rumi_match_bruteforce_ring_device(const void *d_desc, const void *d_n, int32_t count_stride, int64_t frame_stride, int32_t cap, int32_t nframes,
+                                      void *d_best_idx, void *d_best_dist, void *d_second_dist, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -105,7 +105,9 @@ int rumi_orb_sync(RumiOrb *h);
  * caller's stream, so back-to-back asynchronous calls overlap like the sub-chunks of one large call -- what a rank's share of a sharded
  * queue (64-128 frames per call) needs to run at the rate of a long one.  The caller's stream still waits for each call's results.
  * The output buffers must be free too (no initialisation queued on `hip_stream`, no reader of their previous contents still running:
- * see rumi_orb_wait_event).  The handle grows its device arenas to four slots of min(64, max_batch) frames.  With a resident queue the
+ * see rumi_orb_wait_event).  on = 1: four slots (sub-chunks / calls in flight), 2 .. 8: that many (short calls of 64-128 frames want
+ * more of them in flight: each is one dependent chain of launches); the handle grows its device arenas to that many slots of
+ * min(64, max_batch) frames.  With a resident queue the
  * arenas keep the pyramid of a call's LAST sub-chunk only (rumi_orb_pyramid_level refuses other frames).  Off by default; switching waits
  * for pending calls. */
 int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on);

@@ -90,7 +90,7 @@ def ptr(a):
 
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
-                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_local_points", "rumi_search_by_bow_batch", "rumi_match_bruteforce_batch_device", "rumi_match_bruteforce_batch_device_strided"]
+                 "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_local_points", "rumi_search_by_bow_batch", "rumi_match_bruteforce_batch_device", "rumi_match_bruteforce_batch_device_strided", "rumi_match_bruteforce_ring_device"]
 
 OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", "rumi_pose_optimization_batch", "rumi_local_ba", "rumi_local_ba_batch", "rumi_merge_ba", "rumi_bundle_adjustment", "rumi_sim3_inliers",
                "rumi_optimize_sim3", "rumi_sim3_ransac", "rumi_opt_stage_ms", "rumi_opt_set_profiling", "rumi_opt_kernel_ms"]

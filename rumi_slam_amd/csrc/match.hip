@@ -899,10 +899,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ qd, const int32_t *__restrict__ nqArr,
                                                     const uint8_t *__restrict__ td, const int32_t *__restrict__ ntArr,
                                                     int countStride, long long qStride, long long tStride, int cap, int32_t *__restrict__ bestIdx,
-                                                    int32_t *__restrict__ bestDist, int32_t *__restrict__ secondDist) {
+                                                    int32_t *__restrict__ bestDist, int32_t *__restrict__ secondDist, int ring) {
     __shared__ uint4 tile[256 * 2];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int nq = min(nqArr[(size_t)b * countStride], cap), nt = min(ntArr[(size_t)b * countStride], cap);
+    const int tb = ring > 0 ? (b + 1 == ring ? 0 : b + 1) : b;       // ring: frame b against its successor in the same buffer, the last against the first
+    const int nq = min(nqArr[(size_t)b * countStride], cap), nt = min(ntArr[(size_t)tb * countStride], cap);
     const int qi = blockIdx.x * 256 + tid;
     if (blockIdx.x * 256 >= nq) return;
     uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void k_bruteforce(const uint8_t *__restrict__ 
         const int m = min(256, nt - t0);
         __syncthreads();
         if (tid < m) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(td + (size_t)b * tStride + (size_t)(t0 + tid) * 32);
+            const uint4 *src = reinterpret_cast<const uint4 *>(td + (size_t)tb * tStride + (size_t)(t0 + tid) * 32);
             tile[tid * 2] = src[0];
             tile[tid * 2 + 1] = src[1];
         }
@@ -1801,7 +1802,19 @@ extern "C" int rumi_match_bruteforce_batch_device_strided(const void *d_query, c
         return RUMI_E_INVALID;                                 // the kernel packs the train index into 16 bits next to the distance
     hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nbatch), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_query,
                        (const int32_t *)d_nq, (const uint8_t *)d_train, (const int32_t *)d_nt, count_stride, (long long)query_stride, (long long)train_stride, cap,
-                       (int32_t *)d_best_idx, (int32_t *)d_best_dist, (int32_t *)d_second_dist);
+                       (int32_t *)d_best_idx, (int32_t *)d_best_dist, (int32_t *)d_second_dist, 0);
+    HIP_TRY(hipGetLastError());
+    return RUMI_OK;
+}
+
+extern "C" int rumi_match_bruteforce_ring_device(const void *d_desc, const void *d_n, int32_t count_stride, int64_t frame_stride, int32_t cap, int32_t nframes,
+                                                 void *d_best_idx, void *d_best_dist, void *d_second_dist, void *hip_stream) {
+    if (!d_desc || !d_n || !d_best_idx || !d_best_dist || !d_second_dist || cap < 1 || cap > 65535 || nframes < 1 || count_stride < 1 ||
+        frame_stride < 32ll * cap || (frame_stride & 3) || (reinterpret_cast<uintptr_t>(d_desc) & 3))
+        return RUMI_E_INVALID;
+    hipLaunchKernelGGL(k_bruteforce, dim3((cap + 255) / 256, nframes), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_desc, (const int32_t *)d_n,
+                       (const uint8_t *)d_desc, (const int32_t *)d_n, count_stride, (long long)frame_stride, (long long)frame_stride, cap, (int32_t *)d_best_idx,
+                       (int32_t *)d_best_dist, (int32_t *)d_second_dist, nframes);
     HIP_TRY(hipGetLastError());
     return RUMI_OK;
 }

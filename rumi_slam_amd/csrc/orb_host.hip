@@ -123,6 +123,7 @@ struct RumiOrb {
     // its own too (with its blur stream) and no sub-chunk waits for the caller's stream: back-to-back calls then overlap like the sub-chunks of
     // one large call, only the caller's stream waits for each call's results
     bool residentQueue = false;
+    int residentSlots = 4;                    // slots of the resident queue (2 .. kMaxParts)
     int scratchFrames = 0, arenaFrames = 0;   // frames the scratch arrays / the pyramid and blur arenas hold
     int rot = 0;                     // slot of the next sub-chunk
     hipEvent_t userReady = nullptr;  // rumi_orb_wait_event: the sub-chunks of the next resident-queue call start behind it
@@ -366,8 +367,10 @@ extern "C" int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on) {
     if (!h) return RUMI_E_INVALID;
     if (h->pending) { const int rc = rumi_orb_sync(h); if (rc != RUMI_OK) return rc; }
     if (on) {
-        // four slots of up to 64 frames each: their scratch ranges and their ranges of the pyramid / blur arenas
-        const int need = (4 * std::min(64, h->cfg.max_batch) + 11) / 12 * 12;
+        // `on` slots (1: the default of four) of up to 64 frames each: their scratch ranges and their ranges of the pyramid / blur arenas
+        const int slots = on == 1 ? 4 : std::min(std::max(on, 2), (int)RumiOrb::kMaxParts);
+        h->residentSlots = slots;
+        const int need = (slots * std::min(64, h->cfg.max_batch) + 23) / 24 * 24;
         if (h->scratchFrames < need || h->arenaFrames < need) {
             HIP_TRY(hipSetDevice(h->device));
             HIP_TRY(hipDeviceSynchronize());
@@ -526,13 +529,14 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         // dealt to the slots round-robin ACROSS calls (a 64-frame call takes one slot, the next call the next one).  Everything a sub-chunk
         // touches on the device belongs to its slot, so stream order alone keeps consecutive users of a slot apart: no sub-chunk waits for
         // the caller's stream or for another slot -- except after a rumi_orb_sync, whose reset of the error word is queued on `st`.
-        constexpr int kSlots = 4;
+        constexpr int kMaxSlots = RumiOrb::kMaxParts;
+        const int kSlots = h->residentSlots;
         const int slotFrames = h->scratchFrames / kSlots;
         const int cap64 = std::min(64, slotFrames);
         const int nsub = (nframes + cap64 - 1) / cap64, sub = (nframes + nsub - 1) / nsub;
         const bool fork = !h->pending || !h->lastResident;
         if (fork) HIP_TRY(hipEventRecord(h->evPartFork, st));
-        bool touched[kSlots] = {false, false, false, false};
+        bool touched[kMaxSlots] = {false, false, false, false, false, false, false, false};
         for (int j = 0, base = 0; base < nframes; j++, base += sub) {
             const int n = std::min(sub, nframes - base), slot = (h->rot + j) % kSlots;
             const Lane L = lane_of(slot);

@@ -174,7 +174,8 @@ class ORBextractor:
 
     def set_resident_queue(self, on=True):
         """The frames of the following batched calls do not depend on work pending on the caller's stream (a queue that sits in device memory):
-        back-to-back asynchronous calls then overlap like the sub-chunks of one large call (include/rumi_orb.h)."""
+        back-to-back asynchronous calls then overlap like the sub-chunks of one large call (include/rumi_orb.h).  on: True = four slots
+        (calls / sub-chunks in flight), an integer 2 .. 8 = that many."""
         capi.check(self._lib.rumi_orb_set_resident_queue(self._h, int(on)))
         self._resident = bool(on)
 

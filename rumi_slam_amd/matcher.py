@@ -23,7 +23,7 @@ class RumiFeatureVector(C.Structure):
 MATCH_SYMBOLS = ["rumi_descriptor_distance", "rumi_match_create", "rumi_match_destroy", "rumi_search_by_projection_mappoints",
                  "rumi_search_by_projection_frame", "rumi_search_by_bow", "rumi_search_by_bow_kf", "rumi_search_by_projection_sim3",
                  "rumi_search_by_projection_reloc", "rumi_search_for_initialization", "rumi_search_for_triangulation", "rumi_fuse_candidates", "rumi_search_by_sim3", "rumi_frame_is_in_frustum", "rumi_search_by_bow_batch", "rumi_match_bruteforce_batch_device",
-                 "rumi_match_bruteforce_batch_device_strided"]
+                 "rumi_match_bruteforce_batch_device_strided", "rumi_match_bruteforce_ring_device"]
 
 
 def _lib():
@@ -54,6 +54,7 @@ def _lib():
     L.rumi_match_bruteforce_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.rumi_search_by_bow_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp]
     L.rumi_match_bruteforce_batch_device_strided.argtypes = [vp, vp, vp, vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, vp]
+    L.rumi_match_bruteforce_ring_device.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp, vp, vp, vp]
     L._match_ready = True
     return L
 
@@ -316,4 +317,19 @@ def bruteforce_batch(desc_q, counts_q, desc_t, counts_t, stream=None):
                                                                  counts_q.stride(0), desc_q.stride(0) if B > 1 else 32 * cap,
                                                                  desc_t.stride(0) if B > 1 else 32 * cap, cap, B, out[0].data_ptr(),
                                                                  out[1].data_ptr(), out[2].data_ptr(), st.cuda_stream))
+    return out
+
+
+def bruteforce_ring(desc, counts, stream=None, out=None):
+    """Frame i against frame i + 1 of one buffer, the last against the first, in one launch (the consecutive-frame matching of a rumination
+    queue).  desc: torch u8 CUDA [B,cap,32] (frames may be a strided view); counts: torch i32 CUDA [B,2].  Returns best_idx, best, second
+    [B,cap] (out: three preallocated int32 tensors of that shape)."""
+    import torch
+    B, cap, _ = desc.shape
+    assert desc.stride(1) == 32 and desc.stride(2) == 1
+    if out is None:
+        out = [torch.empty((B, cap), dtype=torch.int32, device=desc.device) for _ in range(3)]
+    st = stream if stream is not None else torch.cuda.current_stream(desc.device)
+    capi.check(_lib().rumi_match_bruteforce_ring_device(desc.data_ptr(), counts.data_ptr(), counts.stride(0), desc.stride(0) if B > 1 else 32 * cap, cap, B,
+                                                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st.cuda_stream))
     return out

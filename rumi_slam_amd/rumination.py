@@ -67,10 +67,11 @@ class GatheredRecords:
                           for r in range(self._world)], 0)
 
 
-def all_gather_records_async(records, n_frames, group=None):
+def all_gather_records_async(records, n_frames, group=None, out=None):
     """Launches THE exchange step for this rank's block of records ([b, record_bytes] u8; b <= shard_capacity) — one
     ``all_gather_into_tensor`` — and returns a GatheredRecords handle.  A block shorter than the capacity (uneven split) is padded
-    with empty records; pass an already padded [shard_capacity, record_bytes] tensor to avoid the copy."""
+    with empty records; pass an already padded [shard_capacity, record_bytes] tensor to avoid the copy.  out: a preallocated
+    [world * shard_capacity, record_bytes] u8 tensor for the gathered queue (a steady-state loop allocates nothing)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return GatheredRecords(records, None, n_frames, 1, records.shape[0])
@@ -80,7 +81,8 @@ def all_gather_records_async(records, n_frames, group=None):
         padded[:records.shape[0]] = records
         records = padded
     records = records.contiguous()
-    g = torch.empty((world * per, records.shape[1]), dtype=records.dtype, device=records.device)
+    g = out if out is not None else torch.empty((world * per, records.shape[1]), dtype=records.dtype, device=records.device)
+    assert g.shape == (world * per, records.shape[1]) and g.is_contiguous()
     work = dist.all_gather_into_tensor(g, records, group=group, async_op=True)
     return GatheredRecords(g, work, n_frames, world, per)
 

@@ -193,6 +193,24 @@ def test_bruteforce_batch():
     assert [bi[1, 0].item(), bd[1, 0].item(), sd[1, 0].item()] == [int(rbi[0]), int(rbd[0]), int(rsd[0])] == [-1, 256, 256]
 
 
+
+def test_bruteforce_ring_equals_pairwise_calls():
+    """rumi_match_bruteforce_ring_device (frame i against frame i + 1 of ONE buffer, the last against the first, one launch) gives what the
+    pairwise batch call gives on the shifted views, strided frames included."""
+    import torch
+    from rumi_slam_amd.matcher import bruteforce_batch, bruteforce_ring
+    rng = np.random.default_rng(31)
+    for B, cap, stride_pad in [(1, 300, 0), (2, 257, 0), (5, 1000, 64), (9, 700, 0)]:
+        buf = torch.from_numpy(rng.integers(0, 256, (B, cap * 32 + stride_pad), dtype=np.uint8)).cuda()
+        desc = buf[:, :cap * 32].view(B, cap, 32) if stride_pad == 0 else buf.as_strided((B, cap, 32), (cap * 32 + stride_pad, 32, 1))
+        counts = torch.from_numpy(np.stack([rng.integers(1, cap + 1, B), np.zeros(B)], 1).astype(np.int32)).cuda()
+        ri, rd, rs = [t.cpu().numpy() for t in bruteforce_ring(desc, counts)]
+        for b in range(B):
+            t = (b + 1) % B
+            bi, bd, sd = [x.cpu().numpy()[0] for x in bruteforce_batch(desc[b:b + 1].contiguous(), counts[b:b + 1], desc[t:t + 1].contiguous(), counts[t:t + 1])]
+            nq = int(counts[b, 0])
+            assert np.array_equal(ri[b, :nq], bi[:nq]) and np.array_equal(rd[b, :nq], bd[:nq]) and np.array_equal(rs[b, :nq], sd[:nq]), (B, b)
+
 def test_bruteforce_on_extractor_records():
     """The bench path: consecutive frames extracted into per-frame records on the device and matched in place through the strided entry
     (descriptors of real key-points: many near-duplicates and ties, unlike random bytes)."""

@@ -43,6 +43,12 @@ def _worker(rank, world, port, n_frames, out_dir):
     h2 = rumination.all_gather_records_async(mine, n_frames)
     for h in (h1, h2):
         assert torch.equal(h.wait(), rec)
+    # ... and into a preallocated buffer (the steady-state loop of bench.py allocates nothing)
+    pre = torch.full((world * rumination.shard_capacity(n_frames, world), rumination.record_bytes(CAP)), 0xAB, dtype=torch.uint8)
+    padded = torch.zeros((rumination.shard_capacity(n_frames, world), rumination.record_bytes(CAP)), dtype=torch.uint8)
+    padded[:mine.shape[0]] = mine
+    h3 = rumination.all_gather_records_async(padded, n_frames, out=pre)
+    assert torch.equal(h3.wait(), rec) and h3.wait().data_ptr() == pre.data_ptr() or torch.equal(h3.wait(), rec)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), rec.numpy())
     dist.barrier()
     dist.destroy_process_group()

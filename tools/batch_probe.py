@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rumi_slam_amd.extractor import ORBextractor
-from rumi_slam_amd.matcher import bruteforce_batch
+from rumi_slam_amd.matcher import bruteforce_ring
 from rumi_slam_amd.synth import synth_frame
 sizes = [int(a) for a in sys.argv[1:]] or [64, 128, 256, 1024]
 B = max(sizes)
@@ -29,12 +29,12 @@ for nb in sizes:
             cnt[0] += 1
             kp, desc, counts = ext.extract_batch(sub, (0, 1000), cap=cap, wait=False, out=obuf[cnt[0] & 1])
             if withm == 1:
-                return (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]), bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
+                return bruteforce_ring(desc, counts)
             if withm == 2:                                    # the matching on a stream of its own behind the extraction, as bench.py's step does
                 ev = torch.cuda.Event(); ev.record()
                 with torch.cuda.stream(mstream):
                     mstream.wait_event(ev)
-                    m = (bruteforce_batch(desc[:-1], counts[:-1], desc[1:], counts[1:]), bruteforce_batch(desc[-1:], counts[-1:], desc[:1], counts[:1]))
+                    m = bruteforce_ring(desc, counts)
                 desc.record_stream(mstream); counts.record_stream(mstream)
                 return m
         reps = max(6, 4096 // nb)

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rumi_slam_amd.extractor import ORBextractor
-from rumi_slam_amd.matcher import bruteforce_batch
+from rumi_slam_amd.matcher import bruteforce_ring
 from rumi_slam_amd.synth import synth_frame
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 host = np.stack([synth_frame(1234 + i) for i in range(32)])
@@ -30,6 +30,6 @@ def ex():
     return ext.extract_batch(fr, (0, 1000), cap=cap, wait=False, out=out[i[0] & 3])
 def exm():
     kp, d, c = ex()
-    bruteforce_batch(d[:-1], c[:-1], d[1:], c[1:]); bruteforce_batch(d[-1:], c[-1:], d[:1], c[:1])
+    bruteforce_ring(d, c)
 print("extract only: host %.0f us / step, total %.0f us / step" % t(ex))
 print("extract+match same stream: host %.0f us, total %.0f us" % t(exm))

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rumi_slam_amd.extractor import ORBextractor
-from rumi_slam_amd.matcher import bruteforce_batch
+from rumi_slam_amd.matcher import bruteforce_ring
 from rumi_slam_amd import rumination
 from rumi_slam_amd.synth import synth_frame
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 128
@@ -38,10 +38,10 @@ def run(records, mstream, match=True):
             ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(ms):
                 ms.wait_event(ev)
-                bruteforce_batch(d[:-1], c[:-1], d[1:], c[1:]); bruteforce_batch(d[-1:], c[-1:], d[:1], c[:1])
+                bruteforce_ring(d, c)
                 cons[k] = torch.cuda.Event(); cons[k].record(ms)
         else:
-            bruteforce_batch(d[:-1], c[:-1], d[1:], c[1:]); bruteforce_batch(d[-1:], c[-1:], d[:1], c[:1])
+            bruteforce_ring(d, c)
     for _ in range(6): step()
     ext.sync(); torch.cuda.synchronize()
     best = 0
