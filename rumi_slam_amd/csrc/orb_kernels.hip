@@ -668,7 +668,9 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
 // Edges (no border is stored around a level): rows above / below the level are the mirrored rows (a row index, wave-uniform); the three
 // columns left of column 0 are bytes 3, 2, 1 of the first dword (one v_perm_b32 in the first strip block); columns from w on are mirrored
 // bytes fetched by the few lanes whose dword touches them (byte loads of the same cache lines, only in waves that hold the right edge).
-constexpr int kBlurRows = 32;      // (16 -> 32 in round 3: 6 halo rows per 32 instead of per 16 output rows; +1.7 % on the pipelined step)
+// output rows a wave walks: 64 for batches (6 halo rows per 64: +1.3 % on the pipelined step over 32, which was +1.7 % over 16), 32 for a few
+// frames (more waves, shorter chains: one frame is 5 % slower with 64)
+constexpr int kBlurRowsSmall = 32, kBlurRowsBatch = 64;
 
 // all levels in one launch: workgroup `lin` of a frame belongs to the level whose [base, base + gx * gy) range holds it
 struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; int bw[kMaxLevels]; };   // bw: pixels a wave's strips cover (256, or less: see launch_blur)
@@ -680,7 +682,7 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
 }
 // VARIANT: RumiOrbConfig.blur_variant -- 0: taps {18,34,48,56,..}/256 of the fixed-point GaussianBlur of OpenCV >= 3.4.2; 1: the integer-scaled float
 // kernel {18,34,49,55,..}/256 of 3.4.0 / 3.4.1 (sum 257: the result is saturated)
-template <int VARIANT>
+template <int VARIANT, int kBlurRows>
 __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
     constexpr uint32_t kT2 = VARIANT ? 49u : 48u, kT3 = VARIANT ? 55u : 56u;      // taps at distance 1 and 0 (18 and 34 are common)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1022,15 +1024,22 @@ static int blur_strip_width(int w) {
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st) {
     BlurGrid G{};
     int run = 0;
+    const bool small = nframes < 16;
+    const int rows = small ? kBlurRowsSmall : kBlurRowsBatch;
     for (int l = 0; l < hP.nlevels; l++) {
         G.bw[l] = blur_strip_width(hP.lv[l].w);
         G.gx[l] = (hP.lv[l].w + G.bw[l] - 1) / G.bw[l];
         G.base[l] = run;
-        run += G.gx[l] * ((hP.lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows));
+        run += G.gx[l] * ((hP.lv[l].h + 4 * rows - 1) / (4 * rows));
     }
     G.base[hP.nlevels] = run;
-    if (variant) hipLaunchKernelGGL(k_blur<1>, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
-    else hipLaunchKernelGGL(k_blur<0>, dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+    if (small) {
+        if (variant) hipLaunchKernelGGL((k_blur<1, kBlurRowsSmall>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+        else hipLaunchKernelGGL((k_blur<0, kBlurRowsSmall>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+    } else {
+        if (variant) hipLaunchKernelGGL((k_blur<1, kBlurRowsBatch>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+        else hipLaunchKernelGGL((k_blur<0, kBlurRowsBatch>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
+    }
 }
 void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPacked, const uint32_t *selMeta,
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,

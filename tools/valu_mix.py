@@ -205,7 +205,7 @@ def analyse(sq, fps=None):
                                                       "NMS + emission sweeps (fitted)": round(nw, 3)},
                                closure_salu=round(tot["salu"] / (c["SQ_INSTS_SALU"] / waves), 3), mix=tot, fit="VALU and LDS counts closed by construction (2 unknowns); SALU is the check")
     # ---- kernels whose hot code is one loop: its trips per wave fitted to VALU, LDS as the check
-    for name, f, needle, ops in (("k_blur", "orb_kernels.hip", "k_blurILi0", ("v_dot4_u32_u8",)),):
+    for name, f, needle, ops in (("k_blur", "orb_kernels.hip", "k_blurILi0ELi64", ("v_dot4_u32_u8",)),):
         c = sq[name]; waves = c["SQ_WAVES"]
         regs = kernel(f, needle)
         loop, = pick(regs, *ops)
