@@ -849,7 +849,7 @@ __device__ __forceinline__ void octree_level(const DevParams *__restrict__ P, co
     if (tid == 0) *outCnt = m;
     OCT_STAMP(6);
 #ifdef RUMI_OCT_STAMP
-    if (tid == 0 && frame == 0) printf("oct L%d n=%d N=%d m=%d rounds %d+%d  setup %lld coarse %lld sort %lld fine %lld relabel %lld free %lld select %lld | init %lld pass1 %lld leaf %lld pass2 %lld\n", level, n, N, m, stRounds[0], stRounds[1], stAcc[0], stAcc[1], stAcc[2], stAcc[3], stAcc[4], stAcc[5], stAcc[6], stAcc[7], stAcc[8], stAcc[9], stAcc[10]);
+    if (tid == 0 && frame == 0) printf("oct L%d n=%d N=%d m=%d D=%d %s rounds %d+%d  setup %lld coarse %lld sort %lld fine %lld relabel %lld free %lld select %lld | init %lld pass1 %lld leaf %lld pass2 %lld\n", level, n, N, m, D, table ? "tables" : "relabel", stRounds[0], stRounds[1], stAcc[0], stAcc[1], stAcc[2], stAcc[3], stAcc[4], stAcc[5], stAcc[6], stAcc[7], stAcc[8], stAcc[9], stAcc[10]);
 #endif
 }
 

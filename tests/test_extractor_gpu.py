@@ -367,6 +367,47 @@ def test_level_with_more_keys_than_the_register_path_holds():
         assert g.stage_keypoints(l, 1).tobytes() == o.keypoints(l, True).tobytes(), f"selected key-points level {l}"
 
 
+def _clustered_frame(seed, boxes):
+    """Flat background, white noise inside a few small boxes (every FAST key of a level sits in a handful of quadtree cells) or, for the box
+    "diag", inside a thin diagonal band: the list then grows by a factor of two per round, not four, and the tree is eight levels deep before it
+    has the nodes wanted."""
+    rng = np.random.default_rng(seed)
+    img = np.full((480, 640), 120, np.uint8)
+    for b in boxes:
+        if b == "diag":
+            yy, xx = np.mgrid[0:480, 0:640]
+            band = np.abs(yy - 0.73 * xx - 5) < 9
+            img[band] = rng.integers(0, 256, int(band.sum()), dtype=np.uint8)
+            continue
+        x0, y0, w, h = b
+        img[y0:y0 + h, x0:x0 + w] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("nf", [1000, 2000])
+def test_clustered_corners_take_the_quadtree_past_its_count_tables(nf):
+    """The quadtree kernel takes the quadrant counts of the first 4-6 subdivision levels from one histogram pass (count tables) and falls back
+    to its relabel passes once a cell of the deepest table level is opened.  Corners clustered in a few small boxes force exactly that (the wanted
+    number of nodes can only come from cells a few pixels wide): one frame (keys in registers), and batches of 40 frames (keys in memory: the
+    256-thread kernel at 1000 features, the 512-thread one at 2000), against the oracle."""
+    import torch
+    g, o = _pair(nf=nf, batch=40)
+    layouts = [["diag"], [(300, 200, 90, 70)], [(20, 20, 60, 60), (560, 400, 60, 60)], [(16, 16, 40, 440)], ["diag", (400, 60, 50, 45)],
+               [(100, 100, 30, 30), (130, 130, 30, 30), (400, 90, 50, 45)], [(250, 180, 140, 120), (30, 400, 25, 25)]]
+    frames = [_clustered_frame(40 + i, layouts[i % len(layouts)]) for i in range(40)]
+    outs = [o.extract(f, (0, 1000)) for f in frames]
+    assert max(len(k) for _, k, _ in outs) > 200, "the clusters must yield key-points"
+    for i in range(len(layouts)):
+        _assert_same(g(frames[i], None, (0, 1000)), outs[i], f"clustered layout {i}, one frame")
+    cap = nf + 96
+    kp, desc, counts = g.extract_batch(torch.from_numpy(np.stack(frames)).cuda(), (0, 1000), cap=cap)
+    kp, desc, counts = kp.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()
+    for i, (om, ok, od) in enumerate(outs):
+        n = int(counts[i, 0])
+        gk = kp[i, :n].copy().view(oracle_lib.KP_DTYPE).reshape(-1)
+        _assert_same((int(counts[i, 1]), gk, desc[i, :n]), (om, ok, od), f"clustered batch frame {i}")
+
+
 @pytest.mark.parametrize("ini,mn", [(20, 20), (7, 20), (30, 5), (12, 7), (40, 1)])
 def test_threshold_pairs(ini, mn):
     """The two cv::FAST calls per cell (ORBextractor.cc:771-785) with unusual threshold pairs: equal, inverted (the retry can only find a subset
