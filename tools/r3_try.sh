@@ -1,5 +1,11 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-python tools/with_lib.py tools/bin/librumi_hip_stamp.so tools/oct_stamp.py diagonal 2>&1 | grep "^oct" | tail -8 | cut -c1-150
-timeout -k 10 900 python -m pytest tests/test_extractor_gpu.py -x -q -m gpu -k "clustered" > gpurun_out/oct_tests.log 2>&1; rc=$?
-tail -15 gpurun_out/oct_tests.log
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; rc=$?
+tail -3 gpurun_out/gpu_tests.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 900 python tools/soak_extractor.py 60 > gpurun_out/soak_extractor.log 2>&1; rc=$?
+grep -v amdgpu gpurun_out/soak_extractor.log | tail -2
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python tools/soak_matcher.py > gpurun_out/soak_matcher.log 2>&1; rc=$?
+grep -v amdgpu gpurun_out/soak_matcher.log | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2
