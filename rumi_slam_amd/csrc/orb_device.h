@@ -49,6 +49,8 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
                    hipStream_t st);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st);
+bool fast_blur_fusable(const DevParams &hP);
+bool launch_fast_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes, int variant, hipStream_t st);
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st);
 void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st);

@@ -471,11 +471,16 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         if (resident) return {h->part0Stream, h->part0Side, h->evSide0Fork, h->evSide0Join};      // (no slot runs on the caller's stream)
         return {st, serial || prof ? st : h->sideStream, h->evFork, h->evJoin};        // profiling: the blur on the call's stream too, so that every stage time is a stand-alone duration
     };
+    // A few frames (the Tracking thread's call): FAST and the blur go out as ONE launch on the main stream (k_fast_blur).  As two launches the
+    // blur runs on the side stream, and the event that forks it stalls the main queue for ~20 us on this runtime: more than the blur takes.
+    static const int envFuse = std::getenv("RUMI_FUSE_FAST_BLUR") ? std::atoi(std::getenv("RUMI_FUSE_FAST_BLUR")) : -1;
+    const bool fuseBlur = !prof && !serial && (envFuse >= 0 ? envFuse != 0 : nframes < 16) && fast_blur_fusable(P);
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
         if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
+        if (fuseBlur) return RUMI_OK;
         HIP_TRY(hipEventRecord(L.fork, s));
         HIP_TRY(hipStreamWaitEvent(L.bs, L.fork, 0));
         if (prof) HIP_TRY(hipEventRecord(h->evB0, L.bs));
@@ -509,7 +514,8 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         int32_t *selLevelCnt = h->dSelLevelCnt + (size_t)scr0 * P.nlevels;
         uint32_t *selPacked = h->dSelPacked + (size_t)scr0 * h->capSel, *selMeta = h->dSelMeta + (size_t)scr0 * h->capSel;
         if (timed) HIP_TRY(hipEventRecord(h->ev[3], s));
-        launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
+        if (fuseBlur) (void)launch_fast_blur(h->dP, P, ps, cellBuf, cellCnt, n, h->cfg.blur_variant, s);
+        else launch_fast(h->dP, P, ps, cellBuf, cellCnt, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[4], s));
         launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
@@ -517,7 +523,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
                         (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
-        HIP_TRY(hipStreamWaitEvent(s, L.join, 0));   // join: rBRIEF reads the blurred levels
+        if (!fuseBlur) HIP_TRY(hipStreamWaitEvent(s, L.join, 0));   // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
                            (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
                            (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);

@@ -568,15 +568,16 @@ __device__ __forceinline__ void fast_cell_process(const DevParams *__restrict__ 
 
 // TPC: tile pitch (= score-map pitch) as a compile-time constant: the circle offsets and the NMS neighbours then are immediate LDS
 // offsets instead of one address add each; 0 = run-time
+// (bx, gx): the workgroup's column and the columns of the FAST part of the launch (the whole grid, or its first gx columns in the fused launch)
 template <int TPC>
-__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
-                                                    uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
+__device__ __forceinline__ void fast_cells_body(const DevParams *__restrict__ P, const ImgSrc &src, const FastLds &F, uint32_t *__restrict__ cellBuf,
+                                                int32_t *__restrict__ cellCnt, unsigned bx, unsigned gx) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
     // the wave index as a scalar: everything that depends only on the cell (geometry, magic numbers, LDS bases) then runs on the scalar unit
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const unsigned wg = xcd_swizzle(blockIdx.y * gx + bx, gx * gridDim.y);
     const int wpg = blockDim.x >> 6;
-    const int cell = (wg % gridDim.x) * wpg + wave, frame = wg / gridDim.x;
+    const int cell = (wg % gx) * wpg + wave, frame = wg / gx;
     uint8_t *tile = fl + (size_t)wave * F.perWave;
     uint8_t *sc = tile + F.tileBytes;
     const int TP = TPC ? TPC : F.tp;
@@ -584,6 +585,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict_
     if (!gA.live) return;
     fast_cell_stage<TPC>(gA, tile, TP, lane);
     fast_cell_process<TPC>(P, F, gA, tile, sc, cellBuf, cellCnt, lane);
+}
+template <int TPC>
+__global__ __launch_bounds__(256) void k_fast_cells(const DevParams *__restrict__ P, ImgSrc src, FastLds F,
+                                                    uint32_t *__restrict__ cellBuf, int32_t *__restrict__ cellCnt) {
+    fast_cells_body<TPC>(P, src, F, cellBuf, cellCnt, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,11 +689,11 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
 // VARIANT: RumiOrbConfig.blur_variant -- 0: taps {18,34,48,56,..}/256 of the fixed-point GaussianBlur of OpenCV >= 3.4.2; 1: the integer-scaled float
 // kernel {18,34,49,55,..}/256 of 3.4.0 / 3.4.1 (sum 257: the result is saturated)
 template <int VARIANT, int kBlurRows>
-__global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
+__device__ __forceinline__ void blur_body(const DevParams *__restrict__ P, const ImgSrc &src, const BlurGrid &G, unsigned bxg, unsigned gxg) {
     constexpr uint32_t kT2 = VARIANT ? 49u : 48u, kT3 = VARIANT ? 55u : 56u;      // taps at distance 1 and 0 (18 and 34 are common)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int frame = wg / gridDim.x, lin = wg % gridDim.x;
+    const unsigned wg = xcd_swizzle(blockIdx.y * gxg + bxg, gxg * gridDim.y);
+    const int frame = wg / gxg, lin = wg % gxg;
     int level = 0;
     for (int l = 1; l < P->nlevels; l++)
         if (lin >= G.base[l]) level = l;
@@ -779,6 +785,19 @@ __global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, I
             }
         }
     }
+}
+template <int VARIANT, int kBlurRows>
+__global__ __launch_bounds__(256) void k_blur(const DevParams *__restrict__ P, ImgSrc src, BlurGrid G) {
+    blur_body<VARIANT, kBlurRows>(P, src, G, blockIdx.x, gridDim.x);
+}
+// A few frames (the Tracking thread's call): FAST and the blur in ONE launch, the first gxFast workgroup columns FAST cells, the rest blur strips.
+// Both only read the pyramid; as two launches the blur goes to a side stream, and the event that forks it stalls the main queue for ~20 us on
+// this runtime (and the join for ~5): more than the blur takes.
+template <int TPC, int VARIANT>
+__global__ __launch_bounds__(256) void k_fast_blur(const DevParams *__restrict__ P, ImgSrc src, FastLds F, uint32_t *__restrict__ cellBuf,
+                                                   int32_t *__restrict__ cellCnt, BlurGrid G, unsigned gxFast) {
+    if (blockIdx.x < gxFast) fast_cells_body<TPC>(P, src, F, cellBuf, cellCnt, blockIdx.x, gxFast);
+    else blur_body<VARIANT, kBlurRowsSmall>(P, src, G, blockIdx.x - gxFast, gridDim.x - gxFast);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -979,8 +998,7 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
     dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level);
 }
-void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
-                 hipStream_t st) {
+static FastLds fast_lds_of(const DevParams &hP) {
     // LDS per wave from the largest cell of this geometry
     int wMax = 0, hMax = 0;
     for (int l = 0; l < hP.nlevels; l++) { wMax = std::max(wMax, hP.lv[l].wCell); hMax = std::max(hMax, hP.lv[l].hCell); }
@@ -994,6 +1012,11 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
     // tile | score map | ring of (pixel, polarity) entries that passed the quick test (linear, kRingCap x uint16; the NMS ballots reuse it) |
     // list of scored pixels (kScoredCap x uint16)
     F.perWave = (F.tileBytes + F.scBytes + std::max(kRingCap * 2, F.maxIters * 8) + kScoredCap * 2 + 15) & ~15;
+    return F;
+}
+void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
+                 hipStream_t st) {
+    const FastLds F = fast_lds_of(hP);
     // tile pitches of the common image sizes as compile-time constants (cells up to 36 / 40 / 44 / 48 pixels wide: 44 / 48 / 52 / 56);
     // anything else takes the run-time instantiation
     const int wpg = 4;                                    // cells (= waves) per workgroup
@@ -1021,11 +1044,9 @@ static int blur_strip_width(int w) {
     }
     return 192;
 }
-void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st) {
+static BlurGrid blur_grid_of(const DevParams &hP, int rows, int *total) {
     BlurGrid G{};
     int run = 0;
-    const bool small = nframes < 16;
-    const int rows = small ? kBlurRowsSmall : kBlurRowsBatch;
     for (int l = 0; l < hP.nlevels; l++) {
         G.bw[l] = blur_strip_width(hP.lv[l].w);
         G.gx[l] = (hP.lv[l].w + G.bw[l] - 1) / G.bw[l];
@@ -1033,6 +1054,29 @@ void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nfram
         run += G.gx[l] * ((hP.lv[l].h + 4 * rows - 1) / (4 * rows));
     }
     G.base[hP.nlevels] = run;
+    *total = run;
+    return G;
+}
+bool fast_blur_fusable(const DevParams &hP) { return fast_lds_of(hP).tp == 48; }
+// FAST + blur of a few frames as one launch (k_fast_blur); false: this geometry has no fused instantiation, launch them separately
+bool launch_fast_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes, int variant, hipStream_t st) {
+    const FastLds F = fast_lds_of(hP);
+    if (F.tp != 48) return false;                                  // (640 x 480 and its neighbours; other pitches keep the two launches)
+    int run = 0;
+    const BlurGrid G = blur_grid_of(hP, kBlurRowsSmall, &run);
+    const int wpg = 4;
+    const unsigned gxFast = (unsigned)((hP.totalCells + wpg - 1) / wpg);
+    const dim3 grid(gxFast + (unsigned)run, nframes);
+    const size_t lds = (size_t)wpg * F.perWave;
+    if (variant) hipLaunchKernelGGL((k_fast_blur<48, 1>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt, G, gxFast);
+    else hipLaunchKernelGGL((k_fast_blur<48, 0>), grid, dim3(256), lds, st, dP, src, F, cellBuf, cellCnt, G, gxFast);
+    return true;
+}
+void launch_blur(const DevParams *dP, const DevParams &hP, ImgSrc src, int nframes, int variant, hipStream_t st) {
+    const bool small = nframes < 16;
+    const int rows = small ? kBlurRowsSmall : kBlurRowsBatch;
+    int run = 0;
+    const BlurGrid G = blur_grid_of(hP, rows, &run);
     if (small) {
         if (variant) hipLaunchKernelGGL((k_blur<1, kBlurRowsSmall>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
         else hipLaunchKernelGGL((k_blur<0, kBlurRowsSmall>), dim3(run, nframes), dim3(256), 0, st, dP, src, G);
