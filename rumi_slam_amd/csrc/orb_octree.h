@@ -8,7 +8,8 @@
 //   * keys never move; every key carries the id of the node that currently owns it (owner[i]);
 //   * a node is 32 bytes of LDS: rectangle, list links, the key counts of its four quadrants, child ids;
 //   * one "sweep" over the keys relabels them after a round of splits and counts quadrant populations
-//     of the new nodes (lane-parallel on the GPU, a plain loop on the host);
+//     of the new nodes (a plain loop in the host driver below; the kernel needs it only for trees deeper than its
+//     count tables, which give the counts of the first subdivision levels from one histogram pass);
 //   * the list choreography (push_front / erase / walk order), the (size, UL.x) sort and the early
 //     break are a serial step driven only by those counts, so the result ORDER is the reference's.
 // The reference's result depends on the tie order of libstdc++'s std::sort; sort_like_libstdcxx()

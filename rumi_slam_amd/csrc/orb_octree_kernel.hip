@@ -1,11 +1,12 @@
 // On-device quadtree key-point distribution + output slot assignment (gfx950).
 //
-//   k_octree    one 512-thread workgroup per (frame, level): DistributeOctTree, R/lib_src/ORBextractor.cc:538-724.
-//               Keys stay where the FAST kernel left them (cand[], HBM/L2); each key only carries a 16-bit owner
-//               id (owner[], HBM/L2).  The node pool, the list (an array in list order), the open/sort arrays live in LDS.
-//               Lane-parallel sweeps relabel keys and count quadrant populations with LDS atomics; the list passes
-//               (divide, push children to the front, erase parents) are workgroup prefix sums + scatters, std::sort is
-//               replayed by the whole workgroup (wg_sort_like_libstdcxx), so the result ORDER equals the reference's.
+//   k_octree    one workgroup per (frame, level): DistributeOctTree, R/lib_src/ORBextractor.cc:538-724.
+//               Keys stay where the FAST kernel left them (cand[], HBM/L2; in registers for a handful of frames).  The node pool, the list
+//               (an array in list order), the open/sort arrays live in LDS.  The quadrant counts of the first 4-6 subdivision levels come
+//               from ONE histogram pass over the keys (count tables); only a tree that outgrows them relabels keys and counts round by
+//               round (a 16-bit owner id per key then, owner[]).  The list passes (divide, push children to the front, erase parents) are
+//               prefix sums + scatters -- on one wave without barriers while the list is short -- and std::sort is replayed exactly
+//               (wave_sort_like_libstdcxx up to 64 entries, wg_sort_like_libstdcxx beyond), so the result ORDER equals the reference's.
 //   k_assemble  one workgroup per frame: concatenates the levels and assigns the output slot of every key-point
 //               by the lapping-area rule of operator() (:1067-1088) with a block scan (the reference walks them
 //               serially with monoIndex++ / stereoIndex--).
@@ -344,8 +345,7 @@ __device__ __forceinline__ int quadrants_open(const OctNode &nd) { return (nd.cn
 
 // The std::list of the reference is kept as an ARRAY in list order (front = element 0).  A pass over the list that divides
 // nodes and pushes their children to the front then becomes: children (in reverse creation order) ++ surviving old nodes (in
-// their old order) — two prefix sums and a scatter, done by the whole workgroup.  Only the std::sort replay of the fine
-// rounds stays on one lane (its tie order is libstdc++'s introsort, orb_octree.h).
+// their old order) — two prefix sums and a scatter.
 // One LDS atomic per DISTINCT key of the wave instead of one per lane: the key-points of a level arrive in cell order, so the 64 of a wave
 // fall into a handful of nodes / quadrants, and in the first rounds ALL of them hit the same two or three counters (64 serialised
 // updates per instruction otherwise).
