@@ -46,7 +46,7 @@ struct ImgSrc {
 
 struct RowTap { int32_t r0, r1; uint32_t bh0, bh1; };   // the two (clamped) source rows, vertical taps << 16
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
-                   hipStream_t st);
+                   hipStream_t st, int32_t *clearWord = nullptr);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
                  hipStream_t st);
 bool fast_blur_fusable(const DevParams &hP);

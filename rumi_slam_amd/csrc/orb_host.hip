@@ -461,7 +461,10 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     // latency-bound, few waves) sit beside the wide VALU-bound ones of the others.  Profiling and RUMI_SERIAL keep one stream.
     static const int envParts = std::getenv("RUMI_PARTS") ? std::atoi(std::getenv("RUMI_PARTS")) : 4;
     const int parts = (!prof && !serial) ? std::min(std::min(std::max(envParts, 1), (int)RumiOrb::kMaxParts), std::max(nframes / 32, 1)) : 1;
-    if (!h->pending) HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
+    // the call's error word starts at zero: a memset on the caller's stream, or -- a call that runs as one part on that stream (a handful of
+    // frames: every dispatch counts) -- a store by the first pyramid kernel, which nothing that writes the word precedes
+    bool clearInKernel = !h->pending && parts == 1 && !(h->residentQueue && !prof && !serial && !h->feed) && P.nlevels > 1;
+    if (!h->pending && !clearInKernel) HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(int32_t), st));
     if (h->userReady && !(h->residentQueue && !prof && !serial && !h->feed)) { HIP_TRY(hipStreamWaitEvent(st, h->userReady, 0)); h->userReady = nullptr; }
     // the streams and events of one sub-chunk slot: main stream, blur stream, fork / join of the blur
     struct Lane { hipStream_t s, bs; hipEvent_t fork, join; };
@@ -478,7 +481,10 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
-        for (int l = 1; l < P.nlevels; l++) launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s);
+        for (int l = 1; l < P.nlevels; l++) {
+            launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s, clearInKernel ? h->dErr : nullptr);
+            clearInKernel = false;
+        }
         if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
         if (fuseBlur) return RUMI_OK;
         HIP_TRY(hipEventRecord(L.fork, s));

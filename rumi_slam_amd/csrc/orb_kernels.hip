@@ -63,7 +63,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
-                                                const int16_t *__restrict__ coef, const RowTap *__restrict__ rowTab, int level) {
+                                                const int16_t *__restrict__ coef, const RowTap *__restrict__ rowTab, int level, int32_t *__restrict__ clearWord) {
+    if (clearWord && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *clearWord = 0;    // the call's error word (orb_host.hip)
     const DevLevel &D = P->lv[level];
     const DevLevel &S = P->lv[level - 1];
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
@@ -994,9 +995,9 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
 
 // ---- launch wrappers (called from orb_host.hip) ----
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
-                   hipStream_t st) {
+                   hipStream_t st, int32_t *clearWord) {
     dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
-    hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level);
+    hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
 }
 static FastLds fast_lds_of(const DevParams &hP) {
     // LDS per wave from the largest cell of this geometry

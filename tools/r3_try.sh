@@ -1,6 +1,6 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
-cd /tmp; export TMPDIR=/tmp
-rm -rf $O/prof_single
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/prof_single -- python3 $R/tools/prof_single.py > $O/prof_single.log 2>&1
-tail -1 $O/prof_single.log
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; rc=$?
+tail -3 gpurun_out/gpu_tests.log
+[ $rc -eq 0 ] || exit $rc
+python tools/single_frame_probe.py 2>&1 | grep -v amdgpu | tail -2
