@@ -21,7 +21,8 @@ print("single frame median %.1f us" % (median_call(one, 200) * 1e6))
 import torch
 fr = torch.from_numpy(imgs[0]).cuda()[None].contiguous()
 ext1 = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=1)
+obuf = (torch.empty((1, 1096, 7), dtype=torch.float32, device="cuda"), torch.empty((1, 1096, 32), dtype=torch.uint8, device="cuda"),
+        torch.zeros((1, 2), dtype=torch.int32, device="cuda"))
 def dev():
-    ext1.extract_batch(fr, (0, 1000), cap=1096)
-    torch.cuda.synchronize()
+    ext1.extract_batch(fr, (0, 1000), cap=1096, out=obuf)      # (waits for the results: the blocking form of the call)
 print("single frame, device-resident in and out, median %.1f us" % (median_call(dev, 200) * 1e6))
