@@ -1028,9 +1028,15 @@ void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t 
 #undef RUMI_FAST_CASE
     hipLaunchKernelGGL((k_fast_cells<0>), grid, dim3(64 * wpg), lds, st, dP, src, F, cellBuf, cellCnt);
 }
+// workgroups per frame (each repeats the cheap scan and copies its share of the outputs: the copy is a chain of dependent LDS reads per
+// element, so one workgroup per frame is ~40 us of latency whatever the batch)
+static int compactSlices(int nframes) {
+    static const int env = std::getenv("RUMI_COMPACT_SLICES") ? std::atoi(std::getenv("RUMI_COMPACT_SLICES")) : 0;
+    return env > 0 ? env : (nframes < 32 ? 8 : 4);
+}
 void launch_compact(const DevParams *dP, const DevParams &hP, const uint32_t *cellBuf, const int32_t *cellCnt,
                     uint32_t *cand, int32_t *levelStart, int32_t *errFlag, int nframes, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(nframes, nframes < 32 ? 8 : 1), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
+    hipLaunchKernelGGL(k_compact, dim3(nframes, compactSlices(nframes)), dim3(kCompactThreads), (hP.totalCells + 1) * sizeof(int), st, dP, cellBuf, cellCnt,
                        cand, levelStart, errFlag);
 }
 // strip width of a level's waves: 256 pixels unless that would put the row's partial dword into lane 0 or 1 of a wave (its mirrored bytes
