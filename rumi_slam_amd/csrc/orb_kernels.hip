@@ -833,16 +833,17 @@ constexpr int kKpPerWg = 8;                    // half waves of a workgroup
 // 1.7x the bytes (FETCH_SIZE).  One for a handful of frames: there are not enough workgroups to fill the chip otherwise.
 
 template <int kKpGroups>
-__global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
+__global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
                                                      RumiKeyPoint *__restrict__ kpOut, long long kpStride, uint8_t *__restrict__ descOut,
                                                      long long descStride, int outCap) {
-    // per key-point: the 31-row disc neighbourhood of the un-blurred level and the 37-row patch of the blurred level, staged by the half wave
-    // that owns the key-point and read by nobody else: no workgroup barrier anywhere past the pattern table's
-    __shared__ __attribute__((aligned(16))) uint8_t sDisc[kKpPerWg][31 * kDiscP];
-    __shared__ __attribute__((aligned(16))) uint8_t sPatch[kKpPerWg][37 * kPatchP];
+    // per key-point: the 31-row disc neighbourhood of the un-blurred level, THEN (in the same LDS: the moments are done with the disc before the
+    // descriptor wants the patch) the 37-row patch of the blurred level, staged by the half wave that owns the key-point and read by nobody else:
+    // no workgroup barrier anywhere past the pattern table's.  18 KB per workgroup: seven workgroups per CU (30 KB with both resident: five)
+    static_assert(kDiscP == kPatchP, "the disc and the patch share their rows");
+    __shared__ __attribute__((aligned(16))) uint8_t sWin[kKpPerWg][37 * kPatchP];
     __shared__ __attribute__((aligned(16))) float sPat[256 * 4];
     __shared__ int4 sLv[kMaxLevels];              // per level: offset and pitch of the un-blurred image (level 0 = the caller's frame), of the blurred one
     __shared__ float2 sLvF[kMaxLevels];           // scale, patch size
@@ -874,39 +875,43 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
                   *frameBlur = src.blur + (long long)frame * P->arenaStride;
     // lane = row: a row's 36 / 40 bytes are two 16-byte loads and a 4- / 8-byte one (dword-aligned addresses; the 37 rows of the patch take a
     // second, five-lane trip); no index arithmetic
-    auto fetch = [&](uint32_t pk, uint32_t meta, bool live, Staged &S) {
-        if (!live) return;
+    auto fetch_disc = [&](uint32_t pk, uint32_t meta, bool live, Staged &S) {
+        if (!live || !dRow) return;
         const int level = meta & 0xFF, x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder;
         const int4 lv = sLv[level];                                       // (a frame's arena is far below 2 GB: 32-bit offsets)
-        const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;         // aligned first columns of the two staged windows
-        const uint8_t *cr = (level == 0 ? frame0 : framePyr) + (lv.x + (y - kHalfPatch + lane) * lv.y + xd);
-        const uint8_t *br = frameBlur + (lv.z + (y - 18 + lane) * lv.w + xp), *br2 = br + 32 * lv.w;
-        if (dRow) { S.d0 = ld16(cr); S.d1 = ld16(cr + 16); S.d2 = *reinterpret_cast<const uint32_t *>(cr + 32); }
+        const uint8_t *cr = (level == 0 ? frame0 : framePyr) + (lv.x + (y - kHalfPatch + lane) * lv.y + ((x - kHalfPatch) & ~3));
+        S.d0 = ld16(cr); S.d1 = ld16(cr + 16); S.d2 = *reinterpret_cast<const uint32_t *>(cr + 32);
+    };
+    auto fetch_patch = [&](uint32_t pk, uint32_t meta, bool live, Staged &S) {
+        if (!live) return;
+        const int level = meta & 0xFF, x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder;
+        const int4 lv = sLv[level];
+        const uint8_t *br = frameBlur + (lv.z + (y - 18 + lane) * lv.w + ((x - 18) & ~3)), *br2 = br + 32 * lv.w;
         S.p0 = ld16(br); S.p1 = ld16(br + 16); S.p2 = ld8(br + 32);
         if (qRow) { S.q0 = ld16(br2); S.q1 = ld16(br2 + 16); S.q2 = ld8(br2 + 32); }
     };
-    auto stage = [&](bool live, const Staged &S) {
+    auto stage_disc = [&](bool live, const Staged &S) {
+        if (!live || !dRow) return;
+        uint8_t *dst = &sWin[hw][lane * kDiscP];
+        *reinterpret_cast<uint4 *>(dst) = S.d0; *reinterpret_cast<uint4 *>(dst + 16) = S.d1; *reinterpret_cast<uint32_t *>(dst + 32) = S.d2;
+    };
+    auto stage_patch = [&](bool live, const Staged &S) {
         if (!live) return;
-        if (dRow) {
-            uint8_t *dst = &sDisc[hw][lane * kDiscP];
-            *reinterpret_cast<uint4 *>(dst) = S.d0; *reinterpret_cast<uint4 *>(dst + 16) = S.d1; *reinterpret_cast<uint32_t *>(dst + 32) = S.d2;
-        }
         {
-            uint8_t *dst = &sPatch[hw][lane * kPatchP];
+            uint8_t *dst = &sWin[hw][lane * kPatchP];
             *reinterpret_cast<uint4 *>(dst) = S.p0; *reinterpret_cast<uint4 *>(dst + 16) = S.p1; *reinterpret_cast<uint2 *>(dst + 32) = S.p2;
         }
         if (qRow) {
-            uint8_t *dst = &sPatch[hw][(lane + 32) * kPatchP];
+            uint8_t *dst = &sWin[hw][(lane + 32) * kPatchP];
             *reinterpret_cast<uint4 *>(dst) = S.q0; *reinterpret_cast<uint4 *>(dst + 16) = S.q1; *reinterpret_cast<uint2 *>(dst + 32) = S.q2;
         }
     };
-    auto compute = [&](uint32_t pk, uint32_t meta) {
-        const int level = meta & 0xFF, slot = (int)(meta >> 8);
-        const int x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder, score = (int)(pk >> 24);
-        const int xd = (x - kHalfPatch) & ~3, xp = (x - 18) & ~3;
+    auto orientation = [&](uint32_t pk) -> float {
+        const int x = (int)(pk & 0xFFF) + kBorder;
+        const int xd = (x - kHalfPatch) & ~3;
         // IC_Angle (ORBextractor.cc:73-97): lane = column u of the disc; the disc is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]), so a
         // lane's rows are |v| <= umax[|u|], known before the loop; m10 = u * (sum of the column), m01 = sum of v * pixel
-        const uint8_t *dc = &sDisc[hw][kHalfPatch * kDiscP + (x - xd)];
+        const uint8_t *dc = &sWin[hw][kHalfPatch * kDiscP + (x - xd)];
         const int u = lane - kHalfPatch;
         const int vmaxU = lane < 31 ? P->umax[u < 0 ? -u : u] : -1;
         // rows +v and -v share their bound: one compare masks both; every row of the staged disc exists, so the reads are unconditional
@@ -923,13 +928,17 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
         m10 = half_wave_sum(m10);
         m01 = half_wave_sum(m01);
         OD_STAMP(4);
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-
+        return fast_atan2_deg((float)m01, (float)m10);
+    };
+    auto describe = [&](uint32_t pk, uint32_t meta, float angle) {
+        const int level = meta & 0xFF, slot = (int)(meta >> 8);
+        const int x = (int)(pk & 0xFFF) + kBorder, y = (int)((pk >> 12) & 0xFFF) + kBorder, score = (int)(pk >> 24);
+        const int xp = (x - 18) & ~3;
         // computeOrbDescriptor (ORBextractor.cc:99-143) on the blurred level
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float ang = angle * factorPI;
         const float a = cosf_glibc(ang), b = sinf_glibc(ang);
-        const uint8_t *bc = &sPatch[hw][18 * kPatchP + (x - xp)];
+        const uint8_t *bc = &sWin[hw][18 * kPatchP + (x - xp)];
         uint32_t w = 0;                                                   // lane j of the half wave ends up with descriptor word j
         OD_STAMP(5);
 #pragma unroll
@@ -969,21 +978,27 @@ __global__ __launch_bounds__(256, 5) void k_orient_desc(const DevParams *__restr
     if (liveC) { pkC = selP[kb]; mtC = selM[kb]; }
     if (liveN) { pkN = selP[kb + kKpPerWg]; mtN = selM[kb + kKpPerWg]; }
     Staged S;
-    fetch(pkC, mtC, liveC, S);
+    fetch_disc(pkC, mtC, liveC, S);
+    fetch_patch(pkC, mtC, liveC, S);
 #pragma unroll
     for (int g = 0; g < kKpGroups; g++) {
         if (!__any(liveC)) break;                                         // (key-points of a half wave come in ascending k: nothing further)
         OD_STAMP(0);
-        stage(liveC, S);
+        stage_disc(liveC, S);
         OD_STAMP(1);
-        // the key-point after this one: its pixels travel while this one is computed; the one after that: its record
+        // the key-point after this one: its pixels travel while this one is computed (the disc behind this one's disc store, the patch behind
+        // this one's patch store: the registers are free then); the one after that: its record
         const int k2 = kb + (g + 2) * kKpPerWg;
         const bool liveNN = g + 2 < kKpGroups && k2 < cnt;
         uint32_t pkNN = 0, mtNN = 0;
         if (liveNN) { pkNN = selP[k2]; mtNN = selM[k2]; }
-        if (g + 1 < kKpGroups) fetch(pkN, mtN, liveN, S);
+        if (g + 1 < kKpGroups) fetch_disc(pkN, mtN, liveN, S);
         OD_STAMP(2);
-        if (liveC) compute(pkC, mtC);
+        float angle = 0.f;
+        if (liveC) angle = orientation(pkC);
+        stage_patch(liveC, S);                                            // (the same LDS rows: the moments above have read the disc)
+        if (g + 1 < kKpGroups) fetch_patch(pkN, mtN, liveN, S);
+        if (liveC) describe(pkC, mtC, angle);
         OD_STAMP(3);
         pkC = pkN; mtC = mtN; liveC = liveN;
         pkN = pkNN; mtN = mtNN; liveN = liveNN;
