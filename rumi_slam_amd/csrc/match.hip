@@ -2063,6 +2063,8 @@ struct RumiTracker {
     RumiOrb *ext = nullptr;
     RumiMatcher *m = nullptr;
     uint8_t *dImage = nullptr; size_t imageBytes = 0;
+    uint8_t *hImage = nullptr;           // pinned staging of the caller's (pageable) image: a plain memcpy + one asynchronous copy (the runtime's own
+                                         // staging of a pageable source serialises the call for ~0.1 ms)
     // ONE device block [TrackBlock | mp cap*4 | mp after the motion model cap*4 | outlier cap | in_view maxPts | record 8 + 60 cap] and its pinned mirror: one copy brings a frame's results back
     uint8_t *dBlk = nullptr, *hBlk = nullptr; size_t oMp = 0, oMpM = 0, oOut = 0, oView = 0, oRec = 0, blkBytes = 0, recordBytes = 0;
     float *dInvSigma2 = nullptr, *dXw = nullptr, *dObs = nullptr, *dW = nullptr;
@@ -2083,6 +2085,7 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN};
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
+    if (t->hImage) (void)hipHostFree(t->hImage);
     delete t;
 }
 
@@ -2110,7 +2113,8 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
     TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C));
     TRYA(dalloc(&t->dWord, C)); TRYA(dalloc(&t->dNode, C)); TRYA(dalloc(&t->dWeight, C)); TRYA(dalloc(&t->dNN, 4));
 #undef TRYA
-    if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
+    if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&t->hImage, t->imageBytes + 64, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
     float inv2[64] = {0};
     rumi_orb_tables(cfg, t->scale, nullptr, nullptr, inv2, nullptr, nullptr);
     if (hipMemcpy(t->dInvSigma2, inv2, sizeof(inv2), hipMemcpyHostToDevice) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
@@ -2143,26 +2147,17 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
 
     // ---- stage 1: ORBextractor::operator() on the device; only the two counts come back (launch sizes need n)
     const int wp = (w + 3) & ~3;
-    HIP_TRY(hipMemcpy2DAsync(t->dImage, wp, img, stride, w, h, hipMemcpyHostToDevice, nullptr));
+    for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
+    HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
-    int32_t counts[2] = {0, -1};
-    HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
-    if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
-    const int n = counts[0];
-    res->n = n; res->mono_index = counts[1];
-    t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];      // the frame is resident for the step-wise entries too
-    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
-    const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
-
-    // ---- uploads of the whole step: one pinned block, one copy, scattered on the device; the frame itself is read where the extractor left it
+    // ---- uploads of the whole step: one pinned block, one copy, scattered on the device; the frame itself is read where the extractor left it.
+    // None of it depends on the extraction: the host fills the block while the extraction runs, and only then waits for the two counts.
     RumiFrameFeatures F{};
     F.n = 0;
     F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)w; F.max_y = (float)h;
     FrameDev fd;
     if ((rc = upload_frame(m, &F, &fd)) != RUMI_OK) return rc;
-    fd.n = n; fd.keys = dKp; fd.desc = dDs;
-    m->gridN = n; m->gridKeys = dKp;
     float pose[11];
     std::memcpy(pose, Tcw_pred7, 7 * sizeof(float)); std::memcpy(pose + 7, K4, 4 * sizeof(float));
     H2D(m->dPose, pose, 11);
@@ -2171,7 +2166,21 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
     }
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
-    FLUSH(m);
+    const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below, behind the counts)
+    m->gridPending = false;
+    FLUSH(m);                                               // the copy and the scatter
+    int32_t counts[2] = {0, -1};
+    HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
+    if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
+    const int n = counts[0];
+    res->n = n; res->mono_index = counts[1];
+    t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];      // the frame is resident for the step-wise entries too
+    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
+    const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
+    fd.n = n; fd.keys = dKp; fd.desc = dDs;
+    m->gridN = n; m->gridKeys = dKp;
+    m->gridPending = gridWanted;
+    FLUSH(m);                                               // the grid of the resident frame
     const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
 
@@ -2278,7 +2287,8 @@ extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w,
     t->curN = -1;
     uint8_t *dRecord = t->dBlk + t->oRec;
     const int wp = (w + 3) & ~3;
-    HIP_TRY(hipMemcpy2DAsync(t->dImage, wp, img, stride, w, h, hipMemcpyHostToDevice, nullptr));
+    for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
+    HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
     int32_t counts[2] = {0, -1};
