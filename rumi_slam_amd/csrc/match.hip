@@ -1841,7 +1841,7 @@ struct TrackBlock {                  // the result block's header, device and pi
     int32_t nGood[2];                // PoseOptimization return values
     int32_t counters[2];             // nmatchesMap, mnMatchesInliers
     int32_t start[2];                // correspondences of the optimisation in flight: {0, count}
-    int32_t pad[2];
+    int32_t spec[4];                 // speculative step: result header (matches, overflow word) of the motion search | of the local search
 };
 
 // fill(mvpMapPoints, NULL), cleared flags / counters, both poses = the prediction, result header of the search cleared
@@ -1983,9 +1983,10 @@ __global__ __launch_bounds__(kFvThreads) void k_fv_build(int n, int npad, const 
 // Thread 0 also derives Frame::UpdatePoseMatrices (Frame.cc:522-528) of the optimised pose in Sophus' / Eigen's float arithmetic: Rcw =
 // q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw) (quaternion _transformVector), as [Rcw9 | tcw3 | Ow3 | K4] for k_is_in_frustum.
 __global__ void k_track_after_motion(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, const uint8_t *mpBad, uint8_t *seen,
-                                     const float *K4, TrackBlock *blk) {
+                                     const float *K4, TrackBlock *blk, const int32_t *searchHeader) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0) pose_matrices19(blk->Tout, K4, blk->pose19);
+    if (c == 0 && searchHeader) { blk->spec[0] = searchHeader[0]; blk->spec[1] = searchHeader[1]; }   // (the next search clears the header)
     if (c >= blk->start[1]) return;
     const int i = idx[c], mp = featMp[i];
     seen[mp] = 1;
@@ -2039,8 +2040,9 @@ __global__ void k_track_frustum(int nmp, int n, const int32_t *featMp, int32_t *
 
 // after the last PoseOptimization: mvpMapPoints and mvbOutlier per feature into the result block, mnMatchesInliers (Tracking.cc:2573-2586)
 __global__ void k_track_finish(const int32_t *idx, const uint8_t *outlierC, const int32_t *featMp, const int32_t *mpObs, uint8_t *outlierF, int32_t *mpOut,
-                               int countInliers, TrackBlock *blk) {
+                               int countInliers, TrackBlock *blk, const int32_t *searchHeader) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && searchHeader) { blk->spec[2] = searchHeader[0]; blk->spec[3] = searchHeader[1]; }
     if (c >= blk->start[1]) return;
     const int i = idx[c];
     mpOut[i] = featMp[i];
@@ -2184,6 +2186,55 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
 
+    const bool small = n <= kTrackLdsEdges;                    // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
+    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+    const float logSf = std::log(t->cfg.scale_factor);
+    // ---- the usual case in ONE queue, no host round trip: the first search finds >= 20 matches and no candidate list overflows.  Every launch
+    // of stages 2-5 goes out back to back (the searches' counts stay on the device, their result headers are kept in the block), the block comes
+    // back once, and only if a header says otherwise (fewer than 20 matches: the 2 th retry; a list overflow) the step is redone stage by stage.
+    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
+    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    bool done = false;
+    if (envSpec && !noFusedLists && n > 0 && nlast > 0 && nmp > 0 && m->listCap / (size_t)std::max(nlast, nmp) >= 64 && n16 * 21 <= m->stageCap) {
+        auto search = [&](int mode, int nq, float nnratio, int checkOri) -> int {
+            const int rcl = build_lists(m, mode, nq, fd, m->dQDesc, false, true);
+            if (rcl != RUMI_OK) return rcl;
+            ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dI[1], m->dFeatMp, m->dAssign, m->dNmatches,
+                          nnratio, checkOri, nullptr, 0.f, 0, m->dOverflow};
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
+            return RUMI_OK;
+        };
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
+                           m->dPose + 7, m->dScale, th_motion, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+        if ((rc = search(MODE_FRAME, nlast, 0.f, 1)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB, (const int32_t *)m->dOut);
+        uint8_t *dSkip = m->dU8b;
+        float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
+        int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
+        hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
+        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
+                           far_points, th_far_points, m->dQ);
+        if ((rc = search(MODE_MAPPOINTS, nmp, 0.8f, 0)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)m->dOut);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint) + (size_t)n * 32, hipMemcpyDeviceToHost));
+        const TrackBlock *hS = reinterpret_cast<const TrackBlock *>(t->hBlk);
+        if (hS->spec[0] >= 20 && hS->spec[1] == 0 && hS->spec[3] == 0) {
+            res->nmatches_motion = hS->spec[0];
+            res->nmatches_local = hS->spec[2];
+            done = true;
+        } else {
+            // not the usual case: start over from the cleared frame (the staged inputs are still on the device)
+            hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+        }
+    }
+    bool localRan = done;
+    if (!done) {
     // ---- stage 2: SearchByProjection(Cur, Last, th, mono), once more with 2 * th below 20 matches (Tracking.cc:2466-2474)
     int nm = 0;
     std::vector<int32_t> tmpMp((size_t)std::max(n, 1));
@@ -2197,20 +2248,16 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         if (nm >= 20) break;
     }
     res->nmatches_motion = nm;
-    const bool small = n <= kTrackLdsEdges;                    // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
-    bool localRan = false;
     if (nm >= 20) {
         // ---- stage 3: PoseOptimization on the matches, outliers leave the frame
         hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
-        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB);
+        hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB, (const int32_t *)nullptr);
         // ---- stage 4: SearchLocalPoints with the optimised pose
-        const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
         if (n16 * 21 > m->stageCap) { g_lastError = "rumi_track_frame: point table exceeds the staging block"; return RUMI_E_CAPACITY; }
         uint8_t *dSkip = m->dU8b;
         float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
-        const float logSf = std::log(t->cfg.scale_factor);
         hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
                            fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
         hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
@@ -2222,14 +2269,15 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         // ---- stage 5: PoseOptimization on everything the frame now holds
         hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
-        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB);
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)nullptr);
     } else if (nm > 0) {                                       // fewer than 20 matches: the frame keeps them (the caller falls back to TrackReferenceKeyFrame)
         hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
-        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 0, dB);
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 0, dB, (const int32_t *)nullptr);
     }
     // ---- one copy back: header, mvpMapPoints, mvbOutlier, mbTrackInView and the extractor's record
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint) + (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
     const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
     std::memcpy(res->Tcw_motion, hB->Tout, 28); std::memcpy(res->Tcw, hB->Tout + 7, 28);
     std::memcpy(res->Rcw, hB->pose19, 36); std::memcpy(res->tcw, hB->pose19 + 9, 12); std::memcpy(res->Ow, hB->pose19 + 12, 12);
@@ -2502,7 +2550,7 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
     const bool small = n <= kTrackLdsEdges;
     hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
     if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
-    hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB);
+    hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec, hipMemcpyDeviceToHost));       // header, mvpMapPoints, mvbOutlier, mbTrackInView
     const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
