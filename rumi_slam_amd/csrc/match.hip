@@ -62,8 +62,10 @@ __device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t *d
 // Frame::AssignFeaturesToGrid as a counting sort by cell (cell = column-major ix*48+iy, the order GetFeaturesInArea walks),
 // ascending key-point index inside a cell (= push_back order).  One workgroup; the per-cell segments (a handful of entries) are
 // put in index order by an insertion sort after an unordered atomic placement.
+// (nDev: the feature count where the extractor left it, when the host has not read it yet; n is then its upper bound)
 __global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__restrict__ keys, float minX, float minY, float wInv,
-                                               float hInv, uint16_t *__restrict__ sortedIdx, int32_t *__restrict__ cellStart) {
+                                               float hInv, uint16_t *__restrict__ sortedIdx, int32_t *__restrict__ cellStart, const int32_t *__restrict__ nDev) {
+    if (nDev) n = min(n, *nDev);
     __shared__ int32_t sCnt[kGridCells + 1];
     __shared__ uint16_t sCell[kMaxSortN], sOut[kMaxSortN];
     __shared__ int32_t sPart[1024];
@@ -1090,6 +1092,7 @@ struct RumiMatcher {
     uint8_t *hBow = nullptr, *dBow = nullptr; size_t bowCap = 0;
     uint8_t *hBowOut = nullptr, *dBowOut = nullptr; size_t bowOutCap = 0;
     // k_grid of the uploaded frame, launched by flush_uploads once the key-points are in place
+    const int32_t *gridNDev = nullptr;     // k_grid reads the count from the device (one call only: cleared by the flush)
     bool gridPending = false; int gridN = 0; float gridMinX = 0, gridMinY = 0, gridWInv = 0, gridHInv = 0;
     const RumiKeyPoint *gridKeys = nullptr;      // key-points k_grid reads: dKeys, or a frame that already lies on the device (rumi_track_frame)
 };
@@ -1196,8 +1199,9 @@ static int flush_uploads(RumiMatcher *m) {
     }
     if (m->gridPending) {
         hipLaunchKernelGGL(k_grid, dim3(1), dim3(1024), 0, nullptr, m->gridN, m->gridKeys ? m->gridKeys : m->dKeys, m->gridMinX, m->gridMinY, m->gridWInv, m->gridHInv,
-                           m->dSorted, m->dCellStart);
+                           m->dSorted, m->dCellStart, m->gridNDev);
         m->gridPending = false;
+        m->gridNDev = nullptr;
     }
     return RUMI_OK;
 }
@@ -1834,7 +1838,7 @@ extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const voi
 // ==================================================================================================================
 namespace rumi {
 
-constexpr int kTrackLdsEdges = 1024;     // = kPoseLdsEdges of opt.hip
+constexpr int kTrackLdsEdges = 1152;     // = kPoseLdsEdges of opt.hip
 struct TrackBlock {                  // the result block's header, device and pinned host alike (arrays follow at byte offsets of RumiTracker)
     float Tout[14];                  // pose after the motion model | after the local map
     float pose19[20];                // Rcw9 tcw3 Ow3 K4 of the first (Frame::UpdatePoseMatrices)
@@ -2168,34 +2172,42 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
     }
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
-    const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below, behind the counts)
+    const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below)
     m->gridPending = false;
     FLUSH(m);                                               // the copy and the scatter
-    int32_t counts[2] = {0, -1};
-    HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
-    if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
-    const int n = counts[0];
-    res->n = n; res->mono_index = counts[1];
-    t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];      // the frame is resident for the step-wise entries too
+    // ---- the usual case in ONE queue, no host round trip: the first search finds >= 20 matches and no candidate list overflows.  Every launch
+    // of stages 2-5 goes out back to back behind the extraction -- the feature count and the searches' counts stay on the device (launches are
+    // sized by their upper bounds), the searches' result headers are kept in the block -- the block comes back once, and only if a header says
+    // otherwise (fewer than 20 matches: the 2 th retry; a list overflow; no key-point at all) the step is redone stage by stage.
+    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
+    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+    const float logSf = std::log(t->cfg.scale_factor);
+    const bool canSpec = envSpec && !noFusedLists && nlast > 0 && nmp > 0 && m->listCap / (size_t)std::max(nlast, nmp) >= 64 && n16 * 21 <= m->stageCap;
+    int n = t->cap;                                          // an upper bound until the two counts have been read
+    auto take_counts = [&](const int32_t *counts) {
+        n = counts[0];
+        res->n = n; res->mono_index = counts[1];
+        t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];      // the frame is resident for the step-wise entries too
+    };
+    if (!canSpec) {
+        int32_t counts[2] = {0, -1};
+        HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
+        if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
+        take_counts(counts);
+    }
     const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
     const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
     fd.n = n; fd.keys = dKp; fd.desc = dDs;
-    m->gridN = n; m->gridKeys = dKp;
+    m->gridN = n; m->gridKeys = dKp; m->gridNDev = canSpec ? reinterpret_cast<const int32_t *>(dRecord) : nullptr;
     m->gridPending = gridWanted;
     FLUSH(m);                                               // the grid of the resident frame
-    const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
+    int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256);
+    const int gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
-
-    const bool small = n <= kTrackLdsEdges;                    // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
-    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
-    const float logSf = std::log(t->cfg.scale_factor);
-    // ---- the usual case in ONE queue, no host round trip: the first search finds >= 20 matches and no candidate list overflows.  Every launch
-    // of stages 2-5 goes out back to back (the searches' counts stay on the device, their result headers are kept in the block), the block comes
-    // back once, and only if a header says otherwise (fewer than 20 matches: the 2 th retry; a list overflow) the step is redone stage by stage.
-    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
-    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    bool small = n <= kTrackLdsEdges;                       // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
     bool done = false;
-    if (envSpec && !noFusedLists && n > 0 && nlast > 0 && nmp > 0 && m->listCap / (size_t)std::max(nlast, nmp) >= 64 && n16 * 21 <= m->stageCap) {
+    if (canSpec) {
         auto search = [&](int mode, int nq, float nnratio, int checkOri) -> int {
             const int rcl = build_lists(m, mode, nq, fd, m->dQDesc, false, true);
             if (rcl != RUMI_OK) return rcl;
@@ -2223,13 +2235,18 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)m->dOut);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint) + (size_t)n * 32, hipMemcpyDeviceToHost));
+        if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
+        take_counts(reinterpret_cast<const int32_t *>(t->hBlk + t->oRec));
         const TrackBlock *hS = reinterpret_cast<const TrackBlock *>(t->hBlk);
-        if (hS->spec[0] >= 20 && hS->spec[1] == 0 && hS->spec[3] == 0) {
+        if (n > 0 && hS->spec[0] >= 20 && hS->spec[1] == 0 && hS->spec[3] == 0) {
             res->nmatches_motion = hS->spec[0];
             res->nmatches_local = hS->spec[2];
             done = true;
         } else {
-            // not the usual case: start over from the cleared frame (the staged inputs are still on the device)
+            // not the usual case: start over from the cleared frame (the staged inputs and the frame's grid are still on the device)
+            fd.n = n; m->gridN = n;
+            gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256);
+            small = n <= kTrackLdsEdges;
             hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
         }
     }

@@ -142,7 +142,7 @@ struct PoseArgs {
 
 // LDS = true (frames of up to kPoseLdsEdges correspondences): the edge data, the active flags and the last chi2 of every edge
 // live in LDS for the whole solve, so none of the ~60 passes over the edges waits for global memory.
-constexpr int kPoseLdsEdges = 1024;
+constexpr int kPoseLdsEdges = 1152;          // (nfeatures 1000 + the extractor's slack of 96 fits: the tracker then needs no count to choose the instantiation)
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     constexpr int NW = NT / 64;
