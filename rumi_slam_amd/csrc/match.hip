@@ -1093,6 +1093,7 @@ struct RumiMatcher {
     uint8_t *hBowOut = nullptr, *dBowOut = nullptr; size_t bowOutCap = 0;
     // k_grid of the uploaded frame, launched by flush_uploads once the key-points are in place
     const int32_t *gridNDev = nullptr;     // k_grid reads the count from the device (one call only: cleared by the flush)
+    hipStream_t upStream = nullptr;        // where the next flush queues its copy and scatter (the caller orders its kernels behind them)
     bool gridPending = false; int gridN = 0; float gridMinX = 0, gridMinY = 0, gridWInv = 0, gridHInv = 0;
     const RumiKeyPoint *gridKeys = nullptr;      // key-points k_grid reads: dKeys, or a frame that already lies on the device (rumi_track_frame)
 };
@@ -1192,8 +1193,8 @@ static int stage_add(RumiMatcher *m, void *dst, const void *src, size_t bytes) {
 // One host-to-device copy for everything queued, the scatter, then the grid of the uploaded frame.
 static int flush_uploads(RumiMatcher *m) {
     if (m->nseg > 0) {
-        HIP_TRY(hipMemcpyAsync(m->dStage, m->hStage, m->stageUsed, hipMemcpyHostToDevice, nullptr));
-        hipLaunchKernelGGL(k_scatter, dim3(8, m->nseg), dim3(256), 0, nullptr, m->dStage, m->nseg);
+        HIP_TRY(hipMemcpyAsync(m->dStage, m->hStage, m->stageUsed, hipMemcpyHostToDevice, m->upStream));
+        hipLaunchKernelGGL(k_scatter, dim3(8, m->nseg), dim3(256), 0, m->upStream, m->dStage, m->nseg);
         m->nseg = 0;
         m->stageUsed = kStageHeader;
     }
@@ -2069,6 +2070,8 @@ struct RumiTracker {
     RumiOrb *ext = nullptr;
     RumiMatcher *m = nullptr;
     uint8_t *dImage = nullptr; size_t imageBytes = 0;
+    hipStream_t upStream = nullptr;      // the step's uploads travel beside the extraction (rumi_track_frame)
+    hipEvent_t evUp = nullptr;
     uint8_t *hImage = nullptr;           // pinned staging of the caller's (pageable) image: a plain memcpy + one asynchronous copy (the runtime's own
                                          // staging of a pageable source serialises the call for ~0.1 ms)
     // ONE device block [TrackBlock | mp cap*4 | mp after the motion model cap*4 | outlier cap | in_view maxPts | record 8 + 60 cap] and its pinned mirror: one copy brings a frame's results back
@@ -2092,6 +2095,8 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
     if (t->hImage) (void)hipHostFree(t->hImage);
+    if (t->upStream) (void)hipStreamDestroy(t->upStream);
+    if (t->evUp) (void)hipEventDestroy(t->evUp);
     delete t;
 }
 
@@ -2120,7 +2125,10 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
     TRYA(dalloc(&t->dWord, C)); TRYA(dalloc(&t->dNode, C)); TRYA(dalloc(&t->dWeight, C)); TRYA(dalloc(&t->dNN, 4));
 #undef TRYA
     if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&t->hImage, t->imageBytes + 64, hipHostMallocDefault) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
+        hipHostMalloc((void **)&t->hImage, t->imageBytes + 64, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&t->upStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->evUp, hipEventDisableTiming) != hipSuccess) {
+        rumi_track_destroy(t); return RUMI_E_NO_DEVICE;
+    }
     float inv2[64] = {0};
     rumi_orb_tables(cfg, t->scale, nullptr, nullptr, inv2, nullptr, nullptr);
     if (hipMemcpy(t->dInvSigma2, inv2, sizeof(inv2), hipMemcpyHostToDevice) != hipSuccess) { rumi_track_destroy(t); return RUMI_E_NO_DEVICE; }
@@ -2174,7 +2182,12 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
     const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below)
     m->gridPending = false;
-    FLUSH(m);                                               // the copy and the scatter
+    m->upStream = t->upStream;                              // the copy and the scatter, on a stream of their own beside the extraction
+    const int rcUp = flush_uploads(m);
+    m->upStream = nullptr;
+    if (rcUp != RUMI_OK) return rcUp;
+    HIP_TRY(hipEventRecord(t->evUp, t->upStream));
+    HIP_TRY(hipStreamWaitEvent(nullptr, t->evUp, 0));      // (behind the extraction in the main queue: by then the event has long fired)
     // ---- the usual case in ONE queue, no host round trip: the first search finds >= 20 matches and no candidate list overflows.  Every launch
     // of stages 2-5 goes out back to back behind the extraction -- the feature count and the searches' counts stay on the device (launches are
     // sized by their upper bounds), the searches' result headers are kept in the block -- the block comes back once, and only if a header says
