@@ -2182,21 +2182,29 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
     const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below)
     m->gridPending = false;
+    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
+    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
+    const float logSf = std::log(t->cfg.scale_factor);
+    const bool canSpec = envSpec && !noFusedLists && nlast > 0 && nmp > 0 && m->listCap / (size_t)std::max(nlast, nmp) >= 64 && n16 * 21 <= m->stageCap;
+    const int gC = std::max(1, (t->cap + 255) / 256);
     m->upStream = t->upStream;                              // the copy and the scatter, on a stream of their own beside the extraction
     const int rcUp = flush_uploads(m);
     m->upStream = nullptr;
     if (rcUp != RUMI_OK) return rcUp;
+    if (canSpec) {
+        // what the usual case (below) needs and the extraction does not feed: the cleared frame (sized by the capacity) and the motion-model queries
+        hipLaunchKernelGGL(k_track_init, dim3(std::max(1, (std::max(t->cap, nmp) + 255) / 256)), dim3(256), 0, t->upStream, t->cap, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF,
+                           dMpOut, m->dPose, dB);
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, t->upStream, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
+                           m->dPose + 7, m->dScale, th_motion, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+    }
     HIP_TRY(hipEventRecord(t->evUp, t->upStream));
     HIP_TRY(hipStreamWaitEvent(nullptr, t->evUp, 0));      // (behind the extraction in the main queue: by then the event has long fired)
     // ---- the usual case in ONE queue, no host round trip: the first search finds >= 20 matches and no candidate list overflows.  Every launch
     // of stages 2-5 goes out back to back behind the extraction -- the feature count and the searches' counts stay on the device (launches are
     // sized by their upper bounds), the searches' result headers are kept in the block -- the block comes back once, and only if a header says
     // otherwise (fewer than 20 matches: the 2 th retry; a list overflow; no key-point at all) the step is redone stage by stage.
-    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
-    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
-    const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
-    const float logSf = std::log(t->cfg.scale_factor);
-    const bool canSpec = envSpec && !noFusedLists && nlast > 0 && nmp > 0 && m->listCap / (size_t)std::max(nlast, nmp) >= 64 && n16 * 21 <= m->stageCap;
     int n = t->cap;                                          // an upper bound until the two counts have been read
     auto take_counts = [&](const int32_t *counts) {
         n = counts[0];
@@ -2216,8 +2224,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     m->gridPending = gridWanted;
     FLUSH(m);                                               // the grid of the resident frame
     int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256);
-    const int gC = std::max(1, (t->cap + 255) / 256);
-    hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+    if (!canSpec) hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
     bool small = n <= kTrackLdsEdges;                       // the frame's correspondences fit the LDS instantiation of k_pose_opt for sure
     bool done = false;
     if (canSpec) {
@@ -2229,9 +2236,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
             hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
             return RUMI_OK;
         };
-        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
-                           m->dPose + 7, m->dScale, th_motion, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
-        if ((rc = search(MODE_FRAME, nlast, 0.f, 1)) != RUMI_OK) return rc;
+        if ((rc = search(MODE_FRAME, nlast, 0.f, 1)) != RUMI_OK) return rc;      // (its queries were built beside the extraction, above)
         hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
         hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB, (const int32_t *)m->dOut);
