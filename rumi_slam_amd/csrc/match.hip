@@ -1867,7 +1867,7 @@ __global__ void k_track_init(int n, int nmp, int full, int32_t *featMp, int32_t 
 // One workgroup, ordered compaction (ballot + wave offsets through LDS, chunks of 1024 features).
 __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint *__restrict__ keys, const int32_t *__restrict__ featMp,
                                                        const float *__restrict__ mpPos, const float *__restrict__ invSigma2, float *Xw, float *obs,
-                                                       float *w, int32_t *idx, int32_t *start) {
+                                                       float *w, int32_t *idx, int32_t *start, int32_t *snapshot = nullptr) {
     __shared__ int sWave[16], sBase;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sBase = 0;
@@ -1875,6 +1875,7 @@ __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint
     for (int c0 = 0; c0 < n; c0 += 1024) {
         const int i = c0 + tid;
         const int mp = i < n ? featMp[i] : -1;
+        if (snapshot && i < n) snapshot[i] = mp;            // the frame's map-point vector as the search left it (the optimisation's outliers leave it next)
         const unsigned long long b = __ballot(mp >= 0);
         if (lane == 0) sWave[wave] = __popcll(b);
         __syncthreads();
@@ -1916,8 +1917,10 @@ __device__ __forceinline__ void pose_matrices19(const float *Tcw7, const float *
 // "Discard outliers" of TrackWithMotionModel / TrackReferenceKeyFrame alone (Tracking.cc:2489-2508, 2349-2369): the outliers of the optimisation
 // leave the frame, the others count towards nmatchesMap when their point has observations.  (The step-wise entries: SearchLocalPoints' own
 // loops belong to rumi_track_local.)
-__global__ void k_track_discard(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, TrackBlock *blk) {
+__global__ void k_track_discard(const int32_t *idx, const uint8_t *outlierC, int32_t *featMp, const int32_t *mpObs, TrackBlock *blk,
+                                const int32_t *searchHeader = nullptr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && searchHeader) { blk->spec[0] = searchHeader[0]; blk->spec[1] = searchHeader[1]; }
     if (c >= blk->start[1]) return;
     const int i = idx[c], mp = featMp[i];
     if (outlierC[c]) { featMp[i] = -1; return; }
@@ -2419,6 +2422,37 @@ extern "C" int rumi_track_motion(RumiTracker *t, const float *K4, const float *T
     FLUSH(m);
     const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+    const bool small = n <= kTrackLdsEdges;
+    // the usual case (>= 20 matches at th, no list overflow) in one queue, as in rumi_track_frame: the search's result header and the map-point
+    // vector it leaves travel back with the results; anything else is redone stage by stage below
+    static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
+    static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+    if (envSpec && !noFusedLists && n > 0 && nlast > 0 && nmp > 0 && m->listCap / (size_t)nlast >= 64) {
+        int32_t *dSnap = reinterpret_cast<int32_t *>(t->dBlk + t->oMpM);
+        hipLaunchKernelGGL(k_queries_frame, dim3((nlast + 255) / 256), dim3(256), 0, nullptr, nlast, m->dQKeys, m->dI[0], m->dU8a, m->dF[0], m->dI[1], m->dPose,
+                           m->dPose + 7, m->dScale, th_motion, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
+        if ((rc = build_lists(m, MODE_FRAME, nlast, fd, m->dQDesc, false, true)) != RUMI_OK) return rc;
+        ResolveArgs A{MODE_FRAME, nlast, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dI[1], m->dFeatMp, m->dAssign, m->dNmatches,
+                      0.f, 1, nullptr, 0.f, 0, m->dOverflow};
+        hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start, dSnap);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB, (const int32_t *)m->dOut);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(t->hBlk + t->oMp, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpyAsync(t->hBlk + t->oMpM, dSnap, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, sizeof(TrackBlock), hipMemcpyDeviceToHost));
+        const TrackBlock *hS = reinterpret_cast<const TrackBlock *>(t->hBlk);
+        if (hS->spec[0] >= 20 && hS->spec[1] == 0) {
+            res->nmatches_motion = hS->spec[0];
+            std::memcpy(res->Tcw_motion, hS->Tout, 28); std::memcpy(res->Tcw, hS->Tout, 28);
+            res->ngood_motion = hS->nGood[0]; res->nmatches_map = hS->counters[0];
+            const int32_t *before = reinterpret_cast<const int32_t *>(t->hBlk + t->oMpM), *after = reinterpret_cast<const int32_t *>(t->hBlk + t->oMp);
+            for (int i = 0; i < n; i++) { if (before[i] >= 0 && after[i] < 0) discarded[i] = before[i]; frame_mp[i] = after[i]; }
+            return RUMI_OK;
+        }
+        hipLaunchKernelGGL(k_track_init, dim3(gI), dim3(256), 0, nullptr, n, nmp, 1, m->dFeatMp, m->dOut, t->dSeen, dOutF, dMpOut, m->dPose, dB);
+    }
     int nm = 0;
     std::vector<int32_t> searched((size_t)std::max(n, 1), -1);
     for (int attempt = 0; attempt < 2 && n > 0 && nlast > 0 && nmp > 0; attempt++) {      // Tracking.cc:2466-2474
@@ -2433,7 +2467,6 @@ extern "C" int rumi_track_motion(RumiTracker *t, const float *K4, const float *T
     res->nmatches_motion = nm;
     if (n > 0) std::memcpy(frame_mp, searched.data(), (size_t)n * 4);
     if (nm < 20) return RUMI_OK;                                  // TrackWithMotionModel returns false here (:2476-2483): nothing else has happened to the frame
-    const bool small = n <= kTrackLdsEdges;
     hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
     if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
     hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB);
@@ -2567,6 +2600,7 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
     const int gI = std::max(1, (std::max(std::max(n, nmp), 4) + 255) / 256), gC = std::max(1, (t->cap + 255) / 256);
     hipLaunchKernelGGL(k_track_local_init, dim3(gI), dim3(256), 0, nullptr, n, m->dPose, m->dPose + 7, dOutF, dMpOut, m->dOut, dB);
     int nmLocal = 0;
+    bool speculate = false;
     std::vector<int32_t> tmpMp((size_t)std::max(n, 1));
     if (nmp > 0 && n > 0) {
         const size_t n16 = ((size_t)nmp + 15) & ~(size_t)15;
@@ -2579,16 +2613,35 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
                            fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
         hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
                            far_points, th_far_points, m->dQ);
-        if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
+        // the search's counts are not needed before the end: one queue, the result header travels in the block (a list overflow -- the resolve
+        // did not run then, the frame's vector is untouched -- sends the stage through the sizing path)
+        static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
+        static const bool noFusedLists = std::getenv("RUMI_MATCH_NO_FUSED") != nullptr;
+        speculate = envSpec && !noFusedLists && m->listCap / (size_t)nmp >= 64;
+        if (speculate) {
+            if ((rc = build_lists(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, false, true)) != RUMI_OK) return rc;
+            ResolveArgs A{MODE_MAPPOINTS, nmp, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dI[1], m->dFeatMp, m->dAssign, m->dNmatches,
+                          0.8f, 0, nullptr, 0.f, 0, m->dOverflow};
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
+        } else if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
     }
     res->nmatches_local = nmLocal;
     const bool small = n <= kTrackLdsEdges;
-    hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
-    if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
-    hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec, hipMemcpyDeviceToHost));       // header, mvpMapPoints, mvbOutlier, mbTrackInView
     const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
+    for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
+        if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
+        hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, speculate ? (const int32_t *)m->dOut : (const int32_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, t->oRec, hipMemcpyDeviceToHost));       // header, mvpMapPoints, mvbOutlier, mbTrackInView
+        if (!speculate) break;
+        if (hB->spec[3] == 0) { res->nmatches_local = hB->spec[2]; break; }
+        // a candidate list overflowed: the search again with exact list sizes, then the optimisation on its result
+        speculate = false;
+        hipLaunchKernelGGL(k_track_local_init, dim3(gI), dim3(256), 0, nullptr, n, m->dPose, m->dPose + 7, dOutF, dMpOut, m->dOut, dB);
+        if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
+        res->nmatches_local = nmLocal;
+    }
     std::memcpy(res->Tcw, hB->Tout + 7, 28);
     std::memcpy(res->Rcw, hB->pose19, 36); std::memcpy(res->tcw, hB->pose19 + 9, 12); std::memcpy(res->Ow, hB->pose19 + 12, 12);
     res->ngood_local = hB->nGood[1]; res->matches_inliers = hB->counters[1];
