@@ -1536,8 +1536,11 @@ __global__ void k_ba_mark(BADev B, const double *T, const double *X, uint8_t *of
     off[e] = (B.lastChi2[e] > 5.991 || !(pc.z > 0.0)) ? 1 : 0;
 }
 
-__global__ void k_ba_finalize(BADev B, const double *T, const double *X, int useLast, uint8_t *erase) {
+// erase flags of the edges (Optimizer.cc:1292) and, in the same launch, the final state gathered behind them: [T | X | erase] leaves in one copy
+__global__ void k_ba_finalize(BADev B, const double *T, const double *X, int useLast, uint8_t *erase, double *outT, double *outX) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B.nKF * 8) outT[e] = T[e];
+    if (e < B.nMP * 3) outX[e] = X[e];
     if (e >= B.nE) return;
     const int p = B.eMP[e];
     const D3 pc = se3_map(load_pose(T, B.eKF[e]), D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
@@ -2585,16 +2588,18 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         B.robust = 0;
         if ((rc = lm_any(10)) != RUMI_OK) return rc;
     }
-    if (nE > 0) hipLaunchKernelGGL(k_ba_finalize, dim3(gE), dim3(256), 0, st, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dErase);
-    HIP_TRY(hipEventRecord(o->ev[1], st));
-    HIP_TRY(hipGetLastError());
-    // results gathered on the device into the (now idle) upload mirror and read back with one copy: [T | X | erase]
+    // results gathered by the last kernel into one block and read back with one copy: [T | X | erase].  (Taking a second stream for this, past the
+    // slot the device-side LM loop has enqueued ahead -- nine launches that return at once -- measured no faster for one window and 7 % slower
+    // for batches of windows: by the time the host has seen the loop end, that slot has run.)
     const size_t rT = 0, rX = al(rT + (size_t)nKF * 64), rE = al(rX + (size_t)nMP * 24), dnBytes = al(rE + (size_t)nE);
-    HIP_TRY(hipMemcpyAsync(o->dBaOut + rT, o->dT[cur], (size_t)nKF * 64, hipMemcpyDeviceToDevice, st));
-    if (nMP > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rX, o->dX[cur], (size_t)nMP * 24, hipMemcpyDeviceToDevice, st));
-    if (nE > 0) HIP_TRY(hipMemcpyAsync(o->dBaOut + rE, o->dErase, (size_t)nE, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(o->hBa, o->dBaOut, dnBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    hipStream_t se = st;
+    const int gF = std::max(gE, std::max((nKF * 8 + 255) / 256, (nMP * 3 + 255) / 256));
+    hipLaunchKernelGGL(k_ba_finalize, dim3(gF), dim3(256), 0, se, B, o->dT[cur], o->dX[cur], ranChi2 ? 1 : 0, o->dBaOut + rE, reinterpret_cast<double *>(o->dBaOut + rT),
+                       reinterpret_cast<double *>(o->dBaOut + rX));
+    HIP_TRY(hipEventRecord(o->ev[1], se));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(o->hBa, o->dBaOut, dnBytes, hipMemcpyDeviceToHost, se));
+    HIP_TRY(hipStreamSynchronize(se));
     const double *T1 = reinterpret_cast<const double *>(o->hBa + rT), *X1 = reinterpret_cast<const double *>(o->hBa + rX);
     if (nE > 0) std::memcpy(erase_out, o->hBa + rE, (size_t)nE);
     HIP_TRY(hipEventElapsedTime(&o->stageMs[5], o->ev[0], o->ev[1]));
