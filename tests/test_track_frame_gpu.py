@@ -207,3 +207,22 @@ def test_track_frame_strided_image_and_bad_points():
     got = trk.track(view, K_TUM3, T, last["keys"], last["mp"], last["outlier"], pts, 15.0, 1.0)
     _compare(got, ref, "strided image")
     assert ref["nmatches_local"] > 20
+
+
+def test_single_queue_step_equals_stage_by_stage(tmp_path):
+    """rumi_track_frame queues its usual case (>= 20 matches, no list overflow) in one go and falls back to the stage-by-stage path otherwise.
+    Both paths must return the same step: feature budgets 500 / 1000 / 2000 (the last beyond the LDS form of the pose kernel), last frames with
+    many, fewer than 20 and no known points (tools/track_spec_check.py, once per path: the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dumps = []
+    for spec in ("0", "1"):
+        out = str(tmp_path / f"spec{spec}.npz")
+        env = dict(os.environ, RUMI_TRACK_SPECULATE=spec)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "track_spec_check.py"), out], check=True, env=env, timeout=600)
+        dumps.append(np.load(out))
+    a, b = dumps
+    assert set(a.files) == set(b.files) and len(a.files) > 300
+    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    assert not bad, f"the two paths differ in {bad[:8]}"
+    assert any(int(a[k]) < 20 for k in a.files if k.endswith("_nmatches_motion")) and any(int(a[k]) >= 20 for k in a.files if k.endswith("_nmatches_motion"))
