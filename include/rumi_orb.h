@@ -107,7 +107,7 @@ int rumi_orb_sync(RumiOrb *h);
  * The output buffers must be free too (no initialisation queued on `hip_stream`, no reader of their previous contents still running:
  * see rumi_orb_wait_event).  on = 1: four slots (sub-chunks / calls in flight), 2 .. 8: that many (short calls of 64-128 frames want
  * more of them in flight: each is one dependent chain of launches); the handle grows its device arenas to that many slots of
- * min(64, max_batch) frames.  With a resident queue the
+ * min(256, max_batch) frames (a call is cut into sub-chunks of at most 256 frames).  With a resident queue the
  * arenas keep the pyramid of a call's LAST sub-chunk only (rumi_orb_pyramid_level refuses other frames).  Off by default; switching waits
  * for pending calls. */
 int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on);

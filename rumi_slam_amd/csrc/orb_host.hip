@@ -252,7 +252,7 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
 }
 
 // The per-frame device arrays: candidate / quadtree scratch for `scratch` frames, pyramid and blurred levels for `arena` frames.  Called by
-// rumi_orb_create and again by rumi_orb_set_resident_queue when four 64-frame slots need more than the handle was created with.
+// rumi_orb_create and again by rumi_orb_set_resident_queue when the slots of the resident queue need more than the handle was created with.
 static int alloc_frame_arenas(RumiOrb *h, size_t scratch, size_t arena) {
     void *old[] = {h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart, h->dSelPacked, h->dSelMeta, h->dSelCount, h->dOwner, h->dSelLevel, h->dSelLevelCnt};
     for (void *p : old) if (p) (void)hipFree(p);
@@ -358,6 +358,12 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     return RUMI_OK;
 }
 
+// Frames per sub-chunk of the resident queue.  256 since the end of round 3 (64 before): with the latency-bound kernels of a sub-chunk's chain
+// shortened (compaction, quadtree) larger launches win at every call size (1024-frame steps +3 %, 128-frame calls +5 %); RUMI_RESIDENT_SUB overrides.
+static int resident_sub_frames() {
+    static const int v = std::getenv("RUMI_RESIDENT_SUB") ? std::max(1, std::atoi(std::getenv("RUMI_RESIDENT_SUB"))) : 256;
+    return v;
+}
 extern "C" int rumi_orb_set_profiling(RumiOrb *h, int32_t on) {
     if (!h) return RUMI_E_INVALID;
     h->profiling = on != 0;
@@ -367,10 +373,10 @@ extern "C" int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on) {
     if (!h) return RUMI_E_INVALID;
     if (h->pending) { const int rc = rumi_orb_sync(h); if (rc != RUMI_OK) return rc; }
     if (on) {
-        // `on` slots (1: the default of four) of up to 64 frames each: their scratch ranges and their ranges of the pyramid / blur arenas
+        // `on` slots (1: the default of four) of up to 256 frames each: their scratch ranges and their ranges of the pyramid / blur arenas
         const int slots = on == 1 ? 4 : std::min(std::max(on, 2), (int)RumiOrb::kMaxParts);
         h->residentSlots = slots;
-        const int need = (slots * std::min(64, h->cfg.max_batch) + 23) / 24 * 24;
+        const int need = (slots * std::min(resident_sub_frames(), h->cfg.max_batch) + 23) / 24 * 24;
         if (h->scratchFrames < need || h->arenaFrames < need) {
             HIP_TRY(hipSetDevice(h->device));
             HIP_TRY(hipDeviceSynchronize());
@@ -537,14 +543,14 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         return RUMI_OK;
     };
     if (resident) {
-        // Resident queue: FOUR fixed slots (stream, blur stream, scratch range, pyramid / blur arena range), sub-chunks of at most 64 frames
+        // Resident queue: FOUR fixed slots (stream, blur stream, scratch range, pyramid / blur arena range), sub-chunks of at most 256 frames
         // dealt to the slots round-robin ACROSS calls (a 64-frame call takes one slot, the next call the next one).  Everything a sub-chunk
         // touches on the device belongs to its slot, so stream order alone keeps consecutive users of a slot apart: no sub-chunk waits for
         // the caller's stream or for another slot -- except after a rumi_orb_sync, whose reset of the error word is queued on `st`.
         constexpr int kMaxSlots = RumiOrb::kMaxParts;
         const int kSlots = h->residentSlots;
         const int slotFrames = h->scratchFrames / kSlots;
-        const int cap64 = std::min(64, slotFrames);
+        const int cap64 = std::min(resident_sub_frames(), slotFrames);
         const int nsub = (nframes + cap64 - 1) / cap64, sub = (nframes + nsub - 1) / nsub;
         const bool fork = !h->pending || !h->lastResident;
         if (fork) HIP_TRY(hipEventRecord(h->evPartFork, st));
@@ -573,7 +579,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         // equal sub-chunks: rounds of `parts` sub-chunks, as few rounds as the slots allow, no short tail
         const int slotFrames = h->scratchFrames / parts;
         static const int envSub = std::getenv("RUMI_SUBMAX") ? std::atoi(std::getenv("RUMI_SUBMAX")) : 1 << 30;
-        const int subMax = std::max(1, std::min(slotFrames, envSub));
+        const int subMax = std::max(1, std::min(std::min(slotFrames, 64), envSub));      // (64: the host path's transfer groups; the arenas may hold more since the resident queue grew them)
         const int rounds = (nframes + parts * subMax - 1) / (parts * subMax), sub = (nframes + parts * rounds - 1) / (parts * rounds);
         HIP_TRY(hipEventRecord(h->evPartFork, st));
         int used = 0;

@@ -160,13 +160,13 @@ def test_async_batches_match_blocking_calls():
 @pytest.mark.gpu
 def test_resident_queue_calls_overlap_and_match_blocking_calls():
     """rumi_orb_set_resident_queue: sub-chunks never wait for the caller's stream, consecutive calls rotate through four slots and run side by
-    side.  Calls of different sizes (one, two and four sub-chunks, an odd size, a single frame) enqueued back to back, one sync at the end:
-    every call must equal what the ordinary blocking call gives; the taps serve the last sub-chunk."""
+    side.  Calls of different sizes (one sub-chunk, an odd size, a single frame, three sub-chunks: a call is cut at 256 frames) enqueued back to
+    back, one sync at the end: every call must equal what the ordinary blocking call gives; the taps serve the last sub-chunk."""
     import torch
     from rumi_slam_amd.synth import synth_batch
-    B = 200
+    B = 520
     g, _ = _pair(batch=B)
-    sizes = [64, 64, 128, 64, 200, 37, 1, 64, 128]
+    sizes = [64, 64, 128, 64, 200, 37, 1, 64, 520]
     batches = [torch.from_numpy(synth_batch(n, seed0=7000 + 50 * i)).cuda() for i, n in enumerate(sizes)]
     ref = []
     for fr in batches:
@@ -199,11 +199,11 @@ def test_resident_queue_calls_overlap_and_match_blocking_calls():
                 n = c[f, 0]
                 assert k[f, :n].tobytes() == ref[i][0][f, :n].tobytes(), f"round {rep} call {i} frame {f}: key-points"
                 assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"round {rep} call {i} frame {f}: descriptors"
-    # taps: the last call had two sub-chunks of 64; frame 127 is in the last one, frame 0 is not
-    lvl = g.pyramid_level(3, frame=127)
+    # taps: the last call had three sub-chunks of 174, 174 and 172 frames; frame 519 is in the last one, frame 0 is not
+    lvl = g.pyramid_level(3, frame=519)
     g.set_resident_queue(False)
     g.extract_batch(batches[-1])
-    assert np.array_equal(lvl, g.pyramid_level(3, frame=127))
+    assert np.array_equal(lvl, g.pyramid_level(3, frame=519))
     g.set_resident_queue(True)
     g.extract_batch(batches[-1], out=outs[-1])
     with pytest.raises(Exception):
