@@ -255,10 +255,11 @@ def main():
             k = self.i % self.nbuf
             self.i += 1
             if self.gather[k] is not None:                       # the exchange that still reads this set: its end and the matching's, as ONE event
-                with torch.cuda.stream(xchg_stream):             # (a stream that carries nothing else: no false dependency on later steps)
-                    self.gather[k].wait()
-                    xchg_stream.wait_event(self.consumed[k])
-                    self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(xchg_stream)
+                if self.gather[k]._work is not None:             # (a stream that carries nothing else: no false dependency on later steps)
+                    with torch.cuda.stream(xchg_stream):
+                        self.gather[k].wait()
+                xchg_stream.wait_event(self.consumed[k])
+                self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(xchg_stream)
                 self.gather[k] = None
             if self.consumed[k] is not None:
                 ext.wait_event(self.consumed[k])
