@@ -248,6 +248,8 @@ def main():
                              torch.zeros((n, 2), dtype=torch.int32, device=dev)) for _ in range(self.nbuf)]
             self.mout = [[torch.empty((n, cap), dtype=torch.int32, device=dev) for _ in range(3)] for _ in range(self.nbuf)]
             self.consumed = [None] * self.nbuf
+            self.ev_match = [torch.cuda.Event() for _ in range(self.nbuf)]       # (events are made once: creating two per step shows at 64 frames per step)
+            self.ev_join = [torch.cuda.Event() for _ in range(self.nbuf)]
             self.gather = [None] * self.nbuf
             torch.cuda.synchronize()
 
@@ -259,7 +261,7 @@ def main():
                     with torch.cuda.stream(xchg_stream):
                         self.gather[k].wait()
                 xchg_stream.wait_event(self.consumed[k])
-                self.consumed[k] = torch.cuda.Event(); self.consumed[k].record(xchg_stream)
+                self.ev_join[k].record(xchg_stream); self.consumed[k] = self.ev_join[k]
                 self.gather[k] = None
             if self.consumed[k] is not None:
                 ext.wait_event(self.consumed[k])
@@ -276,7 +278,7 @@ def main():
                 # (RCCL runs on its own stream) and joined when its buffer set comes round again, so it overlaps the next steps' kernels
                 self.gather[k] = rumination.all_gather_records_async(self.rec[k], self.n_queue, out=self.gbuf[k])
             m = match_pairs(desc, counts, self.mout[k])
-            self.consumed[k] = torch.cuda.Event(); self.consumed[k].record()
+            self.ev_match[k].record(); self.consumed[k] = self.ev_match[k]
             return kp, desc, counts, m
 
         def drain(self):
