@@ -569,109 +569,169 @@ __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatche
     return bin;
 }
 
+// wave-wide maximum / sum of one 32-bit value by DPP (row prefix, row_bcast:15, row_bcast:31; the total sits in lane 63)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define RUMI_DPP_MAX(ctl, rows) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctl, rows, 0xf, false))
+    RUMI_DPP_MAX(0x111, 0xf); RUMI_DPP_MAX(0x112, 0xf); RUMI_DPP_MAX(0x114, 0xf); RUMI_DPP_MAX(0x118, 0xf);
+    RUMI_DPP_MAX(0x142, 0xa); RUMI_DPP_MAX(0x143, 0xc);
+#undef RUMI_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#define RUMI_DPP_ADD(ctl, rows) v += __builtin_amdgcn_update_dpp(0, v, ctl, rows, 0xf, false)
+    RUMI_DPP_ADD(0x111, 0xf); RUMI_DPP_ADD(0x112, 0xf); RUMI_DPP_ADD(0x114, 0xf); RUMI_DPP_ADD(0x118, 0xf);
+    RUMI_DPP_ADD(0x142, 0xa); RUMI_DPP_ADD(0x143, 0xc);
+#undef RUMI_DPP_ADD
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One workgroup iterates "every query picks its best candidate among the features no EARLIER query holds" to its fixed point (the
+// result of the reference's sequential loop).  A round is latency, not work: what a round needs of a query -- count, the head of its
+// candidate list, the blocks flag, its current pick -- is read once into registers (the first kResQ queries of a thread, i.e. up to
+// 2048 queries; the rest go through global memory as before), the initial occupancy of a thread's features is a bit mask, and a
+// round is three barriers over LDS.
+constexpr int kResQ = 2, kResK = 4;
 __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
     extern __shared__ int32_t blockedFrom[];      // [nfeat] smallest blocking query index; -1 = taken before the call
-    __shared__ int sChanged, sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH], sCount;
+    __shared__ int sChanged[2], sHist[RUMI_HISTO_LENGTH], sKeep[RUMI_HISTO_LENGTH], sCount;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int kFree = 0x7FFFFFFF;
     if (A.nq > 0 && *A.overflow != 0) return;
-    for (int i = tid; i < A.nq; i += nt) A.assign[i] = -1;
-    if (tid < RUMI_HISTO_LENGTH) sHist[tid] = 0;
-    if (tid == 0) sCount = 0;
-    for (int round = 0; round <= A.nq + 1; round++) {
-        // occupancy as the previous round's assignments imply it
-        for (int f = tid; f < A.nfeat; f += nt) {
-            int b = kFree;
-            if (A.featBlocked0) { if (A.featBlocked0[f]) b = -1; }
-            else if (A.mode != MODE_BOW) {
-                const int id = A.featMp[f];
-                if (id >= 0 && A.mpObs[id] > 0) b = -1;
-            }
-            blockedFrom[f] = b;
+    // ---- read once ----
+    int cCnt[kResQ], cAsg[kResQ], cBlocks[kResQ];
+    const uint32_t *cList[kResQ];
+    uint32_t cHead[kResQ][kResK];
+#pragma unroll
+    for (int j = 0; j < kResQ; j++) {
+        const int i = tid + j * nt;
+        cCnt[j] = 0; cAsg[j] = -1; cBlocks[j] = 0; cList[j] = A.lists;
+        if (i < A.nq) { cCnt[j] = A.counts[i]; cList[j] = A.lists + A.offsets[i]; cBlocks[j] = A.q[i].blocks; }
+#pragma unroll
+        for (int k = 0; k < kResK; k++) cHead[j][k] = k < cCnt[j] ? cList[j][k] : 0u;
+    }
+    for (int i = tid + kResQ * nt; i < A.nq; i += nt) A.assign[i] = -1;
+    uint64_t taken0 = 0;                                                    // bit k: feature tid + k nt is taken before the call (nfeat <= 65536: list entries carry 16 bits)
+    {
+        int k = 0;
+        for (int f = tid; f < A.nfeat; f += nt, k++) {
+            bool t = false;
+            if (A.featBlocked0) t = A.featBlocked0[f] != 0;
+            else if (A.mode != MODE_BOW) { const int id = A.featMp[f]; t = id >= 0 && A.mpObs[id] > 0; }
+            taken0 |= (uint64_t)t << k;
+            blockedFrom[f] = t ? -1 : kFree;
         }
-        if (tid == 0) sChanged = 0;
-        __syncthreads();
-        for (int i = tid; i < A.nq; i += nt) {
+    }
+    if (tid < RUMI_HISTO_LENGTH) sHist[tid] = 0;
+    if (tid < 2) sChanged[tid] = 0;
+    if (tid == 0) sCount = 0;
+    auto pick_of = [&](int i, int cnt, const uint32_t *L, const uint32_t *head /* kResK entries in registers, or null */) -> int {
+        if (cnt <= 0) return -1;
+        int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
+        const bool sortedList = cnt <= kSortMax;                           // then entries come in (distance, candidate order)
+        bool done = false;
+        auto take = [&](uint32_t e) {
+            const int f = (int)(e & 0xFFFF);
+            if (blockedFrom[f] < i) return;                                 // taken by an earlier query (or before the call)
+            const int d = (int)((e >> 16) & 0x1FF), lv = (int)((e >> 25) & 15);
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = f; }
+            else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; done = sortedList; }
+            else done = sortedList;                                         // equal to the second best: nothing later can change either
+        };
+        int k = 0;
+        if (head) {
+#pragma unroll
+            for (int h = 0; h < kResK; h++) if (h < cnt && !done) take(head[h]);
+            k = kResK;
+        }
+        for (; k < cnt && !done; k++) take(L[k]);
+        int pick = -1;
+        if (A.mode == MODE_MAPPOINTS) {                                     // ORBmatcher.cc:106-111
+            if (bestDist <= RUMI_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) pick = bestIdx;
+        } else if (A.mode == MODE_FRAME) {                                  // :1577
+            if (bestDist <= RUMI_TH_HIGH) pick = bestIdx;
+        } else if (A.mode == MODE_BOW) {                                    // :283-285
+            if (bestDist <= RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
+        } else if (A.mode == MODE_BOW_KF) {                                 // :753-754
+            if (bestDist < RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
+        } else if (A.mode == MODE_SIM3) {                                   // :463 / :571
+            if ((float)bestDist <= A.thrF) pick = bestIdx;
+        } else if (A.mode == MODE_FUSE) {                                   // Fuse :1161 / :1277 (TH_LOW), SearchBySim3 :1399 / :1475 (TH_HIGH)
+            if (bestDist <= A.thrI) pick = bestIdx;
+        } else {                                                            // MODE_RELOC :1757
+            if (bestDist <= A.thrI) pick = bestIdx;
+        }
+        return pick;
+    };
+    for (int round = 0; round <= A.nq + 1; round++) {
+        __syncthreads();                                                    // occupancy reset (below, or the initial one above) visible
+        // occupancy as the previous round's assignments imply it
+#pragma unroll
+        for (int j = 0; j < kResQ; j++)
+            if (cAsg[j] >= 0 && cBlocks[j]) atomicMin(&blockedFrom[cAsg[j]], tid + j * nt);
+        for (int i = tid + kResQ * nt; i < A.nq; i += nt) {
             const int f = A.assign[i];
             if (f >= 0 && A.q[i].blocks) atomicMin(&blockedFrom[f], i);
         }
         __syncthreads();
         int changed = 0;
-        for (int i = tid; i < A.nq; i += nt) {
-            const int cnt = A.counts[i];
-            int pick = -1;
-            if (cnt > 0) {
-                const uint32_t *L = A.lists + A.offsets[i];
-                int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
-                const bool sortedList = cnt <= kSortMax;                // then entries come in (distance, candidate order)
-                for (int k = 0; k < cnt; k++) {
-                    const uint32_t e = L[k];
-                    const int f = (int)(e & 0xFFFF);
-                    if (blockedFrom[f] < i) continue;                  // taken by an earlier query (or before the call)
-                    const int d = (int)((e >> 16) & 0x1FF), lv = (int)((e >> 25) & 15);
-                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = f; }
-                    else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; if (sortedList) break; }
-                    else if (sortedList) break;                         // equal to the second best: nothing later can change either
-                }
-                if (A.mode == MODE_MAPPOINTS) {                         // ORBmatcher.cc:106-111
-                    if (bestDist <= RUMI_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) pick = bestIdx;
-                } else if (A.mode == MODE_FRAME) {                      // :1577
-                    if (bestDist <= RUMI_TH_HIGH) pick = bestIdx;
-                } else if (A.mode == MODE_BOW) {                        // :283-285
-                    if (bestDist <= RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
-                } else if (A.mode == MODE_BOW_KF) {                     // :753-754
-                    if (bestDist < RUMI_TH_LOW && (float)bestDist < A.nnratio * (float)bestDist2) pick = bestIdx;
-                } else if (A.mode == MODE_SIM3) {                       // :463 / :571
-                    if ((float)bestDist <= A.thrF) pick = bestIdx;
-                } else if (A.mode == MODE_FUSE) {                       // Fuse :1161 / :1277 (TH_LOW), SearchBySim3 :1399 / :1475 (TH_HIGH)
-                    if (bestDist <= A.thrI) pick = bestIdx;
-                } else {                                                // MODE_RELOC :1757
-                    if (bestDist <= A.thrI) pick = bestIdx;
-                }
-            }
+#pragma unroll
+        for (int j = 0; j < kResQ; j++) {
+            const int i = tid + j * nt;
+            if (i >= A.nq) continue;
+            const int pick = pick_of(i, cCnt[j], cList[j], cHead[j]);
+            if (pick != cAsg[j]) { changed = 1; cAsg[j] = pick; }
+        }
+        for (int i = tid + kResQ * nt; i < A.nq; i += nt) {
+            const int pick = pick_of(i, A.counts[i], A.lists + A.offsets[i], nullptr);
             if (pick != A.assign[i]) { changed = 1; A.assign[i] = pick; }
         }
-        if (changed) sChanged = 1;
+        if (changed) sChanged[round & 1] = 1;
         __syncthreads();
-        const int any = sChanged;
-        __syncthreads();
+        const int any = sChanged[round & 1];
+        if (tid == 0) sChanged[(round + 1) & 1] = 0;                        // last read before this round's barriers, next written after the next round's
         if (!any) break;
+        int k = 0;
+        for (int f = tid; f < A.nfeat; f += nt, k++) blockedFrom[f] = ((taken0 >> k) & 1) ? -1 : kFree;
     }
+#pragma unroll
+    for (int j = 0; j < kResQ; j++) { const int i = tid + j * nt; if (i < A.nq) A.assign[i] = cAsg[j]; }
     // results: a feature keeps the LAST query that assigned it (later assignments overwrite, as in the loop)
     int32_t *last = blockedFrom;                                        // reuse LDS: last assigning query per feature
     for (int f = tid; f < A.nfeat; f += nt) last[f] = -1;
     __syncthreads();
     const bool useHist = A.checkOri && A.mode != MODE_MAPPOINTS && A.mode != MODE_SIM3;
     int local = 0;
-    for (int i = tid; i < A.nq; i += nt) {
-        const int f = A.assign[i];
+    auto assigned = [&](int i, int j) { return j == 0 ? cAsg[0] : j == 1 ? cAsg[1] : A.assign[i]; };
+    static_assert(kResQ == 2, "assigned() spells the register copies out");
+    for (int i = tid, j = 0; i < A.nq; i += nt, j++) {
+        const int f = assigned(i, j);
         if (f < 0) continue;
         local++;
         atomicMax(&last[f], i);
         if (useHist) atomicAdd(&sHist[rot_bin(A.q[i].angle, A.featKeys[f].angle)], 1);
     }
-    atomicAdd(&sCount, local);
+    if (local) atomicAdd(&sCount, local);
     __syncthreads();
-    if (tid == 0) {
-        for (int i = 0; i < RUMI_HISTO_LENGTH; i++) sKeep[i] = 1;
-        if (useHist) {                                                   // ComputeThreeMaxima, ORBmatcher.cc:1795-1826
-            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
-                const int s = sHist[i];
-                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-                else if (s > max3) { max3 = s; ind3 = i; }
-            }
+    if (tid < 64) {                                                      // ComputeThreeMaxima, ORBmatcher.cc:1795-1826, by the lanes of one wave:
+        // the scan with its strict comparisons keeps the three largest counts ordered by (count descending, bin ascending); empty bins never enter
+        const int s = tid < RUMI_HISTO_LENGTH ? sHist[tid] : 0;
+        int keep = 1, removed = 0;
+        if (useHist) {
+            uint32_t key = s > 0 ? ((uint32_t)s << 6) | (uint32_t)(63 - tid) : 0u;
+            const uint32_t k1 = wave_max_u32(key);
+            if (key == k1) key = 0;
+            const uint32_t k2 = wave_max_u32(key);
+            if (key == k2) key = 0;
+            const uint32_t k3 = wave_max_u32(key);
+            const int max1 = (int)(k1 >> 6), max2 = (int)(k2 >> 6), max3 = (int)(k3 >> 6);
+            int ind1 = k1 ? 63 - (int)(k1 & 63) : -1, ind2 = k2 ? 63 - (int)(k2 & 63) : -1, ind3 = k3 ? 63 - (int)(k3 & 63) : -1;
             if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
             else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
-            int removed = 0;
-            for (int i = 0; i < RUMI_HISTO_LENGTH; i++) {
-                sKeep[i] = (i == ind1 || i == ind2 || i == ind3);
-                if (!sKeep[i]) removed += sHist[i];
-            }
-            sCount -= removed;
+            keep = (tid == ind1 || tid == ind2 || tid == ind3);
+            removed = wave_sum_i32(keep ? 0 : s);
         }
-        *A.nmatches = sCount;
+        if (tid < RUMI_HISTO_LENGTH) sKeep[tid] = keep;
+        if (tid == 0) *A.nmatches = sCount - removed;
     }
     __syncthreads();
     // MODE_BOW starts from an all-NULL vector (ORBmatcher.cc:201); the other modes update the frame's vector in place
@@ -683,8 +743,8 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
             if (last[f] >= 0) A.featMp[f] = A.q[last[f]].mpId;
     __syncthreads();
     if (useHist)                                                        // entries of the rejected bins are set to NULL
-        for (int i = tid; i < A.nq; i += nt) {
-            const int f = A.assign[i];
+        for (int i = tid, j = 0; i < A.nq; i += nt, j++) {
+            const int f = assigned(i, j);
             if (f >= 0 && !sKeep[rot_bin(A.q[i].angle, A.featKeys[f].angle)]) {
                 if (A.mode == MODE_BOW_KF) A.assign[i] = -1;           // SearchByBoW(KF,KF) reports per QUERY (vpMatches12[idx1])
                 else A.featMp[f] = -1;
