@@ -58,6 +58,15 @@ __device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t *d
     return s;
 }
 
+// inclusive prefix sum over the lanes of a wave by DPP (row prefix, row_bcast:15, row_bcast:31); lane 63 holds the total
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+#define RUMI_DPP_ADD(ctl, rows) v += __builtin_amdgcn_update_dpp(0, v, ctl, rows, 0xf, false)
+    RUMI_DPP_ADD(0x111, 0xf); RUMI_DPP_ADD(0x112, 0xf); RUMI_DPP_ADD(0x114, 0xf); RUMI_DPP_ADD(0x118, 0xf);
+    RUMI_DPP_ADD(0x142, 0xa); RUMI_DPP_ADD(0x143, 0xc);
+#undef RUMI_DPP_ADD
+    return v;
+}
+
 // ---- 1. grid -----------------------------------------------------------------------------------------------
 // Frame::AssignFeaturesToGrid as a counting sort by cell (cell = column-major ix*48+iy, the order GetFeaturesInArea walks),
 // ascending key-point index inside a cell (= push_back order).  One workgroup; the per-cell segments (a handful of entries) are
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__rest
     if (nDev) n = min(n, *nDev);
     __shared__ int32_t sCnt[kGridCells + 1];
     __shared__ uint16_t sCell[kMaxSortN], sOut[kMaxSortN];
-    __shared__ int32_t sPart[1024];
+    __shared__ int32_t sWave[16];
     const int tid = threadIdx.x;
     for (int c = tid; c <= kGridCells; c += 1024) sCnt[c] = 0;
     __syncthreads();
@@ -81,26 +90,24 @@ __global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__rest
         sCell[i] = cell;
     }
     __syncthreads();
-    // exclusive scan of the 3072 counts: 3 cells per thread + block scan of the partial sums
+    // exclusive scan of the 3072 counts: 3 cells per thread, a DPP scan inside each wave, the 16 wave totals through LDS (one barrier)
     constexpr int kPer = (kGridCells + 1023) / 1024;
     int loc[kPer], sum = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) { const int c = tid * kPer + k; loc[k] = c < kGridCells ? sCnt[c] : 0; sum += loc[k]; }
-    sPart[tid] = sum;
+    const int incl = wave_scan_incl_i32(sum);
+    if ((tid & 63) == 63) sWave[tid >> 6] = incl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? sPart[tid - o] : 0;
-        __syncthreads();
-        sPart[tid] += v;
-        __syncthreads();
-    }
-    int run = sPart[tid] - sum;
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int t = sWave[w]; total += t; if (w < (tid >> 6)) before += t; }
+    int run = before + incl - sum;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         const int c = tid * kPer + k;
         if (c < kGridCells) { cellStart[c] = run; sCnt[c] = run; run += loc[k]; }
     }
-    if (tid == 1023) cellStart[kGridCells] = sPart[1023];
+    if (tid == 1023) cellStart[kGridCells] = total;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const uint16_t cell = sCell[i];
@@ -121,8 +128,7 @@ __global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__rest
         }
     }
     __syncthreads();
-    const int valid = sPart[1023];
-    for (int i = tid; i < valid; i += 1024) sortedIdx[i] = sOut[i];
+    for (int i = tid; i < total; i += 1024) sortedIdx[i] = sOut[i];
 }
 
 // ---- 2. queries ----------------------------------------------------------------------------------------------
@@ -461,6 +467,27 @@ __device__ __forceinline__ int candidates_walk(int mode, const Query &Q, const F
     return count;
 }
 
+// bitonic sort of one wave's (key, val) pairs in LDS by key, then the values to `out`
+__device__ __forceinline__ void wave_bitonic_store(uint32_t *key, uint32_t *val, int total, uint32_t *out, int lane) {
+    int m = 1;
+    while (m < total) m <<= 1;
+    for (int i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
+    wave_lds_fence();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (m >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const uint32_t a = key[i], b = key[l];
+                if ((a > b) == ((i & k) == 0)) {
+                    key[i] = b; key[l] = a;
+                    const uint32_t va = val[i]; val[i] = val[l]; val[l] = va;
+                }
+            }
+            wave_lds_fence();
+        }
+    for (int i = lane; i < total; i += 64) out[i] = val[i];
+}
+
 // PASS 0: count pass (counts[q]).  PASS 1: fill pass at the offsets a scan of the counts produced.  PASS 2: both in one launch, every query's list
 // in a fixed slot of `listCap` entries (offsets[q] = q * listCap written here): two dispatches (~4.5 us each) less per search; a query with more
 // candidates than a slot raises kFusedOverflow and the host repeats the search with passes 0 / scan / 1.
@@ -488,6 +515,92 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
     uint32_t *key = sKey + (threadIdx.x >> 6) * kSortMax, *val = sVal + (threadIdx.x >> 6) * kSortMax;
     uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int total = 0;
+    if (PASS == 2 && mode != MODE_BOW && mode != MODE_BOW_KF) {
+        // The usual search of the Tracking thread (a window of a few grid columns, a handful of candidates) as ONE dependent chain
+        // instead of two walks of four loads per column: the cell ranges of all columns at once (one lane each), the window's
+        // feature slots flat over the lanes (slot -> column by the prefix of the range lengths: the reference's candidate order),
+        // key-point and descriptor of every slot fetched together, and up to 64 candidates ranked in registers.
+        const int nMinCellX = max(0, (int)floorf((Q.u - F.minX - Q.r) * F.wInv));
+        const int nMaxCellX = min(kGridCols - 1, (int)ceilf((Q.u - F.minX + Q.r) * F.wInv));
+        const int nMinCellY = max(0, (int)floorf((Q.v - F.minY - Q.r) * F.hInv));
+        const int nMaxCellY = min(kGridRows - 1, (int)ceilf((Q.v - F.minY + Q.r) * F.hInv));
+        int ncol = 0;
+        if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0 && nMaxCellY >= nMinCellY) ncol = max(0, nMaxCellX - nMinCellX + 1);
+        int c0 = 0, len = 0;
+        if (lane < ncol) {
+            const int cell = (nMinCellX + lane) * kGridRows;
+            c0 = F.cellStart[cell + nMinCellY];
+            len = F.cellStart[cell + nMaxCellY + 1] - c0;
+        }
+        const uint32_t qmine = reinterpret_cast<const uint32_t *>(qDesc + (size_t)Q.descId * 32)[lane & 7];
+        const int incl = wave_scan_incl_i32(len);
+        const int T = __builtin_amdgcn_readlane(incl, 63);
+        if (T <= kSortMax) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) qd[k] = __shfl(qmine, k);
+            const bool checkLevels = Q.minLevel > 0 || Q.maxLevel >= 0;
+            uint32_t *out = lists + qi * listCap;
+            int count = 0;
+            uint32_t myKey = 0xFFFFFFFFu, myVal = 0;
+            unsigned long long b = 0;
+            for (int base = 0; base < T; base += 64) {
+                const int sl = base + lane;
+                const bool live = sl < T;
+                int col = 0;
+                for (int c = 0; c < ncol; c++) col += __builtin_amdgcn_readlane(incl, c) <= sl;
+                const int cc = live ? col : 0;
+                const int p = __shfl(c0, cc) + (sl - (__shfl(incl, cc) - __shfl(len, cc)));
+                bool pass = false;
+                int idx = 0, oct = 0, d = 0;
+                if (live) {
+                    idx = F.sortedIdx[p];
+                    const RumiKeyPoint kp = F.keys[idx];
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(F.desc + (size_t)idx * 32);
+                    const uint4 d0 = dp[0], d1 = dp[1];
+                    oct = kp.octave;
+                    pass = true;
+                    if (checkLevels) {
+                        if (oct < Q.minLevel) pass = false;
+                        if (Q.maxLevel >= 0 && oct > Q.maxLevel) pass = false;
+                    }
+                    const float dx = kp.x - Q.u, dy = kp.y - Q.v;
+                    if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) pass = false;
+                    if (mode == MODE_FUSE && Q.c0 && pass) {                        // mono reprojection gate, ORBmatcher.cc:1138-1145
+                        const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                        const float e2 = ex * ex + ey * ey;
+                        const float s2 = F.scale[oct] * F.scale[oct];              // mvLevelSigma2; mvInvLevelSigma2 = 1.0f / it
+                        if ((double)(e2 * (1.0f / s2)) > 5.99) pass = false;
+                    }
+                    d = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                        __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                }
+                b = __ballot(pass);
+                if (pass) {
+                    const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+                    myKey = ((uint32_t)d << 10) | (uint32_t)pos;
+                    myVal = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(oct & 15) << 25);
+                    if (T > 64) { key[pos] = myKey; val[pos] = myVal; }
+                }
+                count += __popcll(b);
+            }
+            if (lane == 0) counts[qi] = count;
+            if (count > listCap) {
+                if (lane == 0) atomicExch(overflow, kFusedOverflow);
+                return;
+            }
+            if (T <= 64) {                                                  // one trip: rank among the passing lanes (keys are distinct)
+                int rank = 0;
+                for (unsigned long long bb = b; bb; bb &= bb - 1) {
+                    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)myKey, __builtin_ctzll(bb));
+                    rank += kj < myKey;
+                }
+                if (myKey != 0xFFFFFFFFu) out[rank] = myVal;
+            } else if (count > 0) {
+                wave_bitonic_store(key, val, count, out, lane);
+            }
+            return;
+        }
+    }
     if (PASS == 0 || PASS == 2) {
         total = candidates_walk<false>(mode, Q, F, qd, fvIdx, false, nullptr, key, val, lane);
         if (lane == 0) counts[qi] = total;
@@ -506,25 +619,7 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
     }
     uint32_t *out = lists + offsets_of<PASS>(offsets, qi, listCap);
     candidates_walk<true>(mode, Q, F, qd, fvIdx, sorted, out, key, val, lane);
-    if (sorted && total > 0) {
-        int m = 1;
-        while (m < total) m <<= 1;
-        for (int i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
-        wave_lds_fence();
-        for (int k = 2; k <= m; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = lane; t < (m >> 1); t += 64) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                    const uint32_t a = key[i], b = key[l];
-                    if ((a > b) == ((i & k) == 0)) {
-                        key[i] = b; key[l] = a;
-                        const uint32_t va = val[i]; val[i] = val[l]; val[l] = va;
-                    }
-                }
-                wave_lds_fence();
-            }
-        for (int i = lane; i < total; i += 64) out[i] = val[i];
-    }
+    if (sorted && total > 0) wave_bitonic_store(key, val, total, out, lane);
 }
 
 // exclusive scan of counts -> offsets (single workgroup; nq is a few thousand)
@@ -577,13 +672,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #undef RUMI_DPP_MAX
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#define RUMI_DPP_ADD(ctl, rows) v += __builtin_amdgcn_update_dpp(0, v, ctl, rows, 0xf, false)
-    RUMI_DPP_ADD(0x111, 0xf); RUMI_DPP_ADD(0x112, 0xf); RUMI_DPP_ADD(0x114, 0xf); RUMI_DPP_ADD(0x118, 0xf);
-    RUMI_DPP_ADD(0x142, 0xa); RUMI_DPP_ADD(0x143, 0xc);
-#undef RUMI_DPP_ADD
-    return __builtin_amdgcn_readlane(v, 63);
-}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_incl_i32(v), 63); }
 
 // One workgroup iterates "every query picks its best candidate among the features no EARLIER query holds" to its fixed point (the
 // result of the reference's sequential loop).  A round is latency, not work: what a round needs of a query -- count, the head of its
