@@ -142,6 +142,16 @@ struct PoseArgs {
 
 // LDS = true (frames of up to kPoseLdsEdges correspondences): the edge data, the active flags and the last chi2 of every edge
 // live in LDS for the whole solve, so none of the ~60 passes over the edges waits for global memory.
+// (-DRUMI_POSE_STAMP, tools/build_stamp_lib.sh: every wave of frame 0 prints where its cycles went)
+#ifdef RUMI_POSE_STAMP
+#define POSE_STAMP_DECL long long stT = clock64(), stSerial = 0, stPass = 0, stRed = 0, stChi = 0, stOther = 0; int stN = 0, stTr = 0
+#define POSE_STAMP(acc) do { const long long now_ = clock64(); acc += now_ - stT; stT = now_; } while (0)
+#define POSE_COUNT(c) c++
+#else
+#define POSE_STAMP_DECL
+#define POSE_STAMP(acc)
+#define POSE_COUNT(c)
+#endif
 constexpr int kPoseLdsEdges = 1152;          // (nfeatures 1000 + the extractor's slack of 96 fits: the tracker then needs no count to choose the instantiation)
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     DSE3 T = T0;
     bool robust = true;
     int nBadRound = 0;
+    POSE_STAMP_DECL;
 
     auto edge_chi2 = [&](int i, const DSE3 &P, double &e0, double &e1, D3 &pc) -> double {
         pc = se3_map(P, D3{(double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2]});
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
             for (int itl = 0; itl < 10; itl++) {
                 // computeActiveErrors + activeRobustChi2 and buildSystem evaluate every edge at the same estimate: one pass, the
                 // robust chi2 rides along as the 28th reduced value (same per-edge values, same reduction tree as robust_chi2)
+                POSE_STAMP(stSerial);
                 double hb[28];                                             // 21 upper entries of H, 6 of b, robust chi2
 #pragma unroll
                 for (int k = 0; k < 28; k++) hb[k] = 0;
@@ -234,7 +246,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                     for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
                 }
+                POSE_STAMP(stPass);
                 block_sum_butterfly<28, NW>(hb, red);
+                POSE_STAMP(stRed); POSE_COUNT(stN);
                 double currentChi = hb[27];
                 const double iniChi = currentChi;
                 if (itl == 0) {                                            // computeLambdaInit: tau * max |H_jj|
@@ -250,7 +264,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     double x[6];
                     const bool ok2 = chol6_solve(hb, lambda, hb + 21, x);   // setLambda + solve + restoreDiagonal
                     if (ok2) T = se3_mul(se3_exp(x), T);                    // oplusImpl: exp(update) * estimate
+                    POSE_STAMP(stSerial); POSE_COUNT(stTr);
                     double tempChi = robust_chi2(T);
+                    POSE_STAMP(stChi);
                     if (!ok2) tempChi = DBL_MAX;
                     rho = currentChi - tempChi;
                     double scale = 0;
@@ -289,6 +305,10 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         if (it == 2) robust = false;                                       // setRobustKernel(0)
         if (n < 10) break;                                                 // optimizer.edges().size() < 10
     }
+#ifdef RUMI_POSE_STAMP
+    POSE_STAMP(stOther);
+    if (b == 0 && (tid & 63) == 0) printf("pose stamp wave %d n %d builds %d trials %d: serial %lld  build passes %lld  butterfly %lld  chi2 passes+reduce %lld  other %lld\n", tid >> 6, n, stN, stTr, stSerial, stPass, stRed, stChi, stOther);
+#endif
     if (tid == 0) {
         se3_to_float7(T, A.Tout + (size_t)b * 7);
         A.nGood[b] = n - nBadRound;

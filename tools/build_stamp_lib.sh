@@ -10,3 +10,6 @@ F="-O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx
 /opt/rocm/bin/hipcc $F -DRUMI_OCT_STAMP -c orb_octree_kernel.hip -o /tmp/oct_stamp.o
 /opt/rocm/bin/hipcc $F -DRUMI_OD_STAMP -c orb_kernels.hip -o /tmp/orbk_stamp.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_stamp.so /tmp/oct_stamp.o /tmp/orbk_stamp.o $(ls *.o | grep -v -e orb_octree_kernel -e orb_kernels) -lpthread
+# k_pose_opt (-DRUMI_POSE_STAMP: one printf per wave of frame 0): ... && python tools/with_lib.py tools/bin/librumi_hip_pose_stamp.so tools/pose_probe.py
+/opt/rocm/bin/hipcc $F -DRUMI_POSE_STAMP -c opt.hip -o /tmp/opt_stamp.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_pose_stamp.so /tmp/opt_stamp.o $(ls *.o | grep -v -e '^opt.o') -lpthread

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #define CHAIN4(INS) \
@@ -36,6 +37,7 @@ enum Op {
     OR_B32, SUB_U32, LSHLREV, LSHRREV, ASHRREV, MOV_B32, NOT_B32, MUL_F32, MAX_F32, MIN_F32, MAX_U32, MIN_U32, MAX_I32, MIN_U16, SUB_U16, MUL_U32_U24, FMAC_F32,
     BFE_U32, AND_OR_B32, OR3_B32, LSHL_ADD_U32, XAD_U32, BFI_B32, MED3_I32, MAX3_U32, MUL_HI_U32, CVT_F32_I32, CNDMASK_S, CMP_GT_U32_S, CMP_GT_F32,
     SDWA_SUB_U32_BYTES, SDWA_ADD_U32_W1, SDWA_AND_BYTE, SDWA_MIN_U16_BYTES, SDWA_MAX_I32_WORDS, SDWA_SUB_F32, SDWA_CVT_UBYTE, SDWA_MOV_W1, SDWA_CMP_BYTES, DPP_MOV_SHR1, DPP_ADD_SHR1, DPP_MOV_BCAST, READLANE,
+    FMA_F64, MUL_F64, ADD_F64, FMA_F64_DEP, RSQ_F64, RCP_F64,
     DS_READ_U8, DS_READ_U8_D16_HI, DS_READ_B32, DS_READ_B64, DS_READ_B32_MIS1, DS_READ_B64_MIS1, DS_READ_B64_MIS4, DS_READ_B32_STRIDE5, DS_READ_B64_STRIDE7, NOPS
 };
 
@@ -140,6 +142,12 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned *out, unsign
             if (OP == DPP_ADD_SHR1) asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %1, %2, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %2, %3, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
             if (OP == DPP_MOV_BCAST) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
             if (OP == READLANE) asm volatile("v_readlane_b32 s20, %0, 3\n\tv_readlane_b32 s21, %1, 5\n\tv_readlane_b32 s22, %2, 7\n\tv_readlane_b32 s23, %3, 9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "s20", "s21", "s22", "s23");
+            if (OP == FMA_F64) CHAIN4_P3("v_fma_f64")
+            if (OP == MUL_F64) CHAIN4_P2("v_mul_f64")
+            if (OP == ADD_F64) CHAIN4_P2("v_add_f64")
+            if (OP == FMA_F64_DEP) asm volatile("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(A) : "v"(E), "v"(F));
+            if (OP == RSQ_F64) asm volatile("v_rsq_f64 %0, %0\n\tv_rsq_f64 %1, %1\n\tv_rsq_f64 %2, %2\n\tv_rsq_f64 %3, %3" : "+v"(A), "+v"(B), "+v"(C), "+v"(D));
+            if (OP == RCP_F64) asm volatile("v_rcp_f64 %0, %0\n\tv_rcp_f64 %1, %1\n\tv_rcp_f64 %2, %2\n\tv_rcp_f64 %3, %3" : "+v"(A), "+v"(B), "+v"(C), "+v"(D));
             if (OP == DS_READ_U8) LDS4("ds_read_u8")
             if (OP == DS_READ_U8_D16_HI) LDS4("ds_read_u8_d16_hi")
             if (OP == DS_READ_B32) LDS4("ds_read_b32")
@@ -183,8 +191,14 @@ template <int OP> void run(const char *name, int lanesNote = 0) {
     std::printf("\n");
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
+    if (argc > 1 && std::string(argv[1]) == "f64") {                        // the double-precision rows alone (the optimiser kernels)
+        std::printf("# tools/valu_rate.hip f64 on %s: cycles per wave64 instruction and SIMD at 1 / 2 / 4 / 8 resident waves per SIMD (four independent chains per lane; 'dep' = one chain)\n", p.gcnArchName);
+        run<FMA_F32>("v_fma_f32 (control)"); run<FMA_F64>("v_fma_f64"); run<MUL_F64>("v_mul_f64"); run<ADD_F64>("v_add_f64"); run<FMA_F64_DEP>("v_fma_f64 dep");
+        run<RSQ_F64>("v_rsq_f64"); run<RCP_F64>("v_rcp_f64");
+        return 0;
+    }
     std::printf("# tools/valu_rate.hip on %s (%s), %d CUs, clockRate %d kHz\n", p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate);
     std::printf("# cycles per wave64 instruction and SIMD at 1 / 2 / 4 / 8 resident waves per SIMD; 'wall' = HIP-event time priced at 2.4 GHz over 1024 SIMDs,\n");
     std::printf("# 'tick' = the median wave's own s_memtime delta / instructions / waves per SIMD (clock-independent).  LDS rows: per SIMD, so a CU's LDS serves 4x that rate.\n");
