@@ -99,31 +99,6 @@ template <int NV, int NW = 4> __device__ __forceinline__ void block_sum_butterfl
     for (int k = 0; k < NV; k++) v[k] = red[NW * PAD + k];
 }
 
-template <int N> __device__ __forceinline__ bool chol_solve_packed(const double *H /*upper N(N+1)/2, row-major packed*/, double lambda, const double *b, double *x) {
-    double A[N][N];
-    int p = 0;
-    for (int i = 0; i < N; i++)
-        for (int j = i; j < N; j++) { A[i][j] = H[p]; A[j][i] = H[p]; p++; }
-    for (int i = 0; i < N; i++) A[i][i] += lambda;
-    double rd[N];                                          // reciprocals of the factor's diagonal (m_rsqrt: no IEEE divide / square root here)
-    for (int j = 0; j < N; j++) {
-        double d = A[j][j];
-        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
-        if (!(d > 0) || !isfinite(d)) return false;
-        rd[j] = m_rsqrt(d);
-        A[j][j] = d * rd[j];
-        for (int i = j + 1; i < N; i++) {
-            double s = A[i][j];
-            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
-            A[i][j] = s * rd[j];
-        }
-    }
-    double y[N];
-    for (int i = 0; i < N; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i][k] * y[k]; y[i] = s * rd[i]; }
-    for (int i = N - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < N; k++) s -= A[k][i] * x[k]; x[i] = s * rd[i]; }
-    return true;
-}
-__device__ __forceinline__ bool chol6_solve(const double *H, double lambda, const double *b, double *x) { return chol_solve_packed<6>(H, lambda, b, x); }
 
 // ==================================================================================================================
 // PoseOptimization
@@ -140,6 +115,8 @@ struct PoseArgs {
     int skipSmall;        // the global-memory instantiation leaves the frames the LDS instantiation solves
 };
 
+// (compiled with floating-point contraction, on rumi::fused's copy of the math: opt_math.h says why)
+#pragma clang fp contract(fast)
 // LDS = true (frames of up to kPoseLdsEdges correspondences): the edge data, the active flags and the last chi2 of every edge
 // live in LDS for the whole solve, so none of the ~60 passes over the edges waits for global memory.
 // (-DRUMI_POSE_STAMP, tools/build_stamp_lib.sh: every wave of frame 0 prints where its cycles went)
@@ -179,31 +156,31 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         if (tid < 7) A.Tout[(size_t)b * 7 + tid] = A.Tin[(size_t)b * 7 + tid];
         return;
     }
-    const DCam cam{A.K4[0], A.K4[1], A.K4[2], A.K4[3]};
+    const fused::DCam cam{A.K4[0], A.K4[1], A.K4[2], A.K4[3]};
     const double delta = (double)(float)sqrt(5.991), dsqr = delta * delta;  // const float deltaMono = sqrt(5.991)
-    const DSE3 T0 = se3_from_float7(A.Tin + (size_t)b * 7);
-    DSE3 T = T0;
+    const fused::DSE3 T0 = fused::se3_from_float7(A.Tin + (size_t)b * 7);
+    fused::DSE3 T = T0;
     bool robust = true;
     int nBadRound = 0;
     POSE_STAMP_DECL;
 
-    auto edge_chi2 = [&](int i, const DSE3 &P, double &e0, double &e1, D3 &pc) -> double {
-        pc = se3_map(P, D3{(double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2]});
+    auto edge_chi2 = [&](int i, const fused::DSE3 &P, double &e0, double &e1, fused::D3 &pc) -> double {
+        pc = fused::se3_map(P, fused::D3{(double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2]});
         double u, v;
-        cam_project(cam, pc, u, v);
+        fused::cam_project(cam, pc, u, v);
         e0 = (double)obs[2 * i] - u; e1 = (double)obs[2 * i + 1] - v;
         const double w = (double)wgt[i];
         return e0 * w * e0 + e1 * w * e1;
     };
-    auto robust_chi2 = [&](const DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
+    auto robust_chi2 = [&](const fused::DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
         double acc[1] = {0};
         for (int i = tid; i < n; i += NT) {
             if (!active[i]) continue;
-            double e0, e1; D3 pc;
+            double e0, e1; fused::D3 pc;
             const double c = edge_chi2(i, P, e0, e1, pc);
             lastChi2[i] = c;
             double r0 = c, r1 = 1;
-            if (robust) huber(c, delta, dsqr, r0, r1);
+            if (robust) fused::huber(c, delta, dsqr, r0, r1);
             acc[0] += r0;
         }
         block_sum<1, NW>(acc, red);
@@ -228,14 +205,14 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                 for (int k = 0; k < 28; k++) hb[k] = 0;
                 for (int i = tid; i < n; i += NT) {
                     if (!active[i]) continue;
-                    double e0, e1; D3 pc;
+                    double e0, e1; fused::D3 pc;
                     const double c = edge_chi2(i, T, e0, e1, pc);
                     lastChi2[i] = c;
                     double r0 = c, r1 = 1;
-                    if (robust) huber(c, delta, dsqr, r0, r1);
+                    if (robust) fused::huber(c, delta, dsqr, r0, r1);
                     hb[27] += r0;
                     double J0[6], J1[6];
-                    jac_pose(cam, pc, J0, J1);
+                    fused::jac_pose(cam, pc, J0, J1);
                     const double w = (double)wgt[i], rw = r1 * w;
                     int p = 0;
 #pragma unroll
@@ -260,10 +237,10 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                 double rho = 0;
                 int qmax = 0;
                 do {
-                    const DSE3 saved = T;                                  // push()
+                    const fused::DSE3 saved = T;                                  // push()
                     double x[6];
-                    const bool ok2 = chol6_solve(hb, lambda, hb + 21, x);   // setLambda + solve + restoreDiagonal
-                    if (ok2) T = se3_mul(se3_exp(x), T);                    // oplusImpl: exp(update) * estimate
+                    const bool ok2 = fused::chol_solve_packed<6>(hb, lambda, hb + 21, x);   // setLambda + solve + restoreDiagonal
+                    if (ok2) T = fused::se3_mul(fused::se3_exp(x), T);                    // oplusImpl: exp(update) * estimate
                     POSE_STAMP(stSerial); POSE_COUNT(stTr);
                     double tempChi = robust_chi2(T);
                     POSE_STAMP(stChi);
@@ -295,7 +272,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         // re-classification (:916-939): former outliers get a fresh error, active edges keep the last computed one
         double bad[1] = {0};
         for (int i = tid; i < n; i += NT) {
-            double e0, e1; D3 pc;
+            double e0, e1; fused::D3 pc;
             const float chi2 = (float)(outlier[i] ? edge_chi2(i, T, e0, e1, pc) : lastChi2[i]);
             if (chi2 > 5.991f) { outlier[i] = 1; active[i] = 0; bad[0] += 1; }
             else { outlier[i] = 0; active[i] = 1; }
@@ -310,10 +287,12 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     if (b == 0 && (tid & 63) == 0) printf("pose stamp wave %d n %d builds %d trials %d: serial %lld  build passes %lld  butterfly %lld  chi2 passes+reduce %lld  other %lld\n", tid >> 6, n, stN, stTr, stSerial, stPass, stRed, stChi, stOther);
 #endif
     if (tid == 0) {
-        se3_to_float7(T, A.Tout + (size_t)b * 7);
+        fused::se3_to_float7(T, A.Tout + (size_t)b * 7);
         A.nGood[b] = n - nBadRound;
     }
 }
+
+#pragma clang fp contract(off)
 
 // ==================================================================================================================
 // LocalBundleAdjustment
