@@ -218,10 +218,15 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
 #pragma unroll
-                        for (int c2 = a; c2 < 6; c2++) hb[p++] += rw * (J0[a] * J0[c2] + J1[a] * J1[c2]);
+                        for (int c2 = a; c2 < 6; c2++, p++) {
+                            // J0[4] and J1[3] are zero by construction (jac_pose): their products are left out, H[3][4] stays 0
+                            const bool z0 = a == 4 || c2 == 4, z1 = a == 3 || c2 == 3;
+                            if (z0 && z1) continue;
+                            hb[p] += rw * (z0 ? J1[a] * J1[c2] : z1 ? J0[a] * J0[c2] : J0[a] * J0[c2] + J1[a] * J1[c2]);
+                        }
                     }
 #pragma unroll
-                    for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (J0[a] * w * e0 + J1[a] * w * e1);
+                    for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (a == 4 ? J1[a] * w * e1 : a == 3 ? J0[a] * w * e0 : J0[a] * w * e0 + J1[a] * w * e1);
                 }
                 POSE_STAMP(stPass);
                 block_sum_butterfly<28, NW>(hb, red);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     const fused::DSE3 saved = T;                                  // push()
                     double x[6];
                     const bool ok2 = fused::chol_solve_packed<6>(hb, lambda, hb + 21, x);   // setLambda + solve + restoreDiagonal
-                    if (ok2) T = fused::se3_mul(fused::se3_exp(x), T);                    // oplusImpl: exp(update) * estimate
+                    if (ok2) T = fused::se3_mul(fused::se3_exp_series(x), T);                    // oplusImpl: exp(update) * estimate
                     POSE_STAMP(stSerial); POSE_COUNT(stTr);
                     double tempChi = robust_chi2(T);
                     POSE_STAMP(stChi);

@@ -166,3 +166,15 @@ def test_sim3solver_decl_is_minimal():
     assert not missing, f"declared but never used by the shell: {missing}"
     for helper in ("ComputeCentroid", "ComputeSim3", "CheckInliers", "FromCameraToImage", "mT21i", "mSigma2", "mTh"):
         assert helper not in body
+
+
+def test_series_form_of_the_se3_exponential(tmp_path):
+    """opt_math.h's se3_exp_series (PoseOptimization's oplus: no rotation matrix, no square root, no sin / cos call) against the closed form
+    in long double over 200 k random twists, and its hand-over to the general form outside 1e-5 <= theta <= 0.5 (tests/cpp/opt_math_check.cc)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "opt_math_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-I", os.path.join(root, "rumi_slam_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "opt_math_check.cc"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
