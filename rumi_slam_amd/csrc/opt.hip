@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     double scale = 0;
                     if (ok2) for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + hb[21 + j]);
                     scale += 1e-3;
-                    rho /= scale;
+                    rho *= fused::m_rcp(scale);                             // (v_rcp_f64 + two Newton steps instead of the IEEE divide sequence)
                     if (rho > 0 && isfinite(tempChi)) {
                         const double tr = 2 * rho - 1;
                         double alpha = 1. - tr * tr * tr;          // pow(2 rho - 1, 3) (levenberg.cpp:124): the generic pow is ~150 instructions of this serial section
