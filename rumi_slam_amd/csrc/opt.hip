@@ -39,16 +39,43 @@ namespace rumi {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// ---- exchanges between the lanes of a wave without the LDS crossbar ----
+// The value of lane ^ D.  D = 8, 2, 1: DPP (row_ror:8, quad_perm); D = 4 has no DPP form on gfx9 and goes through ds_bpermute.
+template <int D> __device__ __forceinline__ double lane_xor_f64(double v) {
+    static_assert(D == 8 || D == 4 || D == 2 || D == 1, "row-local exchanges");
+    if constexpr (D == 4) return __shfl_xor(v, 4);
+    constexpr int ctl = D == 8 ? 0x128 : D == 2 ? 0x4E : 0xB1;             // row_ror:8 | quad_perm:[2,3,0,1] | quad_perm:[1,0,3,2]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// One butterfly step over lane bit D = 32 or 16: a lane WITHOUT the bit gets lo(own) + lo(lane ^ D), a lane WITH it hi(own) + hi(lane ^ D).
+// v_permlane32_swap / v_permlane16_swap (gfx950) trade the upper half (odd rows) of `lo` for the lower half (even rows) of `hi`: afterwards
+// the two registers hold, in every lane, the kept value and the partner's -- two swaps and an add instead of four selects and two ds_bpermute.
+template <int D> __device__ __forceinline__ double swap_add_f64(double lo, double hi) {
+    static_assert(D == 32 || D == 16, "half-wave or row swap");
+    unsigned a0 = (unsigned)__double2loint(lo), a1 = (unsigned)__double2hiint(lo), b0 = (unsigned)__double2loint(hi), b1 = (unsigned)__double2hiint(hi);
+    if constexpr (D == 32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
+    }
+    return __hiloint2double((int)a1, (int)a0) + __hiloint2double((int)b1, (int)b0);
+}
+// sum over the wave, the same bits in every lane (the pairing of the xor butterfly: lane ^ 32, ^ 16, ... ^ 1)
+__device__ __forceinline__ double wave_allreduce_f64(double s) {
+    s = swap_add_f64<32>(s, s); s = swap_add_f64<16>(s, s);
+    s += lane_xor_f64<8>(s); s += lane_xor_f64<4>(s); s += lane_xor_f64<2>(s); s += lane_xor_f64<1>(s);
+    return s;
+}
+
 // ---- block reduction of NV doubles per thread (NW waves, 4 by default); every thread gets the total ----
 template <int NV, int NW = 4> __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [NW][NV] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        double s = v[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        v[k] = s;
-    }
+    for (int k = 0; k < NV; k++) v[k] = wave_allreduce_f64(v[k]);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
@@ -65,8 +92,24 @@ template <int NV, int NW = 4> __device__ __forceinline__ void block_sum(double (
 }
 
 // The same for up to 64 values per thread by a butterfly that halves the values a lane carries at every step (a lane ends with ONE
-// value summed over its wave): PAD - 1 shuffles instead of 6 per value, then one LDS round for the four waves.  PAD = 32 or 64 slots
+// value summed over its wave): PAD - 1 exchanges instead of 6 per value, then one LDS round for the four waves.  PAD = 32 or 64 slots
 // (NV rounded up); red: (NW + 1) * PAD doubles.
+template <int D, int N, int PAD> __device__ __forceinline__ void butterfly_stage(double (&w)[PAD], int lane) {   // lanes with bit D keep the upper N values, the others the lower N
+    if constexpr (N >= 1) {
+        if constexpr (D >= 16) {
+#pragma unroll
+            for (int i = 0; i < N; i++) w[i] = swap_add_f64<D>(w[i], w[i + N]);
+        } else {
+            const bool up = (lane & D) != 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const double send = up ? w[i] : w[i + N], keep = up ? w[i + N] : w[i];
+                w[i] = keep + lane_xor_f64<D>(send);
+            }
+        }
+        if constexpr (D > 1) butterfly_stage<D / 2, N / 2, PAD>(w, lane);
+    }
+}
 template <int NV, int NW = 4> __device__ __forceinline__ void block_sum_butterfly(double (&v)[NV], double *red) {
     static_assert(NV <= 64, "at most 64 values");
     constexpr int PAD = NV <= 32 ? 32 : 64;
@@ -74,17 +117,9 @@ template <int NV, int NW = 4> __device__ __forceinline__ void block_sum_butterfl
     double w[PAD];
 #pragma unroll
     for (int k = 0; k < PAD; k++) w[k] = k < NV ? v[k] : 0.0;
-#pragma unroll
-    for (int d = 32, n = PAD / 2; n >= 1; d >>= 1, n >>= 1) {   // lanes with bit d keep the upper n values, the others the lower n
-        const bool up = (lane & d) != 0;
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const double send = up ? w[i] : w[i + n], keep = up ? w[i + n] : w[i];
-            w[i] = keep + __shfl_xor(send, d);
-        }
-    }
+    butterfly_stage<32, PAD / 2, PAD>(w, lane);
     int idx = lane;
-    if (PAD == 32) { w[0] += __shfl_xor(w[0], 1); idx = lane >> 1; }      // 32 slots: lane pairs hold the same slot
+    if (PAD == 32) { w[0] += lane_xor_f64<1>(w[0]); idx = lane >> 1; }     // 32 slots: lane pairs hold the same slot
     __syncthreads();
     if (PAD == 64 || (lane & 1) == 0) red[wave * PAD + idx] = w[0];
     __syncthreads();
@@ -199,6 +234,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
             for (int itl = 0; itl < 10; itl++) {
                 // computeActiveErrors + activeRobustChi2 and buildSystem evaluate every edge at the same estimate: one pass, the
                 // robust chi2 rides along as the 28th reduced value (same per-edge values, same reduction tree as robust_chi2)
+#ifdef RUMI_POSE_STAMP
+                asm volatile("" : "+v"(lambda), "+v"(T.r.x), "+v"(T.t.x), "+v"(nBad));      // the trial's decisions are taken before the stamp
+#endif
                 POSE_STAMP(stSerial);
                 double hb[28];                                             // 21 upper entries of H, 6 of b, robust chi2
 #pragma unroll
