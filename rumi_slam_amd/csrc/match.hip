@@ -133,24 +133,27 @@ __global__ __launch_bounds__(1024) void k_grid(int n, const RumiKeyPoint *__rest
 
 // ---- 2. queries ----------------------------------------------------------------------------------------------
 // SearchByProjection(F, map points): ORBmatcher.cc:44-71
+__device__ __forceinline__ Query mappoint_query(int i, bool inView, float px, float py, int lvl, float viewCos, float depth, bool isBad, int obs,
+                                                const float *scaleFactors, float th, int farPoints, float thFar) {
+    Query o{};
+    o.valid = inView && !(farPoints && depth > thFar) && !isBad;
+    if (o.valid) {
+        float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos (float vs double literal)
+        if ((double)th != 1.0) r *= th;
+        o.u = px; o.v = py;
+        o.r = r * scaleFactors[lvl];
+        o.minLevel = lvl - 1; o.maxLevel = lvl;
+    }
+    o.descId = i; o.mpId = i; o.blocks = obs > 0;
+    return o;
+}
 __global__ void k_queries_mappoints(int nmp, const uint8_t *trackInView, const float *projX, const float *projY,
                                     const int32_t *scaleLevel, const float *viewCos, const float *trackDepth,
                                     const uint8_t *isBad, const int32_t *mpObs, const float *scaleFactors, float th,
                                     int farPoints, float thFar, Query *q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nmp) return;
-    Query o{};
-    o.valid = trackInView[i] && !(farPoints && trackDepth[i] > thFar) && !isBad[i];
-    if (o.valid) {
-        const int lvl = scaleLevel[i];
-        float r = (double)viewCos[i] > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos (float vs double literal)
-        if ((double)th != 1.0) r *= th;
-        o.u = projX[i]; o.v = projY[i];
-        o.r = r * scaleFactors[lvl];
-        o.minLevel = lvl - 1; o.maxLevel = lvl;
-    }
-    o.descId = i; o.mpId = i; o.blocks = mpObs[i] > 0;
-    q[i] = o;
+    q[i] = mappoint_query(i, trackInView[i] != 0, projX[i], projY[i], scaleLevel[i], viewCos[i], trackDepth[i], isBad[i] != 0, mpObs[i], scaleFactors, th, farPoints, thFar);
 }
 
 // SearchByProjection(Cur, Last): ORBmatcher.cc:1516-1551 (mono: levels nLastOctave-1 .. nLastOctave+1)
@@ -653,6 +656,11 @@ struct ResolveArgs {
     float thrF;                    // MODE_SIM3: TH_LOW * ratioHamming
     int thrI;                      // MODE_RELOC: ORBdist
     const int32_t *overflow;       // set by the fill pass when the list arena is too small: nothing to resolve
+    // optional tail (the Tracking step): PoseOptimization's correspondences gathered from the vector this search leaves (k_track_gather's work,
+    // one launch less between the search and the optimisation); gXw == nullptr: none
+    const float *gMpPos, *gInvSigma2;
+    float *gXw, *gObs, *gW;
+    int32_t *gIdx, *gStart, *gSnapshot;
 };
 
 __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatcher.cc:1592-1599
@@ -662,6 +670,37 @@ __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatche
     int bin = (int)__builtin_roundf(rot * factor);
     if (bin == RUMI_HISTO_LENGTH) bin = 0;
     return bin;
+}
+
+// Correspondences of Optimizer::PoseOptimization(Frame*) (Optimizer.cc:749-815, mono): the features with a map point, in feature order.
+// One workgroup of 1024 threads, ordered compaction (ballot + wave offsets through LDS, chunks of 1024 features).
+__device__ __forceinline__ void gather_correspondences(int n, const RumiKeyPoint *__restrict__ keys, const int32_t *featMp, const float *__restrict__ mpPos,
+                                                       const float *__restrict__ invSigma2, float *Xw, float *obs, float *w, int32_t *idx, int32_t *start,
+                                                       int32_t *snapshot, int *sWave /* [16] */, int *sBase) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *sBase = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int mp = i < n ? featMp[i] : -1;
+        if (snapshot && i < n) snapshot[i] = mp;            // the frame's map-point vector as the search left it (the optimisation's outliers leave it next)
+        const unsigned long long b = __ballot(mp >= 0);
+        if (lane == 0) sWave[wave] = __popcll(b);
+        __syncthreads();
+        int off = *sBase;
+        for (int k = 0; k < wave; k++) off += sWave[k];
+        if (mp >= 0) {
+            const int c = off + __popcll(b & ((1ull << lane) - 1));
+            Xw[3 * c] = mpPos[3 * mp]; Xw[3 * c + 1] = mpPos[3 * mp + 1]; Xw[3 * c + 2] = mpPos[3 * mp + 2];
+            obs[2 * c] = keys[i].x; obs[2 * c + 1] = keys[i].y;
+            w[c] = invSigma2[keys[i].octave];
+            idx[c] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = *sBase; for (int k = 0; k < 16; k++) t += sWave[k]; *sBase = t; }
+        __syncthreads();
+    }
+    if (tid == 0) { start[0] = 0; start[1] = *sBase; }
 }
 
 // wave-wide maximum / sum of one 32-bit value by DPP (row prefix, row_bcast:15, row_bcast:31; the total sits in lane 63)
@@ -839,6 +878,11 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs A) {
                 else A.featMp[f] = -1;
             }
         }
+    if (A.gXw) {                                                        // (uniform) the Tracking step's next launch would be this gather
+        __shared__ int sGatherWave[16], sGatherBase;
+        __syncthreads();                                                // the vector is final
+        gather_correspondences(A.nfeat, A.featKeys, A.featMp, A.gMpPos, A.gInvSigma2, A.gXw, A.gObs, A.gW, A.gIdx, A.gStart, A.gSnapshot, sGatherWave, &sGatherBase);
+    }
 }
 
 // SearchForInitialization resolve (ORBmatcher.cc:593-679).  The skip rule `vMatchedDistance[i2] <= dist` makes every query depend
@@ -2012,36 +2056,12 @@ __global__ void k_track_init(int n, int nmp, int full, int32_t *featMp, int32_t 
     }
 }
 
-// Correspondences of Optimizer::PoseOptimization(Frame*) (Optimizer.cc:749-815, mono): the features with a map point, in feature order.
-// One workgroup, ordered compaction (ballot + wave offsets through LDS, chunks of 1024 features).
+// (gather_correspondences as a launch of its own: the paths that do not end a search with it)
 __global__ __launch_bounds__(1024) void k_track_gather(int n, const RumiKeyPoint *__restrict__ keys, const int32_t *__restrict__ featMp,
                                                        const float *__restrict__ mpPos, const float *__restrict__ invSigma2, float *Xw, float *obs,
                                                        float *w, int32_t *idx, int32_t *start, int32_t *snapshot = nullptr) {
     __shared__ int sWave[16], sBase;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) sBase = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + tid;
-        const int mp = i < n ? featMp[i] : -1;
-        if (snapshot && i < n) snapshot[i] = mp;            // the frame's map-point vector as the search left it (the optimisation's outliers leave it next)
-        const unsigned long long b = __ballot(mp >= 0);
-        if (lane == 0) sWave[wave] = __popcll(b);
-        __syncthreads();
-        int off = sBase;
-        for (int k = 0; k < wave; k++) off += sWave[k];
-        if (mp >= 0) {
-            const int c = off + __popcll(b & ((1ull << lane) - 1));
-            Xw[3 * c] = mpPos[3 * mp]; Xw[3 * c + 1] = mpPos[3 * mp + 1]; Xw[3 * c + 2] = mpPos[3 * mp + 2];
-            obs[2 * c] = keys[i].x; obs[2 * c + 1] = keys[i].y;
-            w[c] = invSigma2[keys[i].octave];
-            idx[c] = i;
-        }
-        __syncthreads();
-        if (tid == 0) { int t = sBase; for (int k = 0; k < 16; k++) t += sWave[k]; sBase = t; }
-        __syncthreads();
-    }
-    if (tid == 0) { start[0] = 0; start[1] = sBase; }
+    gather_correspondences(n, keys, featMp, mpPos, invSigma2, Xw, obs, w, idx, start, snapshot, sWave, &sBase);
 }
 
 // Frame::UpdatePoseMatrices (Frame.cc:522-528) in Sophus' / Eigen's float arithmetic: Rcw = q.toRotationMatrix(), tcw, Ow = conj(q) * (-tcw)
@@ -2158,14 +2178,19 @@ __global__ void k_track_frustum(int nmp, int n, const int32_t *featMp, int32_t *
                                 int32_t *searchHeader, const float *pose, float minX,
                                 float minY, float maxX, float maxY, float logScaleFactor, int nLevels, float viewingCosLimit, const float *mpPos, const float *mpNormal,
                                 const float *mpMinDist, const float *mpMaxDist, uint8_t *inView, float *projX, float *projY, int32_t *scaleLevel, float *viewCosOut,
-                                float *trackDepth) {
+                                float *trackDepth, const int32_t *mpObs, const float *scaleFactors, float th, int farPoints, float thFar, Query *q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4) searchHeader[i] = 0;
     if (i < n) mpMotion[i] = featMp[i];                    // mvpMapPoints as TrackWithMotionModel leaves them (the local search may replace unobserved points)
     if (i >= nmp) return;
     const uint8_t sk = !local[i] || seen[i] || bad[i];
     skip[i] = sk;
-    if (sk) { inView[i] = 0; projX[i] = -1; projY[i] = -1; scaleLevel[i] = 0; viewCosOut[i] = 0; trackDepth[i] = 0; return; }
+    // (the search's query of this point is built here too: k_queries_mappoints' work on the values at hand, one launch less)
+    if (sk) {
+        inView[i] = 0; projX[i] = -1; projY[i] = -1; scaleLevel[i] = 0; viewCosOut[i] = 0; trackDepth[i] = 0;
+        q[i] = mappoint_query(i, false, -1.f, -1.f, 0, 0.f, 0.f, true, mpObs[i], scaleFactors, th, farPoints, thFar);
+        return;
+    }
     const float *R = pose, *t = pose + 9, *Ow = pose + 12, *K = pose + 15;
     const float *P = mpPos + (size_t)i * 3;
     uint8_t in = 0;
@@ -2193,6 +2218,7 @@ __global__ void k_track_frustum(int nmp, int n, const int32_t *featMp, int32_t *
         }
     }
     inView[i] = in; projX[i] = px; projY[i] = py; scaleLevel[i] = lvl; viewCosOut[i] = vc; trackDepth[i] = depth;
+    q[i] = mappoint_query(i, in != 0, px, py, lvl, vc, depth, false, mpObs[i], scaleFactors, th, farPoints, thFar);
 }
 
 // after the last PoseOptimization: mvpMapPoints and mvbOutlier per feature into the result block, mnMatchesInliers (Tracking.cc:2573-2586)
@@ -2383,24 +2409,22 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         auto search = [&](int mode, int nq, float nnratio, int checkOri) -> int {
             const int rcl = build_lists(m, mode, nq, fd, m->dQDesc, false, true);
             if (rcl != RUMI_OK) return rcl;
+            // (the search ends with the gather of PoseOptimization's correspondences: k_resolve's tail)
             ResolveArgs A{mode, nq, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dI[1], m->dFeatMp, m->dAssign, m->dNmatches,
-                          nnratio, checkOri, nullptr, 0.f, 0, m->dOverflow};
+                          nnratio, checkOri, nullptr, 0.f, 0, m->dOverflow, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start, nullptr};
             hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
             return RUMI_OK;
         };
         if ((rc = search(MODE_FRAME, nlast, 0.f, 1)) != RUMI_OK) return rc;      // (its queries were built beside the extraction, above)
-        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
         hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB, (const int32_t *)m->dOut);
         uint8_t *dSkip = m->dU8b;
         float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
-                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
-        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
-                           far_points, th_far_points, m->dQ);
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ);
         if ((rc = search(MODE_MAPPOINTS, nmp, 0.8f, 0)) != RUMI_OK) return rc;
-        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, dKp, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
         hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)m->dOut);
         HIP_TRY(hipGetLastError());
@@ -2446,9 +2470,8 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         float *dX = reinterpret_cast<float *>(m->dStage + n16), *dY = dX + n16, *dC = dY + n16, *dD = dC + n16;
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
-                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
-        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
-                           far_points, th_far_points, m->dQ);
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ);
         int nmLocal = 0;
         if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
         res->nmatches_local = nmLocal;
@@ -2582,9 +2605,8 @@ extern "C" int rumi_track_motion(RumiTracker *t, const float *K4, const float *T
                            m->dPose + 7, m->dScale, th_motion, fd.minX, fd.minY, fd.maxX, fd.maxY, m->dQ);
         if ((rc = build_lists(m, MODE_FRAME, nlast, fd, m->dQDesc, false, true)) != RUMI_OK) return rc;
         ResolveArgs A{MODE_FRAME, nlast, fd.n, m->dQ, m->dCounts, m->dOffsets, m->dLists, fd.keys, m->dI[1], m->dFeatMp, m->dAssign, m->dNmatches,
-                      0.f, 1, nullptr, 0.f, 0, m->dOverflow};
+                      0.f, 1, nullptr, 0.f, 0, m->dOverflow, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start, dSnap};   // (ends with the gather)
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), (size_t)std::max(fd.n, 1) * sizeof(int32_t), nullptr, A);
-        hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start, dSnap);
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
         hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB, (const int32_t *)m->dOut);
         HIP_TRY(hipGetLastError());
@@ -2759,9 +2781,8 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         const float logSf = std::log(t->cfg.scale_factor);
         hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
-                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD);
-        hipLaunchKernelGGL(k_queries_mappoints, dim3((nmp + 255) / 256), dim3(256), 0, nullptr, nmp, dView, dX, dY, dL, dC, dD, dSkip, m->dI[1], m->dScale, th_local,
-                           far_points, th_far_points, m->dQ);
+                           fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ);
         // the search's counts are not needed before the end: one queue, the result header travels in the block (a list overflow -- the resolve
         // did not run then, the frame's vector is untouched -- sends the stage through the sizing path)
         static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
