@@ -346,7 +346,7 @@ struct BADev {
     const int32_t *ptStart, *ptEdge;           // edges grouped by landmark (CSR)
     const int32_t *rowSlot;                    // edge -> first of its two rows in the key-frame-ordered pose panel (-1 fixed)
     const int32_t *kfRowStart;                 // [nOpt + 1] row ranges of the panel
-    const double *obs, *info;
+    const float *obs, *info;                   // the caller's single-precision measurements and weights as they came (widened where they are read)
     DCam cam;
     double delta, dsqr;
     double *Hll, *bl, *Hpl, *panel, *Hpp, *bp, *Dinv, *S, *bs, *x, *lastChi2;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BADev B, const double *T, const
         const D3 pc = se3_map(load_pose(T, B.eKF[e]), D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
         double u, v;
         cam_project(B.cam, pc, u, v);
-        const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, w = B.info[e];
+        const double e0 = (double)B.obs[2 * e] - u, e1 = (double)B.obs[2 * e + 1] - v, w = (double)B.info[e];
         const double c = e0 * w * e0 + e1 * w * e1;
         if (!B.off[e]) {                                                    // level-1 edges keep the error of their last active pass
             B.lastChi2[e] = c;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
     const D3 pc = se3_map(P, D3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
     double u, v;
     cam_project(B.cam, pc, u, v);
-    const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v, info = B.info[e];
+    const double e0 = (double)B.obs[2 * e] - u, e1 = (double)B.obs[2 * e + 1] - v, info = (double)B.info[e];
     const double c = e0 * info * e0 + e1 * info * e1;
     if (B.off[e]) {                                                         // inactive edge: contributes nothing to H, b, Y
         const int slot0 = B.rowSlot[e];
@@ -1590,8 +1590,8 @@ __global__ void k_ba_finalize(BADev B, const double *T, const double *X, int use
     if (!useLast) {
         double u, v;
         cam_project(B.cam, pc, u, v);
-        const double e0 = B.obs[2 * e] - u, e1 = B.obs[2 * e + 1] - v;
-        chi2 = e0 * B.info[e] * e0 + e1 * B.info[e] * e1;
+        const double e0 = (double)B.obs[2 * e] - u, e1 = (double)B.obs[2 * e + 1] - v, w = (double)B.info[e];
+        chi2 = e0 * w * e0 + e1 * w * e1;
     }
     erase[e] = (chi2 > 5.991 || !(pc.z > 0.0)) ? 1 : 0;       // Optimizer.cc:1292
 }
@@ -2242,8 +2242,8 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     for (int k = 0; k < nKF; k++) nOpt += kf_fixed[k] ? 0 : 1;
     const int n = 6 * nOpt;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t oEM = 0, oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4), oIn = al(oOb + (size_t)nE * 16),
-                 oT = al(oIn + (size_t)nE * 8), oX = al(oT + (size_t)nKF * 64), partA = al(oX + (size_t)nMP * 24),
+    const size_t oEM = 0, oEK = al(oEM + (size_t)nE * 4), oOb = al(oEK + (size_t)nE * 4), oIn = al(oOb + (size_t)nE * 8),
+                 oT = al(oIn + (size_t)nE * 4), oX = al(oT + (size_t)nKF * 64), partA = al(oX + (size_t)nMP * 24),
                  oPC = partA, oPS = al(oPC + (size_t)nKF * 4), oKR = al(oPS + (size_t)(nMP + 1) * 4), oPE = al(oKR + (size_t)(nOpt + 1) * 4),
                  oRS = al(oPE + (size_t)nE * 4), upBytes = al(oRS + (size_t)nE * 4);
     if (upBytes > o->baStageCap) { g_lastError = "local BA: upload block larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
@@ -2269,8 +2269,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     // part A
     if (nE > 0) {
         std::memcpy(hs + oEM, e_mp, (size_t)nE * 4); std::memcpy(hs + oEK, e_kf, (size_t)nE * 4);
-        double *ob = reinterpret_cast<double *>(hs + oOb), *inf = reinterpret_cast<double *>(hs + oIn);
-        for (int e = 0; e < nE; e++) { ob[2 * e] = e_obs[2 * e]; ob[2 * e + 1] = e_obs[2 * e + 1]; inf[e] = e_inv_sigma2[e]; }
+        std::memcpy(hs + oOb, e_obs, (size_t)nE * 8); std::memcpy(hs + oIn, e_inv_sigma2, (size_t)nE * 4);
     }
     {
         double *T0 = reinterpret_cast<double *>(hs + oT), *X0 = reinterpret_cast<double *>(hs + oX);
@@ -2309,7 +2308,7 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
     B.nKF = nKF; B.nMP = nMP; B.nE = nE; B.nOpt = nOpt; B.n = n;
     B.eMP = (const int32_t *)(o->dBa + oEM); B.eKF = (const int32_t *)(o->dBa + oEK); B.poseCol = (const int32_t *)(o->dBa + oPC);
     B.ptStart = (const int32_t *)(o->dBa + oPS); B.ptEdge = (const int32_t *)(o->dBa + oPE); B.rowSlot = (const int32_t *)(o->dBa + oRS);
-    B.kfRowStart = (const int32_t *)(o->dBa + oKR); B.obs = (const double *)(o->dBa + oOb); B.info = (const double *)(o->dBa + oIn);
+    B.kfRowStart = (const int32_t *)(o->dBa + oKR); B.obs = (const float *)(o->dBa + oOb); B.info = (const float *)(o->dBa + oIn);
     B.cam = DCam{K4[0], K4[1], K4[2], K4[3]};
     B.delta = mode == 0 ? (double)(float)std::sqrt(5.991) : (double)(float)std::sqrt(5.99);   // thHuberMono = sqrt(5.991) / thHuber2D = sqrt(5.99)
     B.dsqr = B.delta * B.delta;
