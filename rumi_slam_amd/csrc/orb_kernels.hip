@@ -677,9 +677,10 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
 // Edges (no border is stored around a level): rows above / below the level are the mirrored rows (a row index, wave-uniform); the three
 // columns left of column 0 are bytes 3, 2, 1 of the first dword (one v_perm_b32 in the first strip block); columns from w on are mirrored
 // bytes fetched by the few lanes whose dword touches them (byte loads of the same cache lines, only in waves that hold the right edge).
-// output rows a wave walks: 64 for batches (6 halo rows per 64: +1.3 % on the pipelined step over 32, which was +1.7 % over 16), 32 for a few
-// frames (more waves, shorter chains: one frame is 5 % slower with 64)
-constexpr int kBlurRowsSmall = 32, kBlurRowsBatch = 64;
+// output rows a wave walks: 64 for batches (6 halo rows per 64: +1.3 % on the pipelined step over 32, which was +1.7 % over 16), 16 for a few
+// frames (a wave's walk is a chain of dependent row loads and one frame fills few waves: the device chain of a one-frame call takes 107-110 us
+// with 16 rows, 116-126 with 32, 103-117 with 8 or 4 on the same box)
+constexpr int kBlurRowsSmall = 16, kBlurRowsBatch = 64;
 
 // all levels in one launch: workgroup `lin` of a frame belongs to the level whose [base, base + gx * gy) range holds it
 struct BlurGrid { int base[kMaxLevels + 1]; int gx[kMaxLevels]; int bw[kMaxLevels]; };   // bw: pixels a wave's strips cover (256, or less: see launch_blur)
