@@ -45,6 +45,11 @@ struct ImgSrc {
 };
 
 struct RowTap { int32_t r0, r1; uint32_t bh0, bh1; };   // the two (clamped) source rows, vertical taps << 16
+// The whole pyramid in ONE launch for calls of a few frames (k_pyramid_tiles): per workgroup and level the region it computes (multiples of 4 in x;
+// level 0: the window of the caller's frame it reads), derived on the host from the resize tables
+struct PyrTile { int16_t x0[kMaxLevels], x1[kMaxLevels], y0[kMaxLevels], y1[kMaxLevels]; };
+void launch_pyramid_tiles(const DevParams *dP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, const PyrTile *tiles, int ntiles, int bufBytes,
+                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord = nullptr);
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st, int32_t *clearWord = nullptr);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,

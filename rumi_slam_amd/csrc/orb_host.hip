@@ -66,6 +66,7 @@ struct RumiOrb {
     DevParams *dP = nullptr;
     int16_t *dCoef = nullptr;
     RowTap *dRowTab = nullptr; int capRowTab = 0;   // per level and output row: source rows and vertical taps of the resize
+    PyrTile *dPyrTiles = nullptr; int nPyrTiles = 0, pyrBuf = 0, pyrTab = 0;   // the one-launch pyramid of calls of a few frames (k_pyramid_tiles): 0 tiles = not available for this geometry
     // HBM arenas (sized for max_batch frames unless noted)
     uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame, rows padded to a multiple of 4 bytes)
     uint8_t *dL0 = nullptr;          // staging for device frames whose base / pitch / frame stride is not 4-byte aligned (allocated on first use)
@@ -194,6 +195,55 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
     if ((int)rowTab.size() > h->capRowTab) { g_lastError = "resize row table capacity"; return RUMI_E_CAPACITY; }
     if (!coef.empty()) HIP_TRY(hipMemcpy(h->dCoef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     if (!rowTab.empty()) HIP_TRY(hipMemcpy(h->dRowTab, rowTab.data(), rowTab.size() * sizeof(RowTap), hipMemcpyHostToDevice));
+    // ---- regions of the one-launch pyramid (k_pyramid_tiles): an even partition of the TOP level into tiles of about kPyrTX x kPyrTY pixels; going down, a tile's region of
+    // level l - 1 is the hull of what its region of level l reads (first tap column .. second tap column, first .. second source row) and of its
+    // share of an even partition of level l - 1 (every pixel of every level belongs to some tile); x ranges are widened to multiples of 4 (the
+    // kernels store dwords; the tables carry 4 padded columns).  Level 0's "region" is the window of the frame the tile reads.
+    h->nPyrTiles = 0; h->pyrBuf = 0;
+    if (P.nlevels >= 2) {
+        constexpr int kPyrTX = 32, kPyrTY = 16;
+        const int top = P.nlevels - 1;
+        const int ntx = (P.lv[top].w + kPyrTX - 1) / kPyrTX, nty = (P.lv[top].h + kPyrTY - 1) / kPyrTY;
+        std::vector<PyrTile> tiles((size_t)ntx * nty);
+        int bufMax = 0, tabMax = 0, dimMax = 0, winRows = 0;
+        auto up4 = [](int x) { return (x + 3) & ~3; };
+        for (int ty = 0; ty < nty; ty++)
+            for (int tx = 0; tx < ntx; tx++) {
+                PyrTile &T = tiles[(size_t)ty * ntx + tx];
+                std::memset(&T, 0, sizeof T);
+                int x0 = 0, x1 = 0, y0 = 0, y1 = 0, tab = 0;
+                for (int l = top; l >= 0; l--) {
+                    const DevLevel &D = P.lv[l];
+                    // own share of level l
+                    int ox0 = (int)((long long)D.w * tx / ntx), ox1 = (int)((long long)D.w * (tx + 1) / ntx);
+                    int oy0 = (int)((long long)D.h * ty / nty), oy1 = (int)((long long)D.h * (ty + 1) / nty);
+                    if (l < top) {
+                        // what level l + 1's region [x0, x1) x [y0, y1) reads of level l
+                        const DevLevel &U = P.lv[l + 1];
+                        const int16_t *xofs = coef.data() + U.coefX;
+                        const int nx0 = xofs[x0], nx1 = std::min(D.w, (int)xofs[x1 - 1] + 2);
+                        const int ny0 = rowTab[(size_t)U.rowTab + y0].r0, ny1 = rowTab[(size_t)U.rowTab + y1 - 1].r1 + 1;
+                        if (l == 0) { ox0 = nx0; ox1 = nx1; oy0 = ny0; oy1 = ny1; }          // level 0 is only read
+                        else { ox0 = std::min(ox0, nx0); ox1 = std::max(ox1, nx1); oy0 = std::min(oy0, ny0); oy1 = std::max(oy1, ny1); }
+                    }
+                    if (l > 0) { x0 = ox0 & ~3; x1 = up4(ox1); } else { x0 = ox0 & ~3; x1 = ox1; }    // (level 0: dword loads from an aligned column)
+                    y0 = oy0; y1 = oy1;
+                    T.x0[l] = (int16_t)x0; T.x1[l] = (int16_t)x1; T.y0[l] = (int16_t)y0; T.y1[l] = (int16_t)y1;
+                    bufMax = std::max(bufMax, up4(x1 - x0) * (y1 - y0));
+                    if (l > 0) tab += (x1 - x0) + (y1 - y0);            // the tile's slices of the column and row tables (8 bytes an entry)
+                    dimMax = std::max(dimMax, std::max(x1 - x0, y1 - y0));
+                    if (l == 0) winRows = std::max(winRows, y1 - y0);
+                }
+                tabMax = std::max(tabMax, tab);
+            }
+        bufMax = (bufMax + 15) & ~15;
+        if (2 * bufMax + 8 * tabMax <= 60 * 1024 && tiles.size() <= 4096 && P.nlevels <= 8 && dimMax <= 256 && winRows <= 80) {   // (the kernel's fixed shapes: orb_kernels.hip)
+            if (h->dPyrTiles) { (void)hipFree(h->dPyrTiles); h->dPyrTiles = nullptr; }
+            HIP_TRY(hipMalloc((void **)&h->dPyrTiles, tiles.size() * sizeof(PyrTile)));
+            HIP_TRY(hipMemcpy(h->dPyrTiles, tiles.data(), tiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice));
+            h->nPyrTiles = (int)tiles.size(); h->pyrBuf = bufMax; h->pyrTab = tabMax;
+        }
+    }
     h->octLds = octree_lds_for(P);
     if (h->octLds > 160 * 1024) { g_lastError = "nfeatures too large for the LDS-resident quadtree node pool"; return RUMI_E_INVALID; }
     h->gw = w; h->gh = hgt;
@@ -219,7 +269,7 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->pending) (void)hipStreamSynchronize(h->pendingStream);
-    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
+    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dPyrTiles, h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
                    h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
                    h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -484,9 +534,16 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     // blur runs on the side stream, and the event that forks it stalls the main queue for ~20 us on this runtime: more than the blur takes.
     static const int envFuse = std::getenv("RUMI_FUSE_FAST_BLUR") ? std::atoi(std::getenv("RUMI_FUSE_FAST_BLUR")) : -1;
     const bool fuseBlur = !prof && !serial && (envFuse >= 0 ? envFuse != 0 : nframes < 16) && fast_blur_fusable(P);
+    // A few frames: the pyramid in ONE launch (k_pyramid_tiles) instead of a launch per level
+    static const int envTiles = std::getenv("RUMI_PYRAMID_TILES") ? std::atoi(std::getenv("RUMI_PYRAMID_TILES")) : -1;
+    const bool tilePyramid = !prof && !serial && h->nPyrTiles > 0 && (envTiles >= 0 ? envTiles != 0 : nframes < 16);
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
+        if (tilePyramid) {
+            launch_pyramid_tiles(h->dP, ps, h->dCoef, h->dRowTab, h->dPyrTiles, h->nPyrTiles, h->pyrBuf, h->pyrTab, n, s, clearInKernel ? h->dErr : nullptr);
+            clearInKernel = false;
+        } else
         for (int l = 1; l < P.nlevels; l++) {
             launch_resize(h->dP, P, ps, h->dCoef, h->dRowTab, l, n, s, clearInKernel ? h->dErr : nullptr);
             clearInKernel = false;

@@ -36,7 +36,9 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
 }
 
+struct __attribute__((packed)) U32 { uint32_t v; };      // possibly unaligned 4-byte global access
 struct __attribute__((packed)) U64 { uint64_t v; };      // possibly unaligned 8-byte global access
+constexpr int kPyrLevels = 8, kPyrWinPasses = 20;        // k_pyramid_tiles: levels it is offered for, 4-row passes of its level-0 window
 
 // pixel (0,0) of a pyramid level: level 0 is the caller's frame itself, the others live in the pyramid arena
 __device__ __forceinline__ const uint8_t *level_base(const ImgSrc &s, const DevParams *P, int level, int frame,
@@ -151,6 +153,125 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
             }
             *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pyramid of a call of a few frames in ONE launch.  Seven dependent launches of ~4.4 us are most of such a call's pyramid time, and each
+// level is read back from HBM by the next.  Here a workgroup owns a tile of the top level and computes, level by level in LDS, the region of
+// every level that tile descends from (plus its share of a partition of the level, so that every pixel of every level is produced): level l - 1's
+// region is the source of level l's, the regions (PyrTile, from the host's resize tables) overlap by the taps' reach, and every workgroup
+// stores all it computed -- overlapping stores carry the same bytes.  The arithmetic per pixel is k_resize's general path, tap for tap.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyramid_tiles(const DevParams *__restrict__ P, ImgSrc src, const int16_t *__restrict__ coef,
+                                                       const RowTap *__restrict__ rowTab, const PyrTile *__restrict__ tiles, int bufBytes,
+                                                       int32_t *__restrict__ clearWord) {
+    // LDS: two image buffers of bufBytes (a level's region and the one computed from it), then the tile's slices of the resize tables
+    // (per level and row: source rows relative to the buffer | vertical taps; per level and column: source column relative to the buffer, tap pair)
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyrLds[];
+    if (clearWord && (blockIdx.x | blockIdx.y | threadIdx.x) == 0) *clearWord = 0;    // the call's error word (orb_host.hip)
+    const int frame = blockIdx.y, tid = threadIdx.x, nlevels = P->nlevels;
+    uint8_t *A = pyrLds, *B = pyrLds + bufBytes;
+    uint2 *tab = reinterpret_cast<uint2 *>(pyrLds + 2 * bufBytes);
+    // ---- the per-level parameters first, one lane per level, into LDS: read where they are needed they are a chain of scalar loads from
+    // global memory, two or three per level, ~1 us each
+    struct Lv { int x0, x1, y0, y1, coefX, coefXT, xmax, rowTab, pitch, pad; long long off; };
+    __shared__ Lv sLv[kMaxLevels];
+    if (tid < nlevels) {
+        const PyrTile &T = tiles[blockIdx.x];
+        const DevLevel &D = P->lv[tid];
+        sLv[tid] = Lv{T.x0[tid], T.x1[tid], T.y0[tid], T.y1[tid], D.coefX, D.coefXT, D.xmax, D.rowTab, D.pitch, 0, D.off};
+    }
+    __syncthreads();
+    // ---- everything else this workgroup reads from global memory: the table slices of all levels (one row entry and one column entry per
+    // thread and level) and the window of level 0 (dwords: 64 columns x 4 rows per pass).  ALL loads are issued before the first value is
+    // stored to LDS: as loops of load-then-store they were some fifty dependent round trips, 28 of the kernel's 34 us.
+    // (the host offers this kernel for up to kPyrLevels levels, regions of up to 256 rows / columns and windows of up to 80 rows x 256 columns)
+    int apitch;
+    {
+        RowTap rt[kPyrLevels];
+        int cofs[kPyrLevels];
+        uint32_t ctap[kPyrLevels];
+#pragma unroll
+        for (int level = 1; level < kPyrLevels; level++) {
+            rt[level] = RowTap{0, 0, 0u, 0u}; cofs[level] = 0; ctap[level] = 0;
+            if (level < nlevels) {
+                const Lv D = sLv[level];
+                if (tid < D.y1 - D.y0) rt[level] = rowTab[D.rowTab + D.y0 + tid];
+                if (tid < D.x1 - D.x0) {
+                    const int dx = D.x0 + tid;
+                    cofs[level] = (coef + D.coefX)[dx];
+                    // the tap pair as one dword (a0 in the low half); a single-tap column multiplies its one source byte by 2048
+                    ctap[level] = dx < D.xmax ? reinterpret_cast<const U32 *>(coef + D.coefXT + dx * 2)->v : 2048u;
+                }
+            }
+        }
+        int sp;
+        const uint8_t *sb = level_base(src, P, 0, frame, &sp);
+        const int ax0 = sLv[0].x0, ay0 = sLv[0].y0, aw = sLv[0].x1 - ax0, ah = sLv[0].y1 - ay0, W0 = P->lv[0].w;
+        apitch = (aw + 3) & ~3;
+        uint32_t win[kPyrWinPasses];
+        const int wx = (tid & 63) * 4, wy = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < kPyrWinPasses; k++) {
+            const int y = wy + 4 * k;
+            win[k] = 0;
+            if (y < ah && wx < aw) {
+                const uint8_t *p = sb + (long long)(ay0 + y) * sp + ax0 + wx;
+                if (ax0 + wx + 4 <= W0) win[k] = reinterpret_cast<const U32 *>(p)->v;
+                else for (int i = 0; ax0 + wx + i < W0; i++) win[k] |= (uint32_t)p[i] << (8 * i);      // the frame's last columns: no read past the row
+            }
+        }
+        // ---- now the stores
+        int tb = 0;
+#pragma unroll
+        for (int level = 1; level < kPyrLevels; level++) {
+            if (level < nlevels) {
+                const Lv D = sLv[level];
+                const int cols = D.x1 - D.x0, rows = D.y1 - D.y0, sx0 = sLv[level - 1].x0, sy0 = sLv[level - 1].y0;
+                if (tid < rows) tab[tb + tid] = make_uint2((uint32_t)(rt[level].r0 - sy0) | ((uint32_t)(rt[level].r1 - sy0) << 16), (rt[level].bh0 >> 16) | (rt[level].bh1 & 0xFFFF0000u));
+                if (tid < cols) tab[tb + rows + tid] = make_uint2((uint32_t)(cofs[level] - sx0), ctap[level]);
+                tb += rows + cols;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPyrWinPasses; k++) {
+            const int y = wy + 4 * k;
+            if (y < ah && wx < aw) *reinterpret_cast<uint32_t *>(A + y * apitch + wx) = win[k];
+        }
+    }
+    __syncthreads();
+    int base = 0;
+    for (int level = 1; level < nlevels; level++) {
+        const Lv D = sLv[level];
+        const int X0 = D.x0, Y0 = D.y0, bw = D.x1 - X0, rows = D.y1 - Y0, gpr = bw >> 2;
+        const uint2 *rowT = tab + base, *colT = rowT + rows;
+        base += rows + bw;
+        uint8_t *dbase = src.pyr + (long long)frame * P->arenaStride + D.off + (long long)Y0 * D.pitch + X0;
+        // threads per row of 4-pixel groups: the power of two that holds them (the top levels have eight groups a row)
+        const int tprLog = gpr <= 8 ? 3 : gpr <= 16 ? 4 : gpr <= 32 ? 5 : 6, tpr = 1 << tprLog, rstep = 256 >> tprLog;
+        for (int gx = tid & (tpr - 1); gx < gpr; gx += tpr) {
+            uint32_t sx[4], a0[4], a1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const uint2 c = colT[4 * gx + i]; sx[i] = c.x; a0[i] = c.y & 0xFFFFu; a1[i] = c.y >> 16; }
+            for (int gy = tid >> tprLog; gy < rows; gy += rstep) {
+                const uint2 t = rowT[gy];
+                const uint8_t *r0 = A + (t.x & 0xFFFFu) * apitch, *r1 = A + (t.x >> 16) * apitch;
+                const int b0 = (int)(t.y & 0xFFFFu), b1 = (int)(t.y >> 16);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int q0 = (int)(r0[sx[i]] * a0[i] + (a1[i] ? r0[sx[i] + 1] * a1[i] : 0u));
+                    const int q1 = (int)(r1[sx[i]] * a0[i] + (a1[i] ? r1[sx[i] + 1] * a1[i] : 0u));
+                    packed |= (uint32_t)((((b0 * (q0 >> 4)) >> 16) + ((b1 * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+                }
+                *reinterpret_cast<uint32_t *>(B + gy * bw + 4 * gx) = packed;
+                *reinterpret_cast<uint32_t *>(dbase + (long long)gy * D.pitch + 4 * gx) = packed;
+            }
+        }
+        __syncthreads();
+        uint8_t *t2 = A; A = B; B = t2;
+        apitch = bw;
     }
 }
 
@@ -464,7 +585,6 @@ __device__ __forceinline__ FastCell fast_cell_geom(const DevParams *__restrict__
     g.live = true;
     return g;
 }
-struct __attribute__((packed)) U32 { uint32_t v; };      // possibly unaligned 4-byte global access
 // Staging.  A lane owns ONE dword column c of the tile and one row r0 of every block of rps rows (rps = 64 / dword columns of the tile
 // pitch): its offset into the sub-image and its LDS address are computed once, a block adds a wave-uniform row offset to both.  The
 // last block is moved up so that it ends with the sub-image's last row (it re-loads a few rows of its predecessor): every lane of a
@@ -1016,6 +1136,10 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
                    hipStream_t st, int32_t *clearWord) {
     dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
+}
+void launch_pyramid_tiles(const DevParams *dP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, const PyrTile *tiles, int ntiles, int bufBytes,
+                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord) {
+    hipLaunchKernelGGL(k_pyramid_tiles, dim3(ntiles, nframes), dim3(256), (size_t)2 * bufBytes + (size_t)tabEntries * 8, st, dP, src, coef, rowTab, tiles, bufBytes, clearWord);
 }
 static FastLds fast_lds_of(const DevParams &hP) {
     // LDS per wave from the largest cell of this geometry
