@@ -251,19 +251,37 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(const DevParams *__restri
         // threads per row of 4-pixel groups: the power of two that holds them (the top levels have eight groups a row)
         const int tprLog = gpr <= 8 ? 3 : gpr <= 16 ? 4 : gpr <= 32 ? 5 : 6, tpr = 1 << tprLog, rstep = 256 >> tprLog;
         for (int gx = tid & (tpr - 1); gx < gpr; gx += tpr) {
-            uint32_t sx[4], a0[4], a1[4];
+            uint32_t sx[4], tap[4], sel[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const uint2 c = colT[4 * gx + i]; sx[i] = c.x; a0[i] = c.y & 0xFFFFu; a1[i] = c.y >> 16; }
+            for (int i = 0; i < 4; i++) { const uint2 c = colT[4 * gx + i]; sx[i] = c.x; tap[i] = c.y; }
+            // k_resize's dword form on the LDS tile: the 4 outputs read source bytes sx[0] .. sx[0] + 7 of two rows (one 8-byte read each), v_perm_b32
+            // spreads an output's two bytes into 16-bit halves, v_dot2_u32_u16 multiplies by the tap pair; wider spans take the byte form
+            const bool span8 = sx[3] + 1u - sx[0] <= 7u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const uint32_t k = sx[i] - sx[0]; sel[i] = k | 0x0c000c00u | ((k + 1u) << 16); }
+            typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
             for (int gy = tid >> tprLog; gy < rows; gy += rstep) {
                 const uint2 t = rowT[gy];
                 const uint8_t *r0 = A + (t.x & 0xFFFFu) * apitch, *r1 = A + (t.x >> 16) * apitch;
-                const int b0 = (int)(t.y & 0xFFFFu), b1 = (int)(t.y >> 16);
+                const uint32_t bh0 = t.y << 16, bh1 = t.y & 0xFFFF0000u;       // vertical taps << 16: (b * x) >> 16 == mulhi(b << 16, x)
                 uint32_t packed = 0;
+                if (span8) {
+                    const uint64_t s0 = reinterpret_cast<const U64 *>(r0 + sx[0])->v, s1 = reinterpret_cast<const U64 *>(r1 + sx[0])->v;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int q0 = (int)(r0[sx[i]] * a0[i] + (a1[i] ? r0[sx[i] + 1] * a1[i] : 0u));
-                    const int q1 = (int)(r1[sx[i]] * a0[i] + (a1[i] ? r1[sx[i] + 1] * a1[i] : 0u));
-                    packed |= (uint32_t)((((b0 * (q0 >> 4)) >> 16) + ((b1 * (q1 >> 4)) >> 16) + 2) >> 2) << (8 * i);
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(s0 >> 32), (uint32_t)s0, sel[i]);
+                        const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(s1 >> 32), (uint32_t)s1, sel[i]);
+                        const uint32_t q0 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
+                        const uint32_t q1 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
+                        packed |= ((__umulhi(bh0, q0 >> 4) + __umulhi(bh1, q1 >> 4) + 2u) >> 2) << (8 * i);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t a0 = tap[i] & 0xFFFFu, a1 = tap[i] >> 16;
+                        const uint32_t q0 = r0[sx[i]] * a0 + (a1 ? r0[sx[i] + 1] * a1 : 0u), q1 = r1[sx[i]] * a0 + (a1 ? r1[sx[i] + 1] * a1 : 0u);
+                        packed |= ((__umulhi(bh0, q0 >> 4) + __umulhi(bh1, q1 >> 4) + 2u) >> 2) << (8 * i);
+                    }
                 }
                 *reinterpret_cast<uint32_t *>(B + gy * bw + 4 * gx) = packed;
                 *reinterpret_cast<uint32_t *>(dbase + (long long)gy * D.pitch + 4 * gx) = packed;
