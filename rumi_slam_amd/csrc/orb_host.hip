@@ -195,13 +195,13 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
     if ((int)rowTab.size() > h->capRowTab) { g_lastError = "resize row table capacity"; return RUMI_E_CAPACITY; }
     if (!coef.empty()) HIP_TRY(hipMemcpy(h->dCoef, coef.data(), coef.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     if (!rowTab.empty()) HIP_TRY(hipMemcpy(h->dRowTab, rowTab.data(), rowTab.size() * sizeof(RowTap), hipMemcpyHostToDevice));
-    // ---- regions of the one-launch pyramid (k_pyramid_tiles): an even partition of the TOP level into tiles of about kPyrTX x kPyrTY pixels; going down, a tile's region of
+    // ---- regions of the one-launch pyramid (k_pyramid_tiles): an even partition of the TOP level into tiles of about kPyrTX x kPyrTY pixels (16 x 8: 14.3 us for one 640 x 480 frame; 32 x 16: 19.4, 16 x 16: 16.5, 8 x 8: 15.1); going down, a tile's region of
     // level l - 1 is the hull of what its region of level l reads (first tap column .. second tap column, first .. second source row) and of its
     // share of an even partition of level l - 1 (every pixel of every level belongs to some tile); x ranges are widened to multiples of 4 (the
     // kernels store dwords; the tables carry 4 padded columns).  Level 0's "region" is the window of the frame the tile reads.
     h->nPyrTiles = 0; h->pyrBuf = 0;
     if (P.nlevels >= 2) {
-        constexpr int kPyrTX = 32, kPyrTY = 16;
+        constexpr int kPyrTX = 16, kPyrTY = 8;
         const int top = P.nlevels - 1;
         const int ntx = (P.lv[top].w + kPyrTX - 1) / kPyrTX, nty = (P.lv[top].h + kPyrTY - 1) / kPyrTY;
         std::vector<PyrTile> tiles((size_t)ntx * nty);
@@ -536,7 +536,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     const bool fuseBlur = !prof && !serial && (envFuse >= 0 ? envFuse != 0 : nframes < 16) && fast_blur_fusable(P);
     // A few frames: the pyramid in ONE launch (k_pyramid_tiles) instead of a launch per level
     static const int envTiles = std::getenv("RUMI_PYRAMID_TILES") ? std::atoi(std::getenv("RUMI_PYRAMID_TILES")) : -1;
-    const bool tilePyramid = !prof && !serial && h->nPyrTiles > 0 && (envTiles >= 0 ? envTiles != 0 : nframes < 16);
+    const bool tilePyramid = !prof && !serial && h->nPyrTiles > 0 && (envTiles >= 0 ? envTiles != 0 : nframes <= 4);   // (a tile recomputes the borders it shares: ~1.8x the pixels, paid back only while the chip is far from full)
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
