@@ -416,3 +416,21 @@ def test_threshold_pairs(ini, mn):
     for seed, kw in [(31, {}), (32, dict(n_rect=60, contrast=(8, 25), noise=1)), (33, dict(n_rect=12, contrast=(5, 14), noise=0))]:
         img = synth_frame(seed, **kw)
         _assert_same(g(img, None, (0, 1000)), o.extract(img, (0, 1000)), f"thresholds {ini}/{mn} seed {seed}")
+
+
+@pytest.mark.gpu
+def test_one_launch_pyramid_equals_the_launch_per_level_chain(tmp_path):
+    """Calls of up to 4 frames compute the whole pyramid in one launch (k_pyramid_tiles: tiles of the top level, their regions of every level in
+    LDS); the chain of one launch per level must produce the same bytes: 9 geometries (sizes, scale factors 1.1 / 1.2 / 1.5, 2 to 8 levels), calls
+    of 1 and 3 frames, every level of every frame (tools/pyramid_tiles_check.py, once per path: the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dumps = []
+    for tiles in ("0", "1"):
+        out = str(tmp_path / f"tiles{tiles}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "pyramid_tiles_check.py"), out], check=True, env=dict(os.environ, RUMI_PYRAMID_TILES=tiles), timeout=600)
+        dumps.append(np.load(out))
+    a, b = dumps
+    assert set(a.files) == set(b.files) and len(a.files) > 150
+    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    assert not bad, f"levels differ: {bad[:8]}"
