@@ -199,8 +199,14 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     int nBadRound = 0;
     POSE_STAMP_DECL;
 
+    // (the estimate maps a point by its rotation MATRIX, built once per pass -- 9 multiply-adds an edge instead of the quaternion form's two
+    // cross products; the quaternion is normalised by every update)
+    double Rm[3][3];
+    auto set_pose = [&](const fused::DSE3 &P) { fused::quat_to_matrix(P.r, Rm); };
     auto edge_chi2 = [&](int i, const fused::DSE3 &P, double &e0, double &e1, fused::D3 &pc) -> double {
-        pc = fused::se3_map(P, fused::D3{(double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2]});
+        const double X = (double)Xw[3 * i], Y = (double)Xw[3 * i + 1], Z = (double)Xw[3 * i + 2];
+        pc = fused::D3{Rm[0][0] * X + Rm[0][1] * Y + Rm[0][2] * Z + P.t.x, Rm[1][0] * X + Rm[1][1] * Y + Rm[1][2] * Z + P.t.y,
+                       Rm[2][0] * X + Rm[2][1] * Y + Rm[2][2] * Z + P.t.z};
         double u, v;
         fused::cam_project(cam, pc, u, v);
         e0 = (double)obs[2 * i] - u; e1 = (double)obs[2 * i + 1] - v;
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     };
     auto robust_chi2 = [&](const fused::DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
         double acc[1] = {0};
+        set_pose(P);
         for (int i = tid; i < n; i += NT) {
             if (!active[i]) continue;
             double e0, e1; fused::D3 pc;
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                 double hb[28];                                             // 21 upper entries of H, 6 of b, robust chi2
 #pragma unroll
                 for (int k = 0; k < 28; k++) hb[k] = 0;
+                set_pose(T);
                 for (int i = tid; i < n; i += NT) {
                     if (!active[i]) continue;
                     double e0, e1; fused::D3 pc;
@@ -314,6 +322,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         }
         // re-classification (:916-939): former outliers get a fresh error, active edges keep the last computed one
         double bad[1] = {0};
+        set_pose(T);
         for (int i = tid; i < n; i += NT) {
             double e0, e1; fused::D3 pc;
             const float chi2 = (float)(outlier[i] ? edge_chi2(i, T, e0, e1, pc) : lastChi2[i]);
