@@ -260,19 +260,24 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     double J0[6], J1[6];
                     fused::jac_pose(cam, pc, J0, J1);
                     const double w = (double)wgt[i], rw = r1 * w;
+                    // H += rw J^T J, b -= r1 w J^T e with the weights multiplied into one factor first (two multiply-adds an entry); J0[4] and
+                    // J1[3] are zero by construction (jac_pose): their products are left out, H[3][4] stays 0
+                    double A0[6], A1[6];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) { A0[a] = rw * J0[a]; A1[a] = rw * J1[a]; }
+                    const double we0 = rw * e0, we1 = rw * e1;
                     int p = 0;
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
 #pragma unroll
                         for (int c2 = a; c2 < 6; c2++, p++) {
-                            // J0[4] and J1[3] are zero by construction (jac_pose): their products are left out, H[3][4] stays 0
                             const bool z0 = a == 4 || c2 == 4, z1 = a == 3 || c2 == 3;
                             if (z0 && z1) continue;
-                            hb[p] += rw * (z0 ? J1[a] * J1[c2] : z1 ? J0[a] * J0[c2] : J0[a] * J0[c2] + J1[a] * J1[c2]);
+                            hb[p] += z0 ? A1[a] * J1[c2] : z1 ? A0[a] * J0[c2] : A0[a] * J0[c2] + A1[a] * J1[c2];
                         }
                     }
 #pragma unroll
-                    for (int a = 0; a < 6; a++) hb[21 + a] -= r1 * (a == 4 ? J1[a] * w * e1 : a == 3 ? J0[a] * w * e0 : J0[a] * w * e0 + J1[a] * w * e1);
+                    for (int a = 0; a < 6; a++) hb[21 + a] -= a == 4 ? J1[a] * we1 : a == 3 ? J0[a] * we0 : J0[a] * we0 + J1[a] * we1;
                 }
                 POSE_STAMP(stPass);
                 block_sum_butterfly<28, NW>(hb, red);
