@@ -203,28 +203,42 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     // cross products; the quaternion is normalised by every update)
     double Rm[3][3];
     auto set_pose = [&](const fused::DSE3 &P) { fused::quat_to_matrix(P.r, Rm); };
-    auto edge_chi2 = [&](int i, const fused::DSE3 &P, double &e0, double &e1, fused::D3 &pc) -> double {
-        const double X = (double)Xw[3 * i], Y = (double)Xw[3 * i + 1], Z = (double)Xw[3 * i + 2];
+    // a thread's first kRegEdges edges (all of them up to 512 correspondences) stay in registers as doubles for the whole solve: no LDS read and
+    // no float -> double conversion in the ~60 passes; further edges are read from the LDS (or global) arrays
+    constexpr int kRegEdges = 2;
+    double eX[kRegEdges], eY[kRegEdges], eZ[kRegEdges], eU[kRegEdges], eV[kRegEdges], eW[kRegEdges];
+#pragma unroll
+    for (int k = 0; k < kRegEdges; k++) {
+        const int i = min(tid + k * NT, n - 1);                              // (n >= 3 here)
+        eX[k] = (double)Xw[3 * i]; eY[k] = (double)Xw[3 * i + 1]; eZ[k] = (double)Xw[3 * i + 2];
+        eU[k] = (double)obs[2 * i]; eV[k] = (double)obs[2 * i + 1]; eW[k] = (double)wgt[i];
+    }
+    auto for_edges = [&](auto &&body) {
+#pragma unroll
+        for (int k = 0; k < kRegEdges; k++) { const int i = tid + k * NT; if (i < n) body(i, eX[k], eY[k], eZ[k], eU[k], eV[k], eW[k]); }
+        for (int i = tid + kRegEdges * NT; i < n; i += NT)
+            body(i, (double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2], (double)obs[2 * i], (double)obs[2 * i + 1], (double)wgt[i]);
+    };
+    auto edge_chi2 = [&](double X, double Y, double Z, double ou, double ov, double w, const fused::DSE3 &P, double &e0, double &e1, fused::D3 &pc) -> double {
         pc = fused::D3{Rm[0][0] * X + Rm[0][1] * Y + Rm[0][2] * Z + P.t.x, Rm[1][0] * X + Rm[1][1] * Y + Rm[1][2] * Z + P.t.y,
                        Rm[2][0] * X + Rm[2][1] * Y + Rm[2][2] * Z + P.t.z};
         double u, v;
         fused::cam_project(cam, pc, u, v);
-        e0 = (double)obs[2 * i] - u; e1 = (double)obs[2 * i + 1] - v;
-        const double w = (double)wgt[i];
+        e0 = ou - u; e1 = ov - v;
         return e0 * w * e0 + e1 * w * e1;
     };
     auto robust_chi2 = [&](const fused::DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
         double acc[1] = {0};
         set_pose(P);
-        for (int i = tid; i < n; i += NT) {
-            if (!active[i]) continue;
+        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
+            if (!active[i]) return;
             double e0, e1; fused::D3 pc;
-            const double c = edge_chi2(i, P, e0, e1, pc);
+            const double c = edge_chi2(X, Y, Z, ou, ov, w, P, e0, e1, pc);
             lastChi2[i] = c;
             double r0 = c, r1 = 1;
             if (robust) fused::huber(c, delta, dsqr, r0, r1);
             acc[0] += r0;
-        }
+        });
         block_sum<1, NW>(acc, red);
         return acc[0];
     };
@@ -249,17 +263,17 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                 for (int k = 0; k < 28; k++) hb[k] = 0;
                 set_pose(T);
-                for (int i = tid; i < n; i += NT) {
-                    if (!active[i]) continue;
+                for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
+                    if (!active[i]) return;
                     double e0, e1; fused::D3 pc;
-                    const double c = edge_chi2(i, T, e0, e1, pc);
+                    const double c = edge_chi2(X, Y, Z, ou, ov, w, T, e0, e1, pc);
                     lastChi2[i] = c;
                     double r0 = c, r1 = 1;
                     if (robust) fused::huber(c, delta, dsqr, r0, r1);
                     hb[27] += r0;
                     double J0[6], J1[6];
                     fused::jac_pose(cam, pc, J0, J1);
-                    const double w = (double)wgt[i], rw = r1 * w;
+                    const double rw = r1 * w;
                     // H += rw J^T J, b -= r1 w J^T e with the weights multiplied into one factor first (two multiply-adds an entry); J0[4] and
                     // J1[3] are zero by construction (jac_pose): their products are left out, H[3][4] stays 0
                     double A0[6], A1[6];
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     }
 #pragma unroll
                     for (int a = 0; a < 6; a++) hb[21 + a] -= a == 4 ? J1[a] * we1 : a == 3 ? J0[a] * we0 : J0[a] * we0 + J1[a] * we1;
-                }
+                });
                 POSE_STAMP(stPass);
                 block_sum_butterfly<28, NW>(hb, red);
                 POSE_STAMP(stRed); POSE_COUNT(stN);
@@ -328,12 +342,12 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         // re-classification (:916-939): former outliers get a fresh error, active edges keep the last computed one
         double bad[1] = {0};
         set_pose(T);
-        for (int i = tid; i < n; i += NT) {
+        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
             double e0, e1; fused::D3 pc;
-            const float chi2 = (float)(outlier[i] ? edge_chi2(i, T, e0, e1, pc) : lastChi2[i]);
+            const float chi2 = (float)(outlier[i] ? edge_chi2(X, Y, Z, ou, ov, w, T, e0, e1, pc) : lastChi2[i]);
             if (chi2 > 5.991f) { outlier[i] = 1; active[i] = 0; bad[0] += 1; }
             else { outlier[i] = 0; active[i] = 1; }
-        }
+        });
         block_sum<1, NW>(bad, red);
         nBadRound = (int)bad[0];
         if (it == 2) robust = false;                                       // setRobustKernel(0)
