@@ -245,10 +245,8 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
 
     for (int it = 0; it < 4; it++) {
         T = T0;                                                            // estimate reset every round (:910-911)
-        double cnt[1] = {0};
-        for (int i = tid; i < n; i += NT) cnt[0] += active[i];
-        block_sum<1, NW>(cnt, red);
-        if (cnt[0] > 0) {
+        // (the edges active in this round: all in the first, then those the last re-classification kept -- no pass to count them)
+        if ((it == 0 ? n : n - nBadRound) > 0) {
             // ---- g2o optimize(10): optimization_algorithm_levenberg.cpp:61-169 ----
             double lambda = -1, ni = 2;
             int nBad = 0;
