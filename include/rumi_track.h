@@ -55,6 +55,11 @@ typedef struct RumiTrackResult {
 int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, int32_t device, RumiTracker **out);
 void rumi_track_destroy(RumiTracker *t);
 
+/* The tracker's pinned staging memory for a w x h frame (*stride = w rounded up to 4 bytes per row).  Optional: a caller whose camera driver or
+ * decoder writes frames straight into it (the reference: the cv::Mat Tracking::GrabImageMonocular receives, constructed on this memory) and then
+ * passes this pointer and stride as `img` / `stride` below saves the staging copy of rumi_track_frame / rumi_track_extract (~20 us for 640 x 480). */
+int rumi_track_image_buffer(RumiTracker *t, int32_t w, int32_t h, uint8_t **buf, int32_t *stride);
+
 /* One frame.  img: host, 8-bit grey, `stride` bytes per row.  Tcw_pred7 = mVelocity * mLastFrame.GetPose().  last_*: mLastFrame.mvKeysUn, the
  * table index of mLastFrame.mvpMapPoints[i] (-1: none) and mLastFrame.mvbOutlier.  th_motion = 15 (mono), th_local as SearchLocalPoints
  * chooses it (1 by default), far_points / th_far_points = mpLocalMapper->mbFarPoints / mThFarPoints.

@@ -2407,7 +2407,8 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
 
     // ---- stage 1: ORBextractor::operator() on the device; only the two counts come back (launch sizes need n)
     const int wp = (w + 3) & ~3;
-    for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
+    if (!(img == t->hImage && stride == wp))                // (a caller that captured straight into rumi_track_image_buffer's memory has nothing to stage)
+        for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
     HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
@@ -2607,6 +2608,15 @@ int track_check_points(const RumiTrackPoints *pts, bool needFrustum) {
 }
 }  // namespace
 
+// The tracker's pinned staging buffer for a w x h frame, for a caller that lets its camera driver / decoder write the frame there (e.g. a
+// cv::Mat constructed on this memory): rumi_track_frame / rumi_track_extract called with this pointer and stride skip their staging copy.
+extern "C" int rumi_track_image_buffer(RumiTracker *t, int32_t w, int32_t h, uint8_t **buf, int32_t *stride) {
+    if (!t || !buf || !stride) return RUMI_E_INVALID;
+    if (w <= 0 || h <= 0 || w > t->cfg.max_width || h > t->cfg.max_height) { g_lastError = "rumi_track_image_buffer: frame larger than the tracker was created for"; return RUMI_E_CAPACITY; }
+    *buf = t->hImage; *stride = (w + 3) & ~3;
+    return RUMI_OK;
+}
+
 extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride, RumiKeyPoint *keys_out, uint8_t *desc_out,
                                   int32_t cap, int32_t *n_out, int32_t *mono_out) {
     if (!t || !img || !keys_out || !desc_out || !n_out || !mono_out || stride < w) return RUMI_E_INVALID;
@@ -2617,7 +2627,8 @@ extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w,
     t->curN = -1;
     uint8_t *dRecord = t->dBlk + t->oRec;
     const int wp = (w + 3) & ~3;
-    for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
+    if (!(img == t->hImage && stride == wp))                // (a caller that captured straight into rumi_track_image_buffer's memory has nothing to stage)
+        for (int y = 0; y < h; y++) std::memcpy(t->hImage + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);      // image -> pinned -> device (async)
     HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;

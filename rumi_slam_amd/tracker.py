@@ -34,6 +34,7 @@ def _bind(L):
     L.rumi_track_reference_keyframe.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, C.POINTER(RumiTrackPoints), f32, i32, vp, vp, vp, vp, vp,
                                                 C.POINTER(RumiTrackResult)]
     L.rumi_track_local.argtypes = [vp, vp, vp, vp, C.POINTER(RumiTrackPoints), vp, f32, i32, f32, vp, vp, vp, C.POINTER(RumiTrackResult)]
+    L.rumi_track_image_buffer.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]
     L._track_ready = True
     return L
 
@@ -82,6 +83,14 @@ class Tracker:
         out.update(keys=keys[:k].copy(), desc=desc[:k].copy(), frame_mp_motion=mp_motion[:k].copy(), frame_mp=mp[:k].copy(), outlier=outl[:k].copy(),
                    in_view=in_view[:n].copy())
         return out
+
+    def image_buffer(self, w, h):
+        """rumi_track_image_buffer: an [h, w] uint8 view of the tracker's pinned staging memory; a frame written there and passed to track() /
+        extract() is uploaded without the staging copy."""
+        buf, stride = C.c_void_p(), C.c_int32()
+        capi.check(self._lib.rumi_track_image_buffer(self._h, int(w), int(h), C.byref(buf), C.byref(stride)))
+        flat = np.ctypeslib.as_array((C.c_uint8 * (stride.value * h)).from_address(buf.value))
+        return flat.reshape(h, stride.value)[:, :w]
 
     # ---- step-wise entries: one member function of Tracking per call, the frame resident in between (include/rumi_track.h) ----
     @staticmethod

@@ -226,3 +226,21 @@ def test_single_queue_step_equals_stage_by_stage(tmp_path):
     bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
     assert not bad, f"the two paths differ in {bad[:8]}"
     assert any(int(a[k]) < 20 for k in a.files if k.endswith("_nmatches_motion")) and any(int(a[k]) >= 20 for k in a.files if k.endswith("_nmatches_motion"))
+
+
+@pytest.mark.gpu
+def test_frame_captured_into_the_trackers_pinned_buffer():
+    """rumi_track_image_buffer: a frame written into the tracker's pinned staging memory and passed to rumi_track_frame / rumi_track_extract by
+    that pointer skips the staging copy; the step must be the one a pageable copy of the frame gives."""
+    from rumi_slam_amd.tracker import Tracker
+    from rumi_slam_amd.synth import synth_frame
+    trk = Tracker(1000, 1.2, 8, 20, 7, 640, 480, 4096)
+    img = synth_frame(777)
+    mono_a, keys_a, desc_a = trk.extract(img)
+    buf = trk.image_buffer(640, 480)
+    assert buf.shape == (480, 640) and buf.strides == (640, 1)
+    buf[:] = img
+    mono_b, keys_b, desc_b = trk.extract(buf)
+    assert mono_a == mono_b and keys_a.tobytes() == keys_b.tobytes() and np.array_equal(desc_a, desc_b) and len(keys_a) > 500
+    r_w, r_h = trk.image_buffer(322, 240).shape[1], trk.image_buffer(322, 240).strides[0]
+    assert (r_w, r_h) == (322, 324)                              # a narrower frame: rows padded to 4 bytes
