@@ -81,6 +81,11 @@ int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int
                      int32_t lap0, int32_t lap1, RumiKeyPoint *kp_out, uint8_t *desc_out, int32_t cap,
                      int32_t *n_out, int32_t *mono_out);
 
+/* The handle's pinned staging memory for a w x hgt frame (*stride = w rounded up to 4 bytes per row).  Optional: a caller whose camera driver or
+ * decoder writes the frame straight into it (the cv::Mat ORBextractor::operator() receives, constructed on this memory) and passes this pointer
+ * and stride to rumi_orb_extract saves its staging copy (~20 us for 640 x 480). */
+int rumi_orb_image_buffer(RumiOrb *h, int32_t w, int32_t hgt, uint8_t **buf, int32_t *stride);
+
 /* Batched form for the rumination queue (CloudImageSampler.cc:148-170 collects the frames; KFDSample.cc:113
  * runs the same extractor on them).  All pointers are DEVICE pointers; frames are `frame_stride`
  * bytes apart.  Outputs: d_kp [nframes][cap], d_desc [nframes][cap][32], d_counts [nframes][2] =

@@ -35,7 +35,7 @@ _lib = None
 
 # every symbol include/rumi_orb.h declares (tests check the library exports all of them)
 ORB_SYMBOLS = ["rumi_last_error", "rumi_device_count", "rumi_orb_create", "rumi_orb_destroy", "rumi_orb_tables",
-               "rumi_orb_extract", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync", "rumi_orb_set_resident_queue", "rumi_orb_wait_event", "rumi_orb_extract_batch_records_async", "rumi_orb_extract_batch_host",
+               "rumi_orb_extract", "rumi_orb_image_buffer", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync", "rumi_orb_set_resident_queue", "rumi_orb_wait_event", "rumi_orb_extract_batch_records_async", "rumi_orb_extract_batch_host",
                "rumi_orb_pyramid_level",
                "rumi_orb_stage_keypoints", "rumi_orb_set_profiling", "rumi_orb_stage_ms"]
 
@@ -64,6 +64,7 @@ def lib():
     L.rumi_orb_destroy.restype = None
     L.rumi_orb_tables.argtypes = [C.POINTER(RumiOrbConfig)] + [vp] * 6
     L.rumi_orb_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.rumi_orb_image_buffer.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]
     L.rumi_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, vp, vp, i32, vp]
     L.rumi_orb_extract_batch_device_async.argtypes = L.rumi_orb_extract_batch_device.argtypes
     L.rumi_orb_sync.argtypes = [vp]

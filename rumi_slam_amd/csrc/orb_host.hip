@@ -800,6 +800,15 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
     return rumi_orb_sync(h);
 }
 
+// The handle's pinned staging buffer for a w x hgt frame, for a caller that lets its camera driver / decoder write the frame there (a cv::Mat
+// constructed on this memory): rumi_orb_extract called with this pointer and stride skips its staging copy.
+extern "C" int rumi_orb_image_buffer(RumiOrb *h, int32_t w, int32_t hgt, uint8_t **buf, int32_t *stride) {
+    if (!h || !buf || !stride) return RUMI_E_INVALID;
+    if (w <= 0 || hgt <= 0 || w > h->cfg.max_width || hgt > h->cfg.max_height) { g_lastError = "rumi_orb_image_buffer: frame larger than the handle was created for"; return RUMI_E_CAPACITY; }
+    *buf = h->hIn; *stride = (w + 3) & ~3;
+    return RUMI_OK;
+}
+
 extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32_t hgt, int32_t stride, int32_t lap0,
                                 int32_t lap1, RumiKeyPoint *kp_out, uint8_t *desc_out, int32_t cap, int32_t *n_out,
                                 int32_t *mono_out) {
@@ -811,7 +820,8 @@ extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32
     HIP_TRY(hipSetDevice(h->device));
     // image -> pinned -> device (async), kernels, [counts | key-points | descriptors] -> pinned: one synchronisation in all
     const int wp = (w + 3) & ~3;                                     // rows padded so that level 0 can be read as aligned dwords
-    for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);
+    if (!(img == h->hIn && stride == wp))                    // (a caller that captured straight into rumi_orb_image_buffer's memory has nothing to stage)
+        for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);
     HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)wp * hgt, hipMemcpyHostToDevice, nullptr));
     int32_t *dC = reinterpret_cast<int32_t *>(h->dOut1);
     RumiKeyPoint *dK = reinterpret_cast<RumiKeyPoint *>(h->dOut1 + 16);

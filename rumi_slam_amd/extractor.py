@@ -51,6 +51,14 @@ class ORBextractor:
         return self._tables["inv_sigma2"].copy()
 
     # ---- operator() ----
+    def image_buffer(self, w, h):
+        """rumi_orb_image_buffer: an [h, w] uint8 view of the handle's pinned staging memory; a frame written there and passed to __call__ is
+        uploaded without the staging copy."""
+        buf, stride = C.c_void_p(), C.c_int32()
+        capi.check(self._lib.rumi_orb_image_buffer(self._h, int(w), int(h), C.byref(buf), C.byref(stride)))
+        flat = np.ctypeslib.as_array((C.c_uint8 * (stride.value * h)).from_address(buf.value))
+        return flat.reshape(h, stride.value)[:, :w]
+
     def __call__(self, image, mask=None, vLappingArea=(0, 1000)):
         """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[n,32] u8); monoIndex == -1 for an empty image."""
         if image is None or image.size == 0:

@@ -434,3 +434,19 @@ def test_one_launch_pyramid_equals_the_launch_per_level_chain(tmp_path):
     assert set(a.files) == set(b.files) and len(a.files) > 150
     bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
     assert not bad, f"levels differ: {bad[:8]}"
+
+
+@pytest.mark.gpu
+def test_frame_captured_into_the_extractors_pinned_buffer():
+    """rumi_orb_image_buffer: a frame written into the handle's pinned staging memory and passed by that pointer skips the staging copy; same result."""
+    from rumi_slam_amd.extractor import ORBextractor
+    from rumi_slam_amd.synth import synth_frame
+    ext = ORBextractor(1000, 1.2, 8, 20, 7)
+    img = synth_frame(4711)
+    a = ext(img)
+    buf = ext.image_buffer(640, 480)
+    assert buf.shape == (480, 640) and buf.strides == (640, 1)
+    buf[:] = img
+    b = ext(buf)
+    assert a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) and len(a[1]) > 500
+    assert ext.image_buffer(322, 240).strides == (324, 1)           # rows padded to 4 bytes

@@ -17,6 +17,11 @@ def one():
     k[0] += 1
     return ext(imgs[k[0] & 3])
 print("single frame median %.1f us" % (median_call(one, 200) * 1e6))
+pin = ext.image_buffer(imgs[0].shape[1], imgs[0].shape[0])          # the frame captured straight into the handle's pinned staging memory
+pin[:] = imgs[0]
+rp = ext(pin)
+assert rp[0] == r0[0][0] and rp[1].tobytes() == r0[0][1].tobytes() and np.array_equal(rp[2], r0[0][2])
+print("single frame captured into rumi_orb_image_buffer's memory, median %.1f us" % (median_call(lambda: ext(pin), 200) * 1e6))
 # the same frame already in device memory, results left in device memory (no transfers: the kernels' dependent chain alone)
 import torch
 fr = torch.from_numpy(imgs[0]).cuda()[None].contiguous()
