@@ -213,11 +213,15 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         eX[k] = (double)Xw[3 * i]; eY[k] = (double)Xw[3 * i + 1]; eZ[k] = (double)Xw[3 * i + 2];
         eU[k] = (double)obs[2 * i]; eV[k] = (double)obs[2 * i + 1]; eW[k] = (double)wgt[i];
     }
+    uint8_t rAct[kRegEdges];                                                // ... and so do their active flag and last chi2 (only the owning thread reads them)
+    double rChi[kRegEdges];
+#pragma unroll
+    for (int k = 0; k < kRegEdges; k++) { rAct[k] = 1; rChi[k] = 0; }
     auto for_edges = [&](auto &&body) {
 #pragma unroll
-        for (int k = 0; k < kRegEdges; k++) { const int i = tid + k * NT; if (i < n) body(i, eX[k], eY[k], eZ[k], eU[k], eV[k], eW[k]); }
+        for (int k = 0; k < kRegEdges; k++) { const int i = tid + k * NT; if (i < n) body(i, eX[k], eY[k], eZ[k], eU[k], eV[k], eW[k], rAct[k], rChi[k]); }
         for (int i = tid + kRegEdges * NT; i < n; i += NT)
-            body(i, (double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2], (double)obs[2 * i], (double)obs[2 * i + 1], (double)wgt[i]);
+            body(i, (double)Xw[3 * i], (double)Xw[3 * i + 1], (double)Xw[3 * i + 2], (double)obs[2 * i], (double)obs[2 * i + 1], (double)wgt[i], active[i], lastChi2[i]);
     };
     auto edge_chi2 = [&](double X, double Y, double Z, double ou, double ov, double w, const fused::DSE3 &P, double &e0, double &e1, fused::D3 &pc) -> double {
         pc = fused::D3{Rm[0][0] * X + Rm[0][1] * Y + Rm[0][2] * Z + P.t.x, Rm[1][0] * X + Rm[1][1] * Y + Rm[1][2] * Z + P.t.y,
@@ -230,11 +234,11 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     auto robust_chi2 = [&](const fused::DSE3 &P) -> double {                      // computeActiveErrors + activeRobustChi2
         double acc[1] = {0};
         set_pose(P);
-        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
-            if (!active[i]) return;
+        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w, uint8_t &act, double &last) {
+            if (!act) return;
             double e0, e1; fused::D3 pc;
             const double c = edge_chi2(X, Y, Z, ou, ov, w, P, e0, e1, pc);
-            lastChi2[i] = c;
+            last = c;
             double r0 = c, r1 = 1;
             if (robust) fused::huber(c, delta, dsqr, r0, r1);
             acc[0] += r0;
@@ -261,11 +265,11 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
 #pragma unroll
                 for (int k = 0; k < 28; k++) hb[k] = 0;
                 set_pose(T);
-                for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
-                    if (!active[i]) return;
+                for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w, uint8_t &act, double &last) {
+                    if (!act) return;
                     double e0, e1; fused::D3 pc;
                     const double c = edge_chi2(X, Y, Z, ou, ov, w, T, e0, e1, pc);
-                    lastChi2[i] = c;
+                    last = c;
                     double r0 = c, r1 = 1;
                     if (robust) fused::huber(c, delta, dsqr, r0, r1);
                     hb[27] += r0;
@@ -340,11 +344,11 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
         // re-classification (:916-939): former outliers get a fresh error, active edges keep the last computed one
         double bad[1] = {0};
         set_pose(T);
-        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w) {
+        for_edges([&](int i, double X, double Y, double Z, double ou, double ov, double w, uint8_t &act, double &last) {
             double e0, e1; fused::D3 pc;
-            const float chi2 = (float)(outlier[i] ? edge_chi2(X, Y, Z, ou, ov, w, T, e0, e1, pc) : lastChi2[i]);
-            if (chi2 > 5.991f) { outlier[i] = 1; active[i] = 0; bad[0] += 1; }
-            else { outlier[i] = 0; active[i] = 1; }
+            const float chi2 = (float)(!act ? edge_chi2(X, Y, Z, ou, ov, w, T, e0, e1, pc) : last);       // (an edge is inactive exactly when it is an outlier)
+            if (chi2 > 5.991f) { outlier[i] = 1; act = 0; bad[0] += 1; }
+            else { outlier[i] = 0; act = 1; }
         });
         block_sum<1, NW>(bad, red);
         nBadRound = (int)bad[0];
