@@ -72,11 +72,12 @@ __device__ __forceinline__ double wave_allreduce_f64(double s) {
 }
 
 // ---- block reduction of NV doubles per thread (NW waves, 4 by default); every thread gets the total ----
-template <int NV, int NW = 4> __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [NW][NV] */) {
+// (FENCE_FIRST = false: the caller alternates between two `red` buffers from call to call, so no wave can still be reading the one written here)
+template <int NV, int NW = 4, bool FENCE_FIRST = true> __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [NW][NV] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = wave_allreduce_f64(v[k]);
-    __syncthreads();
+    if (FENCE_FIRST) __syncthreads();
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
@@ -110,7 +111,7 @@ template <int D, int N, int PAD> __device__ __forceinline__ void butterfly_stage
         if constexpr (D > 1) butterfly_stage<D / 2, N / 2, PAD>(w, lane);
     }
 }
-template <int NV, int NW = 4> __device__ __forceinline__ void block_sum_butterfly(double (&v)[NV], double *red) {
+template <int NV, int NW = 4, bool FENCE_FIRST = true> __device__ __forceinline__ void block_sum_butterfly(double (&v)[NV], double *red) {
     static_assert(NV <= 64, "at most 64 values");
     constexpr int PAD = NV <= 32 ? 32 : 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,7 +121,7 @@ template <int NV, int NW = 4> __device__ __forceinline__ void block_sum_butterfl
     butterfly_stage<32, PAD / 2, PAD>(w, lane);
     int idx = lane;
     if (PAD == 32) { w[0] += lane_xor_f64<1>(w[0]); idx = lane >> 1; }     // 32 slots: lane pairs hold the same slot
-    __syncthreads();
+    if (FENCE_FIRST) __syncthreads();
     if (PAD == 64 || (lane & 1) == 0) red[wave * PAD + idx] = w[0];
     __syncthreads();
     if (threadIdx.x < PAD) {
@@ -168,7 +169,9 @@ constexpr int kPoseLdsEdges = 1152;          // (nfeatures 1000 + the extractor'
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     constexpr int NW = NT / 64;
-    __shared__ double red[(NW + 1) * 32];
+    __shared__ double redBuf[2 * (NW + 1) * 32];                            // two reduction buffers used in turn: a reduction then needs no barrier before its first store
+    int redFlip = 0;
+    auto next_red = [&]() { redFlip ^= 1; return redBuf + redFlip * (NW + 1) * 32; };
     __shared__ float sXw[LDS ? 3 * kPoseLdsEdges : 1], sObs[LDS ? 2 * kPoseLdsEdges : 1], sW[LDS ? kPoseLdsEdges : 1];
     __shared__ double sChi[LDS ? kPoseLdsEdges : 1];
     __shared__ uint8_t sAct[LDS ? kPoseLdsEdges : 1];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
             if (robust) fused::huber(c, delta, dsqr, r0, r1);
             acc[0] += r0;
         });
-        block_sum<1, NW>(acc, red);
+        block_sum<1, NW, false>(acc, next_red());
         return acc[0];
     };
 
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
                     for (int a = 0; a < 6; a++) hb[21 + a] -= a == 4 ? J1[a] * we1 : a == 3 ? J0[a] * we0 : J0[a] * we0 + J1[a] * we1;
                 });
                 POSE_STAMP(stPass);
-                block_sum_butterfly<28, NW>(hb, red);
+                block_sum_butterfly<28, NW, false>(hb, next_red());
                 POSE_STAMP(stRed); POSE_COUNT(stN);
                 double currentChi = hb[27];
                 const double iniChi = currentChi;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
             if (chi2 > 5.991f) { outlier[i] = 1; act = 0; bad[0] += 1; }
             else { outlier[i] = 0; act = 1; }
         });
-        block_sum<1, NW>(bad, red);
+        block_sum<1, NW, false>(bad, next_red());
         nBadRound = (int)bad[0];
         if (it == 2) robust = false;                                       // setRobustKernel(0)
         if (n < 10) break;                                                 // optimizer.edges().size() < 10
