@@ -144,6 +144,16 @@ inline void replay_discard(FrameT &Cur, const std::vector<MapPointT *> &byId, co
 
 }  // namespace track_detail
 
+// The capture target that saves ExtractFrame / TrackFrame their staging copy: a cv::Mat header on the Tracking thread's tracker's pinned staging
+// memory (rumi_track_image_buffer).  The camera driver / decoder writes the grey frame into it (or the caller copies it there where it converts
+// to grey anyway: Tracking::GrabImageMonocular's cvtColor can take it as destination) and the same Mat is passed on.  Empty Mat on failure.
+template <class ExtractorT> inline cv::Mat CaptureBuffer(ExtractorT &extractor, int cols, int rows, int maxPoints = 0) {
+    RumiTracker *t = track_detail::tracker_for(extractor, cols, rows, maxPoints);
+    uint8_t *buf = nullptr; int32_t stride = 0;
+    if (!t || rumi_track_image_buffer(t, cols, rows, &buf, &stride) != RUMI_OK) return cv::Mat();
+    return cv::Mat(rows, cols, CV_8UC1, buf, (size_t)stride);
+}
+
 // Frame::ExtractORB(0, im, 0, 1000) for a Frame built without it: the features land in the frame AND stay on the device for the calls below.
 // Returns monoIndex (-1 on failure, reported through rumi_status.h; the frame stays empty -- no CPU fallback).
 template <class FrameT, class ExtractorT> int ExtractFrame(FrameT &Cur, const cv::Mat &im, ExtractorT &extractor, int maxPoints = 0) {

@@ -514,7 +514,11 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < mps.size(); i++) { visF[i] = mps[i].nVisible; foundF[i] = mps[i].nFound; mps[i].nVisible = 0; mps[i].nFound = 0; mps[i].mnLastFrameSeen = -1; mps[i].mbTrackInView = false; }
         Frame F2; F2.mnId = 32;
         rumi_facade::TrackStep ss;
-        const int monoS = rumi_facade::ExtractFrame(F2, image1, ext, (int)mps.size());
+        // (the step-wise path reads the frame from the tracker's pinned capture buffer: no staging copy, same features)
+        cv::Mat capture = rumi_facade::CaptureBuffer(ext, 640, 480, (int)mps.size());
+        CHECK(!capture.empty() && capture.rows == 480 && capture.cols == 640 && capture.step == 640, "CaptureBuffer: a 640 x 480 Mat on the tracker's pinned memory");
+        for (int y = 0; y < 480; y++) std::memcpy(capture.data + (size_t)y * capture.step, image1.data + (size_t)y * image1.step, 640);
+        const int monoS = rumi_facade::ExtractFrame(F2, capture, ext, (int)mps.size());
         const bool okM = rumi_facade::TrackWithMotionModel(F2, fr[0], T7, 15.f, &ss);
         int heldAfterMotion = 0, seenAfterMotion = 0;
         for (int i = 0; i < F2.N; i++) heldAfterMotion += F2.mvpMapPoints[i] != nullptr;
