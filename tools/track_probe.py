@@ -63,6 +63,18 @@ def measure(reps=60):
         return r["ngood_local"], r["Tcw"]
 
 
+    def c_call_ms(reps):                                           # the C entry alone, without the Python mirror's array allocations and copies
+        real, spent = trk._lib.rumi_track_frame, []
+        def timed(*a):
+            t0 = time.perf_counter(); rc = real(*a); spent.append(time.perf_counter() - t0); return rc
+        trk._lib.rumi_track_frame = timed
+        try:
+            for _ in range(reps + 5): fused_pinned()
+        finally:
+            trk._lib.rumi_track_frame = real
+        return float(np.median(spent[5:])) * 1e3
+
+
     def med(f, reps):
         for _ in range(5): f()
         ts = []
@@ -108,12 +120,12 @@ def measure(reps=60):
     per = {k: round(float(np.median(v[5:])) * 1e3, 3) for k, v in stage.items()}
     return dict(step_wise_ms=round(step_ms, 3), extract_plus_reference_keyframe_ms=round(ref_ms, 3), stage_ms=per, workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
                 inliers=int(b[0]), separate_entries_ms=round(med(separate, reps), 3), rumi_track_frame_ms=round(med(fused, reps), 3),
-                rumi_track_frame_pinned_ms=round(med(fused_pinned, reps), 3))
+                rumi_track_frame_pinned_ms=round(med(fused_pinned, reps), 3), c_call_pinned_ms=round(c_call_ms(reps), 3))
 
 
 if __name__ == "__main__":
     r = measure()
-    print("%s: separate entries %.3f ms, rumi_track_frame %.3f ms (inliers %d); the frame captured into rumi_track_image_buffer's pinned memory: %.3f ms" %
-          (r["workload"], r["separate_entries_ms"], r["rumi_track_frame_ms"], r["inliers"], r["rumi_track_frame_pinned_ms"]))
+    print("%s: separate entries %.3f ms, rumi_track_frame %.3f ms (inliers %d); the frame captured into rumi_track_image_buffer's pinned memory: %.3f ms (the C call alone, without the Python mirror's allocations: %.3f ms)" %
+          (r["workload"], r["separate_entries_ms"], r["rumi_track_frame_ms"], r["inliers"], r["rumi_track_frame_pinned_ms"], r["c_call_pinned_ms"]))
     print("step-wise entries on the resident frame: extract + motion + local %.3f ms; extract + reference key-frame %.3f ms; per call (ms): %s" %
           (r["step_wise_ms"], r["extract_plus_reference_keyframe_ms"], r["stage_ms"]))
