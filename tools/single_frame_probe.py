@@ -22,6 +22,14 @@ pin[:] = imgs[0]
 rp = ext(pin)
 assert rp[0] == r0[0][0] and rp[1].tobytes() == r0[0][1].tobytes() and np.array_equal(rp[2], r0[0][2])
 print("single frame captured into rumi_orb_image_buffer's memory, median %.1f us" % (median_call(lambda: ext(pin), 200) * 1e6))
+import time
+real, spent = ext._lib.rumi_orb_extract, []
+def timed(*a):
+    t0 = time.perf_counter(); rc = real(*a); spent.append(time.perf_counter() - t0); return rc
+ext._lib.rumi_orb_extract = timed                                   # the C entry alone, without the Python mirror's array allocations and copies
+for _ in range(205): ext(pin)
+ext._lib.rumi_orb_extract = real
+print("  the C call alone (pinned capture buffer): median %.1f us" % (float(np.median(spent[5:])) * 1e6))
 # the same frame already in device memory, results left in device memory (no transfers: the kernels' dependent chain alone)
 import torch
 fr = torch.from_numpy(imgs[0]).cuda()[None].contiguous()
