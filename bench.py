@@ -17,7 +17,7 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (per-stag
 kernels run on, every kernel alone on it); `cpu_baseline` is the CPU oracle (kind "port": the reference itself cannot be built in
 this image) timed single-threaded on a bounded sample of the same frames, rank 0, N = 1 only.  N = 1 also reports
 `value_h2d_inclusive` (the same step with the frames starting in pinned HOST memory, transfers overlapped with the kernels),
-`single_frame_host_api_fps`, a `batch_sweep`, and the `lba` / `pose_opt` side legs.
+`single_frame_host_api_fps` (and `single_frame_c_call_fps`: the C entry alone on the pinned capture buffer), a `batch_sweep`, and the `lba` / `pose_opt` side legs.
 """
 import argparse
 import json
@@ -400,6 +400,20 @@ def main():
             for i in range(200):
                 ext1(host[i % len(host)], None, (0, 1000))
             line["single_frame_host_api_fps"] = round(200 / (time.perf_counter() - t0), 1)
+            # (the same with the frame captured into the handle's pinned staging memory, rumi_orb_image_buffer, and the C entry timed alone:
+            # the Python mirror above allocates and copies the result arrays of every call)
+            pin = ext1.image_buffer(W, H)
+            c_real, c_spent = ext1._lib.rumi_orb_extract, []
+            def c_timed(*a):
+                t1 = time.perf_counter(); rc = c_real(*a); c_spent.append(time.perf_counter() - t1); return rc
+            ext1._lib.rumi_orb_extract = c_timed
+            try:
+                for i in range(208):
+                    pin[:] = host[i % len(host)]
+                    ext1(pin, None, (0, 1000))
+            finally:
+                ext1._lib.rumi_orb_extract = c_real
+            line["single_frame_c_call_fps"] = round(1.0 / float(np.median(c_spent[8:])), 1)
             ext1.close()
             # ---- frames per call: device-resident extract + match, the step above at other queue lengths (a rank's share of configs[4] is 128) ----
             sweep, recs = {}, {}
