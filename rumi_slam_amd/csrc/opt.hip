@@ -1067,17 +1067,20 @@ __device__ __forceinline__ bool panel_factor(double (&a)[16], int w, int lane, d
     return bad;
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, double *__restrict__ G, int NP, const LmState *S = nullptr) {
-    if (S) { if (S->done) return; lambda = S->lambda; }
+// What the factorisation reads and writes.  WIN = false: G is the row-major Gram matrix the atomics of k_ba_syrk_mfma filled (left zeroed for the
+// next trial); WIN = true (ba_windows.inc): G holds the lower-triangle tiles in the tile layout itself, summed in a fixed order by k_baw_reduce.
+struct SolveIO { int n, NP; const double *Hpp, *bp; double *x, *okFlag, *scalZero; };
+template <bool WIN>
+__device__ __forceinline__ void solve_tiles_core(const SolveIO &B, double lambda, double *__restrict__ G) {
     extern __shared__ double T[];                             // tiles | y[NT*16]
     __shared__ int sFail;
     __shared__ double sBuf[kSolveWaves][16];                           // per wave: the scaled pivot column of the panel step in flight
-    const int n = B.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = B.n, NP = B.NP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = NP / 16;                                   // tile rows (the right-hand side is row n)
     const int PT = (n + 15) / 16;                             // tile columns that hold pivots
     const int nT = NT * (NT + 1) / 2;
     double *ys = T + (size_t)nT * 256;
-    if (tid == 0) { sFail = 0; B.scal[0] = 0.0; B.scal[1] = 0.0; }      // chi2 and scale of the trial are accumulated by the kernels after this one
+    if (tid == 0) { sFail = 0; if (!WIN) { B.scalZero[0] = 0.0; B.scalZero[1] = 0.0; } }      // chi2 and scale of the trial are accumulated by the kernels after this one
     // ---- assemble: element (i, j) = -G[j][i] (+ b_p in row n), one wave per tile and all of a wave's loads in flight at once (G was just
     // written: one L2 latency, not one per tile); then the 6x6 blocks of H_pp + lambda I are added by one thread per entry
     {
@@ -1098,10 +1101,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
 #pragma unroll
                 for (int q = 0; q < 4; q++) {                  // loads without a branch around them (clamped addresses): all in flight together
                     const int j = r * 16 + cq + 4 * q, jc = min(j, n - 1);
-                    const double gv = G[(size_t)jc * NP + min(i, n)], bv = B.bp[jc];
+                    double gv;
+                    if constexpr (WIN) gv = G[(size_t)t * 256 + (cq + 4 * q) * 16 + m];       // tile (I, r), element (row i, column j) at (j & 15) * 16 + (i & 15)
+                    else gv = G[(size_t)jc * NP + min(i, n)];
+                    const double bv = B.bp[jc];
                     v[u][q] = (i <= n && j < n) ? (i == n ? bv - gv : -gv) : 0.0;
-                    if (i <= n && j < n) G[(size_t)j * NP + i] = 0.0;      // G is an accumulator of atomics: left zeroed for the next trial
-
+                    if constexpr (!WIN) { if (i <= n && j < n) G[(size_t)j * NP + i] = 0.0; }      // G is an accumulator of atomics: left zeroed for the next trial
                 }
             }
         }
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
         __syncthreads();
     }
     if (sFail) {
-        if (tid == 0) B.scal[3] = 0.0;
+        if (tid == 0) *B.okFlag = 0.0;
         for (int i = tid; i < n; i += kSolveThreads) B.x[i] = 0;
         return;
     }
@@ -1244,8 +1249,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, doubl
                 }
             }
         }
-        if (lane == 0) B.scal[3] = 1.0;
+        if (lane == 0) *B.okFlag = 1.0;
     }
+}
+
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_tiles(BADev B, double lambda, double *__restrict__ G, int NP, const LmState *S = nullptr) {
+    if (S) { if (S->done) return; lambda = S->lambda; }
+    const SolveIO io{B.n, NP, B.Hpp, B.bp, B.x, B.scal + 3, B.scal};
+    solve_tiles_core<false>(io, lambda, G);
 }
 
 
@@ -2037,6 +2048,14 @@ __global__ __launch_bounds__(256) void k_sim3_opt(Sim3Args A) {
     if (tid == 0) { sim3_to8(est, A.Sout); A.res[0] = (int)in[0]; A.res[1] = nBad; A.res[2] = 0; }
 }
 
+__device__ __forceinline__ double wave_allreduce_max(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+    return v;
+}
+
+#include "ba_windows.inc"
+
 }  // namespace rumi
 
 using namespace rumi;
@@ -2066,6 +2085,13 @@ struct RumiOptimizer {
     rumi::LmState *hLmInit = nullptr;    // pinned staging of the initial state
     unsigned long long lmSeq = 0;
     unsigned long long pubSeq = 0;
+    // window-batched local BA (ba_windows.inc): per-arena extras, allocated on first use; the window table lives in the handle that runs the batch
+    double *dGpart = nullptr, *dGw = nullptr, *dChiPart = nullptr, *dSclPart = nullptr;
+    uint8_t *dWinSmall = nullptr;
+    rumi::LmCtl *dLmCtl = nullptr, *hLmCtl = nullptr;
+    rumi::WinMirror *hWm = nullptr, *dhWm = nullptr;
+    rumi::BAWin *hWinTab = nullptr, *dWinTab = nullptr;
+    unsigned bawRun = 0;
     hipStream_t stream = nullptr;    // bundle adjustments of this handle (created non-blocking)
     std::vector<RumiOptimizer *> workers;   // rumi_local_ba_batch: one child handle per worker thread, created on first use
     int maxKFc = 0, maxMPc = 0, maxEc = 0;   // creation arguments (children are created alike)
@@ -2098,6 +2124,10 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
                  o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW, o->dColOf};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->dPairs) (void)hipFree(o->dPairs);
+    { void *q[] = {o->dGpart, o->dGw, o->dChiPart, o->dSclPart, o->dWinSmall, o->dLmCtl, o->dWinTab}; for (void *x : q) if (x) (void)hipFree(x); }
+    if (o->hLmCtl) (void)hipHostFree(o->hLmCtl);
+    if (o->hWm) (void)hipHostFree((void *)o->hWm);
+    if (o->hWinTab) (void)hipHostFree(o->hWinTab);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hLm) (void)hipHostFree(o->hLm);
     if (o->hStop) (void)hipHostFree(o->hStop);
@@ -2241,6 +2271,8 @@ extern "C" int rumi_pose_optimization(RumiOptimizer *o, const float *Xw, const f
     return rumi_pose_optimization_batch(o, 1, start, Xw, obs, inv_sigma2, K4, Tcw7, outlier_out, n_good_out);
 }
 
+#include "ba_windows_host.inc"
+
 // mode 0: Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, ...) — one optimize(10) with Huber(sqrt(5.991)).
 // mode 1: Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, vpAdjustKF, vpFixedKF, bool*) (merge window, Optimizer.cc:3768-4183) —
 //         optimize(5) with Huber(sqrt(5.99)); unless stopped: outlier edges to level 1, kernels off, initializeOptimization(0) +
@@ -2254,6 +2286,14 @@ static int ba_run(RumiOptimizer *o, int mode, int32_t nKF, float *kf_pose7, cons
         (nE > 0 && (!e_mp || !e_kf || !e_obs || !e_inv_sigma2 || !erase_out)))
         return RUMI_E_INVALID;
     if (nKF > o->maxKF || nMP > o->maxMP || nE > o->maxE) { g_lastError = "local BA: problem larger than the optimiser's arenas"; return RUMI_E_CAPACITY; }
+    // windows the tile solver takes (up to 29 optimised key-frames): the window-batched kernels, as a batch of one
+    if (!o->profiling && !std::getenv("RUMI_BA_HOST_LM") && baw_eligible(nKF, kf_fixed, nMP, nE) && !(mode == 2 && (gbaIterations < 1 || (stop_flag && *stop_flag)))) {
+        const BawArgs a{nKF, kf_pose7, kf_fixed, nMP, mp_pos3, nE, e_mp, e_kf, e_obs, e_inv_sigma2, K4, stop_flag, erase_out, stats};
+        RumiOptimizer *arena = o;
+        int32_t status = RUMI_OK;
+        const int rc = baw_run(o, mode, 1, &a, &arena, gbaIterations, gbaRobust, &status);
+        return rc != RUMI_OK ? rc : status;
+    }
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     int nFixed = 0;
     for (int k = 0; k < nKF; k++) nFixed += kf_fixed[k] ? 1 : 0;
@@ -2699,26 +2739,56 @@ extern "C" int rumi_local_ba(RumiOptimizer *o, int32_t nKF, float *kf_pose7, con
 // window's host thread waits for the eight scalars of an LM trial, the kernels of the others fill the device.
 extern "C" int rumi_local_ba_batch(RumiOptimizer *o, int32_t n_windows, RumiBaWindow *win, int32_t n_workers) {
     if (!o || n_windows < 0 || (n_windows > 0 && !win) || n_workers < 1) return RUMI_E_INVALID;
-    n_workers = std::min(std::min(n_workers, n_windows), 16);
     if (n_windows == 0) return RUMI_OK;
-    while ((int)o->workers.size() < n_workers) {
-        RumiOptimizer *c = nullptr;
-        const int rc = rumi_opt_create(o->maxPoseEdges, 1, o->maxKF, o->maxMP, o->maxE, o->device, &c);
-        if (rc != RUMI_OK) return rc;
-        o->workers.push_back(c);
-    }
-    std::atomic<int> next{0};
-    auto work = [&](RumiOptimizer *c) {
-        for (int i = next.fetch_add(1); i < n_windows; i = next.fetch_add(1)) {
-            RumiBaWindow &W = win[i];
-            W.status = ba_run(c, 0, W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3, W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2, W.K4, W.stop_flag,
-                              W.erase_out, W.stats);
+    auto need_children = [&](int cnt) -> int {
+        while ((int)o->workers.size() < cnt) {
+            RumiOptimizer *c = nullptr;
+            const int rc = rumi_opt_create(o->maxPoseEdges, 1, o->maxKF, o->maxMP, o->maxE, o->device, &c);
+            if (rc != RUMI_OK) return rc;
+            o->workers.push_back(c);
         }
+        return RUMI_OK;
     };
-    std::vector<std::thread> th;
-    for (int k = 1; k < n_workers; k++) th.emplace_back(work, o->workers[k]);
-    work(o->workers[0]);
-    for (auto &t : th) t.join();
+    // windows of up to 29 optimised key-frames: the window is a batch dimension of the kernels (ba_windows.inc), driven by THIS thread alone, in
+    // groups of kBawMaxWindows; a child handle per window of a group lends its arenas
+    std::vector<int> batched, others;
+    for (int i = 0; i < n_windows; i++) {
+        const RumiBaWindow &W = win[i];
+        const bool ok = W.kf_pose7 && W.kf_fixed && W.K4 && W.mp_pos3 && W.e_mp && W.e_kf && W.e_obs && W.e_inv_sigma2 && W.erase_out &&
+                        W.n_kf <= o->maxKF && W.n_mp <= o->maxMP && W.n_edges <= o->maxE && !o->profiling && !std::getenv("RUMI_BA_HOST_LM") &&
+                        baw_eligible(W.n_kf, W.kf_fixed, W.n_mp, W.n_edges);
+        (ok ? batched : others).push_back(i);
+    }
+    for (size_t g0 = 0; g0 < batched.size(); g0 += kBawMaxWindows) {
+        const int cnt = (int)std::min<size_t>(kBawMaxWindows, batched.size() - g0);
+        { const int rc = need_children(cnt); if (rc != RUMI_OK) return rc; }
+        std::vector<BawArgs> args((size_t)cnt);
+        std::vector<int32_t> status((size_t)cnt, RUMI_OK);
+        for (int j = 0; j < cnt; j++) {
+            RumiBaWindow &W = win[batched[g0 + j]];
+            args[j] = BawArgs{W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3, W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2, W.K4, W.stop_flag, W.erase_out, W.stats};
+        }
+        const int rc = baw_run(o, 0, cnt, args.data(), o->workers.data(), 0, 1, status.data());
+        for (int j = 0; j < cnt; j++) win[batched[g0 + j]].status = status[j];
+        if (rc != RUMI_OK && rc != RUMI_E_INVALID && rc != RUMI_E_CAPACITY) return rc;      // a HIP failure: nothing more to run
+    }
+    // everything else (larger windows, structure-only windows, the profiled path): one single-window run each, over worker threads as before
+    if (!others.empty()) {
+        n_workers = std::min(std::min(n_workers, (int)others.size()), 16);
+        { const int rc = need_children(n_workers); if (rc != RUMI_OK) return rc; }
+        std::atomic<int> next{0};
+        auto work = [&](RumiOptimizer *c) {
+            for (int q = next.fetch_add(1); q < (int)others.size(); q = next.fetch_add(1)) {
+                RumiBaWindow &W = win[others[q]];
+                W.status = ba_run(c, 0, W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3, W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2, W.K4, W.stop_flag,
+                                  W.erase_out, W.stats);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_workers; k++) th.emplace_back(work, o->workers[k]);
+        work(o->workers[0]);
+        for (auto &t : th) t.join();
+    }
     int worst = RUMI_OK;
     for (int i = 0; i < n_windows; i++) if (win[i].status != RUMI_OK) worst = win[i].status;
     return worst;

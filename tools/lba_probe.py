@@ -15,18 +15,12 @@ for n_opt in (int(x) for x in (sys.argv[1:] or ["20"])):
     for _ in range(20):
         t0 = time.perf_counter(); stats, *_ = opt.LocalBundleAdjustment(*a); ts.append((time.perf_counter() - t0) * 1e3)
     dev = opt.stage_ms()[5]
-    opt.set_profiling(True)
-    opt.LocalBundleAdjustment(*a)
-    k = opt.kernel_ms()
-    opt.set_profiling(False)
-    print("n_opt %d  wall ms median %.3f min %.3f  device %.3f  stats %s  per trial us: hpp %.1f syrk %.1f solve %.1f" % (
-        n_opt, float(np.median(ts)), min(ts), dev, list(stats), 1e3 * k["hpp"] / max(k["trials"], 1), 1e3 * k["syrk"] / max(k["trials"], 1), 1e3 * k["solve"] / max(k["trials"], 1)))
+    print("n_opt %d  wall ms median %.3f min %.3f  device %.3f  stats %s" % (n_opt, float(np.median(ts)), min(ts), dev, [int(x) for x in stats]))
 
 # R windows through rumi_local_ba_batch
 b = ba_problem(seed=0, n_opt=20, n_fixed=5, n_points=3000)
 w = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"])
-for workers in (1, 2, 4, 8):
-    R = 16
+for R, workers in ((16, 1), (32, 1), (4, 1)):
     opt.LocalBundleAdjustmentBatch([w] * R, workers)
     dts, cpu = [], []
     for _ in range(5):
