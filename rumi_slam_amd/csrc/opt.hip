@@ -2087,7 +2087,7 @@ struct RumiOptimizer {
     unsigned long long pubSeq = 0;
     // window-batched local BA (ba_windows.inc): per-arena extras, allocated on first use; the window table lives in the handle that runs the batch
     double *dGpart = nullptr, *dGw = nullptr, *dChiPart = nullptr, *dSclPart = nullptr;
-    uint8_t *dWinSmall = nullptr;
+    uint8_t *dWinSmall = nullptr, *dSorted = nullptr; size_t sortedBytes = 0;
     rumi::LmCtl *dLmCtl = nullptr, *hLmCtl = nullptr;
     rumi::WinMirror *hWm = nullptr, *dhWm = nullptr;
     rumi::BAWin *hWinTab = nullptr, *dWinTab = nullptr;
@@ -2124,7 +2124,7 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
                  o->dAglob, o->dErase, o->dEOff, o->dYt, o->dG, o->dLp, o->dW, o->dColOf};
     for (void *q : p) if (q) (void)hipFree(q);
     if (o->dPairs) (void)hipFree(o->dPairs);
-    { void *q[] = {o->dGpart, o->dGw, o->dChiPart, o->dSclPart, o->dWinSmall, o->dLmCtl, o->dWinTab}; for (void *x : q) if (x) (void)hipFree(x); }
+    { void *q[] = {o->dGpart, o->dGw, o->dChiPart, o->dSclPart, o->dWinSmall, o->dLmCtl, o->dWinTab, o->dSorted}; for (void *x : q) if (x) (void)hipFree(x); }
     if (o->hLmCtl) (void)hipHostFree(o->hLmCtl);
     if (o->hWm) (void)hipHostFree((void *)o->hWm);
     if (o->hWinTab) (void)hipHostFree(o->hWinTab);

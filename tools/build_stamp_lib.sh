@@ -13,3 +13,6 @@ F="-O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx
 # k_pose_opt (-DRUMI_POSE_STAMP: one printf per wave of frame 0): ... && python tools/with_lib.py tools/bin/librumi_hip_pose_stamp.so tools/pose_probe.py
 /opt/rocm/bin/hipcc $F -DRUMI_POSE_STAMP -c opt.hip -o /tmp/opt_stamp.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_pose_stamp.so /tmp/opt_stamp.o $(ls *.o | grep -v -e '^opt.o') -lpthread
+# k_baw_system (-DRUMI_BAW_STAMP: workgroups 1 and 5 of window 0 print their phases at the third LM trial): ... && python tools/with_lib.py tools/bin/librumi_hip_baw_stamp.so tools/prof_lba_batch.py 0 1
+/opt/rocm/bin/hipcc $F -DRUMI_BAW_STAMP -c opt.hip -o /tmp/opt_baw_stamp.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/librumi_hip_baw_stamp.so /tmp/opt_baw_stamp.o $(ls *.o | grep -v -e '^opt.o') -lpthread
