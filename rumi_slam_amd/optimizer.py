@@ -93,8 +93,12 @@ class Optimizer:
         stats = np.zeros(4, np.int32)
         sp = capi.ptr(stop_flag) if stop_flag is not None else None
         fn = self._lib.rumi_merge_ba if merge else self._lib.rumi_local_ba
-        capi.check(fn(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
-                      capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats)))
+        import time
+        t0 = time.perf_counter()
+        rc = fn(self._h, len(kfix), capi.ptr(kp), capi.ptr(kfix), len(mp), capi.ptr(mp), len(em), capi.ptr(em),
+                capi.ptr(ek), capi.ptr(eo), capi.ptr(ew), capi.ptr(K4), sp, capi.ptr(erase), capi.ptr(stats))
+        self.last_call_s = time.perf_counter() - t0
+        capi.check(rc)
         return stats, kp, mp, erase[:len(em)]
 
     def LocalBundleAdjustmentBatch(self, windows, n_workers=4):
@@ -112,7 +116,11 @@ class Optimizer:
             W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3 = len(kfix), kp.ctypes.data, kfix.ctypes.data, len(mp), mp.ctypes.data
             W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2 = len(em), em.ctypes.data, ek.ctypes.data, eo.ctypes.data, ew.ctypes.data
             W.K4, W.stop_flag, W.erase_out = K4.ctypes.data, None, erase.ctypes.data
-        capi.check(self._lib.rumi_local_ba_batch(self._h, len(windows), C.cast(arr, C.c_void_p), int(n_workers)))
+        import time
+        t0 = time.perf_counter()
+        rc = self._lib.rumi_local_ba_batch(self._h, len(windows), C.cast(arr, C.c_void_p), int(n_workers))
+        self.last_call_s = time.perf_counter() - t0         # the C entry alone (the mirror above copies every array of every window)
+        capi.check(rc)
         return [(np.array(W.stats, np.int32), k[0], k[2], k[8][:len(k[3])]) for W, k in zip(arr, keep)]
 
     def BundleAdjustment(self, kf_pose, kf_fixed, mp_pos, e_mp, e_kf, e_obs, e_inv_sigma2, K4, n_iterations=5, robust=True, stop_flag=None):

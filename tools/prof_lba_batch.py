@@ -10,7 +10,7 @@ a = (b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"],
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 for _ in range(reps):
-    t0 = time.perf_counter(); stats, *_ = opt.LocalBundleAdjustment(*a); print("lba ms", (time.perf_counter() - t0) * 1e3, stats, opt.stage_ms()[5])
+    t0 = time.perf_counter(); stats, *_ = opt.LocalBundleAdjustment(*a); print("lba ms", (time.perf_counter() - t0) * 1e3, "C call ms", opt.last_call_s * 1e3, stats, opt.stage_ms()[5])
 if R > 0:
     for _ in range(reps):
-        t0 = time.perf_counter(); r = opt.LocalBundleAdjustmentBatch([a] * R, 1); print("batch of %d: ms per window" % R, (time.perf_counter() - t0) * 1e3 / R, r[0][0])
+        t0 = time.perf_counter(); r = opt.LocalBundleAdjustmentBatch([a] * R, 1); print("batch of %d: ms per window" % R, (time.perf_counter() - t0) * 1e3 / R, "C call ms per window", opt.last_call_s * 1e3 / R, r[0][0])
