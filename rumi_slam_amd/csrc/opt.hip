@@ -2092,6 +2092,7 @@ struct RumiOptimizer {
     rumi::WinMirror *hWm = nullptr, *dhWm = nullptr;
     rumi::BAWin *hWinTab = nullptr, *dWinTab = nullptr;
     unsigned bawRun = 0;
+    uint8_t *dGroupOut = nullptr, *hGroupOut = nullptr; size_t groupOutCap = 0;     // results of a launch group, gathered for one copy back
     hipStream_t stream = nullptr;    // bundle adjustments of this handle (created non-blocking)
     std::vector<RumiOptimizer *> workers;   // rumi_local_ba_batch: one child handle per worker thread, created on first use
     int maxKFc = 0, maxMPc = 0, maxEc = 0;   // creation arguments (children are created alike)
@@ -2128,6 +2129,8 @@ extern "C" void rumi_opt_destroy(RumiOptimizer *o) {
     if (o->hLmCtl) (void)hipHostFree(o->hLmCtl);
     if (o->hWm) (void)hipHostFree((void *)o->hWm);
     if (o->hWinTab) (void)hipHostFree(o->hWinTab);
+    if (o->dGroupOut) (void)hipFree(o->dGroupOut);
+    if (o->hGroupOut) (void)hipHostFree(o->hGroupOut);
     if (o->hScal) (void)hipHostFree(o->hScal);
     if (o->hLm) (void)hipHostFree(o->hLm);
     if (o->hStop) (void)hipHostFree(o->hStop);
