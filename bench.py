@@ -66,6 +66,27 @@ def whole_path_valu_issue(fps):
         return None
 
 
+def lba_roofline(dev_ms, trials):
+    """MFMA roofline of the local BA's dominant kernel (k_baw_system: linearisation + the Schur product Y^T Y on the f64 matrix cores), from the
+    committed counter passes; `this_run` prices the same counted flops against this run's whole device time."""
+    out = {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r04_lba_pmc_mfma.json")))
+        for tag in ("batch16", "single"):
+            k = prof[tag]["kernels"]["k_baw_system"]
+            out[tag] = {"kernel": "k_baw_system", "mfma_flops_per_launch": k["mfma_flops"], "duration_us": k["duration_us"],
+                        "achieved": round(k["mfma_flops"] / (k["duration_us"] * 1e-6) / 1e12, 2), "frac": k["mfma_util_vs_78.6TF"],
+                        "mfma_busy_cycles": k["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_instructions": k["SQ_INSTS_VALU_MFMA_F64"]}
+        one = prof["single"]["kernels"]
+        flops_trial = one["k_baw_system"]["mfma_flops"] + one["k_baw_reduce"]["mfma_flops"] + one["k_baw_solve"]["mfma_flops"]
+        out["this_run"] = {"device_ms": round(dev_ms, 3), "lm_trials": trials, "mfma_flops_per_trial_counted": flops_trial,
+                           "frac_of_whole_device_time": round(flops_trial * trials / (dev_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4)}
+        out["source"] = "profiles/r04_lba_pmc_mfma.json: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 (tools/pmc_lba.sh), not this run; this_run: HIP events of this run"
+    except Exception as e:
+        out["error"] = str(e)
+    return out
+
+
 def side_legs(args):
     """BASELINE.json configs[3] (local BA) and PoseOptimization, GPU next to the CPU oracle (rank 0, N = 1)."""
     import numpy as np
@@ -91,33 +112,20 @@ def side_legs(args):
            "edges": E, "lm_iterations": int(stats[0]), "lm_trials": int(stats[1]),
            "gpu_ms_wall": round(min(g) * 1e3, 3), "gpu_ms_device": round(dev_ms, 3), "cpu_ms": round(min(c) * 1e3, 2),
            "speedup_wall": round(min(c) / min(g), 1), "max_rel_landmark_diff_vs_oracle": rel, "cpu_cores": 1}
-    # MFMA accounting of the two matrix kernels, from the per-kernel device times the library records with HIP events on its stream
-    # (stage_ms slots 8..: hpp, syrk, solve, summed over the call's trials): flops per trial over time per trial over the f64 matrix peak
+    lba["gpu_ms_c_call"] = round(opt.last_call_s * 1e3, 3)
+    # MFMA accounting from the matrix-core COUNTERS of the committed rocprofv3 passes (tools/pmc_lba.sh -> profiles/r04_lba_pmc_mfma.json: the
+    # launches of this very workload, 16 windows per launch and one), next to this run's own device time
+    lba["roofline"] = lba_roofline(dev_ms, trials)
+    # R independent windows: the window is a batch dimension of the kernels, ONE host thread drives the batch (rumi_local_ba_batch)
     try:
-        opt.set_profiling(True)
-        opt.LocalBundleAdjustment(*a)
-        opt.set_profiling(False)
-        det = opt.kernel_ms()
-        trials = max(det["trials"], 1)
-        syrk_flops = 2.0 * (3 * 3000) * (6 * K) * (6 * K) / 2          # upper tiles of G = Yt^T Yt
-        hpp_flops = 2.0 * (2 * E) * 36                                   # per key-frame Gram product of its [2 E_k] x 6 panel
-        lba["roofline"] = {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "syrk_us_per_trial": round(det["syrk"] * 1e3 / trials, 2),
-                           "syrk_mfma_util": round(syrk_flops / (det["syrk"] * 1e-3 / trials) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4) if det["syrk"] > 0 else None,
-                           "hpp_us_per_trial": round(det["hpp"] * 1e3 / trials, 2),
-                           "hpp_mfma_util": round(hpp_flops / (det["hpp"] * 1e-3 / trials) / 1e12 / F64_MFMA_PEAK_TFLOPS, 5) if det["hpp"] > 0 else None,
-                           "solve_us": round(det["solve"] * 1e3 / trials, 2)}
-        lba["roofline"]["note"] = "per-kernel times are HIP-event brackets on the library's stream: each carries about 6.5 us of bracket overhead (an empty kernel measures 6.4-6.8 us); the rocprofv3 durations are in profiles/"
-    except Exception as e:                                               # older library without the per-kernel slots
-        lba["roofline"] = {"error": str(e)}
-    # R independent windows (the only multi-window form local BA has): worker threads with child handles and streams of their own
-    try:
-        R, workers = 16, 8
-        opt.LocalBundleAdjustmentBatch([a] * R, workers)
-        bts = []
+        R = 16
+        opt.LocalBundleAdjustmentBatch([a] * R, 1)
+        bts, cpu = [], []
         for _ in range(5):
-            t0 = time.perf_counter(); opt.LocalBundleAdjustmentBatch([a] * R, workers); bts.append(time.perf_counter() - t0)
-        lba["batch"] = {"windows": R, "workers": workers, "ms_per_window": round(min(bts) / R * 1e3, 3), "note": "best of 5; the LM decisions are taken on the device, the worker threads nap while a trial runs (tools/lba_probe.py prints the busy host cores)"}
+            c0 = time.process_time(); opt.LocalBundleAdjustmentBatch([a] * R, 1); cpu.append(time.process_time() - c0); bts.append(opt.last_call_s)
+        lba["batch"] = {"windows": R, "host_threads": 1, "ms_per_window": round(min(bts) / R * 1e3, 4), "ms_per_window_median": round(sorted(bts)[2] / R * 1e3, 4),
+                        "host_cores_busy": round(sorted(cpu)[2] / (sorted(bts)[2] + 1e-9), 2),
+                        "note": "the C entry alone (the Python mirror's per-window array copies excluded); host_cores_busy = process CPU time of the whole Python call / wall time of the C call (an upper bound)"}
     except Exception as e:
         lba["batch"] = {"error": str(e)}
     probs = [pose_problem(100 + i, 300, 0.1) for i in range(256)]

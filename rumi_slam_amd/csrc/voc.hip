@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,7 +22,8 @@ struct VocDev {
     const uint8_t *desc;        // [nNodes][32]
     const double *weight;       // [nNodes]
     const uint32_t *wordId;     // [nNodes] (leaves)
-};
+    const uint2 *range;         // [nNodes] (first child, number of children) when every node's children have consecutive ids (DBoW2 creates a node's
+};                              // children in one loop, TemplatedVocabulary.h:615-640, so every file it wrote is of that kind); nullptr otherwise
 
 // 16 lanes per feature, 4 features per wave.  Every level: each lane takes children j, j+16, ... of the current node, the
 // group keeps the minimum of (distance << 20 | child position) — FORB::distance is an int and `d < best_d` is strict, so the
@@ -64,6 +66,54 @@ __global__ __launch_bounds__(256) void k_voc_descend(VocDev V, const uint8_t *__
     }
 }
 
+// The same descent for trees whose children lists are id ranges (ORBvoc.txt: k = 10, L = 6, 1.1 M nodes, a 35 MB descriptor table that no cache
+// level of one XCD holds): ONE dependent memory round trip per level instead of three.  The lane that scores a child also fetches the child's own
+// (first child, count) record -- the same dependency level as its descriptor -- and the winner's record is handed to the group by a lane read, so the
+// next level's descriptor addresses are known as soon as the arg-min is.  The descriptor comes in as two 16-byte loads.
+__global__ __launch_bounds__(256) void k_voc_descend_ranges(VocDev V, const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts,
+                                                            int cap, int nTotal, int nidLevel, uint32_t *__restrict__ wordOut,
+                                                            double *__restrict__ weightOut, uint32_t *__restrict__ nodeOut) {
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+    if (g >= nTotal) return;
+    if (counts) {
+        const int frame = g / cap, i = g - frame * cap;
+        if (i >= counts[2 * frame]) return;
+    }
+    const uint4 *qs = reinterpret_cast<const uint4 *>(desc + (size_t)g * 32);
+    const uint4 q0 = qs[0], q1 = qs[1];
+    uint2 cur = V.range[0];
+    uint32_t node = 0, nid = 0;
+    int level = 0;
+    const int rowBase = (threadIdx.x & 63) & ~15;
+    while (cur.y != 0) {
+        uint32_t best = 0xFFFFFFFFu;
+        uint2 bestRange = make_uint2(0, 0);
+        for (uint32_t c = j; c < cur.y; c += 16) {
+            const uint32_t child = cur.x + c;
+            const uint4 *d = reinterpret_cast<const uint4 *>(V.desc + (size_t)child * 32);
+            const uint4 d0 = d[0], d1 = d[1];
+            const uint2 r = V.range[child];
+            const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) + __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) +
+                             __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+            const uint32_t key = ((uint32_t)dist << 20) | c;
+            if (key < best) { best = key; bestRange = r; }
+        }
+        uint32_t m = best;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 16));
+        const uint32_t c = m & 0xFFFFFu;
+        const int src = rowBase + (int)(c & 15);             // the lane that scored the winner (it kept the winner's record: keys are distinct)
+        node = cur.x + c;
+        cur.x = (uint32_t)__shfl((int)bestRange.x, src); cur.y = (uint32_t)__shfl((int)bestRange.y, src);
+        if (++level == nidLevel) nid = node;
+    }
+    if (j == 0) {
+        wordOut[g] = V.wordId[node];
+        weightOut[g] = V.weight[node];
+        nodeOut[g] = nid;
+    }
+}
+
 }  // namespace rumi
 
 using namespace rumi;
@@ -71,6 +121,7 @@ using namespace rumi;
 struct RumiVocabulary {
     int device = 0, nNodes = 0, nWords = 0, L = 0, weighting = 0, scoring = 0;
     int32_t *dChildOff = nullptr; uint32_t *dChildIds = nullptr; uint8_t *dDesc = nullptr; double *dWeight = nullptr; uint32_t *dWordId = nullptr;
+    uint2 *dRange = nullptr;         // children as id ranges, when the tree allows it (k_voc_descend_ranges)
     // scratch of the host-array entry points
     int cap = 0;
     uint8_t *dQ = nullptr; uint32_t *dWord = nullptr, *dNode = nullptr; double *dW = nullptr;
@@ -79,7 +130,7 @@ struct RumiVocabulary {
 extern "C" void rumi_voc_destroy(RumiVocabulary *v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
-    void *p[] = {v->dChildOff, v->dChildIds, v->dDesc, v->dWeight, v->dWordId, v->dQ, v->dWord, v->dNode, v->dW};
+    void *p[] = {v->dChildOff, v->dChildIds, v->dDesc, v->dWeight, v->dWordId, v->dQ, v->dWord, v->dNode, v->dW, v->dRange};
     for (void *q : p) if (q) (void)hipFree(q);
     delete v;
 }
@@ -130,7 +181,17 @@ extern "C" int rumi_voc_create(int32_t n_nodes, const int32_t *parent, const uin
     std::vector<uint8_t> d(desc, desc + (size_t)n_nodes * 32);
     std::memset(d.data(), 0, 32);                                   // the root has no descriptor
     std::vector<double> w(weight, weight + n_nodes);
+    // children as id ranges?  (a lane of the descent then needs one record per child instead of the offset / id / descriptor chain)
+    bool consecutive = true;
+    std::vector<uint2> range((size_t)n_nodes);
+    for (int i = 0; i < n_nodes && consecutive; i++) {
+        const int c0 = off[i], c1 = off[i + 1];
+        range[i] = make_uint2(c1 > c0 ? ids[c0] : 0u, (uint32_t)(c1 - c0));
+        for (int c = c0 + 1; c < c1; c++) if (ids[c] != ids[c - 1] + 1) { consecutive = false; break; }
+    }
+    static const bool noRanges = std::getenv("RUMI_VOC_NO_RANGES") != nullptr;     // (A/B measurements and tests of the general kernel)
     int rc;
+    if (consecutive && !noRanges && (rc = upload(&v->dRange, range)) != RUMI_OK) { rumi_voc_destroy(v); return rc; }
     if ((rc = upload(&v->dChildOff, off)) != RUMI_OK || (rc = upload(&v->dChildIds, ids)) != RUMI_OK || (rc = upload(&v->dDesc, d)) != RUMI_OK ||
         (rc = upload(&v->dWeight, w)) != RUMI_OK || (rc = upload(&v->dWordId, wid)) != RUMI_OK) {
         rumi_voc_destroy(v);
@@ -148,28 +209,54 @@ extern "C" int rumi_voc_set_levels(RumiVocabulary *v, int32_t L) {
 
 extern "C" int rumi_voc_load_text(const char *path, int32_t device, RumiVocabulary **out) {
     if (!path || !out) return RUMI_E_INVALID;
-    FILE *f = std::fopen(path, "r");
+    FILE *f = std::fopen(path, "rb");
     if (!f) { g_lastError = "rumi_voc_load_text: cannot open file"; return RUMI_E_INVALID; }
+    // ORBvoc.txt is 145 MB of decimal numbers (1.1 M lines of 35): read whole and parsed by hand (the stream extraction of loadFromTextFile,
+    // TemplatedVocabulary.h:1338-1425, takes ~10 s on it; 39 M fscanf calls are no better)
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)std::max(sz, 0L) + 1);
+    const size_t got = sz > 0 ? std::fread(buf.data(), 1, (size_t)sz, f) : 0;
+    std::fclose(f);
+    buf[got] = 0;
+    const char *p = buf.data(), *end = buf.data() + got;
+    auto skip = [&]() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; };
+    auto read_int = [&](int *v) -> bool {
+        skip();
+        if (p >= end) return false;
+        bool neg = false;
+        if (*p == '-') { neg = true; p++; }
+        if (p >= end || *p < '0' || *p > '9') return false;
+        long x = 0;
+        while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); p++; }
+        *v = (int)(neg ? -x : x);
+        return true;
+    };
     int k = 0, L = 0, n1 = 0, n2 = 0;
-    if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
-        std::fclose(f);
+    if (!read_int(&k) || !read_int(&L) || !read_int(&n1) || !read_int(&n2) || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
         g_lastError = "rumi_voc_load_text: not a vocabulary text file";       // the same header test as TemplatedVocabulary.h:1359
         return RUMI_E_INVALID;
     }
     std::vector<int32_t> parent(1, -1);
     std::vector<uint8_t> leaf(1, 0), desc(32, 0);
     std::vector<double> weight(1, 0.0);
+    const size_t guess = (size_t)got / 100 + 16;
+    parent.reserve(guess); leaf.reserve(guess); desc.reserve(guess * 32); weight.reserve(guess);
     while (true) {
         int pid, isLeaf;
-        if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+        if (!read_int(&pid) || !read_int(&isLeaf)) break;
         uint8_t d[32];
         bool ok = true;
-        for (int i = 0; i < 32; i++) { int b; if (std::fscanf(f, "%d", &b) != 1) { ok = false; break; } d[i] = (uint8_t)b; }
-        double w;
-        if (!ok || std::fscanf(f, "%lf", &w) != 1) break;
+        for (int i = 0; i < 32; i++) { int b; if (!read_int(&b)) { ok = false; break; } d[i] = (uint8_t)b; }
+        if (!ok) break;
+        skip();
+        char *e2 = nullptr;
+        const double w = std::strtod(p, &e2);
+        if (e2 == p) break;
+        p = e2;
         parent.push_back(pid); leaf.push_back(isLeaf > 0); desc.insert(desc.end(), d, d + 32); weight.push_back(w);
     }
-    std::fclose(f);
     const int rc = rumi_voc_create((int32_t)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), n2, n1, device, out);
     // DBoW2 keeps the HEADER's L as m_L (TemplatedVocabulary.h:1367) and uses it for the FeatureVector level (nid_level = m_L - levelsup, :1229),
     // whatever the depth of the tree that follows: a file whose deepest leaf is shallower than its header says groups features differently
@@ -179,8 +266,9 @@ extern "C" int rumi_voc_load_text(const char *path, int32_t device, RumiVocabula
 
 static int launch_descend(RumiVocabulary *v, const uint8_t *dDesc, const int32_t *dCounts, int cap, int nTotal, int levelsup, uint32_t *dWord,
                           double *dW, uint32_t *dNode, hipStream_t st) {
-    VocDev V{v->dChildOff, v->dChildIds, v->dDesc, v->dWeight, v->dWordId};
-    hipLaunchKernelGGL(k_voc_descend, dim3((nTotal + 15) / 16), dim3(256), 0, st, V, dDesc, dCounts, cap, nTotal, v->L - levelsup, dWord, dW, dNode);
+    VocDev V{v->dChildOff, v->dChildIds, v->dDesc, v->dWeight, v->dWordId, v->dRange};
+    if (v->dRange) hipLaunchKernelGGL(k_voc_descend_ranges, dim3((nTotal + 15) / 16), dim3(256), 0, st, V, dDesc, dCounts, cap, nTotal, v->L - levelsup, dWord, dW, dNode);
+    else hipLaunchKernelGGL(k_voc_descend, dim3((nTotal + 15) / 16), dim3(256), 0, st, V, dDesc, dCounts, cap, nTotal, v->L - levelsup, dWord, dW, dNode);
     HIP_TRY(hipGetLastError());
     return RUMI_OK;
 }

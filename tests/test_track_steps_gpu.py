@@ -197,3 +197,49 @@ def test_reference_keyframe_with_too_few_matches_and_stage_order_errors():
     got = trk.reference_keyframe(g, K_TUM3, T, FrameView(last["keys"], pts["desc"], W, H, sf), FeatureVector.from_csr(kn, ko, ki), last["mp"], pts, 2, 0.7, True)
     assert nm_ref < 15 and got["nmatches_motion"] == nm_ref and np.array_equal(got["frame_mp"], vp)
     assert got["ngood_motion"] == 0 and (got["discarded"] == -1).all() and np.array_equal(got["Tcw_motion"], T)
+
+
+def test_reference_keyframe_on_orbvoc_geometry():
+    """TrackReferenceKeyFrame with the reference's real vocabulary shape: k = 10, L = 6 (1 111 111 nodes, a synthetic tree: ORBvoc.txt is a missing
+    blob) and levelsup = 4, as Frame::ComputeBoW calls it (Frame.cc:763-768): the FeatureVectors group by the 100 level-2 nodes.  Per-feature
+    transform, the assembled vectors, the BoW matches and whatever follows (fewer than 15 matches: nothing; otherwise the optimised pose and the
+    discard list) equal the oracle chain."""
+    from rumi_slam_amd.matcher import FeatureVector, FrameView
+    from rumi_slam_amd.tracker import Tracker
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    from voc_scene import synthetic_vocabulary_fast
+    trk = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    img0, sf, inv_sigma2, pts, last = _scene(n_keep=0.9)
+    n0 = len(pts["obs"])
+    rng = np.random.default_rng(6)
+    pts["obs"] = np.where(rng.random(n0) < 0.1, 0, 2).astype(np.int32)
+    pts["bad"] = (rng.random(n0) < 0.04).astype(np.uint8)
+    voc = synthetic_vocabulary_fast(21, 10, 6)
+    g, o = ORBVocabulary(*voc), O.OracleVocabulary(*voc)
+    q_gt, t_gt = _pose_gt(2)
+    img = warp_homography(img0, _homography(q_gt, t_gt))
+    mono, keys, desc = trk.extract(img)
+    levelsup = 4
+    kf_keys, kf_desc, kf_mp = last["keys"], pts["desc"], last["mp"]
+    (_, _), (kn, ko, ki) = o.transform(kf_desc, levelsup)
+    wq, vq, nq = o.transform_features(desc, levelsup)
+    (bi2, bv2), (fn, fo, fi) = o.transform(desc, levelsup)
+    assert 11 <= fn.min() and fn.max() <= 110, "level-2 node ids"
+    nm_ref, vp = O.search_by_bow(kf_keys, kf_desc, kf_mp, pts["bad"], (kn, ko, ki), keys, desc, (fn, fo, fi), 0.7, True)
+    T_init = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    got = trk.reference_keyframe(g, K_TUM3, T_init, FrameView(kf_keys, kf_desc, W, H, sf), FeatureVector.from_csr(kn, ko, ki), kf_mp, pts, levelsup, 0.7, True)
+    assert np.array_equal(got["word_id"], wq) and np.array_equal(got["node_id"], nq) and np.array_equal(got["word_weight"], vq), "Frame::ComputeBoW per feature"
+    (bi, bv), (an, ao, ai) = g.assemble(got["word_id"], got["word_weight"], got["node_id"])
+    assert np.array_equal(bi, bi2) and bv.tobytes() == bv2.tobytes() and np.array_equal(an, fn) and np.array_equal(ao, fo) and np.array_equal(ai, fi)
+    print(f"BoW matches on the k=10, L=6 tree at levelsup 4: {nm_ref}")
+    assert got["nmatches_motion"] == nm_ref
+    if nm_ref < 15:
+        assert np.array_equal(got["frame_mp"], vp) and got["ngood_motion"] == 0 and (got["discarded"] == -1).all() and np.array_equal(got["Tcw_motion"], T_init)
+        return
+    idx = np.nonzero(vp >= 0)[0]
+    ng, T1, out = O.pose_optimization(pts["pos"][vp[idx]], np.stack([keys["x"][idx], keys["y"][idx]], 1), inv_sigma2[keys["octave"][idx]], K_TUM3, T_init)
+    exp_mp, exp_dis = vp.copy(), np.full(len(keys), -1, np.int32)
+    exp_dis[idx[out != 0]] = vp[idx[out != 0]]
+    exp_mp[idx[out != 0]] = -1
+    assert got["ngood_motion"] == ng and np.array_equal(got["frame_mp"], exp_mp) and np.array_equal(got["discarded"], exp_dis)
+    _pose_close(got["Tcw_motion"], T1, "pose after TrackReferenceKeyFrame")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from voc_scene import synthetic_vocabulary, write_text
+from voc_scene import synthetic_vocabulary, synthetic_vocabulary_fast, write_text, write_text_fast
 
 pytestmark = pytest.mark.gpu
 
@@ -104,3 +104,69 @@ def test_batch_transform_feeds_search_by_bow():
         assert np.array_equal(word[f, :n].cpu().numpy().view(np.uint32), w2)
         assert np.array_equal(node[f, :n].cpu().numpy().view(np.uint32), n2)
         assert np.array_equal(w[f, :n].cpu().numpy(), v2)
+
+
+def _shuffle_levels(voc, seed):
+    """The same tree with the node ids permuted inside every level (file order stays level order, parents still precede children): a node's children
+    are no longer an id range, which is what routes the descent through the general kernel (child-list indirection)."""
+    parent, leaf, desc, weight = voc
+    n = len(parent)
+    depth = np.zeros(n, np.int32)
+    for i in range(1, n):
+        depth[i] = depth[parent[i]] + 1
+    rng = np.random.default_rng(seed)
+    new_of_old = np.arange(n)
+    for lv in range(1, depth.max() + 1):
+        ids = np.nonzero(depth == lv)[0]
+        new_of_old[ids] = rng.permutation(ids)
+    old_of_new = np.argsort(new_of_old)
+    p2 = np.where(parent[old_of_new] < 0, -1, new_of_old[np.maximum(parent[old_of_new], 0)]).astype(np.int32)
+    return p2, leaf[old_of_new].copy(), desc[old_of_new].copy(), weight[old_of_new].copy()
+
+
+def test_general_tree_whose_children_are_not_id_ranges():
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = _shuffle_levels(synthetic_vocabulary(5, 9, 4, True), 1)
+    kids = {}
+    for i in range(1, len(voc[0])):
+        kids.setdefault(int(voc[0][i]), []).append(i)
+    assert any(np.any(np.diff(v) != 1) for v in kids.values()), "the permutation must break the id ranges"
+    g, o = ORBVocabulary(*voc), O.OracleVocabulary(*voc)
+    d = _features(voc, np.random.default_rng(3), 1200)
+    for levelsup in (1, 2, 4):
+        a, b = g.transform_features(d, levelsup), o.transform_features(d, levelsup)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), f"levelsup {levelsup}"
+    a, b = g.transform(d, 2), o.transform(d, 2)
+    assert np.array_equal(a[0][0], b[0][0]) and a[0][1].tobytes() == b[0][1].tobytes() and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+
+
+def test_orbvoc_geometry_k10_L6_levelsup4(tmp_path):
+    """The reference's real vocabulary geometry: Frame::ComputeBoW calls transform(..., 4) (Frame.cc:763-768) on ORBvoc.txt's k = 10, L = 6 tree
+    (1 111 111 nodes, 10^6 words; the file itself is a missing blob: a synthetic tree of the same shape, built in memory AND written to / read back
+    from a 170 MB text file by rumi_voc_load_text).  2000 features: word, weight, node per feature and the assembled BowVector / FeatureVector
+    identical to the oracle's; the FeatureVector groups by level-2 nodes (100 of them), as levelsup = 4 means on a 6-level tree."""
+    import time
+    from rumi_slam_amd.vocabulary import ORBVocabulary
+    voc = synthetic_vocabulary_fast(3, 10, 6)
+    assert len(voc[0]) == 1111111 and int(voc[1].sum()) == 10 ** 6
+    o = O.OracleVocabulary(*voc)
+    rng = np.random.default_rng(8)
+    d = _features(voc, rng, 2000)
+    t0 = time.time(); write_text_fast(tmp_path / "big.txt", voc, 10, 6); t_write = time.time() - t0
+    t0 = time.time(); gf = ORBVocabulary(path=tmp_path / "big.txt"); t_load = time.time() - t0
+    gm = ORBVocabulary(*voc)
+    print(f"ORBvoc-sized tree: text file written in {t_write:.1f} s, rumi_voc_load_text {t_load:.2f} s")
+    assert gf.size() == 10 ** 6 and gf.levels() == 6 and gm.levels() == 6
+    for g in (gf, gm):
+        for levelsup in (4, 2, 6):
+            a, b = g.transform_features(d, levelsup), o.transform_features(d, levelsup)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), f"levelsup {levelsup}"
+        (bi, bv), (fn, fo, fi) = g.transform(d, 4)
+        (bi2, bv2), (fn2, fo2, fi2) = o.transform(d, 4)
+        assert np.array_equal(bi, bi2) and bv.tobytes() == bv2.tobytes()
+        assert np.array_equal(fn, fn2) and np.array_equal(fo, fo2) and np.array_equal(fi, fi2)
+        assert 20 < len(fn) <= 110 and fn.min() >= 11 and fn.max() <= 110          # level-2 node ids: 11 .. 110
+    t0 = time.time()
+    for _ in range(20):
+        gm.transform_features(d, 4)
+    print(f"transform_features, 2000 features, host arrays in and out: {(time.time() - t0) / 20 * 1e3:.3f} ms per call")

@@ -95,6 +95,11 @@ def measure(reps=60):
     kfv, kview = FeatureVector.from_csr(kn, ko, ki), FrameView(keys0, desc0, W, H, sf)
     kf_mp = np.arange(n0, dtype=np.int32)
     stage = {}
+    # the reference's real vocabulary geometry (ORBvoc.txt: k = 10, L = 6, 1.1 M nodes; Frame::ComputeBoW asks for levelsup = 4): a synthetic tree of that shape
+    from voc_scene import synthetic_vocabulary_fast
+    voc_big = ORBVocabulary(*synthetic_vocabulary_fast(21, 10, 6))
+    (_, _), (bn, bo, bi_) = voc_big.transform(desc0, 4)
+    kfv_big = FeatureVector.from_csr(bn, bo, bi_)
 
     def steps_motion():
         t0 = time.perf_counter(); trk.extract(img); t1 = time.perf_counter()
@@ -106,8 +111,14 @@ def measure(reps=60):
 
     def steps_refkf():
         trk.extract(img); t1 = time.perf_counter()
-        m = trk.reference_keyframe(voc, K_TUM3, T, kview, kfv, kf_mp, pts, 2, 0.7, True); t2 = time.perf_counter()
+        m = trk.reference_keyframe(voc_big, K_TUM3, T, kview, kfv_big, kf_mp, pts, 4, 0.7, True); t2 = time.perf_counter()
         stage.setdefault("reference_keyframe", []).append(t2 - t1)
+        return m["ngood_motion"], m["Tcw_motion"]
+
+    def steps_refkf_small():
+        trk.extract(img); t1 = time.perf_counter()
+        m = trk.reference_keyframe(voc, K_TUM3, T, kview, kfv, kf_mp, pts, 2, 0.7, True); t2 = time.perf_counter()
+        stage.setdefault("reference_keyframe_small_tree_k10_L3", []).append(t2 - t1)
         return m["ngood_motion"], m["Tcw_motion"]
 
     a, b = separate(), fused()
@@ -117,8 +128,10 @@ def measure(reps=60):
     c = steps_motion()
     assert c[0] == b[0] and np.allclose(c[1], b[1], atol=1e-5), (c, b)
     step_ms, ref_ms = med(steps_motion, reps), med(steps_refkf, reps)
+    med(steps_refkf_small, reps)
     per = {k: round(float(np.median(v[5:])) * 1e3, 3) for k, v in stage.items()}
-    return dict(step_wise_ms=round(step_ms, 3), extract_plus_reference_keyframe_ms=round(ref_ms, 3), stage_ms=per, workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
+    return dict(step_wise_ms=round(step_ms, 3), extract_plus_reference_keyframe_ms=round(ref_ms, 3), stage_ms=per,
+                reference_keyframe_vocabulary="synthetic tree of ORBvoc.txt's geometry: k = 10, L = 6, 1 111 111 nodes, levelsup = 4 (the k = 10, L = 3 tree of round 3 beside it)", workload="one Tracking-thread frame: extract (640x480, 1000 features) -> SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints (%d map points) -> PoseOptimization; host image in, host results out" % n0,
                 inliers=int(b[0]), separate_entries_ms=round(med(separate, reps), 3), rumi_track_frame_ms=round(med(fused, reps), 3),
                 rumi_track_frame_pinned_ms=round(med(fused_pinned, reps), 3), c_call_pinned_ms=round(c_call_ms(reps), 3))
 
