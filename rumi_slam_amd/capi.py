@@ -35,7 +35,7 @@ _lib = None
 
 # every symbol include/rumi_orb.h declares (tests check the library exports all of them)
 ORB_SYMBOLS = ["rumi_last_error", "rumi_device_count", "rumi_orb_create", "rumi_orb_destroy", "rumi_orb_tables",
-               "rumi_orb_extract", "rumi_orb_image_buffer", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync", "rumi_orb_set_resident_queue", "rumi_orb_wait_event", "rumi_orb_extract_batch_records_async", "rumi_orb_extract_batch_host",
+               "rumi_orb_extract", "rumi_orb_image_buffer", "rumi_orb_extract_batch_device", "rumi_orb_extract_batch_device_async", "rumi_orb_sync", "rumi_orb_set_resident_queue", "rumi_orb_wait_event", "rumi_orb_extract_batch_records_async", "rumi_orb_extract_batch_host", "rumi_orb_extract_batch_host_records",
                "rumi_orb_pyramid_level",
                "rumi_orb_stage_keypoints", "rumi_orb_set_profiling", "rumi_orb_stage_ms"]
 
@@ -70,6 +70,7 @@ def lib():
     L.rumi_orb_sync.argtypes = [vp]
     L.rumi_orb_extract_batch_records_async.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32, vp, i64, i32, vp]
     L.rumi_orb_extract_batch_host.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.rumi_orb_extract_batch_host_records.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]
     L.rumi_orb_pyramid_level.argtypes = [vp, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.rumi_orb_stage_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.rumi_orb_set_profiling.argtypes = [vp, i32]
@@ -100,6 +101,8 @@ VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rum
                "rumi_voc_transform_batch_device", "rumi_voc_transform"]
 TRACK_SYMBOLS = ["rumi_track_create", "rumi_track_destroy", "rumi_track_frame", "rumi_track_extract", "rumi_track_motion",
                  "rumi_track_reference_keyframe", "rumi_track_local", "rumi_track_image_buffer"]
+QUEUE_SYMBOLS = ["rumi_queue_create", "rumi_queue_destroy", "rumi_queue_shards", "rumi_queue_record_bytes", "rumi_queue_block_capacity", "rumi_queue_row",
+                 "rumi_queue_uses_rccl", "rumi_queue_extract", "rumi_queue_last_ms"]
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_sort_device", "rumi_hook_std_sort", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",
                 "rumi_hook_fast_atan2", "rumi_hook_cv_round", "rumi_hook_magic_div"]
 

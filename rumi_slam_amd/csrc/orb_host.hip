@@ -719,10 +719,9 @@ extern "C" int rumi_orb_extract_batch_records_async(RumiOrb *h, const void *d_im
 // in groups of 64 on a copy stream of their own, each group's extraction waits only for its own group, so the transfers run under the kernels
 // of the groups before it.  Pinned sources (hipHostMalloc / hipHostRegister) are copied from where they lie; pageable ones pass through four
 // pinned staging slots filled by the handle's host threads.
-extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
-                                           int32_t lap0, int32_t lap1, void *d_kp, void *d_desc, void *d_counts, int32_t cap,
-                                           RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream) {
-    if (!h || !imgs || !d_kp || !d_desc || !d_counts || nframes < 1 || cap < 1 || stride < w) {
+static int extract_batch_host_impl(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
+                                   int32_t lap0, int32_t lap1, const OutLayout &out, int32_t cap, void *hip_stream, const std::function<int(hipStream_t)> &tail) {
+    if (!h || !imgs || !out.kp || !out.desc || !out.counts || nframes < 1 || cap < 1 || stride < w) {
         g_lastError = "rumi_orb_extract_batch_host: bad argument";
         return RUMI_E_INVALID;
     }
@@ -791,13 +790,37 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
         if (twoCopyStreams && group >= 2) HIP_TRY(hipStreamWaitEvent(s, h->evFeed[(group - 2) % S], 0));
         return RUMI_OK;
     };
-    rc = rumi_orb_extract_batch_device_async(h, h->dHostIn, nframes, w, hgt, wp, (int64_t)frameBytes, lap0, lap1, d_kp, d_desc, d_counts, cap, hip_stream);
+    rc = extract_async_impl(h, h->dHostIn, nframes, w, hgt, wp, (int64_t)frameBytes, lap0, lap1, out, cap, hip_stream);
     h->feed = nullptr;
     if (rc != RUMI_OK) { if (h->pending) (void)rumi_orb_sync(h); return rc; }
-    if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (h_kp) HIP_TRY(hipMemcpyAsync(h_kp, d_kp, (size_t)nframes * cap * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, st));
-    if (h_desc) HIP_TRY(hipMemcpyAsync(h_desc, d_desc, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, st));
+    if (tail && (rc = tail(st)) != RUMI_OK) { (void)rumi_orb_sync(h); return rc; }
     return rumi_orb_sync(h);
+}
+
+extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
+                                           int32_t lap0, int32_t lap1, void *d_kp, void *d_desc, void *d_counts, int32_t cap,
+                                           RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream) {
+    const OutLayout out{d_kp, (long long)cap * (long long)sizeof(RumiKeyPoint), d_desc, (long long)cap * 32, d_counts, 8};
+    return extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
+        if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (h_kp) HIP_TRY(hipMemcpyAsync(h_kp, d_kp, (size_t)nframes * cap * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, st));
+        if (h_desc) HIP_TRY(hipMemcpyAsync(h_desc, d_desc, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, st));
+        return RUMI_OK;
+    });
+}
+
+// The host-resident queue with ONE record per frame as output (the all-gather payload, rumi_orb_extract_batch_records_async's layout); h_records:
+// optional host copy of the nframes records.
+extern "C" int rumi_orb_extract_batch_host_records(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
+                                                   int32_t lap0, int32_t lap1, void *d_records, int64_t record_bytes, int32_t cap, uint8_t *h_records,
+                                                   void *hip_stream) {
+    if (!d_records || cap < 1 || record_bytes < 8 + 60ll * cap || (record_bytes & 3)) { g_lastError = "rumi_orb_extract_batch_host_records: bad record size"; return RUMI_E_INVALID; }
+    uint8_t *r = (uint8_t *)d_records;
+    const OutLayout out{r + 8, record_bytes, r + 8 + (size_t)cap * sizeof(RumiKeyPoint), record_bytes, r, record_bytes};
+    return extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
+        if (h_records) HIP_TRY(hipMemcpyAsync(h_records, d_records, (size_t)nframes * record_bytes, hipMemcpyDeviceToHost, st));
+        return RUMI_OK;
+    });
 }
 
 // The handle's pinned staging buffer for a w x hgt frame, for a caller that lets its camera driver / decoder write the frame there (a cv::Mat

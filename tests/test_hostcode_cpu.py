@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     L = capi.lib()
     declared = set()
-    for hdr in ("rumi_orb.h", "rumi_testhooks.h", "rumi_match.h", "rumi_opt.h", "rumi_voc.h", "rumi_track.h", "rumi_dist.h"):
+    for hdr in ("rumi_orb.h", "rumi_testhooks.h", "rumi_match.h", "rumi_opt.h", "rumi_voc.h", "rumi_track.h", "rumi_queue.h", "rumi_dist.h"):
         p = os.path.join(ROOT, "include", hdr)
         if not os.path.exists(p):
             continue
