@@ -179,6 +179,33 @@ def make_frames(torch, np, dev, n, rank):
     return fr, host
 
 
+def one_process_queue(args):
+    """`bench.py --gpus N --one-process`: the reference is ONE C++ process (System.cc:193-240), so is this leg: rumi_queue_extract cuts the host
+    queue into N contiguous blocks, one extractor per device, ONE ncclAllGather of the records (include/rumi_queue.h).  Extraction only."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from rumi_slam_amd.queue import RuminationQueue
+    from rumi_slam_amd.synth import synth_frame
+    N, F = args.gpus, args.batch
+    logical = bool(os.environ.get("RUMI_BENCH_LOGICAL_SHARDS"))
+    base = [synth_frame(1234 + i) for i in range(32)]
+    frames = [base[i] if i < 32 else np.roll(base[i % 32], (7 * (i // 32), 11 * (i // 32)), (0, 1)) for i in range(F)]
+    q = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [0] * N if logical else list(range(N)), max_block=(F + N - 1) // N, cap=args.nfeatures + 96)
+    rec = np.zeros((F, q.record_bytes), np.uint8)
+    for _ in range(args.warmup):
+        q.extract(frames, (0, 1000), out=rec)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        q.extract(frames, (0, 1000), out=rec)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "frames/sec ORB extract, rumination queue from one process (host frames in, gathered records on every device, host records out)",
+                      "value": round(F * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+                      "data": "synthetic", "config": {"workload": "BASELINE.json configs[4]: %d queued 640x480 frames over %d %s, one process, rumi_queue_extract" % (F, N, "logical shards on device 0" if logical else "devices"),
+                                                      "exchange": "RCCL ncclAllGather" if q.uses_rccl else "device-to-device copies (logical shards)"},
+                      "last_call_ms": q.last_ms()}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +216,12 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the side legs (profiling runs)")
+    ap.add_argument("--one-process", action="store_true", help="the queue over --gpus devices from ONE process through include/rumi_queue.h (RCCL all-gather inside the library) instead of one rank per GPU; "
+                    "RUMI_BENCH_LOGICAL_SHARDS=1 aliases every shard to device 0 (a one-GPU box)")
     args = ap.parse_args()
+
+    if args.one_process:
+        return one_process_queue(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -399,6 +431,51 @@ def main():
             dth, _ = timed(step_h2d, max(3, args.steps // 2), 1)
             line["value_h2d_inclusive"] = round(B * max(3, args.steps // 2) / dth, 1)
             line["h2d_note"] = "%d x 307 200 B per step from pinned host memory, 64-frame groups on a copy stream under the kernels (rumi_orb_extract_batch_host)" % B
+            # ---- ... and with the results brought back to the host as well: key-points, descriptors, counts and the match indices land in pinned host
+            # buffers (preallocated: nothing is allocated in the timed region).  Host frames in, host results out: what a host consumer of the queue sees.
+            import ctypes as C_
+            from rumi_slam_amd import capi as capi_
+            hk = torch.empty((B, cap, 7), dtype=torch.float32).pin_memory(); hd = torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()
+            hc = torch.zeros((B, 2), dtype=torch.int32).pin_memory()
+            hm = [torch.empty((B, cap), dtype=torch.int32).pin_memory() for _ in range(3)]
+            okp = torch.empty((B, cap, 7), dtype=torch.float32, device=dev); odesc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+            ocnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+            mo = [torch.empty((B, cap), dtype=torch.int32, device=dev) for _ in range(3)]
+            ptrs = (C_.c_void_p * B)(*[hostq.data_ptr() + f * hostq.stride(0) for f in range(B)])
+
+            def step_h2d_d2h():
+                st_ = torch.cuda.current_stream(dev)
+                capi_.check(ext._lib.rumi_orb_extract_batch_host(ext._h, ptrs, B, W, H, hostq.stride(1), 0, 1000, okp.data_ptr(), odesc.data_ptr(), ocnt.data_ptr(), cap,
+                                                                 hk.data_ptr(), hd.data_ptr(), hc.data_ptr(), st_.cuda_stream))
+                m = match_pairs(odesc, ocnt, mo)
+                for a_, b_ in zip(hm, m):
+                    a_.copy_(b_, non_blocking=True)
+                torch.cuda.synchronize()
+                return okp, odesc, ocnt, m
+            dtd, _ = timed(step_h2d_d2h, max(3, args.steps // 2), 1)
+            line["value_h2d_d2h_inclusive"] = round(B * max(3, args.steps // 2) / dtd, 1)
+            line["h2d_d2h_note"] = "host frames in (pinned), key-points + descriptors + counts + match indices out to pinned host buffers (%.1f MB per step back); every step ends synchronised" % ((hk.numel() * 4 + hd.numel() + hc.numel() * 4 + 3 * hm[0].numel() * 4) / 1e6)
+            del hk, hd, hm, okp, odesc, mo
+            # ---- the queue behind the C ABI, ONE process (include/rumi_queue.h): host frames in, every shard's device holds the gathered records, host
+            # records out.  One shard = this GPU (its exchange is RCCL's ncclAllGather on one rank); two LOGICAL shards on this GPU for the sharded code path.
+            try:
+                from rumi_slam_amd.queue import RuminationQueue
+                ql = {}
+                nq = min(B, 512)
+                hq = [hostq[f].numpy() for f in range(nq)]
+                for shards in (1, 2):
+                    rq = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [local_rank] * shards, max_block=(nq + shards - 1) // shards, cap=cap)
+                    rec = np.zeros((nq, rq.record_bytes), np.uint8)
+                    rq.extract(hq, (0, 1000), out=rec)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        rq.extract(hq, (0, 1000), out=rec)
+                    ql["%d_shard%s" % (shards, "s_logical" if shards > 1 else "")] = {"fps": round(3 * nq / (time.perf_counter() - t0), 1), "exchange": "RCCL all-gather" if rq.uses_rccl else "device-to-device copies",
+                                                                                     "last_ms": {k: round(v, 3) for k, v in rq.last_ms().items()}}
+                    rq.close()
+                line["queue_c_abi_one_process"] = dict(frames=nq, note="rumi_queue_extract: extraction only (no matching), pinned host frames in, pageable host records out", **ql)
+            except Exception as e:
+                line["queue_c_abi_one_process"] = {"error": str(e)}
             del hostq
             # ---- one frame at a time through the drop-in host API (ORBextractor::operator(): host image in, host key-points out) ----
             ext1 = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, device=local_rank)

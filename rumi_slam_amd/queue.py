@@ -56,14 +56,15 @@ class RuminationQueue:
     def row(self, n_frames, frame):
         return int(self._lib.rumi_queue_row(self._h, int(n_frames), int(frame)))
 
-    def extract(self, frames, lapping=(0, 1000), want_host=True):
+    def extract(self, frames, lapping=(0, 1000), want_host=True, out=None):
         """frames: list of HxW u8 arrays (or one [F,H,W] array), time order.  Returns (records [F, record_bytes] u8 or None, device pointers of the
         gathered queue per shard)."""
         fr = [np.ascontiguousarray(f, np.uint8) for f in frames]
         F, (H, W) = len(fr), fr[0].shape
         ptrs = (C.c_void_p * F)(*[f.ctypes.data for f in fr])
         dg = (C.c_void_p * self.n_shards)()
-        rec = np.zeros((F, self.record_bytes), np.uint8) if want_host else None
+        rec = out if out is not None else (np.zeros((F, self.record_bytes), np.uint8) if want_host else None)
+        assert rec is None or (rec.shape == (F, self.record_bytes) and rec.dtype == np.uint8 and rec.flags.c_contiguous)
         capi.check(self._lib.rumi_queue_extract(self._h, C.cast(ptrs, C.c_void_p), F, W, H, fr[0].strides[0], int(lapping[0]), int(lapping[1]),
                                                 C.cast(dg, C.c_void_p), capi.ptr(rec) if rec is not None else None))
         return rec, [int(p or 0) for p in dg]

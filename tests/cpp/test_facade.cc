@@ -17,6 +17,7 @@
 #include "Optimizer.h"
 #include "FrameFrustum.h"
 #include "TrackingStep.h"
+#include "RuminationQueue.h"
 #include "orb_oracle.h"
 
 extern "C" {
@@ -156,6 +157,20 @@ int main(int argc, char **argv) {
     cv::Mat empty, mask;
     std::vector<cv::KeyPoint> k0; cv::Mat d0;
     CHECK(ext(empty, mask, k0, d0, lap) == -1, "empty image returns -1");
+    {   // ---- the rumination queue helper: three frames over two logical shards of device 0 == operator() frame by frame ----
+        ORB_SLAM3::RuminationQueue queue(1000, 1.2f, 8, 20, 7, {0, 0}, 2, 640, 480);
+        std::vector<cv::Mat> vImages = {cv::Mat(480, 640, CV_8U, im[0].data(), 640), cv::Mat(480, 640, CV_8U, im[1].data(), 640), cv::Mat(480, 640, CV_8U, im[0].data(), 640)};
+        std::vector<std::vector<cv::KeyPoint>> qk; std::vector<cv::Mat> qd;
+        CHECK(queue.Extract(vImages, qk, qd, lap) == 3 && qk.size() == 3, "RuminationQueue::Extract");
+        bool qsame = qk.size() == 3;
+        for (int i = 0; qsame && i < 3; i++) {
+            const Frame &f = fr[i == 1 ? 1 : 0];
+            qsame = qk[i].size() == f.mvKeysUn.size() && std::memcmp(qk[i].data(), f.mvKeysUn.data(), f.mvKeysUn.size() * 28) == 0 && qd[i].rows == f.mDescriptors.rows;
+            for (int r = 0; qsame && r < qd[i].rows; r++) qsame = std::memcmp(qd[i].ptr(r), f.mDescriptors.ptr(r), 32) == 0;
+        }
+        CHECK(qsame, "RuminationQueue: key-points and descriptors of every queued frame = ORBextractor::operator()");
+        CHECK(queue.GatheredDevicePointer(0) && queue.GatheredDevicePointer(1) && queue.Row(3, 2) == 3 && queue.RecordBytes() == 8 + 60 * 1096, "RuminationQueue: gathered layout");
+    }
 
     // ---- SearchByProjection(Cur, Last) facade == oracle ----
     std::mt19937 rng(5);
