@@ -20,6 +20,7 @@
 #include <cstring>
 #include <vector>
 
+#include "rumi_internal.h"
 #include "rumi_common.h"
 #include "rumi_match.h"
 
@@ -2032,7 +2033,7 @@ extern "C" int rumi_match_bruteforce_batch_device(const void *d_query, const voi
 // ==================================================================================================================
 namespace rumi {
 
-constexpr int kTrackLdsEdges = 1152;     // = kPoseLdsEdges of opt.hip
+constexpr int kTrackLdsEdges = rumi::kPoseLdsEdges;     // (rumi_internal.h: one number for both files)
 struct TrackBlock {                  // the result block's header, device and pinned host alike (arrays follow at byte offsets of RumiTracker)
     float Tout[14];                  // pose after the motion model | after the local map
     float pose19[20];                // Rcw9 tcw3 Ow3 K4 of the first (Frame::UpdatePoseMatrices)

@@ -165,7 +165,7 @@ struct PoseArgs {
 #define POSE_STAMP(acc)
 #define POSE_COUNT(c)
 #endif
-constexpr int kPoseLdsEdges = 1152;          // (nfeatures 1000 + the extractor's slack of 96 fits: the tracker then needs no count to choose the instantiation)
+// (kPoseLdsEdges: rumi_internal.h, shared with the tracker)
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void k_pose_opt(PoseArgs A) {
     constexpr int NW = NT / 64;

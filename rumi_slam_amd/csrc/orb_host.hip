@@ -310,6 +310,7 @@ static int alloc_frame_arenas(RumiOrb *h, size_t scratch, size_t arena) {
     h->dSelCount = nullptr; h->dOwner = nullptr; h->dSelLevel = nullptr; h->dSelLevelCnt = nullptr;
     const size_t C = scratch;
     int rc;
+    h->scratchFrames = 0; h->arenaFrames = 0;          // until everything below has succeeded the handle has NO arenas (extract refuses to run: RUMI_E_CAPACITY)
 #define TRY_A(x) if ((rc = (x)) != RUMI_OK) return rc;
     TRY_A(dev_alloc(&h->dPyr, (size_t)h->capArena * arena));
     TRY_A(dev_alloc(&h->dBlur, (size_t)h->capArena * arena));
@@ -430,8 +431,14 @@ extern "C" int rumi_orb_set_resident_queue(RumiOrb *h, int32_t on) {
         if (h->scratchFrames < need || h->arenaFrames < need) {
             HIP_TRY(hipSetDevice(h->device));
             HIP_TRY(hipDeviceSynchronize());
-            const int rc = alloc_frame_arenas(h, (size_t)std::max(h->scratchFrames, need), (size_t)std::max(h->arenaFrames, need));
-            if (rc != RUMI_OK) { g_lastError = "resident queue: device arenas"; return rc; }
+            const size_t oldS = (size_t)h->scratchFrames, oldA = (size_t)h->arenaFrames;
+            int rc = alloc_frame_arenas(h, std::max(oldS, (size_t)need), std::max(oldA, (size_t)need));
+            if (rc != RUMI_OK) {                             // back to the sizes the handle had (those fitted before); if even that fails the handle refuses to extract
+                h->residentQueue = false;
+                (void)alloc_frame_arenas(h, oldS, oldA);
+                g_lastError = "resident queue: device arenas";
+                return rc;
+            }
             h->lastFrames = 0; h->tapValid = false;
         }
     }
@@ -484,6 +491,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     }
     if (w <= 0 || hgt <= 0) return RUMI_E_EMPTY;
     if (nframes > h->cfg.max_batch) { g_lastError = "nframes > max_batch"; return RUMI_E_CAPACITY; }
+    if (h->scratchFrames <= 0 || h->arenaFrames <= 0) { g_lastError = "the handle has no device arenas (an earlier rumi_orb_set_resident_queue failed to allocate them)"; return RUMI_E_CAPACITY; }
     HIP_TRY(hipSetDevice(h->device));
     int rc;
     if (h->pending && (h->gw != w || h->gh != hgt) && (rc = rumi_orb_sync(h)) != RUMI_OK) return rc;   // new tables must not overtake running kernels
@@ -495,7 +503,9 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     const DevParams &P = h->hP;
     // Level 0 is read where the caller has it, as aligned dwords.  Frames whose base, pitch or frame stride is not a multiple of 4 are
     // first copied into an aligned staging arena (the only case that costs a copy).
+    bool stagedL0 = false;       // the frames were copied on `st`: the slot streams of a resident call must then wait for `st` (below)
     if ((reinterpret_cast<uintptr_t>(d_imgs) & 3) || (stride & 3) || (frame_stride & 3)) {
+        stagedL0 = true;
         const int wp = (w + 3) & ~3;
         if (!h->dL0) HIP_TRY(hipMalloc((void **)&h->dL0, (size_t)((h->cfg.max_width + 3) & ~3) * h->cfg.max_height * h->cfg.max_batch));
         for (int f = 0; f < nframes; f++)
@@ -609,7 +619,9 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         const int slotFrames = h->scratchFrames / kSlots;
         const int cap64 = std::min(resident_sub_frames(), slotFrames);
         const int nsub = (nframes + cap64 - 1) / cap64, sub = (nframes + nsub - 1) / nsub;
-        const bool fork = !h->pending || !h->lastResident;
+        // (unaligned frames were staged into dL0 by copies queued on `st`: every slot stream this call touches waits for them.  The previous
+        // call's readers of dL0 are behind `st` already: the caller's stream waited for that call's results at its end.)
+        const bool fork = !h->pending || !h->lastResident || stagedL0;
         if (fork) HIP_TRY(hipEventRecord(h->evPartFork, st));
         bool touched[kMaxSlots] = {false, false, false, false, false, false, false, false};
         for (int j = 0, base = 0; base < nframes; j++, base += sub) {

@@ -5,6 +5,10 @@
 
 namespace rumi {
 
+// Correspondences the LDS instantiation of k_pose_opt holds (opt.hip).  The tracker (match.hip) launches ONLY that instantiation when it knows a
+// frame cannot have more (nfeatures 1000 + the extractor's slack of 96 fits), so both files take the number from here.
+constexpr int kPoseLdsEdges = 1152;
+
 // Optimizer::PoseOptimization of ONE frame whose correspondences already lie on the device (opt.hip, k_pose_opt): dStart = {0, n} (n read by the
 // kernel, not by the host), Xw [n][3], obs [n][2], w [n] (invLevelSigma2), K4, Tin [7] -> Tout [7], outlier [n], nGood [1].  dActive [cap] and
 // dLastChi2 [cap] are scratch for frames of more than 1024 correspondences; fitsLds: the caller knows the count is at most 1024 (the second

@@ -190,6 +190,7 @@ class ORBextractor:
     def wait_event(self, event):
         """The next batched call starts behind `event` (a recorded torch.cuda.Event): the end of whoever still reads the buffers the call is
         about to overwrite (rumi_orb_wait_event)."""
+        self._wait_event_ref = event          # the library keeps the raw hipEvent_t until the next batched call: the torch Event must outlive it
         capi.check(self._lib.rumi_orb_wait_event(self._h, event.cuda_event if event is not None else None))
 
     def set_profiling(self, on=True):

@@ -127,6 +127,7 @@ class Tracker:
         K4 = np.ascontiguousarray(K4, np.float32); T = np.ascontiguousarray(Tcw_pred7, np.float32)
         lk = np.ascontiguousarray(last_keys, KP_DTYPE); lm = np.ascontiguousarray(last_mp, np.int32); lo = np.ascontiguousarray(last_outlier, np.uint8)
         _, keep, P = self._points(points, False)
+        assert len(lm) >= len(lk) and len(lo) >= len(lk), "last_mp / last_outlier must cover every last-frame key-point (the C entry reads nlast of each)"
         mp = np.full(self.cap, -1, np.int32); dis = np.full(self.cap, -1, np.int32)
         res = RumiTrackResult()
         capi.check(self._lib.rumi_track_motion(self._h, capi.ptr(K4), capi.ptr(T), capi.ptr(lk), len(lk), capi.ptr(lm), capi.ptr(lo), C.byref(P), float(th_motion),
@@ -158,6 +159,9 @@ class Tracker:
         fin = np.ascontiguousarray(frame_mp_in, np.int32)
         n, keep, P = self._points(points, True)
         si = np.ascontiguousarray(seen_in, np.uint8) if seen_in is not None else None
+        # the C entry reads frame_mp_in[0 .. n of the resident frame) and seen_in[0 .. points): shorter arrays would be host out-of-bounds reads
+        assert getattr(self, "_n", None) is None or len(fin) >= self._n, f"frame_mp_in has {len(fin)} entries, the resident frame {self._n} features"
+        assert si is None or len(si) >= n, f"seen_in has {len(si)} entries for {n} points"
         mp = np.full(self.cap, -1, np.int32); outl = np.zeros(self.cap, np.uint8); in_view = np.zeros(max(n, 1), np.uint8)
         res = RumiTrackResult()
         capi.check(self._lib.rumi_track_local(self._h, capi.ptr(K4), capi.ptr(T), capi.ptr(fin), C.byref(P), capi.ptr(si) if si is not None else None,

@@ -158,6 +158,40 @@ def test_async_batches_match_blocking_calls():
             assert np.array_equal(d[f, :n], ref[i][1][f, :n]), f"batch {i} frame {f}: descriptors"
 
 @pytest.mark.gpu
+def test_resident_queue_with_unaligned_frames_back_to_back():
+    """Advisor finding of round 3: with the resident queue on, frames whose width / pitch is not a multiple of 4 are first copied into an aligned
+    staging arena by copies queued on the CALLER's stream -- which the slot streams of a resident call do not wait for from the second
+    back-to-back call on.  Three different 641-pixel-wide batches enqueued without waiting must give what the blocking calls give (before the
+    fix the later calls read the staging arena before their own copies had landed: the previous call's frames)."""
+    import torch
+    from rumi_slam_amd.synth import synth_batch
+    W, H, n = 641, 480, 40
+    g, _ = _pair(w=W, h=H, batch=n)
+    batches = [torch.from_numpy(synth_batch(n, seed0=8100 + 100 * i, w=W, h=H)).cuda() for i in range(3)]
+    ref = []
+    for fr in batches:
+        kp, desc, counts = g.extract_batch(fr)
+        ref.append((kp.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()))
+    assert not np.array_equal(ref[0][2], ref[1][2]), "the batches must differ"
+    g.set_resident_queue(True)
+    cap = 1000 + 4 * 8 + 64
+    outs = [(torch.empty((n, cap, 7), dtype=torch.float32, device="cuda"), torch.empty((n, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.empty((n, 2), dtype=torch.int32, device="cuda")) for _ in batches]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for fr, o in zip(batches, outs):
+            g.extract_batch(fr, wait=False, out=o)
+        g.sync()
+        torch.cuda.synchronize()
+        for i, (kp, desc, counts) in enumerate(outs):
+            c = counts.cpu().numpy()
+            assert np.array_equal(c, ref[i][2]), f"round {rep} call {i}: counts"
+            k, d = kp.cpu().numpy(), desc.cpu().numpy()
+            for f in range(n):
+                m = c[f, 0]
+                assert k[f, :m].tobytes() == ref[i][0][f, :m].tobytes() and np.array_equal(d[f, :m], ref[i][1][f, :m]), f"round {rep} call {i} frame {f}"
+
+
 def test_resident_queue_calls_overlap_and_match_blocking_calls():
     """rumi_orb_set_resident_queue: sub-chunks never wait for the caller's stream, consecutive calls rotate through four slots and run side by
     side.  Calls of different sizes (one sub-chunk, an odd size, a single frame, three sub-chunks: a call is cut at 256 frames) enqueued back to
