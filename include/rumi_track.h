@@ -34,6 +34,15 @@ typedef struct RumiTrackPoints {
     const int32_t *obs;      /* [n] Observations() */
     const uint8_t *bad;      /* [n] isBad() */
     const uint8_t *local;    /* [n] member of mvpLocalMapPoints */
+    /* Optional (NULL = no point carries it): what an EARLIER frame's SearchLocalPoints left in the MapPoint.  The "discard outliers" loop of
+     * TrackWithMotionModel / TrackReferenceKeyFrame (Tracking.cc:2489-2508) tests `i < mCurrentFrame.Nleft`; a monocular frame has Nleft = -1
+     * (Frame.cc:420), so it clears mbTrackInViewR and leaves mbTrackInView as it was -- SearchLocalPoints then skips the point (mnLastFrameSeen ==
+     * mnId) without refreshing it, and SearchByProjection (ORBmatcher.cc:46-60) searches it at its OLD projection.  stale_in_view[i] = the point's
+     * mbTrackInView before this frame; stale_proj[i] = {mTrackProjX, mTrackProjY, (float)mnTrackScaleLevel, mTrackViewCos, mTrackDepth}.  Read for
+     * discarded outliers only; such a point is searched with these values, does not count in nToMatch and comes back as in_view = 2 (mbTrackInView
+     * still set, no IncreaseVisible owed). */
+    const uint8_t *stale_in_view;
+    const float *stale_proj;
 } RumiTrackPoints;
 
 typedef struct RumiTrackResult {
@@ -118,6 +127,12 @@ int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc, int32_t l
 int rumi_track_local(RumiTracker *t, const float *K4, const float *Tcw7, const int32_t *frame_mp_in, const RumiTrackPoints *pts,
                      const uint8_t *seen_in, float th_local, int32_t far_points, float th_far_points, int32_t *frame_mp, uint8_t *outlier,
                      uint8_t *in_view, RumiTrackResult *res);
+
+/* mTrackProjX, mTrackProjY, (float)mnTrackScaleLevel, mTrackViewCos, mTrackDepth of every table point, proj5_out [n_points][5], as the
+ * SearchLocalPoints of the LAST rumi_track_frame / rumi_track_local call left them (Frame::isInFrustum writes these into the MapPoint, Frame.cc:558-630;
+ * meaningful for points with in_view = 1).  A caller that keeps MapPoint objects (the facade) stores them back: a later frame's discarded outlier is
+ * searched at these values (RumiTrackPoints.stale_proj).  One more device-to-host copy; valid until the next rumi_track_* call on the tracker. */
+int rumi_track_last_projections(RumiTracker *t, int32_t n_points, float *proj5_out);
 
 #ifdef __cplusplus
 }

@@ -2166,7 +2166,7 @@ __device__ __forceinline__ void after_motion_body(int c, const int32_t *idx, con
     if (c == 0 && searchHeader) { blk->spec[0] = searchHeader[0]; blk->spec[1] = searchHeader[1]; }   // (the next search clears the header)
     if (c >= blk->start[1]) return;
     const int i = idx[c], mp = featMp[i];
-    seen[mp] = 1;
+    seen[mp] = outlierC[c] ? 2 : 1;                        // 2: discarded as an outlier (k_track_frustum: its mbTrackInView may still be set from an earlier frame)
     if (outlierC[c]) { featMp[i] = -1; return; }
     if (mpObs[mp] > 0) atomicAdd(&blk->counters[0], 1);
     if (mpBad[mp]) featMp[i] = -1;
@@ -2212,6 +2212,8 @@ struct FrustumArgs {
     int farPoints;
     float thFar;
     Query *q;
+    const uint8_t *staleIn;      // RumiTrackPoints.stale_in_view / stale_proj (nullptr: none)
+    const float *staleProj;
 };
 __device__ __forceinline__ void frustum_body(int i, const FrustumArgs &F) {
     const auto nmp = F.nmp;
@@ -2250,6 +2252,15 @@ __device__ __forceinline__ void frustum_body(int i, const FrustumArgs &F) {
     if (i < 4) searchHeader[i] = 0;
     if (i < n) mpMotion[i] = featMp[i];                    // mvpMapPoints as TrackWithMotionModel leaves them (the local search may replace unobserved points)
     if (i >= nmp) return;
+    // A discarded outlier (seen == 2) is not re-projected (mnLastFrameSeen == mnId) -- but a monocular frame's discard loop left its mbTrackInView
+    // as an earlier frame set it (Nleft = -1, Tracking.cc:2489-2508), and SearchByProjection searches it at that OLD projection (ORBmatcher.cc:46-60)
+    if (local[i] && !bad[i] && seen[i] == 2 && F.staleIn && F.staleIn[i]) {
+        const float *sp = F.staleProj + (size_t)i * 5;
+        skip[i] = 0;
+        inView[i] = 2; projX[i] = sp[0]; projY[i] = sp[1]; scaleLevel[i] = (int)sp[2]; viewCosOut[i] = sp[3]; trackDepth[i] = sp[4];
+        q[i] = mappoint_query(i, true, sp[0], sp[1], (int)sp[2], sp[3], sp[4], false, mpObs[i], scaleFactors, th, farPoints, thFar);
+        return;
+    }
     const uint8_t sk = !local[i] || seen[i] || bad[i];
     skip[i] = sk;
     // (the search's query of this point is built here too: k_queries_mappoints' work on the values at hand, one launch less)
@@ -2325,7 +2336,9 @@ struct RumiTracker {
     uint8_t *dBlk = nullptr, *hBlk = nullptr; size_t oMp = 0, oMpM = 0, oOut = 0, oView = 0, oRec = 0, blkBytes = 0, recordBytes = 0;
     float *dInvSigma2 = nullptr, *dXw = nullptr, *dObs = nullptr, *dW = nullptr;
     int32_t *dIdx = nullptr;
-    uint8_t *dOutC = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr;
+    uint8_t *dOutC = nullptr, *dActive = nullptr, *dSeen = nullptr, *dBad = nullptr, *dLocal = nullptr, *dStaleIn = nullptr;
+    float *dStaleProj = nullptr;
+    size_t projN16 = 0; int projN = 0;       // the projection arrays the last SearchLocalPoints left in the matcher's staging block (rumi_track_last_projections)
     double *dChi = nullptr;
     float scale[64] = {0};
     // the step-wise entries (rumi_track_extract / _motion / _reference_keyframe / _local): the frame that is resident, and its BoW transform
@@ -2338,7 +2351,7 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     (void)hipSetDevice(t->device);
     rumi_orb_destroy(t->ext);
     rumi_match_destroy(t->m);
-    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN};
+    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN, t->dStaleIn, t->dStaleProj};
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
     if (t->hImage) (void)hipHostFree(t->hImage);
@@ -2368,7 +2381,7 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
 #define TRYA(x) if ((rc = (x)) != RUMI_OK) { rumi_track_destroy(t); return rc; }
     TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dBlk, t->blkBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
     TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dIdx, C));
-    TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dChi, C));
+    TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dStaleIn, P)); TRYA(dalloc(&t->dStaleProj, P * 5)); TRYA(dalloc(&t->dChi, C));
     TRYA(dalloc(&t->dWord, C)); TRYA(dalloc(&t->dNode, C)); TRYA(dalloc(&t->dWeight, C)); TRYA(dalloc(&t->dNN, 4));
 #undef TRYA
     if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess ||
@@ -2401,6 +2414,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     for (int i = 0; i < nlast; i++) if (last_mp[i] >= nmp) { g_lastError = "rumi_track_frame: last_mp index outside the point table"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(t->device));
     std::memset(res, 0, sizeof(*res));
+    t->projN = 0;
     res->mono_index = -1; res->th_motion = (int32_t)th_motion;
     TrackBlock *dB = reinterpret_cast<TrackBlock *>(t->dBlk);
     int32_t *dMpOut = reinterpret_cast<int32_t *>(t->dBlk + t->oMp), *dMpMotion = reinterpret_cast<int32_t *>(t->dBlk + t->oMpM);
@@ -2426,6 +2440,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     if (nmp > 0) {
         H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dF[1], pts->normal, (size_t)nmp * 3); H2D(m->dF[2], pts->min_dist, nmp); H2D(m->dF[3], pts->max_dist, nmp);
         H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
+        if (pts->stale_in_view && pts->stale_proj) { H2D(t->dStaleIn, pts->stale_in_view, nmp); H2D(t->dStaleProj, pts->stale_proj, (size_t)nmp * 5); }
     }
     if (nlast > 0) { H2D(m->dQKeys, last_keys_un, nlast); H2D(m->dI[0], last_mp, nlast); H2D(m->dU8a, last_outlier, nlast); }
     const bool gridWanted = m->gridPending;                 // (the grid needs the feature count: it is built below)
@@ -2492,11 +2507,12 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         { const FrustumArgs FA{nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
                            fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
-                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ};
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ,
+                           (pts->stale_in_view && pts->stale_proj) ? t->dStaleIn : nullptr, (pts->stale_in_view && pts->stale_proj) ? t->dStaleProj : nullptr};
           hipLaunchKernelGGL(k_track_after_motion, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], t->dBad, t->dSeen, m->dPose + 7, dB, (const int32_t *)m->dOut);
           // (both as ONE 1024-thread workgroup -- the frustum test reads the seen flags and the pose matrices the first half writes -- measured: 0.427-0.436 ms
           // against 0.430-0.431 for the frame, no gain; not kept)
-          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); }
+          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); t->projN16 = n16; t->projN = nmp; }
         if ((rc = search(MODE_MAPPOINTS, nmp, 0.8f, 0)) != RUMI_OK) return rc;
         if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, dB->Tout, dB->Tout + 7, t->dOutC, dB->nGood + 1, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
         hipLaunchKernelGGL(k_track_finish, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dOutF, dMpOut, 1, dB, (const int32_t *)m->dOut);
@@ -2544,8 +2560,9 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         int32_t *dL = reinterpret_cast<int32_t *>(dD + n16);
         { const FrustumArgs FA{nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
                            fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
-                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ};
-          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); }
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ,
+                           (pts->stale_in_view && pts->stale_proj) ? t->dStaleIn : nullptr, (pts->stale_in_view && pts->stale_proj) ? t->dStaleProj : nullptr};
+          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); t->projN16 = n16; t->projN = nmp; }
         int nmLocal = 0;
         if ((rc = run_search(m, MODE_MAPPOINTS, nmp, fd, m->dQDesc, m->dI[1], 0.8f, 0, tmpMp.data(), &nmLocal)) != RUMI_OK) return rc;
         res->nmatches_local = nmLocal;
@@ -2574,7 +2591,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     int nTo = 0;
     if (nmp > 0) {
         if (localRan) std::memcpy(in_view, t->hBlk + t->oView, (size_t)nmp); else std::memset(in_view, 0, (size_t)nmp);
-        for (int j = 0; j < nmp; j++) nTo += in_view[j];
+        for (int j = 0; j < nmp; j++) nTo += in_view[j] == 1;         // (2: a stale flag of an earlier frame, not an isInFrustum of this one)
     }
     res->n_to_match = nTo;
     if (n > 0) std::memcpy(frame_mp_motion, localRan ? t->hBlk + t->oMpM : t->hBlk + t->oMp, (size_t)n * 4);
@@ -2661,6 +2678,7 @@ extern "C" int rumi_track_motion(RumiTracker *t, const float *K4, const float *T
     for (int i = 0; i < nlast; i++) if (last_mp[i] >= nmp) { g_lastError = "rumi_track_motion: last_mp index outside the point table"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(t->device));
     std::memset(res, 0, sizeof(*res));
+    t->projN = 0;
     res->n = n; res->mono_index = t->curMono; res->th_motion = (int32_t)th_motion;
     std::memcpy(res->Tcw_motion, Tcw_pred7, 28); std::memcpy(res->Tcw, Tcw_pred7, 28);
     for (int i = 0; i < n; i++) { frame_mp[i] = -1; discarded[i] = -1; }
@@ -2753,6 +2771,7 @@ extern "C" int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc
     for (int i = 0; i < KF->n; i++) if (kf_mp[i] >= nmp) { g_lastError = "rumi_track_reference_keyframe: kf_mp index outside the point table"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(t->device));
     std::memset(res, 0, sizeof(*res));
+    t->projN = 0;
     res->n = n; res->mono_index = t->curMono;
     std::memcpy(res->Tcw_motion, Tcw_init7, 28); std::memcpy(res->Tcw, Tcw_init7, 28);
     for (int i = 0; i < n; i++) { frame_mp[i] = -1; discarded[i] = -1; }
@@ -2823,13 +2842,14 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
     for (int i = 0; i < n; i++) if (frame_mp_in[i] >= nmp) { g_lastError = "rumi_track_local: frame_mp_in index outside the point table"; return RUMI_E_INVALID; }
     HIP_TRY(hipSetDevice(t->device));
     std::memset(res, 0, sizeof(*res));
+    t->projN = 0;
     res->n = n; res->mono_index = t->curMono;
     std::memcpy(res->Tcw_motion, Tcw7, 28); std::memcpy(res->Tcw, Tcw7, 28);
     // SearchLocalPoints, first loop (Tracking.cc:2998-3010), on the host while the arrays are being staged: a bad point leaves the frame, the
     // others are "seen in this frame"; seen_in carries the points the caller's discard loop has marked (mnLastFrameSeen == mCurrentFrame.mnId)
     std::vector<int32_t> mpIn((size_t)std::max(n, 1), -1);
     std::vector<uint8_t> seen((size_t)std::max(nmp, 1), 0);
-    if (seen_in && nmp > 0) std::memcpy(seen.data(), seen_in, (size_t)nmp);
+    if (seen_in) for (int j = 0; j < nmp; j++) seen[j] = seen_in[j] ? 2 : 0;       // the caller's discard loop: 2 (k_track_frustum tells them from the frame's own points)
     for (int i = 0; i < n; i++) {
         const int mp = frame_mp_in[i];
         if (mp < 0) continue;
@@ -2849,6 +2869,7 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
     if (nmp > 0) {
         H2D(m->dF[0], pts->pos, (size_t)nmp * 3); H2D(m->dF[1], pts->normal, (size_t)nmp * 3); H2D(m->dF[2], pts->min_dist, nmp); H2D(m->dF[3], pts->max_dist, nmp);
         H2D(m->dI[1], pts->obs, nmp); H2D(m->dQDesc, pts->desc, (size_t)nmp * 32); H2D(t->dBad, pts->bad, nmp); H2D(t->dLocal, pts->local, nmp);
+        if (pts->stale_in_view && pts->stale_proj) { H2D(t->dStaleIn, pts->stale_in_view, nmp); H2D(t->dStaleProj, pts->stale_proj, (size_t)nmp * 5); }
         H2D(t->dSeen, seen.data(), nmp);
     }
     FLUSH(m);
@@ -2866,8 +2887,9 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
         const float logSf = std::log(t->cfg.scale_factor);
         { const FrustumArgs FA{nmp, n, m->dFeatMp, dMpMotion, t->dLocal, t->dSeen, t->dBad, dSkip, m->dOut, dB->pose19, fd.minX,
                            fd.minY, fd.maxX, fd.maxY, logSf, t->nlevels, 0.5f, m->dF[0], m->dF[1], m->dF[2], m->dF[3], dView, dX, dY, dL, dC, dD,
-                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ};
-          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); }
+                           m->dI[1], m->dScale, th_local, far_points, th_far_points, m->dQ,
+                           (pts->stale_in_view && pts->stale_proj) ? t->dStaleIn : nullptr, (pts->stale_in_view && pts->stale_proj) ? t->dStaleProj : nullptr};
+          hipLaunchKernelGGL(k_track_frustum, dim3(gI), dim3(256), 0, nullptr, FA); t->projN16 = n16; t->projN = nmp; }
         // the search's counts are not needed before the end: one queue, the result header travels in the block (a list overflow -- the resolve
         // did not run then, the frame's vector is untouched -- sends the stage through the sizing path)
         static const int envSpec = std::getenv("RUMI_TRACK_SPECULATE") ? std::atoi(std::getenv("RUMI_TRACK_SPECULATE")) : 1;
@@ -2904,8 +2926,25 @@ extern "C" int rumi_track_local(RumiTracker *t, const float *K4, const float *Tc
     int nTo = 0;
     if (nmp > 0) {
         if (n > 0) std::memcpy(in_view, t->hBlk + t->oView, (size_t)nmp); else std::memset(in_view, 0, (size_t)nmp);
-        for (int j = 0; j < nmp; j++) nTo += in_view[j];
+        for (int j = 0; j < nmp; j++) nTo += in_view[j] == 1;         // (2: a stale flag of an earlier frame, not an isInFrustum of this one)
     }
     res->n_to_match = nTo;
+    return RUMI_OK;
+}
+
+/* mTrackProjX, mTrackProjY, mnTrackScaleLevel, mTrackViewCos, mTrackDepth of every table point as the SearchLocalPoints of the LAST rumi_track_frame /
+ * rumi_track_local call left them (Frame::isInFrustum writes them into the MapPoint, Frame.cc:558-630; the values of a point that is not in view are
+ * not meaningful).  They are still in the matcher's staging block: one more copy brings them.  Valid until the next rumi_track_* call. */
+extern "C" int rumi_track_last_projections(RumiTracker *t, int32_t n_points, float *proj5_out) {
+    if (!t || !proj5_out || n_points < 0) return RUMI_E_INVALID;
+    if (t->projN <= 0 || n_points != t->projN) { g_lastError = "rumi_track_last_projections: no SearchLocalPoints result of that size is resident"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    RumiMatcher *m = t->m;
+    const size_t n16 = t->projN16;
+    std::vector<float> h(5 * n16);
+    HIP_TRY(hipMemcpy(h.data(), m->dStage + n16, 5 * n16 * sizeof(float), hipMemcpyDeviceToHost));
+    const float *X = h.data(), *Y = X + n16, *Cc = Y + n16, *D = Cc + n16;
+    const int32_t *L = reinterpret_cast<const int32_t *>(D + n16);
+    for (int i = 0; i < n_points; i++) { float *o = proj5_out + (size_t)i * 5; o[0] = X[i]; o[1] = Y[i]; o[2] = (float)L[i]; o[3] = Cc[i]; o[4] = D[i]; }
     return RUMI_OK;
 }

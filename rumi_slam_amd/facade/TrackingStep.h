@@ -21,9 +21,13 @@
 //                bOK = st.mnMatchesInliers >= 30; }      // (50 shortly after a relocalisation: the caller's rule, :2589-2607)
 // Every function replays on the host exactly what its reference counterpart does to Frame and MapPoint objects, under the reference's own
 // conditions: nothing at all when the motion model finds fewer than 20 matches (it returns before optimising), nothing when the BoW search finds
-// fewer than 15, the discard loop (mbTrackInView = false, mnLastFrameSeen) otherwise; IncreaseVisible / mbTrackInView / IncreaseFound only
-// in TrackLocalMap.  Not replayed, because their only reader is the search that already ran on the device: mTrackProjX/Y, mnTrackScaleLevel,
-// mTrackViewCos, mTrackDepth of the points in view.
+// fewer than 15, the discard loop otherwise; IncreaseVisible / mbTrackInView / IncreaseFound only in TrackLocalMap.
+// The discard loop follows the reference's MONOCULAR behaviour to the letter (Tracking.cc:2489-2508: `if (i < mCurrentFrame.Nleft) mbTrackInView =
+// false; else mbTrackInViewR = false;` with Nleft = -1, Frame.cc:420): mbTrackInViewR is cleared, mbTrackInView stays as the previous frame's
+// SearchLocalPoints left it -- and the next SearchByProjection searches such a point at its OLD mTrackProjX / Y, level and viewing cosine
+// (ORBmatcher.cc:46-60).  So the tracking fields ARE part of the replayed state: TrackLocalMap / TrackFrame store mTrackProjX/Y, mnTrackScaleLevel,
+// mTrackViewCos, mTrackDepth of the points isInFrustum accepted back into the MapPoints (rumi_track_last_projections) and hand the flags of the
+// table's points to the device (RumiTrackPoints.stale_in_view / stale_proj).
 #pragma once
 #include <algorithm>
 #include <cstring>
@@ -57,8 +61,8 @@ namespace track_detail {
 template <class MapPointT> struct PointTable {
     std::unordered_map<const MapPointT *, int> idOf;
     std::vector<MapPointT *> byId;
-    std::vector<float> pos, nrm, mn, mx;
-    std::vector<uint8_t> desc, bad, local;
+    std::vector<float> pos, nrm, mn, mx, staleProj;
+    std::vector<uint8_t> desc, bad, local, staleIn;
     std::vector<int32_t> obs;
     int id_of(MapPointT *p) {
         auto it = idOf.find(p);
@@ -71,8 +75,13 @@ template <class MapPointT> struct PointTable {
         const int np = (int)byId.size();
         pos.assign((size_t)np * 3 + 3, 0.f); nrm.assign((size_t)np * 3 + 3, 0.f); mn.assign(np + 1, 0.f); mx.assign(np + 1, 0.f);
         desc.assign((size_t)np * 32 + 32, 0); bad.assign(np + 1, 0); local.assign(np + 1, 0); obs.assign(np + 1, 0);
+        staleIn.assign(np + 1, 0); staleProj.assign((size_t)np * 5 + 5, 0.f);
         for (int j = 0; j < np; j++) {
             MapPointT *p = byId[j];
+            // what an earlier frame's SearchLocalPoints left in the point (read by the device for discarded outliers only)
+            staleIn[j] = p->mbTrackInView ? 1 : 0;
+            float *sp = &staleProj[(size_t)j * 5];
+            sp[0] = p->mTrackProjX; sp[1] = p->mTrackProjY; sp[2] = (float)p->mnTrackScaleLevel; sp[3] = p->mTrackViewCos; sp[4] = p->mTrackDepth;
             const auto P = p->GetWorldPos(), N = p->GetNormal();
             for (int c = 0; c < 3; c++) { pos[3 * j + c] = P(c); nrm[3 * j + c] = N(c); }
             mn[j] = p->GetMinDistance(); mx[j] = p->GetMaxDistance(); obs[j] = p->Observations(); bad[j] = p->isBad() ? 1 : 0;
@@ -81,7 +90,23 @@ template <class MapPointT> struct PointTable {
             std::memcpy(&desc[(size_t)j * 32], d.ptr(0), 32);
         }
     }
-    RumiTrackPoints view() const { return RumiTrackPoints{(int32_t)byId.size(), pos.data(), nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), bad.data(), local.data()}; }
+    RumiTrackPoints view() const {
+        return RumiTrackPoints{(int32_t)byId.size(), pos.data(), nrm.data(), mn.data(), mx.data(), desc.data(), obs.data(), bad.data(), local.data(), staleIn.data(), staleProj.data()};
+    }
+    // Frame::isInFrustum's writes into the MapPoints (Frame.cc:558-630) for the points the device's SearchLocalPoints accepted (in_view == 1)
+    void store_projections(RumiTracker *t, const uint8_t *inView) {
+        const int np = (int)byId.size();
+        if (np == 0) return;
+        std::vector<float> pr((size_t)np * 5);
+        const int rc = rumi_track_last_projections(t, np, pr.data());
+        if (rc != RUMI_OK) { report("rumi_track_last_projections", rc); return; }
+        for (int j = 0; j < np; j++) {
+            if (inView[j] != 1) continue;
+            MapPointT *p = byId[j];
+            const float *sp = &pr[(size_t)j * 5];
+            p->mTrackProjX = sp[0]; p->mTrackProjY = sp[1]; p->mnTrackScaleLevel = (int)sp[2]; p->mTrackViewCos = sp[3]; p->mTrackDepth = sp[4];
+        }
+    }
 };
 
 // the tracker of this thread (re-created when the extractor's configuration changes or a table outgrows it)
@@ -138,7 +163,8 @@ inline void replay_discard(FrameT &Cur, const std::vector<MapPointT *> &byId, co
     for (int i = 0; i < Cur.N; i++) {
         Cur.mvpMapPoints[i] = frameMp[i] >= 0 ? byId[frameMp[i]] : nullptr;
         Cur.mvbOutlier[i] = false;
-        if (discarded[i] >= 0) { MapPointT *p = byId[discarded[i]]; p->mbTrackInView = false; p->mnLastFrameSeen = Cur.mnId; }
+        // monocular: `i < mCurrentFrame.Nleft` is false for every i (Nleft = -1), the loop clears mbTrackInViewR and leaves mbTrackInView alone
+        if (discarded[i] >= 0) { MapPointT *p = byId[discarded[i]]; p->mbTrackInViewR = false; p->mnLastFrameSeen = Cur.mnId; }
     }
 }
 
@@ -315,10 +341,11 @@ int TrackLocalMap(FrameT &Cur, const std::vector<MapPointT *> &vpLocalMapPoints,
     }
     for (int j = 0; j < nLocal; j++) {                       // second loop (:3015-3030): isInFrustum sets mbTrackInView either way for the points it sees
         MapPointT *p = tab.byId[j];
-        if (p->mnLastFrameSeen == Cur.mnId || p->isBad()) continue;
+        if (p->mnLastFrameSeen == Cur.mnId || p->isBad()) continue;     // (a discarded outlier keeps whatever mbTrackInView it had: inView[j] == 2 if that was true)
         p->mbTrackInView = inView[j] != 0;
         if (inView[j]) p->IncreaseVisible();
     }
+    tab.store_projections(t, inView.data());
     st.mnMatchesInliers = 0;
     for (int i = 0; i < Cur.N; i++) {                        // TrackLocalMap (:2573-2586)
         Cur.mvpMapPoints[i] = mp[i] >= 0 ? tab.byId[mp[i]] : nullptr;
@@ -384,10 +411,13 @@ int TrackFrame(FrameT &Cur, const cv::Mat &im, ExtractorT &extractor, const floa
         MapPointT *p = tab.byId[mpMotion[i]];
         p->IncreaseVisible(); p->mnLastFrameSeen = Cur.mnId; p->mbTrackInView = false;
     }
-    for (int j = 0; j < np; j++) {                           // second loop (:3015-3030): the local points the frustum test accepted
-        if (!inView[j]) continue;
-        tab.byId[j]->mbTrackInView = true; tab.byId[j]->IncreaseVisible();
+    for (int j = 0; j < nLocal; j++) {                       // second loop (:3015-3030): isInFrustum clears mbTrackInView of every point it tests and sets it
+        MapPointT *p = tab.byId[j];                          // again for the ones it accepts.  Not tested: points seen in this frame -- the kept matches (cleared
+        if (inView[j] == 2 || p->mnLastFrameSeen == Cur.mnId || p->isBad()) continue;     // above) and the discarded outliers (flag untouched: 2 if it was set) -- and bad points
+        p->mbTrackInView = inView[j] == 1;
+        if (inView[j] == 1) p->IncreaseVisible();
     }
+    tab.store_projections(t, inView.data());
     for (int i = 0; i < n; i++) {                            // TrackLocalMap (:2573-2586)
         if (mpFinal[i] < 0) continue;
         Cur.mvpMapPoints[i] = tab.byId[mpFinal[i]];

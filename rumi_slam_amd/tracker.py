@@ -10,7 +10,18 @@ from .capi import KP_DTYPE, RumiOrbConfig
 
 class RumiTrackPoints(C.Structure):
     _fields_ = [("n", C.c_int32), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
-                ("desc", C.c_void_p), ("obs", C.c_void_p), ("bad", C.c_void_p), ("local", C.c_void_p)]
+                ("desc", C.c_void_p), ("obs", C.c_void_p), ("bad", C.c_void_p), ("local", C.c_void_p),
+                ("stale_in_view", C.c_void_p), ("stale_proj", C.c_void_p)]       # optional: points["stale_in_view"] [n] u8, points["stale_proj"] [n,5] f32
+
+
+def _stale(points, a):
+    """The optional stale-mbTrackInView arrays of include/rumi_track.h (RumiTrackPoints.stale_in_view / stale_proj) as two pointers (None, None when absent)."""
+    if points.get("stale_in_view") is None:
+        return None, None
+    a["stale_in"] = np.ascontiguousarray(points["stale_in_view"], np.uint8)
+    a["stale_proj"] = np.ascontiguousarray(points["stale_proj"], np.float32).reshape(-1, 5)
+    assert len(a["stale_in"]) == len(a["stale_proj"]) == len(points["obs"])
+    return capi.ptr(a["stale_in"]), capi.ptr(a["stale_proj"])
 
 
 class RumiTrackResult(C.Structure):
@@ -34,6 +45,7 @@ def _bind(L):
     L.rumi_track_reference_keyframe.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, C.POINTER(RumiTrackPoints), f32, i32, vp, vp, vp, vp, vp,
                                                 C.POINTER(RumiTrackResult)]
     L.rumi_track_local.argtypes = [vp, vp, vp, vp, C.POINTER(RumiTrackPoints), vp, f32, i32, f32, vp, vp, vp, C.POINTER(RumiTrackResult)]
+    L.rumi_track_last_projections.argtypes = [vp, i32, vp]
     L.rumi_track_image_buffer.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]
     L._track_ready = True
     return L
@@ -66,7 +78,7 @@ class Tracker:
                  mn=np.ascontiguousarray(points["min_dist"], np.float32), mx=np.ascontiguousarray(points["max_dist"], np.float32),
                  desc=np.ascontiguousarray(points["desc"], np.uint8), obs=np.ascontiguousarray(points["obs"], np.int32),
                  bad=np.ascontiguousarray(points["bad"], np.uint8), local=np.ascontiguousarray(points["local"], np.uint8))
-        P = RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")))
+        P = RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")), *_stale(points, a))
         keys = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
         mp_motion = np.full(self.cap, -1, np.int32); mp = np.full(self.cap, -1, np.int32); outl = np.zeros(self.cap, np.uint8)
         in_view = np.zeros(max(n, 1), np.uint8)
@@ -101,7 +113,13 @@ class Tracker:
                  mn=np.ascontiguousarray(points.get("min_dist", z1), np.float32), mx=np.ascontiguousarray(points.get("max_dist", z1), np.float32),
                  desc=np.ascontiguousarray(points["desc"], np.uint8), obs=np.ascontiguousarray(points["obs"], np.int32),
                  bad=np.ascontiguousarray(points["bad"], np.uint8), local=np.ascontiguousarray(points.get("local", np.zeros(n, np.uint8)), np.uint8))
-        return n, a, RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")))
+        return n, a, RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")), *_stale(points, a))
+
+    def last_projections(self, n_points):
+        """rumi_track_last_projections: [n_points, 5] f32 = mTrackProjX, mTrackProjY, mnTrackScaleLevel, mTrackViewCos, mTrackDepth of the last SearchLocalPoints."""
+        out = np.zeros((int(n_points), 5), np.float32)
+        capi.check(self._lib.rumi_track_last_projections(self._h, int(n_points), capi.ptr(out)))
+        return out
 
     @staticmethod
     def _result(res, fields):

@@ -58,7 +58,7 @@ struct MapPoint {
     bool IsInKeyFrame(KeyFrame *k) { return obs.count(k) > 0; }
     void AddObservation(KeyFrame *k, int idx) { if (!obs.count(k)) nObs++; obs[k] = std::make_tuple(idx, -1); }
     void Replace(MapPoint *other);                     // defined after KeyFrame
-    bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
+    bool mbTrackInView = false, mbTrackInViewR = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1, mTrackDepth = 1; int mnTrackScaleLevel = 0;
     long mnLastFrameSeen = -1; int nVisible = 0, nFound = 0;
     void IncreaseVisible() { nVisible++; }
     void IncreaseFound() { nFound++; }
@@ -552,6 +552,54 @@ int main(int argc, char **argv) {
         for (size_t i = 0; sameStats && i < mps.size(); i++) sameStats = mps[i].nVisible == visF[i] && mps[i].nFound == foundF[i];
         CHECK(sameS && std::memcmp(F1.pose.T, F2.pose.T, 28) == 0, "step-wise: the frame after TrackLocalMap equals the fused call's");
         CHECK(sameStats, "step-wise: IncreaseVisible / IncreaseFound per point as in the fused call");
+        {   // (a2) isInFrustum's writes reach the MapPoints, and a discarded outlier that still carries the PREVIOUS frame's mbTrackInView is searched at
+            // its old projection (monocular: the discard loop clears mbTrackInViewR only, Tracking.cc:2489-2508 with Nleft = -1), in both forms alike
+            int stored = 0;
+            for (auto &m : mps) if (m.mbTrackInView) stored += m.mTrackProjX >= 0 && m.mTrackProjX <= 640 && m.mTrackProjY >= 0 && m.mTrackProjY <= 480 && m.mnTrackScaleLevel >= 0 && m.mnTrackScaleLevel < 8 && m.mTrackDepth > 0;
+            int inViewNow = 0;
+            for (auto &m : mps) inViewNow += m.mbTrackInView;
+            CHECK(inViewNow == ss.nToMatch && stored == inViewNow && inViewNow > 0, "TrackLocalMap stores mTrackProjX/Y, mnTrackScaleLevel, mTrackDepth of the points in view");
+            // every point "was in view in the previous frame" at the feature frame 0 saw it at
+            struct Saved { bool v; float x, y, c, d; int l; };
+            std::vector<Saved> init(mps.size());
+            for (size_t i = 0; i < mps.size(); i++) {
+                const cv::KeyPoint &k = fr[0].mvKeysUn[i];
+                init[i] = Saved{true, k.pt.x, k.pt.y, 1.f, 1.f, k.octave};
+            }
+            auto restore = [&]() {
+                for (size_t i = 0; i < mps.size(); i++) {
+                    MapPoint &m = mps[i];
+                    m.mbTrackInView = init[i].v; m.mTrackProjX = init[i].x; m.mTrackProjY = init[i].y; m.mTrackViewCos = init[i].c; m.mTrackDepth = init[i].d; m.mnTrackScaleLevel = init[i].l;
+                    m.mnLastFrameSeen = -1; m.nVisible = 0; m.nFound = 0;
+                }
+            };
+            restore();
+            Frame G1; G1.mnId = 41;
+            rumi_facade::TrackStep g1;
+            rumi_facade::TrackFrame(G1, image1, ext, T7, fr[0], localPts, 15.f, 1.f, false, 50.f, &g1);
+            int trueAfterFused = 0;                                  // (bad points are skipped by both loops: their flag stays whatever it was)
+            for (auto &m : mps) trueAfterFused += m.mbTrackInView && !m.bad;
+            std::vector<char> flagsFused(mps.size());
+            for (size_t i = 0; i < mps.size(); i++) flagsFused[i] = mps[i].mbTrackInView;
+            restore();
+            Frame G2; G2.mnId = 42;
+            rumi_facade::TrackStep g2;
+            rumi_facade::ExtractFrame(G2, capture, ext, (int)mps.size());
+            rumi_facade::TrackWithMotionModel(G2, fr[0], T7, 15.f, &g2);
+            int staleKept = 0;
+            for (auto &m : mps) staleKept += m.mnLastFrameSeen == G2.mnId && m.mbTrackInView && !m.bad;      // discarded, flag untouched
+            rumi_facade::TrackLocalMap(G2, localPts, 1.f, false, 50.f, &g2);
+            bool sameG = G1.N == G2.N, sameFlags = true;
+            for (int i = 0; sameG && i < G1.N; i++) sameG = G1.mvpMapPoints[i] == G2.mvpMapPoints[i] && G1.mvbOutlier[i] == G2.mvbOutlier[i];
+            for (size_t i = 0; i < mps.size(); i++) sameFlags = sameFlags && flagsFused[i] == (char)mps[i].mbTrackInView;
+            const int nStale = trueAfterFused - g1.nToMatch;
+            CHECK(staleKept > 0 && nStale == staleKept, "discard loop (monocular): mbTrackInView of a discarded outlier is left as the previous frame set it");
+            CHECK(sameG && sameFlags && g1.nmatchesLocal == g2.nmatchesLocal && g1.mnMatchesInliers == g2.mnMatchesInliers && g1.nToMatch == g2.nToMatch,
+                  "stale in-view flags: fused and step-wise forms agree");
+            CHECK(g1.nmatchesLocal != sf.nmatchesLocal || g1.mnMatchesInliers != sf.mnMatchesInliers || nStale > 0, "stale in-view flags take part in the local search");
+            std::printf("stale mbTrackInView: %d discarded outliers searched at their old projection (local matches %d, %d without the flags)\n", nStale, g1.nmatchesLocal, sf.nmatchesLocal);
+            for (auto &m : mps) { m.mbTrackInView = false; m.mnLastFrameSeen = -1; m.nVisible = 0; m.nFound = 0; }
+        }
         // (b) a hopeless prediction: the fused call reports okMotion = false, has replayed NOTHING of TrackLocalMap, and the frame is in
         // TrackWithMotionModel's failure state; TrackReferenceKeyFrame takes over on the resident frame
         for (auto &m : mps) { m.nVisible = 0; m.nFound = 0; m.mnLastFrameSeen = -1; m.mbTrackInView = false; }

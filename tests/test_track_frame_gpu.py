@@ -34,6 +34,22 @@ def _pose_matrices(T):
     return R, t, ((v + w * u) + c).astype(np.float32)
 
 
+def _apply_stale(fr, skip, discarded_ids, pts):
+    """Discarded outliers whose mbTrackInView an earlier frame left set (a monocular frame's discard loop clears mbTrackInViewR only: Nleft = -1,
+    Tracking.cc:2489-2508) are not re-projected but searched at their OLD projection (ORBmatcher.cc:46-60): pts["stale_in_view"] / ["stale_proj"]
+    (mTrackProjX, mTrackProjY, mnTrackScaleLevel, mTrackViewCos, mTrackDepth).  Returns the in_view array the device reports (2 = such a point)."""
+    in_view = fr["track_in_view"].copy()
+    if pts.get("stale_in_view") is None:
+        return in_view
+    for j in np.unique(discarded_ids):
+        if pts["local"][j] and not pts["bad"][j] and pts["stale_in_view"][j]:
+            sp = pts["stale_proj"][j]
+            skip[j] = 0
+            fr["track_in_view"][j] = 1; fr["proj_x"][j] = sp[0]; fr["proj_y"][j] = sp[1]; fr["scale_level"][j] = int(sp[2]); fr["view_cos"][j] = sp[3]; fr["track_depth"][j] = sp[4]
+            in_view[j] = 2
+    return in_view
+
+
 def _oracle_step(orc, img, sf, inv_sigma2, T_pred, last, pts, th_local):
     """The reference's sequence with the oracle's functions; returns everything rumi_track_frame reports."""
     mono, keys, desc = orc.extract(img)
@@ -57,6 +73,7 @@ def _oracle_step(orc, img, sf, inv_sigma2, T_pred, last, pts, th_local):
     seen[cur[idx]] = 1
     inl = idx[out == 0]
     r.update(ngood_motion=ng, Tcw_motion=T1, nmatches_map=int((pts["obs"][cur[inl]] > 0).sum()))
+    discarded_ids = cur[idx[out != 0]].copy()
     cur[idx[out != 0]] = -1
     cur[inl[pts["bad"][cur[inl]] != 0]] = -1
     r["frame_mp_motion"] = cur.copy()
@@ -66,7 +83,8 @@ def _oracle_step(orc, img, sf, inv_sigma2, T_pred, last, pts, th_local):
     fr = O.is_in_frustum(R, t, Ow, K_TUM3, W, H, log_sf, 8, 0.5, pts)
     for k in fr:
         fr[k] = np.where(skip != 0, np.array(-1 if k in ("proj_x", "proj_y") else 0, fr[k].dtype), fr[k])
-    r.update(in_view=fr["track_in_view"], n_to_match=int(fr["track_in_view"].sum()), Rcw=R, tcw=t, Ow=Ow)
+    n_to_match = int(fr["track_in_view"].sum())
+    r.update(in_view=_apply_stale(fr, skip, discarded_ids, pts), n_to_match=n_to_match, Rcw=R, tcw=t, Ow=Ow)
     nml, cur2 = O.search_by_projection_mappoints(keys, desc, W, H, sf, dict(fr, is_bad=skip, desc=pts["desc"], obs=pts["obs"]), cur, th_local, False, 0.0, 0.8)
     idx2 = np.nonzero(cur2 >= 0)[0]
     ng2, T2, out2 = O.pose_optimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)

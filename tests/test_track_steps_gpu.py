@@ -8,7 +8,7 @@ import pytest
 import oracle_lib as O
 from rumi_slam_amd.synth import synth_frame, warp_homography
 from scene import K_TUM3
-from test_track_frame_gpu import H, W, _oracle_step, _pose_close, _pose_matrices, _scene
+from test_track_frame_gpu import H, W, _apply_stale, _oracle_step, _pose_close, _pose_matrices, _scene
 from test_tracking_loop_gpu import _homography, _pose_gt
 from voc_scene import synthetic_vocabulary
 
@@ -55,12 +55,14 @@ def _oracle_local(keys, desc, sf, inv_sigma2, T1, frame_mp_in, seen_in, pts, th_
     fr = O.is_in_frustum(R, t, Ow, K_TUM3, W, H, float(np.log(np.float32(1.2))), 8, 0.5, pts)
     for k in fr:
         fr[k] = np.where(skip != 0, np.array(-1 if k in ("proj_x", "proj_y") else 0, fr[k].dtype), fr[k])
+    n_to_match = int(fr["track_in_view"].sum())
+    in_view = _apply_stale(fr, skip, np.nonzero(seen_in)[0], pts)
     nml, cur2 = O.search_by_projection_mappoints(keys, desc, W, H, sf, dict(fr, is_bad=skip, desc=pts["desc"], obs=pts["obs"]), cur, th_local, False, 0.0, 0.8)
     idx2 = np.nonzero(cur2 >= 0)[0]
     ng2, T2, out2 = O.pose_optimization(pts["pos"][cur2[idx2]], np.stack([keys["x"][idx2], keys["y"][idx2]], 1), inv_sigma2[keys["octave"][idx2]], K_TUM3, T1)
     outl = np.zeros(n, np.uint8)
     outl[idx2] = out2
-    return dict(in_view=fr["track_in_view"], n_to_match=int(fr["track_in_view"].sum()), nmatches_local=nml, frame_mp=cur2, ngood_local=ng2, Tcw=T2, outlier=outl,
+    return dict(in_view=in_view, n_to_match=n_to_match, nmatches_local=nml, frame_mp=cur2, ngood_local=ng2, Tcw=T2, outlier=outl,
                 matches_inliers=int(((out2 == 0) & (pts["obs"][cur2[idx2]] > 0)).sum()), Rcw=R, tcw=t, Ow=Ow)
 
 
@@ -243,3 +245,51 @@ def test_reference_keyframe_on_orbvoc_geometry():
     exp_mp[idx[out != 0]] = -1
     assert got["ngood_motion"] == ng and np.array_equal(got["frame_mp"], exp_mp) and np.array_equal(got["discarded"], exp_dis)
     _pose_close(got["Tcw_motion"], T1, "pose after TrackReferenceKeyFrame")
+
+
+def test_discarded_outliers_with_a_stale_in_view_flag_are_searched_at_their_old_projection():
+    """Advisor finding of round 3 (low): the reference's "discard outliers" loop tests `i < mCurrentFrame.Nleft`; a monocular frame has Nleft = -1
+    (Frame.cc:420), so the loop clears mbTrackInViewR and LEAVES mbTrackInView as the previous frame's SearchLocalPoints set it.  SearchLocalPoints
+    then skips the point (mnLastFrameSeen == mnId) and SearchByProjection searches it with its old mTrackProjX / Y, level and viewing cosine
+    (ORBmatcher.cc:46-60).  The device path now does the same when the caller hands the flags over (RumiTrackPoints.stale_in_view / stale_proj):
+    fused call and step-wise calls against the oracle chain, on a frame where a few map points are wrong enough to be discarded."""
+    from rumi_slam_amd.tracker import Tracker
+    fused, steps = Tracker(1000, 1.2, 8, 20, 7, W, H, 4096), Tracker(1000, 1.2, 8, 20, 7, W, H, 4096)
+    orc = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img0, sf, inv_sigma2, pts, last = _scene(n_keep=0.6)
+    n0 = len(pts["obs"])
+    rng = np.random.default_rng(11)
+    wrong = rng.choice(np.nonzero(last["mp"] >= 0)[0], 40, replace=False)          # 40 points of the last frame sit 6-9 cm off: matched, then discarded
+    pts["pos"][wrong, :2] += rng.choice([-1, 1], (40, 2)) * rng.uniform(0.06, 0.09, (40, 2)).astype(np.float32)
+    # what the previous frame's SearchLocalPoints left in every MapPoint: in view, at the feature it was seen at in frame 0
+    dist = np.linalg.norm(pts["pos"], axis=1).astype(np.float32)
+    pts["stale_in_view"] = (rng.random(n0) < 0.7).astype(np.uint8)
+    pts["stale_proj"] = np.stack([last["keys"]["x"], last["keys"]["y"], last["keys"]["octave"].astype(np.float32), np.ones(n0, np.float32), dist], 1).astype(np.float32)
+    q_gt, t_gt = _pose_gt(2)
+    img = warp_homography(img0, _homography(q_gt, t_gt))
+    T0 = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    ref = _oracle_step(orc, img, sf, inv_sigma2, T0, last, pts, 3.0)
+    n_stale = int((ref["in_view"] == 2).sum())
+    assert n_stale >= 5, f"the scene must discard points that carry the stale flag ({n_stale})"
+    got = fused.track(img, K_TUM3, T0, last["keys"], last["mp"], last["outlier"], pts, 15.0, 3.0)
+    for k in ("nmatches_motion", "ngood_motion", "nmatches_map", "n_to_match", "nmatches_local", "ngood_local", "matches_inliers"):
+        assert got[k] == ref[k], f"fused: {k} {got[k]} vs {ref[k]}"
+    for k in ("frame_mp_motion", "in_view", "frame_mp", "outlier"):
+        assert np.array_equal(got[k], ref[k]), f"fused: {k}"
+    # without the flags the same call must differ (otherwise the path is untested): the stale points are then simply not searched
+    plain = dict(pts); plain.pop("stale_in_view"); plain.pop("stale_proj")
+    ref_plain = _oracle_step(orc, img, sf, inv_sigma2, T0, last, plain, 3.0)
+    assert (ref_plain["in_view"] == 2).sum() == 0
+    rematched = int((np.isin(ref["frame_mp"], np.nonzero(ref["in_view"] == 2)[0])).sum())
+    print(f"stale in-view flags: {n_stale} discarded points searched at their old projection, {rematched} of them matched again; nmatches_local {ref['nmatches_local']} vs {ref_plain['nmatches_local']} without")
+    # step-wise: motion -> (host discard loop) -> local with seen_in and the same flags
+    steps.extract(img)
+    gm = steps.motion(K_TUM3, T0, last["keys"], last["mp"], last["outlier"], pts)
+    seen = _seen_from(gm["discarded"], n0)
+    rl = _oracle_local(ref["keys"], ref["desc"], sf, inv_sigma2, gm["Tcw_motion"], gm["frame_mp"], seen, pts, 3.0)
+    gl = steps.local(K_TUM3, gm["Tcw_motion"], gm["frame_mp"], pts, seen, 3.0)
+    for k in ("n_to_match", "nmatches_local", "ngood_local", "matches_inliers"):
+        assert gl[k] == rl[k], f"step-wise: {k} {gl[k]} vs {rl[k]}"
+    for k in ("frame_mp", "outlier", "in_view"):
+        assert np.array_equal(gl[k], rl[k]), f"step-wise: {k}"
+    assert np.array_equal(gl["frame_mp"], got["frame_mp"]) and np.array_equal(gl["in_view"], got["in_view"])
