@@ -128,6 +128,16 @@ int rumi_track_local(RumiTracker *t, const float *K4, const float *Tcw7, const i
                      const uint8_t *seen_in, float th_local, int32_t far_points, float th_far_points, int32_t *frame_mp, uint8_t *outlier,
                      uint8_t *in_view, RumiTrackResult *res);
 
+/* Lens distortion (Frame::UndistortKeyPoints, Frame::ComputeImageBounds: R/lib_src/Frame.cc:770-826, cv::undistortPoints(mat, mat, K, mDistCoef,
+ * cv::Mat(), mK): 5 fixed-point iterations of the inverse radial-tangential model in double, then P = K; OpenCV's arithmetic restated, parity
+ * unpinned).  K4 = fx, fy, cx, cy of mK, dist5 = (k1, k2, p1, p2, k3) (R/config/euroc_ori.yaml:23-31: k1 = -0.283).  From the next
+ * rumi_track_extract / rumi_track_frame on, the resident frame carries mvKeysUn -- the grid (AssignFeaturesToGrid), every search and
+ * PoseOptimization read those -- and the bounds mnMinX .. mnMaxY of the undistorted corners; keys_out of those calls stays mvKeys.
+ * dist5 == NULL or dist5[0] == 0 switches it off (the reference's own test, Frame.cc:771). */
+int rumi_track_set_distortion(RumiTracker *t, const float *K4, const float *dist5);
+/* mvKeysUn of the resident frame (keys_un_out [cap >= n], may be NULL) and bounds4 = {mnMinX, mnMinY, mnMaxX, mnMaxY} (may be NULL). */
+int rumi_track_undistorted(RumiTracker *t, RumiKeyPoint *keys_un_out, int32_t cap, float *bounds4);
+
 /* mTrackProjX, mTrackProjY, (float)mnTrackScaleLevel, mTrackViewCos, mTrackDepth of every table point, proj5_out [n_points][5], as the
  * SearchLocalPoints of the LAST rumi_track_frame / rumi_track_local call left them (Frame::isInFrustum writes these into the MapPoint, Frame.cc:558-630;
  * meaningful for points with in_view = 1).  A caller that keeps MapPoint objects (the facade) stores them back: a later frame's discarded outlier is

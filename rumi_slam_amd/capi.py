@@ -100,7 +100,7 @@ OPT_SYMBOLS = ["rumi_opt_create", "rumi_opt_destroy", "rumi_pose_optimization", 
 VOC_SYMBOLS = ["rumi_voc_create", "rumi_voc_load_text", "rumi_voc_destroy", "rumi_voc_words", "rumi_voc_levels", "rumi_voc_set_levels", "rumi_voc_assemble", "rumi_voc_transform_features",
                "rumi_voc_transform_batch_device", "rumi_voc_transform"]
 TRACK_SYMBOLS = ["rumi_track_create", "rumi_track_destroy", "rumi_track_frame", "rumi_track_extract", "rumi_track_motion",
-                 "rumi_track_reference_keyframe", "rumi_track_local", "rumi_track_image_buffer", "rumi_track_last_projections"]
+                 "rumi_track_reference_keyframe", "rumi_track_local", "rumi_track_image_buffer", "rumi_track_last_projections", "rumi_track_set_distortion", "rumi_track_undistorted"]
 QUEUE_SYMBOLS = ["rumi_queue_create", "rumi_queue_destroy", "rumi_queue_shards", "rumi_queue_record_bytes", "rumi_queue_block_capacity", "rumi_queue_row",
                  "rumi_queue_uses_rccl", "rumi_queue_extract", "rumi_queue_last_ms"]
 HOOK_SYMBOLS = ["rumi_hook_sort_like_std", "rumi_hook_sort_device", "rumi_hook_std_sort", "rumi_hook_quadtree", "rumi_hook_sinf", "rumi_hook_cosf",

@@ -2322,6 +2322,35 @@ __global__ void k_track_finish(const int32_t *idx, const uint8_t *outlierC, cons
 #include "rumi_track.h"
 #include "rumi_voc.h"
 
+// Frame::UndistortKeyPoints / ComputeImageBounds (R/lib_src/Frame.cc:770-826): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) per point,
+// in double, operation by operation as OpenCV 3.4's cvUndistortPointsInternal does it (not in the tree: restated from the published algorithm,
+// parity unpinned; oracle/frame_oracle.cc is the CPU statement the tests compare with): normalise, 5 fixed-point iterations of the inverse
+// radial-tangential model, project with P = K.  Terms that are zero for (k1, k2, p1, p2, k3) keep their place: 0 * r2 is not dropped.
+struct UndistortArgs { double fx, fy, cx, cy, ifx, ify, k1, k2, p1, p2, k3; };
+__host__ __device__ inline void undistort_point(const UndistortArgs &A, float u, float v, float *uo, float *vo) {
+    double x = u, y = v;
+    x = (x - A.cx) * A.ifx; y = (y - A.cy) * A.ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((A.k3 * r2 + A.k2) * r2 + A.k1) * r2);
+        const double deltaX = 2 * A.p1 * x * y + A.p2 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+        const double deltaY = A.p1 * (r2 + 2 * y * y) + 2 * A.p2 * x * y + 0 * r2 + 0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = A.fx * x + 0 * y + A.cx, yy = 0 * x + A.fy * y + A.cy, ww = 1. / (0 * x + 0 * y + 1);
+    *uo = (float)(xx * ww); *vo = (float)(yy * ww);
+}
+// mvKeysUn: the extractor's key-points with pt replaced (Frame.cc:791-796); the count is read where the extractor left it (nDev) or given (n)
+__global__ void k_undistort_keys(const int32_t *nDev, int n, const RumiKeyPoint *__restrict__ keys, RumiKeyPoint *__restrict__ keysUn, UndistortArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (nDev ? *nDev : n)) return;
+    RumiKeyPoint k = keys[i];
+    undistort_point(A, k.x, k.y, &k.x, &k.y);
+    keysUn[i] = k;
+}
+
 struct RumiTracker {
     int device = 0, cap = 0, maxPts = 0, nlevels = 0;
     RumiOrbConfig cfg{};
@@ -2343,15 +2372,25 @@ struct RumiTracker {
     float scale[64] = {0};
     // the step-wise entries (rumi_track_extract / _motion / _reference_keyframe / _local): the frame that is resident, and its BoW transform
     int curN = -1, curW = 0, curH = 0, curMono = -1;
+    // lens distortion (rumi_track_set_distortion): mvKeysUn of the resident frame and the undistorted image bounds (mnMinX .. mnMaxY)
+    bool distort = false;
+    UndistortArgs ua{};
+    RumiKeyPoint *dKeysUn = nullptr;
+    float bounds[4] = {0, 0, 0, 0};
     uint32_t *dWord = nullptr, *dNode = nullptr; double *dWeight = nullptr; int32_t *dNN = nullptr;
 };
+
+namespace {
+void track_bounds(RumiTracker *t, int w, int h, RumiFrameFeatures *F);
+void track_undistort(RumiTracker *t);
+}  // namespace
 
 extern "C" void rumi_track_destroy(RumiTracker *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     rumi_orb_destroy(t->ext);
     rumi_match_destroy(t->m);
-    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN, t->dStaleIn, t->dStaleProj};
+    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN, t->dStaleIn, t->dStaleProj, t->dKeysUn};
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
     if (t->hImage) (void)hipHostFree(t->hImage);
@@ -2427,11 +2466,13 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
     HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
+    track_undistort(t);
     // ---- uploads of the whole step: one pinned block, one copy, scattered on the device; the frame itself is read where the extractor left it.
     // None of it depends on the extraction: the host fills the block while the extraction runs, and only then waits for the two counts.
     RumiFrameFeatures F{};
     F.n = 0;
-    F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)w; F.max_y = (float)h;
+    F.nlevels = t->nlevels; F.scale_factors = t->scale;
+    track_bounds(t, w, h, &F);
     FrameDev fd;
     if ((rc = upload_frame(m, &F, &fd)) != RUMI_OK) return rc;
     float pose[11];
@@ -2480,7 +2521,7 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
         if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
         take_counts(counts);
     }
-    const RumiKeyPoint *dKp = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
+    const RumiKeyPoint *dKp = t->distort ? t->dKeysUn : reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);      // mvKeysUn: what every stage below reads
     const uint8_t *dDs = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
     fd.n = n; fd.keys = dKp; fd.desc = dDs;
     m->gridN = n; m->gridKeys = dKp; m->gridNDev = canSpec ? reinterpret_cast<const int32_t *>(dRecord) : nullptr;
@@ -2604,16 +2645,36 @@ extern "C" int rumi_track_frame(RumiTracker *t, const uint8_t *img, int32_t w, i
 // flow between the calls (the decisions of TrackWithMotionModel / TrackReferenceKeyFrame, UpdateLocalMap).
 // ==================================================================================================================
 namespace {
+// Frame::ComputeImageBounds (Frame.cc:799-826): the image rectangle, or the undistorted corners' hull with lens distortion
+void track_bounds(RumiTracker *t, int w, int h, RumiFrameFeatures *F) {
+    if (!t->distort) { t->bounds[0] = 0; t->bounds[1] = 0; t->bounds[2] = (float)w; t->bounds[3] = (float)h; }
+    else {
+        const float c[8] = {0, 0, (float)w, 0, 0, (float)h, (float)w, (float)h};
+        float u[8];
+        for (int i = 0; i < 4; i++) undistort_point(t->ua, c[2 * i], c[2 * i + 1], &u[2 * i], &u[2 * i + 1]);
+        t->bounds[0] = std::min(u[0], u[4]); t->bounds[2] = std::max(u[2], u[6]);
+        t->bounds[1] = std::min(u[1], u[3]); t->bounds[3] = std::max(u[5], u[7]);
+    }
+    F->min_x = t->bounds[0]; F->min_y = t->bounds[1]; F->max_x = t->bounds[2]; F->max_y = t->bounds[3];
+}
+// mvKeysUn of the frame the extractor has just been asked for (same queue, behind the extraction)
+void track_undistort(RumiTracker *t) {
+    if (!t->distort) return;
+    const uint8_t *dRecord = t->dBlk + t->oRec;
+    hipLaunchKernelGGL(k_undistort_keys, dim3((t->cap + 255) / 256), dim3(256), 0, nullptr, reinterpret_cast<const int32_t *>(dRecord), t->cap,
+                       reinterpret_cast<const RumiKeyPoint *>(dRecord + 8), t->dKeysUn, t->ua);
+}
 // the resident frame as the matcher's kernels address it (upload_frame of an empty frame queues the scale table and the cleared result header)
 int track_frame_dev(RumiTracker *t, FrameDev *fd) {
     RumiMatcher *m = t->m;
     RumiFrameFeatures F{};
-    F.n = 0; F.nlevels = t->nlevels; F.scale_factors = t->scale; F.min_x = 0; F.min_y = 0; F.max_x = (float)t->curW; F.max_y = (float)t->curH;
+    F.n = 0; F.nlevels = t->nlevels; F.scale_factors = t->scale;
+    track_bounds(t, t->curW, t->curH, &F);
     const int rc = upload_frame(m, &F, fd);
     if (rc != RUMI_OK) return rc;
     const uint8_t *dRecord = t->dBlk + t->oRec;
     fd->n = t->curN;
-    fd->keys = reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
+    fd->keys = t->distort ? t->dKeysUn : reinterpret_cast<const RumiKeyPoint *>(dRecord + 8);
     fd->desc = dRecord + 8 + (size_t)t->cap * sizeof(RumiKeyPoint);
     m->gridN = t->curN; m->gridKeys = fd->keys;
     return RUMI_OK;
@@ -2650,6 +2711,7 @@ extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w,
     HIP_TRY(hipMemcpyAsync(t->dImage, t->hImage, (size_t)wp * h, hipMemcpyHostToDevice, nullptr));
     int rc = rumi_orb_extract_batch_records_async(t->ext, t->dImage, 1, w, h, wp, (int64_t)wp * h, 0, 1000, dRecord, (int64_t)t->recordBytes, t->cap, nullptr);
     if (rc != RUMI_OK) return rc;
+    track_undistort(t);
     int32_t counts[2] = {0, -1};
     HIP_TRY(hipMemcpy(counts, dRecord, 8, hipMemcpyDeviceToHost));
     if ((rc = rumi_orb_sync(t->ext)) != RUMI_OK) return rc;
@@ -2661,6 +2723,7 @@ extern "C" int rumi_track_extract(RumiTracker *t, const uint8_t *img, int32_t w,
         std::memcpy(desc_out, t->hBlk + t->oRec + 8 + (size_t)t->cap * sizeof(RumiKeyPoint), (size_t)n * 32);
     }
     t->curN = n; t->curW = w; t->curH = h; t->curMono = counts[1];
+    { RumiFrameFeatures Fb{}; track_bounds(t, w, h, &Fb); }    // mnMinX .. mnMaxY of this frame (rumi_track_undistorted)
     *n_out = n; *mono_out = counts[1];
     return RUMI_OK;
 }
@@ -2946,5 +3009,36 @@ extern "C" int rumi_track_last_projections(RumiTracker *t, int32_t n_points, flo
     const float *X = h.data(), *Y = X + n16, *Cc = Y + n16, *D = Cc + n16;
     const int32_t *L = reinterpret_cast<const int32_t *>(D + n16);
     for (int i = 0; i < n_points; i++) { float *o = proj5_out + (size_t)i * 5; o[0] = X[i]; o[1] = Y[i]; o[2] = (float)L[i]; o[3] = Cc[i]; o[4] = D[i]; }
+    return RUMI_OK;
+}
+
+/* Lens distortion of the camera (Frame::UndistortKeyPoints / ComputeImageBounds, R/lib_src/Frame.cc:770-826; R/config/euroc_ori.yaml:23-31 has
+ * k1 = -0.283): K4 = fx, fy, cx, cy of mK, dist5 = mDistCoef (k1, k2, p1, p2, k3).  From the next rumi_track_extract / rumi_track_frame on the
+ * resident frame carries mvKeysUn (the grid, every search and PoseOptimization read those) and the undistorted image bounds; keys_out of those calls
+ * stays mvKeys, as ExtractORB returns them.  dist5 == NULL or dist5[0] == 0: none (mvKeysUn = mvKeys, the reference's own test, Frame.cc:771). */
+extern "C" int rumi_track_set_distortion(RumiTracker *t, const float *K4, const float *dist5) {
+    if (!t) return RUMI_E_INVALID;
+    if (!dist5 || dist5[0] == 0.0f) { t->distort = false; return RUMI_OK; }
+    if (!K4 || !(K4[0] != 0.0f) || !(K4[1] != 0.0f)) { g_lastError = "rumi_track_set_distortion: camera matrix"; return RUMI_E_INVALID; }
+    HIP_TRY(hipSetDevice(t->device));
+    if (!t->dKeysUn) HIP_TRY(hipMalloc((void **)&t->dKeysUn, (size_t)t->cap * sizeof(RumiKeyPoint)));
+    UndistortArgs &A = t->ua;
+    A.fx = K4[0]; A.fy = K4[1]; A.cx = K4[2]; A.cy = K4[3]; A.ifx = 1. / A.fx; A.ify = 1. / A.fy;
+    A.k1 = dist5[0]; A.k2 = dist5[1]; A.p1 = dist5[2]; A.p2 = dist5[3]; A.k3 = dist5[4];
+    t->distort = true;
+    t->curN = -1;                                          // a frame extracted under other coefficients is not this camera's
+    return RUMI_OK;
+}
+/* mvKeysUn of the resident frame (keys_un_out [cap >= n]) and {mnMinX, mnMinY, mnMaxX, mnMaxY} (bounds4); either may be NULL. */
+extern "C" int rumi_track_undistorted(RumiTracker *t, RumiKeyPoint *keys_un_out, int32_t cap, float *bounds4) {
+    if (!t) return RUMI_E_INVALID;
+    if (t->curN < 0) { g_lastError = "rumi_track_undistorted: no frame is resident"; return RUMI_E_INVALID; }
+    if (bounds4) std::memcpy(bounds4, t->bounds, 16);
+    if (keys_un_out && t->curN > 0) {
+        if (cap < t->curN) return RUMI_E_CAPACITY;
+        HIP_TRY(hipSetDevice(t->device));
+        const RumiKeyPoint *src = t->distort ? t->dKeysUn : reinterpret_cast<const RumiKeyPoint *>(t->dBlk + t->oRec + 8);
+        HIP_TRY(hipMemcpy(keys_un_out, src, (size_t)t->curN * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost));
+    }
     return RUMI_OK;
 }

@@ -54,6 +54,18 @@ struct TrackStep {
 inline RumiTracker *&tracker_slot() { thread_local RumiTracker *t = nullptr; return t; }
 inline RumiOrbConfig &tracker_cfg() { thread_local RumiOrbConfig c{}; return c; }
 inline int &tracker_points() { thread_local int n = 16384; return n; }
+// lens distortion of this thread's camera (SetDistortion below): mK and mDistCoef (k1, k2, p1, p2, k3); k1 == 0 = none
+struct TrackerDistortion { bool on = false; float K4[4] = {0, 0, 0, 0}, dist5[5] = {0, 0, 0, 0, 0}; };
+inline TrackerDistortion &tracker_distortion() { thread_local TrackerDistortion d; return d; }
+namespace track_detail_fwd {
+inline void TrackerDistortion_set(const float K4[4], const float *distCoef, int nCoef) {
+    TrackerDistortion &d = tracker_distortion();
+    for (int i = 0; i < 4; i++) d.K4[i] = K4[i];
+    for (int i = 0; i < 5; i++) d.dist5[i] = (distCoef && i < nCoef) ? distCoef[i] : 0.f;
+    d.on = d.dist5[0] != 0.0f;                               // the reference's own test (Frame.cc:771)
+    if (tracker_slot()) { const int rc = rumi_track_set_distortion(tracker_slot(), d.K4, d.on ? d.dist5 : nullptr); if (rc != RUMI_OK) report("rumi_track_set_distortion", rc); }
+}
+}  // namespace track_detail_fwd
 
 namespace track_detail {
 
@@ -119,6 +131,8 @@ template <class ExtractorT> inline RumiTracker *tracker_for(ExtractorT &extracto
         const int rc = rumi_track_create(&cfg, tracker_points(), -1, &tracker_slot());
         if (rc != RUMI_OK) { report("rumi_track_create", rc); tracker_slot() = nullptr; return nullptr; }
         have = cfg;
+        const TrackerDistortion &d = tracker_distortion();
+        if (d.on) { const int rd = rumi_track_set_distortion(tracker_slot(), d.K4, d.dist5); if (rd != RUMI_OK) report("rumi_track_set_distortion", rd); }
     }
     return tracker_slot();
 }
@@ -148,7 +162,12 @@ template <class FrameT> inline void get_pose(const FrameT &F, float *T7) {
 template <class FrameT> inline void set_features(FrameT &Cur, std::vector<cv::KeyPoint> &keys, const std::vector<uint8_t> &dsc, int n) {
     keys.resize(n);
     Cur.N = n;
-    Cur.mvKeysUn = keys;                                     // distortion-free camera: mvKeysUn == mvKeys
+    Cur.mvKeysUn = keys;                                     // distortion-free camera: mvKeysUn == mvKeys (Frame.cc:771-774)
+    if (tracker_distortion().on && tracker_slot() && n > 0) {   // Frame::UndistortKeyPoints ran on the device: the resident frame's mvKeysUn
+        static_assert(sizeof(cv::KeyPoint) == sizeof(RumiKeyPoint), "cv::KeyPoint must be the 28-byte POD");
+        const int rc = rumi_track_undistorted(tracker_slot(), reinterpret_cast<RumiKeyPoint *>(Cur.mvKeysUn.data()), n, nullptr);
+        if (rc != RUMI_OK) report("rumi_track_undistorted", rc);
+    }
 #ifdef RUMI_TRACK_FRAME_HAS_MVKEYS
     Cur.mvKeys = keys;
 #endif
@@ -178,6 +197,20 @@ template <class ExtractorT> inline cv::Mat CaptureBuffer(ExtractorT &extractor, 
     uint8_t *buf = nullptr; int32_t stride = 0;
     if (!t || rumi_track_image_buffer(t, cols, rows, &buf, &stride) != RUMI_OK) return cv::Mat();
     return cv::Mat(rows, cols, CV_8UC1, buf, (size_t)stride);
+}
+
+// Lens distortion of the Tracking thread's camera: mK (fx, fy, cx, cy) and mDistCoef (k1, k2, p1, p2[, k3]) as Tracking::ParseCamParamFile reads them.
+// Call once before the first frame (and again when the calibration changes).  From then on ExtractFrame / TrackFrame fill mvKeysUn with
+// Frame::UndistortKeyPoints' result (Frame.cc:770-797) -- computed on the device, where the grid, the searches and PoseOptimization read it too --
+// and ImageBounds gives Frame::ComputeImageBounds' mnMinX .. mnMaxY (:799-826) of the resident frame for the Frame's static members.
+inline void SetDistortion(const float K4[4], const float *distCoef, int nCoef) {
+    track_detail_fwd::TrackerDistortion_set(K4, distCoef, nCoef);
+}
+inline bool ImageBounds(float &mnMinX, float &mnMinY, float &mnMaxX, float &mnMaxY) {
+    float b[4];
+    if (!tracker_slot() || rumi_track_undistorted(tracker_slot(), nullptr, 0, b) != RUMI_OK) return false;
+    mnMinX = b[0]; mnMinY = b[1]; mnMaxX = b[2]; mnMaxY = b[3];
+    return true;
 }
 
 // Frame::ExtractORB(0, im, 0, 1000) for a Frame built without it: the features land in the frame AND stay on the device for the calls below.

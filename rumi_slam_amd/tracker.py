@@ -46,6 +46,8 @@ def _bind(L):
                                                 C.POINTER(RumiTrackResult)]
     L.rumi_track_local.argtypes = [vp, vp, vp, vp, C.POINTER(RumiTrackPoints), vp, f32, i32, f32, vp, vp, vp, C.POINTER(RumiTrackResult)]
     L.rumi_track_last_projections.argtypes = [vp, i32, vp]
+    L.rumi_track_set_distortion.argtypes = [vp, vp, vp]
+    L.rumi_track_undistorted.argtypes = [vp, vp, i32, vp]
     L.rumi_track_image_buffer.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]
     L._track_ready = True
     return L
@@ -114,6 +116,18 @@ class Tracker:
                  desc=np.ascontiguousarray(points["desc"], np.uint8), obs=np.ascontiguousarray(points["obs"], np.int32),
                  bad=np.ascontiguousarray(points["bad"], np.uint8), local=np.ascontiguousarray(points.get("local", np.zeros(n, np.uint8)), np.uint8))
         return n, a, RumiTrackPoints(n, *(capi.ptr(a[k]) for k in ("pos", "normal", "mn", "mx", "desc", "obs", "bad", "local")), *_stale(points, a))
+
+    def set_distortion(self, K4, dist5):
+        """rumi_track_set_distortion: mK and mDistCoef (k1, k2, p1, p2, k3); dist5 None / k1 == 0 switches undistortion off."""
+        K = np.ascontiguousarray(K4, np.float32)
+        d = np.ascontiguousarray(dist5, np.float32) if dist5 is not None else None
+        capi.check(self._lib.rumi_track_set_distortion(self._h, capi.ptr(K), capi.ptr(d) if d is not None else None))
+
+    def undistorted(self):
+        """(mvKeysUn of the resident frame, (mnMinX, mnMinY, mnMaxX, mnMaxY))."""
+        keys = np.zeros(self.cap, KP_DTYPE); b = np.zeros(4, np.float32)
+        capi.check(self._lib.rumi_track_undistorted(self._h, capi.ptr(keys), self.cap, capi.ptr(b)))
+        return keys[:self._n].copy(), b
 
     def last_projections(self, n_points):
         """rumi_track_last_projections: [n_points, 5] f32 = mTrackProjX, mTrackProjY, mnTrackScaleLevel, mTrackViewCos, mTrackDepth of the last SearchLocalPoints."""

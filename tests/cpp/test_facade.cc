@@ -600,6 +600,28 @@ int main(int argc, char **argv) {
             std::printf("stale mbTrackInView: %d discarded outliers searched at their old projection (local matches %d, %d without the flags)\n", nStale, g1.nmatchesLocal, sf.nmatchesLocal);
             for (auto &m : mps) { m.mbTrackInView = false; m.mnLastFrameSeen = -1; m.nVisible = 0; m.nFound = 0; }
         }
+        {   // (a3) a camera with lens distortion (euroc_ori.yaml's coefficients): ExtractFrame fills mvKeysUn with Frame::UndistortKeyPoints' result,
+            // mvKeys stay the extractor's, ImageBounds gives ComputeImageBounds' hull of the undistorted corners; switched off again afterwards
+            const float Kd[4] = {F1.fx, F1.fy, F1.cx, F1.cy}, dist4[4] = {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f};
+            rumi_facade::SetDistortion(Kd, dist4, 4);
+            Frame D1; D1.mnId = 51;
+            const int monoD = rumi_facade::ExtractFrame(D1, capture, ext, (int)mps.size());
+            float bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+            const bool okB = rumi_facade::ImageBounds(bx0, by0, bx1, by1);
+            double maxShift = 0;
+            bool levelsKept = D1.N == F2.N;
+            for (int i = 0; levelsKept && i < D1.N; i++) {
+                maxShift = std::fmax(maxShift, std::hypot(D1.mvKeysUn[i].pt.x - F2.mvKeysUn[i].pt.x, D1.mvKeysUn[i].pt.y - F2.mvKeysUn[i].pt.y));
+                levelsKept = D1.mvKeysUn[i].octave == F2.mvKeysUn[i].octave && D1.mvKeysUn[i].angle == F2.mvKeysUn[i].angle;
+            }
+            CHECK(monoD == monoS && levelsKept && maxShift > 5.0 && okB && bx0 < -5.f && by0 < -5.f && bx1 > 645.f && by1 > 485.f, "SetDistortion: mvKeysUn undistorted on the device, bounds = the undistorted corners");
+            rumi_facade::SetDistortion(Kd, nullptr, 0);
+            Frame D2; D2.mnId = 52;
+            rumi_facade::ExtractFrame(D2, capture, ext, (int)mps.size());
+            bool backSame = D2.N == F2.N;
+            for (int i = 0; backSame && i < D2.N; i++) backSame = D2.mvKeysUn[i].pt.x == F2.mvKeysUn[i].pt.x && D2.mvKeysUn[i].pt.y == F2.mvKeysUn[i].pt.y;
+            CHECK(backSame && rumi_facade::ImageBounds(bx0, by0, bx1, by1) && bx0 == 0.f && bx1 == 640.f && by1 == 480.f, "SetDistortion off: mvKeysUn = mvKeys, the image rectangle");
+        }
         // (b) a hopeless prediction: the fused call reports okMotion = false, has replayed NOTHING of TrackLocalMap, and the frame is in
         // TrackWithMotionModel's failure state; TrackReferenceKeyFrame takes over on the resident frame
         for (auto &m : mps) { m.nVisible = 0; m.nFound = 0; m.mnLastFrameSeen = -1; m.mbTrackInView = false; }

@@ -146,6 +146,10 @@ def _mlib():
     L.orc_search_by_projection_mappoints.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32] + [vp] * 9 + [f32, i32, f32, f32, vp]
     L.orc_search_by_projection_frame.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp]
     L.orc_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
+    L.orc_undistort_points.argtypes = [vp, i32, vp, vp, vp]
+    L.orc_undistort_points.restype = None
+    L.orc_image_bounds.argtypes = [i32, i32, vp, vp, vp]
+    L.orc_image_bounds.restype = None
     L.orc_bruteforce_match.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.orc_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, i32, vp]
     L.orc_search_for_initialization.restype = i32
@@ -180,11 +184,44 @@ def search_by_projection_mappoints(keys, desc, w, h, sf, mp, frame_mp, th, far, 
                                                          ("scale_level", np.int32), ("view_cos", np.float32), ("track_depth", np.float32),
                                                          ("is_bad", np.uint8), ("desc", np.uint8), ("obs", np.int32)]}
     fm = np.ascontiguousarray(frame_mp, np.int32).copy()
-    n = _mlib().orc_search_by_projection_mappoints(_p(keys), _p(desc), len(keys), 0.0, 0.0, float(w), float(h), _p(sf), len(a["proj_x"]),
+    n = _mlib().orc_search_by_projection_mappoints(_p(keys), _p(desc), len(keys), *_bounds(w, h), _p(sf), len(a["proj_x"]),
                                                   _p(a["track_in_view"]), _p(a["proj_x"]), _p(a["proj_y"]), _p(a["scale_level"]),
                                                   _p(a["view_cos"]), _p(a["track_depth"]), _p(a["is_bad"]), _p(a["desc"]), _p(a["obs"]),
                                                   th, int(far), th_far, nnratio, _p(fm))
     return n, fm
+
+
+def undistort_points(xy, K4, dist5):
+    """Frame::UndistortKeyPoints' cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) (oracle/frame_oracle.cc): [n,2] f32 -> [n,2] f32."""
+    a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); K = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+    out = np.zeros_like(a)
+    _mlib().orc_undistort_points(_p(a), len(a), _p(K), _p(d), _p(out))
+    return out
+
+
+def undistort_keys(keys, K4, dist5):
+    """mvKeysUn from mvKeys (Frame.cc:770-797): copies of the key-points with pt replaced; mvKeysUn = mvKeys when mDistCoef[0] == 0."""
+    out = np.ascontiguousarray(keys, KP_DTYPE).copy()
+    if float(np.float32(dist5[0])) == 0.0:
+        return out
+    u = undistort_points(np.stack([out["x"], out["y"]], 1), K4, dist5)
+    out["x"], out["y"] = u[:, 0], u[:, 1]
+    return out
+
+
+def image_bounds(w, h, K4, dist5):
+    """Frame::ComputeImageBounds (Frame.cc:799-826): (mnMinX, mnMinY, mnMaxX, mnMaxY) f32."""
+    K = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+    b = np.zeros(4, np.float32)
+    _mlib().orc_image_bounds(int(w), int(h), _p(K), _p(d), _p(b))
+    return b
+
+
+def _bounds(w, h):
+    """(w, h) of an undistorted camera, or w = (minX, minY, maxX, maxY) with h ignored."""
+    if np.ndim(w) > 0:
+        return tuple(float(x) for x in w)
+    return 0.0, 0.0, float(w), float(h)
 
 
 def search_by_projection_frame(cur_keys, cur_desc, w, h, sf, Tcw7, K4, last_keys, last_mp, last_outlier, mp_pos, mp_desc, mp_obs, cur_mp,
@@ -194,7 +231,7 @@ def search_by_projection_frame(cur_keys, cur_desc, w, h, sf, Tcw7, K4, last_keys
             np.ascontiguousarray(last_mp, np.int32), np.ascontiguousarray(last_outlier, np.uint8), np.ascontiguousarray(mp_pos, np.float32),
             np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(mp_obs, np.int32)]
     cm = np.ascontiguousarray(cur_mp, np.int32).copy()
-    n = _mlib().orc_search_by_projection_frame(_p(arrs[0]), _p(arrs[1]), len(arrs[0]), 0.0, 0.0, float(w), float(h), _p(arrs[2]), _p(arrs[3]),
+    n = _mlib().orc_search_by_projection_frame(_p(arrs[0]), _p(arrs[1]), len(arrs[0]), *_bounds(w, h), _p(arrs[2]), _p(arrs[3]),
                                               _p(arrs[4]), _p(arrs[5]), len(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]),
                                               _p(arrs[10]), th, int(check_ori), _p(cm))
     return n, cm
@@ -317,7 +354,7 @@ def is_in_frustum(Rcw9, tcw3, Ow3, K4, w, h, log_sf, nlevels, cos_limit, pts):
     R, t, Ow, K, pos, nrm, mn, mx = f(Rcw9), f(tcw3), f(Ow3), f(K4), f(pts["pos"]), f(pts["normal"]), f(pts["min_dist"]), f(pts["max_dist"])
     out = dict(track_in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32),
                scale_level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32), track_depth=np.zeros(n, np.float32))
-    _mlib().orc_is_in_frustum(_p(R), _p(t), _p(Ow), _p(K), 0.0, 0.0, float(w), float(h), float(log_sf), int(nlevels), float(cos_limit), n, _p(pos), _p(nrm),
+    _mlib().orc_is_in_frustum(_p(R), _p(t), _p(Ow), _p(K), *_bounds(w, h), float(log_sf), int(nlevels), float(cos_limit), n, _p(pos), _p(nrm),
                               _p(mn), _p(mx), _p(out["track_in_view"]), _p(out["proj_x"]), _p(out["proj_y"]), _p(out["scale_level"]), _p(out["view_cos"]),
                               _p(out["track_depth"]))
     return out
