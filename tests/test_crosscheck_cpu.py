@@ -188,3 +188,30 @@ def test_fast_against_the_definition(seed, threshold):
     ref = _fast_bruteforce(img, threshold)
     assert len(ref) > 5, "the patch is supposed to have corners"
     assert [(int(k["x"]), int(k["y"]), int(k["response"])) for k in got] == ref
+
+
+def test_undistort_points_inverts_the_published_distortion_model():
+    """oracle/frame_oracle.cc restates cv::undistortPoints (not in the tree: parity unpinned).  Independent check with numpy: pushing the undistorted
+    points through the FORWARD radial-tangential model (the one cv::projectPoints documents) must give the original pixels back, up to what five
+    fixed-point iterations leave (a few hundredths of a pixel in the image corners for EuRoC's k1 = -0.28)."""
+    K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    d = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0], np.float32)
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.uniform(0, 752, 4000), rng.uniform(0, 480, 4000)], 1).astype(np.float32)
+    xy[:4] = [[0, 0], [752, 0], [0, 480], [752, 480]]
+    u = O.undistort_points(xy, K, d).astype(np.float64)
+    fx, fy, cx, cy = K.astype(np.float64)
+    k1, k2, p1, p2, k3 = d.astype(np.float64)
+    x, y = (u[:, 0] - cx) / fx, (u[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    back = np.stack([fx * xd + cx, fy * yd + cy], 1)
+    err = np.linalg.norm(back - xy.astype(np.float64), axis=1)
+    inner = (np.abs(xy[:, 0] - 376) < 250) & (np.abs(xy[:, 1] - 240) < 160)
+    assert err[inner].max() < 0.08, err[inner].max()          # (0.04 px measured: five iterations, k1 = -0.28)
+    assert err.max() < 1.5, err.max()                          # the corners: five iterations stop short, as they do in OpenCV
+    b = O.image_bounds(752, 480, K, d)
+    assert b[0] < -100 and b[1] < -60 and b[2] > 850 and b[3] > 540, b
+    assert np.array_equal(O.image_bounds(752, 480, K, np.zeros(5, np.float32)), np.array([0, 0, 752, 480], np.float32))
