@@ -49,7 +49,7 @@ struct RowTap { int32_t r0, r1; uint32_t bh0, bh1; };   // the two (clamped) sou
 // level 0: the window of the caller's frame it reads), derived on the host from the resize tables
 struct PyrTile { int16_t x0[kMaxLevels], x1[kMaxLevels], y0[kMaxLevels], y1[kMaxLevels]; };
 void launch_pyramid_tiles(const DevParams *dP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, const PyrTile *tiles, int ntiles, int bufBytes,
-                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord = nullptr);
+                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord = nullptr, bool copyL0 = false);
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st, int32_t *clearWord = nullptr);
 void launch_fast(const DevParams *dP, const DevParams &hP, ImgSrc src, uint32_t *cellBuf, int32_t *cellCnt, int nframes,
@@ -68,7 +68,7 @@ void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *can
                    int nframes, size_t ldsBytes, hipStream_t st);
 void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,
                      int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts, long long countsStride,
-                     int32_t *errFlag, int nframes, hipStream_t st);
+                     int32_t *errFlag, int nframes, hipStream_t st, int32_t *errMirror = nullptr);
 size_t octree_lds_for(const DevParams &hP);
 
 }  // namespace rumi

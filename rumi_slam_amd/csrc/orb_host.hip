@@ -72,6 +72,12 @@ struct RumiOrb {
     uint8_t *dL0 = nullptr;          // staging for device frames whose base / pitch / frame stride is not 4-byte aligned (allocated on first use)
     uint8_t *hIn = nullptr, *hOut1 = nullptr, *dOut1 = nullptr;   // pinned image / pinned + device [counts | kp | desc] block of that API
     size_t out1Bytes = 0;             // > 0 while rumi_orb_extract wants the block copied back before the call's one synchronisation
+    uint8_t *dhOut1 = nullptr;        // the pinned block as the device addresses it: a one-frame call's kernels write counts, key-points and descriptors
+    int32_t *dhErr = nullptr;         // straight into host memory (and k_assemble the final error word): no copy back, the call ends with its last kernel
+    bool zeroCopyOut = false;         // set by rumi_orb_extract around its call
+    uint8_t *dhIn = nullptr;          // the pinned image as the device addresses it
+    bool hostImagePending = false;    // rumi_orb_extract: the frame of this call still sits in hIn (w x hgt, pitch wp): extract_async_impl either lets the
+                                      // one-launch pyramid read it over PCIe (and keep a copy as the arena's level 0) or copies it to dIn first
     uint8_t *dPyr = nullptr, *dBlur = nullptr;
     uint32_t *dCellBuf = nullptr;    // kChunk frames
     int32_t *dCellCnt = nullptr;
@@ -390,6 +396,11 @@ extern "C" int rumi_orb_create(const RumiOrbConfig *cfg, RumiOrb **out) {
     }
     TRY_ALLOC(dev_alloc(&h->dErr, 1));
     TRY_ALLOC(pin_alloc(&h->hErr, 1));
+    if (hipHostGetDevicePointer((void **)&h->dhOut1, h->hOut1, 0) != hipSuccess || hipHostGetDevicePointer((void **)&h->dhErr, h->hErr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        h->dhOut1 = nullptr; h->dhErr = nullptr;            // (no device view of the pinned blocks: the copies stay)
+    }
+    if (hipHostGetDevicePointer((void **)&h->dhIn, h->hIn, 0) != hipSuccess) { (void)hipGetLastError(); h->dhIn = nullptr; }
 #undef TRY_ALLOC
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { rumi_orb_destroy(h); g_lastError = "hipEventCreate"; return RUMI_E_NO_DEVICE; }
@@ -547,11 +558,12 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     // A few frames: the pyramid in ONE launch (k_pyramid_tiles) instead of a launch per level
     static const int envTiles = std::getenv("RUMI_PYRAMID_TILES") ? std::atoi(std::getenv("RUMI_PYRAMID_TILES")) : -1;
     const bool tilePyramid = !prof && !serial && h->nPyrTiles > 0 && (envTiles >= 0 ? envTiles != 0 : nframes <= 4);   // (a tile recomputes the borders it shares: ~1.8x the pixels, paid back only while the chip is far from full)
+    bool copyL0 = false;
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         if (tilePyramid) {
-            launch_pyramid_tiles(h->dP, ps, h->dCoef, h->dRowTab, h->dPyrTiles, h->nPyrTiles, h->pyrBuf, h->pyrTab, n, s, clearInKernel ? h->dErr : nullptr);
+            launch_pyramid_tiles(h->dP, ps, h->dCoef, h->dRowTab, h->dPyrTiles, h->nPyrTiles, h->pyrBuf, h->pyrTab, n, s, clearInKernel ? h->dErr : nullptr, copyL0);
             clearInKernel = false;
         } else
         for (int l = 1; l < P.nlevels; l++) {
@@ -569,10 +581,26 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         HIP_TRY(hipGetLastError());
         return RUMI_OK;
     };
+    // rumi_orb_extract's frame, still in pinned host memory: copied to dIn first.  (RUMI_ORB_ZERO_COPY_IN=1: read in place by the one-launch pyramid,
+    // which keeps a copy as the arena's level 0 for everything after it -- one dependent transfer less, but MEASURED SLOWER: the kernel's 550 KB of
+    // window reads over PCIe take 25 us more than the 13 us copy + queue latency they replace: 124.8 against 99.8 us per call.  Off by default.)
+    static const bool zcIn = std::getenv("RUMI_ORB_ZERO_COPY_IN") && std::atoi(std::getenv("RUMI_ORB_ZERO_COPY_IN")) != 0;
+    bool l0FromHost = false;
+    if (h->hostImagePending) {
+        h->hostImagePending = false;
+        if (zcIn && h->dhIn && tilePyramid && parts == 1 && !resident && nframes == 1) { l0FromHost = true; src.l0 = h->dhIn; }
+        else HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)stride * hgt, hipMemcpyHostToDevice, st));
+    }
     if (parts == 1 && !resident) {
         if (h->feed && (rc = h->feed(nframes, st)) != RUMI_OK) return rc;
+        copyL0 = l0FromHost;
         rc = stage_a(src, nframes, lane_of(0));
+        copyL0 = false;
         if (rc != RUMI_OK) return rc;
+        if (l0FromHost) {                                    // from here on level 0 is the arena's copy
+            src.l0 = h->dPyr + P.lv[0].off; src.l0FrameStride = P.arenaStride; src.l0Pitch = P.lv[0].pitch;
+            frame_stride = P.arenaStride; stride = P.lv[0].pitch;
+        }
     }
 
     // FAST -> compaction -> quadtree -> orientation + descriptors for the frames [frame0, frame0 + n) of the batch on stream s, in the scratch
@@ -600,7 +628,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
         launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)scr0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
         launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
-                        (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s);
+                        (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s, h->zeroCopyOut ? h->dhErr : nullptr);
         if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
         if (!fuseBlur) HIP_TRY(hipStreamWaitEvent(s, L.join, 0));   // join: rBRIEF reads the blurred levels
         launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
@@ -688,7 +716,7 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     // The call's error word (and, for the single-frame host API, its result block) follow the kernels on the stream; rumi_orb_sync waits
     // for them.  Nothing here blocks, so a caller can queue the next batch while this one runs.
     if (h->out1Bytes) HIP_TRY(hipMemcpyAsync(h->hOut1, h->dOut1, h->out1Bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (!h->zeroCopyOut) HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));       // (zero-copy: k_assemble has published it)
     h->pending = true; h->pendingStream = st;
     if (prof) {
         float ms;
@@ -857,13 +885,23 @@ extern "C" int rumi_orb_extract(RumiOrb *h, const uint8_t *img, int32_t w, int32
     const int wp = (w + 3) & ~3;                                     // rows padded so that level 0 can be read as aligned dwords
     if (!(img == h->hIn && stride == wp))                    // (a caller that captured straight into rumi_orb_image_buffer's memory has nothing to stage)
         for (int y = 0; y < hgt; y++) std::memcpy(h->hIn + (size_t)y * wp, img + (size_t)y * stride, (size_t)w);
-    HIP_TRY(hipMemcpyAsync(h->dIn, h->hIn, (size_t)wp * hgt, hipMemcpyHostToDevice, nullptr));
-    int32_t *dC = reinterpret_cast<int32_t *>(h->dOut1);
-    RumiKeyPoint *dK = reinterpret_cast<RumiKeyPoint *>(h->dOut1 + 16);
-    uint8_t *dD = h->dOut1 + 16 + (size_t)h->capSel * sizeof(RumiKeyPoint);
-    h->out1Bytes = (size_t)16 + (size_t)h->capSel * 60;
+    h->hostImagePending = true;                              // (extract_async_impl reads it in place or copies it: see there)
+    // Results straight into pinned host memory: the kernels' output pointers are the device's view of hOut1 (k_assemble writes the counts and the
+    // final error word, k_orient_desc key-points and descriptors), so the call ends with its last kernel -- no copy back, no second copy for the
+    // error word (two dependent transfers of ~6 + 2 us with ~9 us of queue latency each).  RUMI_ORB_ZERO_COPY=0 keeps the copies (A/B measurements).
+    static const bool zc = !(std::getenv("RUMI_ORB_ZERO_COPY") && std::atoi(std::getenv("RUMI_ORB_ZERO_COPY")) == 0);
+    const bool zero = zc && h->dhOut1 && h->dhErr && !h->profiling;
+    uint8_t *ob = zero ? h->dhOut1 : h->dOut1;
+    int32_t *dC = reinterpret_cast<int32_t *>(ob);
+    RumiKeyPoint *dK = reinterpret_cast<RumiKeyPoint *>(ob + 16);
+    uint8_t *dD = ob + 16 + (size_t)h->capSel * sizeof(RumiKeyPoint);
+    h->out1Bytes = zero ? 0 : (size_t)16 + (size_t)h->capSel * 60;
+    h->zeroCopyOut = zero;
+    if (zero) *h->hErr = 0;
     const int rc = rumi_orb_extract_batch_device(h, h->dIn, 1, w, hgt, wp, (int64_t)wp * hgt, lap0, lap1, dK, dD, dC, h->capSel, nullptr);
     h->out1Bytes = 0;
+    h->zeroCopyOut = false;
+    h->hostImagePending = false;
     if (rc != RUMI_OK) return rc;
     const int32_t *counts = reinterpret_cast<const int32_t *>(h->hOut1);
     *n_out = counts[0];

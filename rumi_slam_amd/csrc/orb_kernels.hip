@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
 // region is the source of level l's, the regions (PyrTile, from the host's resize tables) overlap by the taps' reach, and every workgroup
 // stores all it computed -- overlapping stores carry the same bytes.  The arithmetic per pixel is k_resize's general path, tap for tap.
 // ------------------------------------------------------------------------------------------------
+// copyL0: the caller's frame is PINNED HOST memory read over PCIe (a one-frame call without its host-to-device copy): the windows, which cover the frame,
+// are stored into the arena's level-0 slot as they pass through the registers, and every later kernel of the call reads level 0 there.
 __global__ __launch_bounds__(256) void k_pyramid_tiles(const DevParams *__restrict__ P, ImgSrc src, const int16_t *__restrict__ coef,
                                                        const RowTap *__restrict__ rowTab, const PyrTile *__restrict__ tiles, int bufBytes,
-                                                       int32_t *__restrict__ clearWord) {
+                                                       int32_t *__restrict__ clearWord, int copyL0) {
     // LDS: two image buffers of bufBytes (a level's region and the one computed from it), then the tile's slices of the resize tables
     // (per level and row: source rows relative to the buffer | vertical taps; per level and column: source column relative to the buffer, tap pair)
     extern __shared__ __attribute__((aligned(16))) uint8_t pyrLds[];
@@ -238,6 +240,15 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(const DevParams *__restri
         for (int k = 0; k < kPyrWinPasses; k++) {
             const int y = wy + 4 * k;
             if (y < ah && wx < aw) *reinterpret_cast<uint32_t *>(A + y * apitch + wx) = win[k];
+        }
+        if (copyL0) {
+            const DevLevel &D0 = P->lv[0];
+            uint8_t *l0 = src.pyr + (long long)frame * P->arenaStride + D0.off;
+#pragma unroll
+            for (int k = 0; k < kPyrWinPasses; k++) {
+                const int y = wy + 4 * k;
+                if (y < ah && wx < aw && ax0 + wx + 4 <= D0.pitch) *reinterpret_cast<uint32_t *>(l0 + (long long)(ay0 + y) * D0.pitch + ax0 + wx) = win[k];
+            }
         }
     }
     __syncthreads();
@@ -1156,8 +1167,8 @@ void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const i
     hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
 }
 void launch_pyramid_tiles(const DevParams *dP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, const PyrTile *tiles, int ntiles, int bufBytes,
-                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord) {
-    hipLaunchKernelGGL(k_pyramid_tiles, dim3(ntiles, nframes), dim3(256), (size_t)2 * bufBytes + (size_t)tabEntries * 8, st, dP, src, coef, rowTab, tiles, bufBytes, clearWord);
+                          int tabEntries, int nframes, hipStream_t st, int32_t *clearWord, bool copyL0) {
+    hipLaunchKernelGGL(k_pyramid_tiles, dim3(ntiles, nframes), dim3(256), (size_t)2 * bufBytes + (size_t)tabEntries * 8, st, dP, src, coef, rowTab, tiles, bufBytes, clearWord, copyL0 ? 1 : 0);
 }
 static FastLds fast_lds_of(const DevParams &hP) {
     // LDS per wave from the largest cell of this geometry

@@ -880,7 +880,9 @@ __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ 
                                                   const int32_t *__restrict__ selLevelCnt, int selLevelCap, int lap0,
                                                   int lap1, uint32_t *__restrict__ selPacked, uint32_t *__restrict__ selMeta,
                                                   int32_t *__restrict__ selCount, int selCap, int32_t *__restrict__ countsBase, long long countsStride,
-                                                  int32_t *__restrict__ errFlag) {
+                                                  int32_t *__restrict__ errFlag, int32_t *__restrict__ errMirror) {
+    // errMirror (one-frame calls whose results go straight to pinned host memory): the call's error word is final when this workgroup ends -- every
+    // kernel that can set a bit has run, the descriptor kernel sets none -- and is published beside the results: no copy of it follows
     __shared__ int lvStart[kMaxLevels + 1];
     __shared__ int part[256];
     const int tid = threadIdx.x, frame = blockIdx.x;
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ 
     __syncthreads();
     const int total = lvStart[nl];
     if (total > selCap) {
-        if (tid == 0) { selCount[frame] = 0; counts[0] = total; counts[1] = 0; atomicOr(errFlag, 8); }
+        if (tid == 0) { selCount[frame] = 0; counts[0] = total; counts[1] = 0; const int old = atomicOr(errFlag, 8); if (errMirror) *errMirror = old | 8; }
         return;
     }
     const int chunk = (total + 255) / 256;
@@ -916,6 +918,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DevParams *__restrict__ 
         selCount[frame] = total;
         counts[0] = total;
         counts[1] = total - run;      // monoIndex
+        if (errMirror) *errMirror = *errFlag;
     }
     __syncthreads();
     int before = part[tid];                       // flagged key-points before k0
@@ -994,9 +997,9 @@ void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *can
 }
 void launch_assemble(const DevParams *dP, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0,
                      int lap1, uint32_t *selPacked, uint32_t *selMeta, int32_t *selCount, int selCap, int32_t *counts, long long countsStride,
-                     int32_t *errFlag, int nframes, hipStream_t st) {
+                     int32_t *errFlag, int nframes, hipStream_t st, int32_t *errMirror) {
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), 0, st, dP, selLevel, selLevelCnt, selLevelCap, lap0, lap1,
-                       selPacked, selMeta, selCount, selCap, counts, countsStride, errFlag);
+                       selPacked, selMeta, selCount, selCap, counts, countsStride, errFlag, nframes == 1 ? errMirror : nullptr);
 }
 size_t octree_lds_for(const DevParams &hP) {
     size_t mx = 0;
