@@ -63,6 +63,10 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         const int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut, long long kpStride, uint8_t *descOut,
                         long long descStride, int outCap, int nframes, hipStream_t st);   // strides: bytes from one frame's outputs to the next
 
+void launch_assemble_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0, int lap1,
+                                 int32_t *counts, long long countsStride, int32_t *errFlag, int32_t *errMirror, uint32_t *selPacked, uint32_t *selMeta,
+                                 int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut,
+                                 long long kpStride, uint8_t *descOut, long long descStride, int outCap, int nframes, hipStream_t st);
 void launch_octree(const DevParams *dP, const DevParams &hP, const uint32_t *cand, const int32_t *levelStart,
                    uint16_t *owner, uint32_t *selLevel, int32_t *selLevelCnt, int selLevelCap, int32_t *errFlag,
                    int nframes, size_t ldsBytes, hipStream_t st);

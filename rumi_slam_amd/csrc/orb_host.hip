@@ -627,10 +627,21 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
         launch_compact(h->dP, P, cellBuf, cellCnt, candp, lvStart, h->dErr, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[5], s));
         launch_octree(h->dP, P, candp, lvStart, h->dOwner + (size_t)scr0 * P.totalCand, selLevel, selLevelCnt, h->selLevelCap, h->dErr, n, h->octLds, s);
-        launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
-                        (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride), out.countsStride, h->dErr, n, s, h->zeroCopyOut ? h->dhErr : nullptr);
+        // a few frames: the slot assignment (k_assemble) inside the descriptor kernel's prologue, one launch less on the dependent chain
+        static const int envFuseA = std::getenv("RUMI_FUSE_ASSEMBLE") ? std::atoi(std::getenv("RUMI_FUSE_ASSEMBLE")) : -1;
+        const bool fuseAssemble = !timed && !serial && (envFuseA >= 0 ? envFuseA != 0 : n <= 4) && (long long)((h->capSel + 7) / 8) * n <= 2048;
+        int32_t *countsOut = (int32_t *)((uint8_t *)d_counts + (size_t)frame0 * out.countsStride);
+        if (!fuseAssemble)
+            launch_assemble(h->dP, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, selPacked, selMeta, h->dSelCount + scr0, h->capSel,
+                            countsOut, out.countsStride, h->dErr, n, s, h->zeroCopyOut ? h->dhErr : nullptr);
         if (timed) HIP_TRY(hipEventRecord(h->ev[6], s));
         if (!fuseBlur) HIP_TRY(hipStreamWaitEvent(s, L.join, 0));   // join: rBRIEF reads the blurred levels
+        if (fuseAssemble)
+            launch_assemble_orient_desc(h->dP, ps, selLevel, selLevelCnt, h->selLevelCap, lap0, lap1, countsOut, out.countsStride, h->dErr,
+                                        h->zeroCopyOut ? h->dhErr : nullptr, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
+                                        (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
+                                        (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);
+        else
         launch_orient_desc(h->dP, ps, selPacked, selMeta, h->dSelCount + scr0, h->capSel, h->capSel,
                            (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
                            (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);

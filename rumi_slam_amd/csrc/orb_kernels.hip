@@ -984,13 +984,22 @@ constexpr int kKpPerWg = 8;                    // half waves of a workgroup
 // the workgroups resident on an XCD span five frames instead of two and a half, their pyramids no longer fit its L2 and the kernel fetches
 // 1.7x the bytes (FETCH_SIZE).  One for a handful of frames: there are not enough workgroups to fill the chip otherwise.
 
-template <int kKpGroups>
+// kAssemble (calls of a few frames): k_assemble's work -- concatenate the levels, the lapping rule's slots (ORBextractor.cc:1077-1085), the frame's
+// {n, monoIndex} -- is done by every workgroup for its own key-points in its prologue (a count over the frame's <= ~1100 selected key-points: four
+// loads a thread), so that launch and its ~7 us on the dependent chain of a one-frame call disappear; workgroup 0 of a frame writes the counts and,
+// for calls whose results go straight to pinned host memory, the call's final error word.
+struct AssembleArgs {
+    const uint32_t *selLevel; const int32_t *selLevelCnt; int selLevelCap, lap0, lap1;
+    int32_t *counts; long long countsStride; int32_t *errFlag, *errMirror;
+    uint32_t *selPackedOut, *selMetaOut; int32_t *selCountOut;      // k_assemble's arrays are still written (the parity taps read them)
+};
+template <int kKpGroups, bool kAssemble>
 __global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restrict__ P, ImgSrc src,
                                                      const uint32_t *__restrict__ selPacked,
                                                      const uint32_t *__restrict__ selMeta,
                                                      const int32_t *__restrict__ selCount, int selCap,
                                                      RumiKeyPoint *__restrict__ kpOut, long long kpStride, uint8_t *__restrict__ descOut,
-                                                     long long descStride, int outCap) {
+                                                     long long descStride, int outCap, AssembleArgs A) {
     // per key-point: the 31-row disc neighbourhood of the un-blurred level, THEN (in the same LDS: the moments are done with the disc before the
     // descriptor wants the patch) the 37-row patch of the blurred level, staged by the half wave that owns the key-point and read by nobody else:
     // no workgroup barrier anywhere past the pattern table's.  18 KB per workgroup: seven workgroups per CU (30 KB with both resident: five)
@@ -1008,8 +1017,79 @@ __global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restr
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;             // lane within the half wave, half-wave index 0..7
     const unsigned wg = xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // a frame's key-points share one L2
     const int kb = (wg % gridDim.x) * (kKpPerWg * kKpGroups) + hw, frame = wg / gridDim.x;
-    const int cnt = selCount[frame];
-    __syncthreads();
+    int cnt;
+    __shared__ uint32_t sOwnPk[kAssemble ? kKpPerWg * kKpGroups : 1], sOwnMt[kAssemble ? kKpPerWg * kKpGroups : 1];
+    if constexpr (!kAssemble) {
+        cnt = selCount[frame];
+        __syncthreads();
+    } else {
+        __shared__ int sLvStart[kMaxLevels + 1], sRed[2], sOwnF[kKpPerWg * kKpGroups];
+        const int nl = P->nlevels, tid = threadIdx.x;
+        if (tid == 0) {
+            int run = 0;
+            for (int l = 0; l < nl; l++) { sLvStart[l] = run; run += A.selLevelCnt[(long long)frame * nl + l]; }
+            sLvStart[nl] = run; sRed[0] = 0; sRed[1] = 0;
+        }
+        __syncthreads();
+        const int total = sLvStart[nl], kbase = (wg % gridDim.x) * (kKpPerWg * kKpGroups);
+        const bool first = wg % gridDim.x == 0, over = total > selCap;
+        int32_t *counts = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(A.counts) + frame * A.countsStride);
+        if (over) {                                           // k_assemble's refusal: more key-points than the selection arrays hold
+            if (first && tid == 0) { A.selCountOut[frame] = 0; counts[0] = total; counts[1] = 0; const int old = atomicOr(A.errFlag, 8); if (A.errMirror) *A.errMirror = old | 8; }
+            return;
+        }
+        cnt = total;
+        auto key_at = [&](int k, int *levelOut) -> uint32_t {
+            int level = 0;
+            while (k >= sLvStart[level + 1]) level++;
+            *levelOut = level;
+            return A.selLevel[((long long)frame * nl + level) * A.selLevelCap + (k - sLvStart[level])];
+        };
+        auto lapped = [&](uint32_t pk, int level) -> bool {
+            float x = (float)((int)(pk & 0xFFF) + kBorder);
+            if (level != 0) x = x * P->lv[level].scale;
+            return x >= (float)A.lap0 && x <= (float)A.lap1;
+        };
+        int before = 0, all = 0;
+        for (int k = tid; k < total; k += 256) {
+            int level;
+            const uint32_t pk = key_at(k, &level);
+            const int f = lapped(pk, level) ? 1 : 0;
+            all += f; before += k < kbase ? f : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+        if ((tid & 63) == 0) { atomicAdd(&sRed[0], before); atomicAdd(&sRed[1], all); }
+        if (tid < kKpPerWg * kKpGroups) {
+            const int k = kbase + tid;
+            int level = 0;
+            uint32_t pk = 0;
+            int f = 0;
+            if (k < total) { pk = key_at(k, &level); f = lapped(pk, level) ? 1 : 0; }
+            sOwnPk[tid] = pk; sOwnMt[tid] = (uint32_t)level; sOwnF[tid] = f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int b = sRed[0];
+            for (int j = 0; j < kKpPerWg * kKpGroups; j++) {
+                const int k = kbase + j;
+                if (k >= total) break;
+                const int f = sOwnF[j], slot = f ? (total - 1 - b) : (k - b);
+                b += f;
+                sOwnMt[j] |= (uint32_t)slot << 8;
+            }
+            if (first) {
+                counts[0] = total; counts[1] = total - sRed[1];      // {n, monoIndex}
+                A.selCountOut[frame] = total;
+                if (A.errMirror) *A.errMirror = *A.errFlag;
+            }
+        }
+        __syncthreads();
+        if (tid < kKpPerWg * kKpGroups && kbase + tid < total) {
+            A.selPackedOut[(long long)frame * selCap + kbase + tid] = sOwnPk[tid];
+            A.selMetaOut[(long long)frame * selCap + kbase + tid] = sOwnMt[tid];
+        }
+    }
 #ifdef RUMI_OD_STAMP
     long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stLast = clock64();
 #define OD_STAMP(k) do { const long long t_ = clock64(); st[k] += t_ - stLast; stLast = t_; } while (0)
@@ -1125,10 +1205,15 @@ __global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restr
     };
 
     const uint32_t *selP = selPacked + (long long)frame * selCap, *selM = selMeta + (long long)frame * selCap;
+    auto key_rec = [&](int k, uint32_t &pk, uint32_t &mt) {     // key-point k of the frame: from k_assemble's arrays, or from this workgroup's own prologue
+        if constexpr (kAssemble) { const int j = k - (kb - hw); pk = sOwnPk[j]; mt = sOwnMt[j]; }
+        else { pk = selP[k]; mt = selM[k]; }
+    };
     bool liveC = kb < cnt, liveN = kb + kKpPerWg < cnt;
     uint32_t pkC = 0, mtC = 0, pkN = 0, mtN = 0;
-    if (liveC) { pkC = selP[kb]; mtC = selM[kb]; }
-    if (liveN) { pkN = selP[kb + kKpPerWg]; mtN = selM[kb + kKpPerWg]; }
+    if (liveC) key_rec(kb, pkC, mtC);
+    if (liveN && kKpGroups > 1) key_rec(kb + kKpPerWg, pkN, mtN);
+    if (kKpGroups == 1) liveN = false;
     Staged S;
     fetch_disc(pkC, mtC, liveC, S);
     fetch_patch(pkC, mtC, liveC, S);
@@ -1143,7 +1228,7 @@ __global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restr
         const int k2 = kb + (g + 2) * kKpPerWg;
         const bool liveNN = g + 2 < kKpGroups && k2 < cnt;
         uint32_t pkNN = 0, mtNN = 0;
-        if (liveNN) { pkNN = selP[k2]; mtNN = selM[k2]; }
+        if (liveNN) key_rec(k2, pkNN, mtNN);
         if (g + 1 < kKpGroups) fetch_disc(pkN, mtN, liveN, S);
         OD_STAMP(2);
         float angle = 0.f;
@@ -1268,12 +1353,24 @@ void launch_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selPack
                         long long descStride, int outCap, int nframes, hipStream_t st) {
     if (maxSel <= 0) return;
     const int wg1 = (maxSel + kKpPerWg - 1) / kKpPerWg;
+    const AssembleArgs none{};
     if ((long long)wg1 * nframes <= 2048)
-        hipLaunchKernelGGL(k_orient_desc<1>, dim3(wg1, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride, descOut,
-                           descStride, outCap);
+        hipLaunchKernelGGL((k_orient_desc<1, false>), dim3(wg1, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride, descOut,
+                           descStride, outCap, none);
     else
-        hipLaunchKernelGGL(k_orient_desc<2>, dim3((wg1 + 1) / 2, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride,
-                           descOut, descStride, outCap);
+        hipLaunchKernelGGL((k_orient_desc<2, false>), dim3((wg1 + 1) / 2, nframes), dim3(256), 0, st, dP, src, selPacked, selMeta, selCount, selCap, kpOut, kpStride,
+                           descOut, descStride, outCap, none);
+}
+// k_assemble + k_orient_desc in ONE launch, for calls of a few frames (the caller guarantees (maxSel / 8) * nframes <= 2048 workgroups)
+void launch_assemble_orient_desc(const DevParams *dP, ImgSrc src, const uint32_t *selLevel, const int32_t *selLevelCnt, int selLevelCap, int lap0, int lap1,
+                                 int32_t *counts, long long countsStride, int32_t *errFlag, int32_t *errMirror, uint32_t *selPacked, uint32_t *selMeta,
+                                 int32_t *selCount, int selCap, int maxSel, RumiKeyPoint *kpOut,
+                                 long long kpStride, uint8_t *descOut, long long descStride, int outCap, int nframes, hipStream_t st) {
+    if (maxSel <= 0) return;
+    const int wg1 = (maxSel + kKpPerWg - 1) / kKpPerWg;
+    const AssembleArgs A{selLevel, selLevelCnt, selLevelCap, lap0, lap1, counts, countsStride, errFlag, nframes == 1 ? errMirror : nullptr, selPacked, selMeta, selCount};
+    hipLaunchKernelGGL((k_orient_desc<1, true>), dim3(wg1, nframes), dim3(256), 0, st, dP, src, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (const int32_t *)nullptr, selCap, kpOut, kpStride, descOut, descStride, outCap, A);
 }
 
 }  // namespace rumi
