@@ -66,7 +66,7 @@ struct RumiOrb {
     DevParams *dP = nullptr;
     int16_t *dCoef = nullptr;
     RowTap *dRowTab = nullptr; int capRowTab = 0;   // per level and output row: source rows and vertical taps of the resize
-    PyrTile *dPyrTiles = nullptr; int nPyrTiles = 0, pyrBuf = 0, pyrTab = 0;   // the one-launch pyramid of calls of a few frames (k_pyramid_tiles): 0 tiles = not available for this geometry
+    PyrTile *dPyrTiles[2] = {nullptr, nullptr}; int nPyrTiles[2] = {0, 0}, pyrBuf[2] = {0, 0}, pyrTab[2] = {0, 0};   // the one-launch pyramid (k_pyramid_tiles), [0] small tiles for calls of a few frames, [1] large tiles for batches: 0 tiles = not available for this geometry
     // HBM arenas (sized for max_batch frames unless noted)
     uint8_t *dIn = nullptr;          // staging for the single-frame host API (1 frame, rows padded to a multiple of 4 bytes)
     uint8_t *dL0 = nullptr;          // staging for device frames whose base / pitch / frame stride is not 4-byte aligned (allocated on first use)
@@ -205,13 +205,16 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
     // level l - 1 is the hull of what its region of level l reads (first tap column .. second tap column, first .. second source row) and of its
     // share of an even partition of level l - 1 (every pixel of every level belongs to some tile); x ranges are widened to multiples of 4 (the
     // kernels store dwords; the tables carry 4 padded columns).  Level 0's "region" is the window of the frame the tile reads.
-    h->nPyrTiles = 0; h->pyrBuf = 0;
-    if (P.nlevels >= 2) {
-        constexpr int kPyrTX = 16, kPyrTY = 8;
+    // Two tile sets: small tiles (16 x 8 of the top level) for calls of a few frames, where the dependent chain is what counts (216 workgroups for
+    // one 640 x 480 frame); large tiles (RUMI_PYR_BATCH_TILE, default 48 x 16) for batches (opt-in, RUMI_PYRAMID_TILES=3: measured slower, see extract_async_impl), where the chip is full and what counts is the recomputed
+    // border (~1.2x the pixels instead of 1.8x) and the traffic: the frame is read once and every level written once, no level is read back.
+    auto build_tiles = [&](int kPyrTX, int kPyrTY, int set) -> int {
+        h->nPyrTiles[set] = 0; h->pyrBuf[set] = 0;
+        if (P.nlevels < 2) return RUMI_OK;
         const int top = P.nlevels - 1;
         const int ntx = (P.lv[top].w + kPyrTX - 1) / kPyrTX, nty = (P.lv[top].h + kPyrTY - 1) / kPyrTY;
         std::vector<PyrTile> tiles((size_t)ntx * nty);
-        int bufMax = 0, tabMax = 0, dimMax = 0, winRows = 0;
+        int bufMax = 0, tabMax = 0, dimMax = 0, winRows = 0, winCols = 0;
         auto up4 = [](int x) { return (x + 3) & ~3; };
         for (int ty = 0; ty < nty; ty++)
             for (int tx = 0; tx < ntx; tx++) {
@@ -237,18 +240,26 @@ static int set_geometry(RumiOrb *h, int w, int hgt) {
                     T.x0[l] = (int16_t)x0; T.x1[l] = (int16_t)x1; T.y0[l] = (int16_t)y0; T.y1[l] = (int16_t)y1;
                     bufMax = std::max(bufMax, up4(x1 - x0) * (y1 - y0));
                     if (l > 0) tab += (x1 - x0) + (y1 - y0);            // the tile's slices of the column and row tables (8 bytes an entry)
-                    dimMax = std::max(dimMax, std::max(x1 - x0, y1 - y0));
-                    if (l == 0) winRows = std::max(winRows, y1 - y0);
+                    if (l > 0) dimMax = std::max(dimMax, std::max(x1 - x0, y1 - y0));
+                    if (l == 0) { winRows = std::max(winRows, y1 - y0); winCols = std::max(winCols, x1 - x0); }
                 }
                 tabMax = std::max(tabMax, tab);
             }
         bufMax = (bufMax + 15) & ~15;
-        if (2 * bufMax + 8 * tabMax <= 60 * 1024 && tiles.size() <= 4096 && P.nlevels <= 8 && dimMax <= 256 && winRows <= 80) {   // (the kernel's fixed shapes: orb_kernels.hip)
-            if (h->dPyrTiles) { (void)hipFree(h->dPyrTiles); h->dPyrTiles = nullptr; }
-            HIP_TRY(hipMalloc((void **)&h->dPyrTiles, tiles.size() * sizeof(PyrTile)));
-            HIP_TRY(hipMemcpy(h->dPyrTiles, tiles.data(), tiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice));
-            h->nPyrTiles = (int)tiles.size(); h->pyrBuf = bufMax; h->pyrTab = tabMax;
+        if (2 * bufMax + 8 * tabMax <= 60 * 1024 && tiles.size() <= 4096 && P.nlevels <= 8 && dimMax <= 256 && winRows <= 80 && winCols <= 256) {   // (the kernel's fixed shapes: orb_kernels.hip)
+            if (h->dPyrTiles[set]) { (void)hipFree(h->dPyrTiles[set]); h->dPyrTiles[set] = nullptr; }
+            HIP_TRY(hipMalloc((void **)&h->dPyrTiles[set], tiles.size() * sizeof(PyrTile)));
+            HIP_TRY(hipMemcpy(h->dPyrTiles[set], tiles.data(), tiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice));
+            h->nPyrTiles[set] = (int)tiles.size(); h->pyrBuf[set] = bufMax; h->pyrTab[set] = tabMax;
         }
+        return RUMI_OK;
+    };
+    {
+        int rcT = build_tiles(16, 8, 0);
+        if (rcT != RUMI_OK) return rcT;
+        int btx = 48, bty = 16;
+        if (const char *e = std::getenv("RUMI_PYR_BATCH_TILE")) { if (std::sscanf(e, "%dx%d", &btx, &bty) != 2 || btx < 4 || bty < 2) { btx = 48; bty = 16; } }
+        if ((rcT = build_tiles(btx, bty, 1)) != RUMI_OK) return rcT;
     }
     h->octLds = octree_lds_for(P);
     if (h->octLds > 160 * 1024) { g_lastError = "nfeatures too large for the LDS-resident quadtree node pool"; return RUMI_E_INVALID; }
@@ -275,7 +286,7 @@ extern "C" void rumi_orb_destroy(RumiOrb *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->pending) (void)hipStreamSynchronize(h->pendingStream);
-    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dPyrTiles, h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
+    void *dev[] = {h->dP, h->dCoef, h->dRowTab, h->dPyrTiles[0], h->dPyrTiles[1], h->dIn, h->dL0, h->dPyr, h->dBlur, h->dCellBuf, h->dCellCnt, h->dCand, h->dLevelStart,
                    h->dSelPacked, h->dSelMeta, h->dSelCount, h->dKp, h->dDesc, h->dCounts,
                    h->dOwner, h->dSelLevel, h->dSelLevelCnt, h->dErr};
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -557,13 +568,19 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
     const bool fuseBlur = !prof && !serial && (envFuse >= 0 ? envFuse != 0 : nframes < 16) && fast_blur_fusable(P);
     // A few frames: the pyramid in ONE launch (k_pyramid_tiles) instead of a launch per level
     static const int envTiles = std::getenv("RUMI_PYRAMID_TILES") ? std::atoi(std::getenv("RUMI_PYRAMID_TILES")) : -1;
-    const bool tilePyramid = !prof && !serial && h->nPyrTiles > 0 && (envTiles >= 0 ? envTiles != 0 : nframes <= 4);   // (a tile recomputes the borders it shares: ~1.8x the pixels, paid back only while the chip is far from full)
+    // RUMI_PYRAMID_TILES: unset = the small tiles for calls of up to 4 frames, a launch per level beyond; 0 = a launch per level for every call;
+    // 1 = the small tiles for every call; 3 = small tiles up to 4 frames and the LARGE ones beyond.  (3 was MEASURED for batches in round 4 and is
+    // not the default: 1024-frame steps run at 208-210 k fps with 32 x 16 / 48 x 16 top-level tiles against 234 k with the per-level launches -- a
+    // workgroup walks seven levels between barriers and its threads idle on the small ones, which costs more than the saved re-reads bring.)
+    const int tileSet = nframes <= 4 || envTiles == 1 ? 0 : 1;
+    const bool tilePyramid = !prof && h->nPyrTiles[tileSet] > 0 &&
+                             (tileSet == 0 ? (!serial && (envTiles >= 0 ? envTiles != 0 : true)) : envTiles == 3);
     bool copyL0 = false;
     auto stage_a = [&](const ImgSrc &ps, int n, const Lane &L) -> int {
         hipStream_t s = L.s;
         if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
         if (tilePyramid) {
-            launch_pyramid_tiles(h->dP, ps, h->dCoef, h->dRowTab, h->dPyrTiles, h->nPyrTiles, h->pyrBuf, h->pyrTab, n, s, clearInKernel ? h->dErr : nullptr, copyL0);
+            launch_pyramid_tiles(h->dP, ps, h->dCoef, h->dRowTab, h->dPyrTiles[tileSet], h->nPyrTiles[tileSet], h->pyrBuf[tileSet], h->pyrTab[tileSet], n, s, clearInKernel ? h->dErr : nullptr, copyL0);
             clearInKernel = false;
         } else
         for (int l = 1; l < P.nlevels; l++) {
