@@ -892,22 +892,38 @@ __device__ __forceinline__ void blur_body(const DevParams *__restrict__ P, const
     // the walk is unrolled by seven so that the ring never moves: source row r0 + j lands in slot j, and the taps of the output row it
     // completes sit at compile-time slots (a runtime ring costs 24 register moves per row)
     uint8_t *orow = out + (long long)(y0 - 6) * L.pitch + xa - L.pitch;
-    for (int r0 = y0 - 3; r0 < rEnd; r0 += 7) {
+    // the halo dword of the wave's outer lanes: lane 0 reads the dword left of its own (but in the first strip block, where it is the mirrored
+    // bytes of its own), lane 63 of a 256-pixel wave the one to the right
+    const int haloOff = lane == 0 ? (firstBlock ? 0 : -4) : (lane == 63 && !edgeWave && bw == 256 ? 4 : 0);
+    // the source rows of the NEXT seven are fetched while the current seven are filtered (a wave's walk is otherwise a chain of
+    // load -> filter -> load; rows past the walk's end re-read its last row).  256 frames alone on the device: 260 -> 192 us at 83 registers
+    // (5 waves a SIMD); forced to 80 registers / 6 waves (one spill) 217 us, held at 4 waves 207 us, two register sets taking turns 88 registers
+    uint32_t Cn[7], Hn[7];
+    auto fetch = [&](int r, uint32_t &C, uint32_t &H) {
+        const int rc = min(r, rEnd - 1);
+        const int rr = rc < 0 ? -rc : (rc >= h ? 2 * (h - 1) - rc : rc);        // rows -3..-1 and h..h+2 mirror into the level
+        const uint8_t *row = img + (long long)rr * pitch + xl;
+        C = *reinterpret_cast<const uint32_t *>(row);
+        H = 0;
+        if (haloOff) H = *reinterpret_cast<const uint32_t *>(row + haloOff);
+    };
+#pragma unroll
+    for (int j = 0; j < 7; j++) fetch(y0 - 3 + j, Cn[j], Hn[j]);
+    uint32_t Cm[7], Hm[7];                                       // the seven being filtered
+    auto walk7 = [&](const uint32_t (&Cc)[7], const uint32_t (&Hc)[7], int r0) {
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int r = r0 + j;
             if (r >= rEnd) break;                                // wave-uniform
             orow += L.pitch;
-            const int rr = r < 0 ? -r : (r >= h ? 2 * (h - 1) - r : r);           // rows -3..-1 and h..h+2 mirror into the level
-            const uint8_t *row = img + (long long)rr * pitch;
-            uint32_t C = *reinterpret_cast<const uint32_t *>(row + xl);
+            uint32_t C = Cc[j];
             if (edgeWave) {
                 const uint32_t c1 = __shfl_up(C, 1), c2 = __shfl_up(c1, 1);
                 C = __builtin_amdgcn_perm(C, __builtin_amdgcn_perm(c1, c2, selA), selB);
             }
             uint32_t Lw = __shfl_up(C, 1), Rw = __shfl_down(C, 1);
-            if (lane == 0) Lw = firstBlock ? __builtin_amdgcn_perm(C, C, 0x01020300u) : *reinterpret_cast<const uint32_t *>(row + xl - 4);
-            if (lane == 63 && !edgeWave && bw == 256) Rw = *reinterpret_cast<const uint32_t *>(row + xl + 4);   // (only a 256-pixel wave has a producing lane 63)
+            if (lane == 0) Lw = firstBlock ? __builtin_amdgcn_perm(C, C, 0x01020300u) : Hc[j];
+            if (lane == 63 && !edgeWave && bw == 256) Rw = Hc[j];   // (only a 256-pixel wave has a producing lane 63)
             // row pass on packed bytes: output i needs the 7 bytes S[i+1 .. i+7] of the 12-byte run {Lw, C, Rw}; two byte-dot-products
             // (v_dot4_u32_u8) against the taps {18,34,48,56} and {48,34,18,0} give the exact integer sum (<= 65 280)
             constexpr uint32_t tA = 18u | (34u << 8) | (kT2 << 16) | (kT3 << 24), tB = kT2 | (34u << 8) | (18u << 16);
@@ -937,6 +953,15 @@ __device__ __forceinline__ void blur_body(const DevParams *__restrict__ P, const
                 *reinterpret_cast<uint32_t *>(orow) = p01 | p23;         // orow = out + y * pitch + xa
             }
         }
+    };
+    for (int r0 = y0 - 3; r0 < rEnd; r0 += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) Cm[j] = Cn[j], Hm[j] = Hn[j];
+        if (r0 + 7 < rEnd) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) fetch(r0 + 7 + j, Cn[j], Hn[j]);
+        }
+        walk7(Cm, Hm, r0);
     }
 }
 template <int VARIANT, int kBlurRows>
