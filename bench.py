@@ -52,16 +52,16 @@ def algorithmic_bytes_per_frame(n_kp, w=640, h=480):
 def whole_path_valu_issue(fps):
     """The step against the vector-issue ceiling, as ONE number: every kernel's VALU wave-instructions per 256-frame pass (committed SQ counters)
     priced with the measured issue cost of ITS OWN instruction mix -- each opcode of the disassembled hot loops in the 2.4-, 4.2- or 8.2-cycle
-    class of profiles/r02_valu_issue_rates.txt, loops weighted by their trip counts (tools/valu_mix.py -> profiles/r03_valu_mix.json) -- over the
+    class of profiles/r02_valu_issue_rates.txt, loops weighted by their trip counts (tools/valu_mix.py -> profiles/r04_valu_mix.json) -- over the
     SIMD-cycles available at the rate measured in THIS run."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_mix.json")))
         simd_cycles = 1024 * 2.4e9 * (256.0 / fps)
         return {"valu_wave_insts_per_256_frames": mix["valu_wave_insts_per_256_frames"], "weighted_cycles": mix["weighted_cycles_per_256_frames"],
                 "avg_cycles_per_inst": mix["avg_cycles_per_inst"], "frac_of_weighted_ceiling": round(mix["weighted_cycles_per_256_frames"] / simd_cycles, 4),
                 "per_kernel_mix": {k: {"M_insts": round(v["valu_wave_insts_per_256_frames"] / 1e6, 1), "fast": v["fast_frac"], "slow": v["slow_frac"], "v8": v["v8_frac"],
                                        "avg_cycles": v["avg_cycles_per_inst"]} for k, v in mix["kernels"].items()},
-                "source": "instruction counts and mix: committed profile profiles/r03_valu_mix.json (separate --pmc passes + disassembly), not this run; rate: this run"}
+                "source": "instruction counts and mix: committed profile profiles/r04_valu_mix.json (separate --pmc passes + disassembly), not this run; rate: this run"}
     except Exception:
         return None
 
@@ -198,12 +198,30 @@ def one_process_queue(args):
     for _ in range(args.steps):
         q.extract(frames, (0, 1000), out=rec)
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "frames/sec ORB extract, rumination queue from one process (host frames in, gathered records on every device, host records out)",
+    emit(dict({"metric": "frames/sec ORB extract, rumination queue from one process (host frames in, gathered records on every device, host records out)",
                       "value": round(F * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
                       "data": "synthetic", "config": {"workload": "BASELINE.json configs[4]: %d queued 640x480 frames over %d %s, one process, rumi_queue_extract" % (F, N, "logical shards on device 0" if logical else "devices"),
                                                       "exchange": "RCCL ncclAllGather" if q.uses_rccl else "device-to-device copies (logical shards)"},
                       "last_call_ms": q.last_ms()}))
+
+
+_LINE_OUT = None
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line and nothing else: libraries that greet on stdout (RCCL prints a version banner at communicator creation on
+    this image) are sent to stderr, the line goes to the original descriptor."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _LINE_OUT or sys.stdout
+    out.write(json.dumps(line) + "\n"); out.flush()
 
 
 def main():
@@ -219,12 +237,13 @@ def main():
     ap.add_argument("--one-process", action="store_true", help="the queue over --gpus devices from ONE process through include/rumi_queue.h (RCCL all-gather inside the library) instead of one rank per GPU; "
                     "RUMI_BENCH_LOGICAL_SHARDS=1 aliases every shard to device 0 (a one-GPU box)")
     args = ap.parse_args()
-
     if args.one_process:
+        claim_stdout()
         return one_process_queue(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
+    claim_stdout()
 
     import numpy as np
     import torch
@@ -383,17 +402,17 @@ def main():
         achieved = kern_bytes[dom] * B / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         kname = {"fast": "k_fast_cells", "blur": "k_blur", "orient_desc": "k_orient_desc", "quadtree": "k_octree", "pyramid": "k_resize"}[dom]
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot wrap this process from inside, so these two numbers are the committed
-        # results of separate --pmc passes of this command line (profiles/r03_pmc_*.json); `*_source` says so, and they are used only when
+        # results of separate --pmc passes of this command line (profiles/r04_pmc_*.json); `*_source` says so, and they are used only when
         # taken at the same frames-per-launch.
         traffic, valu = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
             if pm.get("frames_per_launch") == per_launch and kname in pm["kernels"]:
                 traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_counters.json")))["kernels"][kname]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq_counters.json")))["kernels"][kname]
             if per_launch == 256:
                 valu = {"wave_insts_per_launch": int(sq["SQ_INSTS_VALU"]), "lds_insts_per_launch": int(sq.get("SQ_INSTS_LDS", 0)),
                         "lds_bank_conflict_cycles": int(sq.get("SQ_LDS_BANK_CONFLICT", 0)),
@@ -411,12 +430,12 @@ def main():
                        "exchange": "one all_gather_into_tensor of %d-byte per-frame records over RCCL, overlapped with the next step" % rumination.record_bytes(cap) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "committed profile profiles/r03_pmc_traffic.json (separate --pmc passes), not this run" if traffic else None,
+                         "traffic_source": "committed profile profiles/r04_pmc_traffic.json (separate --pmc passes), not this run" if traffic else None,
                          "algorithmic_bytes_per_launch": int(kern_bytes[dom] * per_launch), "frames_per_launch": per_launch,
                          "launch_ms": round(kern_ms[dom] / n_launch, 4),
                          "whole_path_GBps": round(ab["total"] * fps / 1e9, 2),
                          "whole_path_frac": round(ab["total"] * fps / 1e9 / HBM_PEAK_GBS, 5), "valu": valu,
-                         "valu_source": "committed profile profiles/r03_pmc_sq_counters.json, not this run" if valu else None},
+                         "valu_source": "committed profile profiles/r04_pmc_sq_counters.json, not this run" if valu else None},
             "valu_issue": whole_path_valu_issue(fps),
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
             "stage_ms_note": "one extra profiled step: every kernel alone on ONE stream (RUMI_SERIAL-equivalent: the blur too), launches of up to 256 frames, summed over the step's launches",
@@ -546,7 +565,7 @@ def main():
             line["cpu_baseline"] = {"value": round(n / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": "%d of the same synthetic frames (extract + brute-force match), oracle/ (g++ -O2, scalar, 1 thread), %.1f s" % (n, cdt)}
             line.update(side_legs(args))
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag: first argument, default r03) and prints a summary.
+"""Copies the newest rocprofv3 outputs of a measurement pass from gpurun_out/ into profiles/ (round tag: first argument, default r04) and prints a summary.
 Expects gpurun_out/{prof_default,prof_serial,prof_lba,pmc_fetch,pmc_write,pmc_a,pmc_b}, bench_r02.json, stage_serial.log, host_batch.log, r02_valu_issue_rates.txt."""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def newest(pattern):
@@ -20,18 +20,30 @@ except (ValueError, OSError):
     print("missing the 128-frame serial pass / the records-path bench line")
 shutil.copy(newest("prof_lba/*/*kernel_stats.csv"), os.path.join(P, TAG + "_lba_20kf_3000mp_kernel_stats.csv"))
 # second pass (tools/measure_more.sh): latency paths
-for src, dst in (("prof_track/*/*kernel_stats.csv", TAG + "_track_frame_kernel_stats.csv"),):
+for src, dst in (("prof_track/*/*kernel_stats.csv", TAG + "_track_frame_kernel_stats.csv"), ("prof_single/*/*kernel_stats.csv", TAG + "_single_frame_kernel_stats.csv"),
+                 ("pmc_lba_time16/*/*kernel_stats.csv", TAG + "_lba_batch16_kernel_stats.csv"), ("pmc_lba_time1/*/*kernel_stats.csv", TAG + "_lba_single_window_kernel_stats.csv")):
     try:
         shutil.copy(newest(src), os.path.join(P, dst))
     except ValueError:
         print("missing", src)
 for src, dst in (("track_probe.log", TAG + "_track_frame_probe.txt"), ("lba_probe.log", TAG + "_lba_probe.txt"), ("bow_batch.log", TAG + "_bow_batch_probe.txt"),
-                 ("pose_probe.log", TAG + "_pose_probe.txt"), ("rsq_probe.log", TAG + "_rsq_rcp_accuracy.txt"), ("bench_matrix.json", TAG + "_bench_matrix.json")):
+                 ("pose_probe.log", TAG + "_pose_probe.txt"), ("rsq_probe.log", TAG + "_rsq_rcp_accuracy.txt"), ("bench_matrix.json", TAG + "_bench_matrix.json"),
+                 ("single_frame.log", TAG + "_single_frame_probe.txt"), ("bench_one_process.json", TAG + "_bench_line_one_process_queue.json"),
+                 ("test_queue_cc.log", TAG + "_queue_c_test.txt")):
     if os.path.exists(os.path.join(G, src)):
         txt = open(os.path.join(G, src)).read()
         open(os.path.join(P, dst), "w").write("\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l) + "\n")
     else:
         print("missing", src)
+try:
+    res = {}
+    for tag, key in (("16", "batch16"), ("1", "single")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_lba_summary.py"), G, tag, "/tmp/_lba_%s.json" % tag], stdout=subprocess.DEVNULL)
+        res[key] = json.load(open("/tmp/_lba_%s.json" % tag))
+    res["command"] = "tools/pmc_lba.sh: RUMI_BAW_GROUPS=1 rocprofv3 --kernel-trace --pmc <counters> -- python3 tools/prof_lba_batch.py {16|0} 2 (separate passes for the MFMA counters, the SQ counters and --stats)"
+    json.dump(res, open(os.path.join(P, TAG + "_lba_pmc_mfma.json"), "w"), indent=1)
+except Exception as e:
+    print("local BA counter passes missing:", e)
 for d, tmp in (("pmc_fetch", "/tmp/_pf"), ("pmc_write", "/tmp/_pw")):
     shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/x")
     shutil.copy(newest(d + "/*/*counter_collection.csv"), tmp + "/x/")
@@ -48,7 +60,7 @@ for d in ("pmc_a", "pmc_b"):
     for n, c in agg.items():
         out["kernels"].setdefault(n, {}).update({k: round(sum(v) / len(v)) for k, v in c.items()})
 json.dump(out, open(os.path.join(P, TAG + "_pmc_sq_counters.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "bench_%s.json" % TAG), os.path.join(P, TAG + "_bench_line.json"))
+open(os.path.join(P, TAG + "_bench_line.json"), "w").write([l for l in open(os.path.join(G, "bench_%s.json" % TAG)).read().splitlines() if l.startswith("{")][-1] + "\n")
 shutil.copy(os.path.join(G, "host_batch.log"), os.path.join(P, TAG + "_host_batch_probe.txt"))
 shutil.copy(os.path.join(G, TAG + "_valu_issue_rates.txt"), os.path.join(P, TAG + "_valu_issue_rates.txt"))
 shutil.copy(os.path.join(G, "stage_serial.log"), os.path.join(P, TAG + "_stage_ms_standalone.txt"))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# One full measurement pass on the GPU box (run through gpurun); outputs land in gpurun_out/, then `python tools/collect_profiles.py` (round tag $TAG, default r03).
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${TAG:-r03}
+# One full measurement pass on the GPU box (run through gpurun); outputs land in gpurun_out/, then `python tools/collect_profiles.py` (round tag $TAG, default r04).
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${TAG:-r04}
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 cd /tmp; export TMPDIR=/tmp
