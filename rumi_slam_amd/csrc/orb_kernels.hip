@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     const unsigned wg = xcd_swizzle((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, frame = wg / (gridDim.x * gridDim.y);
     const int ox = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int oyBase = (by * 4 + (threadIdx.x >> 6)) * kResizeRows;
+    // (the wave index as a scalar: the row table entries, the source-row pointers and the vertical taps then live in scalar registers)
+    const int oyBase = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kResizeRows;
     if (ox >= D.w || oyBase >= D.h) return;
     int sp;
     const uint8_t *sb = level_base(src, P, level - 1, frame, &sp);
@@ -844,7 +845,7 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
 template <int VARIANT, int kBlurRows>
 __device__ __forceinline__ void blur_body(const DevParams *__restrict__ P, const ImgSrc &src, const BlurGrid &G, unsigned bxg, unsigned gxg) {
     constexpr uint32_t kT2 = VARIANT ? 49u : 48u, kT3 = VARIANT ? 55u : 56u;      // taps at distance 1 and 0 (18 and 34 are common)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the row walk is scalar arithmetic)
     const unsigned wg = xcd_swizzle(blockIdx.y * gxg + bxg, gxg * gridDim.y);
     const int frame = wg / gxg, lin = wg % gxg;
     int level = 0;
