@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
     constexpr bool FILL = PASS != 0;
     __shared__ uint32_t sKey[FILL ? 4 * kSortMax : 1], sVal[FILL ? 4 * kSortMax : 1];
     const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (qi >= nq) return;
     if (PASS == 1 && offsets[nq] > listCap) {            // the arena cannot hold this call's lists: report the need, write nothing
         if (qi == 0 && lane == 0) *overflow = offsets[nq];
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_candidates(int mode, int nq, const Quer
         if (PASS != 1 && lane == 0) counts[qi] = 0;
         return;
     }
-    uint32_t *key = sKey + (threadIdx.x >> 6) * kSortMax, *val = sVal + (threadIdx.x >> 6) * kSortMax;
+    uint32_t *key = sKey + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kSortMax, *val = sVal + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kSortMax;
     uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int total = 0;
     if (PASS == 2 && mode != MODE_BOW && mode != MODE_BOW_KF) {
@@ -678,7 +678,7 @@ __device__ __forceinline__ int rot_bin(float a, float b) {          // ORBmatche
 __device__ __forceinline__ void gather_correspondences(int n, const RumiKeyPoint *__restrict__ keys, const int32_t *featMp, const float *__restrict__ mpPos,
                                                        const float *__restrict__ invSigma2, float *Xw, float *obs, float *w, int32_t *idx, int32_t *start,
                                                        int32_t *snapshot, int *sWave /* [16] */, int *sBase) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) *sBase = 0;
     __syncthreads();
     for (int c0 = 0; c0 < n; c0 += 1024) {
@@ -2135,7 +2135,7 @@ __global__ __launch_bounds__(kFvThreads) void k_fv_build(int n, int npad, const 
         }
     if (tid == 0) { sBase = 0; sValid = 0; }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int c0 = 0; c0 < npad; c0 += kFvThreads) {
         const int i = c0 + tid;
         const unsigned long long key = i < npad ? fvKey[i] : ~0ull;

@@ -74,7 +74,7 @@ __device__ __forceinline__ double wave_allreduce_f64(double s) {
 // ---- block reduction of NV doubles per thread (NW waves, 4 by default); every thread gets the total ----
 // (FENCE_FIRST = false: the caller alternates between two `red` buffers from call to call, so no wave can still be reading the one written here)
 template <int NV, int NW = 4, bool FENCE_FIRST = true> __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [NW][NV] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = wave_allreduce_f64(v[k]);
     if (FENCE_FIRST) __syncthreads();
@@ -114,7 +114,7 @@ template <int D, int N, int PAD> __device__ __forceinline__ void butterfly_stage
 template <int NV, int NW = 4, bool FENCE_FIRST = true> __device__ __forceinline__ void block_sum_butterfly(double (&v)[NV], double *red) {
     static_assert(NV <= 64, "at most 64 values");
     constexpr int PAD = NV <= 32 ? 32 : 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double w[PAD];
 #pragma unroll
     for (int k = 0; k < PAD; k++) w[k] = k < NV ? v[k] : 0.0;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BADev B, const double *T, cons
 constexpr int kHppSlices = 16;
 __global__ __launch_bounds__(256) void k_ba_hpp_mfma(BADev B, const LmState *S = nullptr) {
     if (lm_skip(S, true)) return;
-    const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kf = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = B.kfRowStart[kf], r1 = B.kfRowStart[kf + 1];
     const int col = lane & 15, sub = lane >> 4;
     const int nw = kHppSlices * 4, w = blockIdx.y * 4 + wave;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void k_ba_dinv_yfill(BADev B, double lambda, d
 // chunks in flight before the first MFMA, so the kernel pays the memory latency once per wave, not once per 16 rows.
 __global__ __launch_bounds__(256) void k_ba_syrk_mfma(const double *__restrict__ Yt, int K, int NP, int nSlices, double *G, const LmState *S = nullptr) {
     if (lm_skip(S, false)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = NP / 16;
     // 1-D grid of tiles x slice groups.  Workgroups go round-robin over the 8 XCDs, each with its own L2: the mapping below gives every XCD
     // its own slice groups (all tiles of them), so that a row of Yt is fetched from memory by ONE L2 instead of by all eight
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void solve_tiles_core(const SolveIO &B, double lambda
     extern __shared__ double T[];                             // tiles | y[NT*16]
     __shared__ int sFail;
     __shared__ double sBuf[kSolveWaves][16];                           // per wave: the scaled pivot column of the panel step in flight
-    const int n = B.n, NP = B.NP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = B.n, NP = B.NP, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = NP / 16;                                   // tile rows (the right-hand side is row n)
     const int PT = (n + 15) / 16;                             // tile columns that hold pivots
     const int nT = NT * (NT + 1) / 2;
@@ -1307,7 +1307,7 @@ __global__ void k_big_w(BADev B, const double *Lp, double *W, int32_t *colOf) {
 // row strip per key-frame 0.9 - 1.6 ms, this one 0.05 ms).
 constexpr int kSchurSeg = 32;   // pairs per wave: long blocks (the diagonal ones: every observation of the key-frame) are cut into segments
 __global__ __launch_bounds__(256) void k_big_schur(BADev B, const int32_t *blk, int nb, const int32_t *pairs, const double *W, const double *z, double *A, int ld) {
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wv >= nb) return;
     const int ca = blk[4 * wv], cbm = blk[4 * wv + 1], s = blk[4 * wv + 2], len = blk[4 * wv + 3] - s;
     const int cb = cbm & 0x3fffffff;

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kCompactThreads) void k_compact(const DevParams *__
         if (c < nc) sum += cnt[c];
     }
     // exclusive scan of the per-thread sums: shuffles inside a wave, the 16 wave totals through LDS
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 // exclusive scan of one 64-bit value per thread over the workgroup (three packed 20-bit counters); *total = sum over all threads
 template <int NT>
 __device__ __forceinline__ unsigned long long block_scan64(unsigned long long v, unsigned long long *sWave, unsigned long long *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void wave_fence_lds() {
 __device__ void wg_sort_like_libstdcxx(OctEntry *a, int n, OctEntry *tmp, uint16_t *sf, uint16_t *sr, SortSeg *segA, SortSeg *segB,
                                        int *sCount /* [2] in LDS */) {
     using namespace sortimpl;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nWaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nWaves = blockDim.x >> 6;
     if (n <= 1) return;
     if (tid == 0) {
         int lg = 0;
