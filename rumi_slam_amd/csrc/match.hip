@@ -2377,6 +2377,8 @@ struct RumiTracker {
     UndistortArgs ua{};
     RumiKeyPoint *dKeysUn = nullptr;
     float bounds[4] = {0, 0, 0, 0};
+    // the frame's BoW transform: one block [weight f64 x cap | word u32 x cap | node u32 x cap] and its pinned mirror (one copy back)
+    uint8_t *dBow = nullptr, *hBow = nullptr;
     uint32_t *dWord = nullptr, *dNode = nullptr; double *dWeight = nullptr; int32_t *dNN = nullptr;
 };
 
@@ -2390,9 +2392,10 @@ extern "C" void rumi_track_destroy(RumiTracker *t) {
     (void)hipSetDevice(t->device);
     rumi_orb_destroy(t->ext);
     rumi_match_destroy(t->m);
-    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dWord, t->dNode, t->dWeight, t->dNN, t->dStaleIn, t->dStaleProj, t->dKeysUn};
+    void *p[] = {t->dImage, t->dBlk, t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, t->dOutC, t->dActive, t->dSeen, t->dBad, t->dLocal, t->dChi, t->dBow, t->dNN, t->dStaleIn, t->dStaleProj, t->dKeysUn};
     for (void *q : p) if (q) (void)hipFree(q);
     if (t->hBlk) (void)hipHostFree(t->hBlk);
+    if (t->hBow) (void)hipHostFree(t->hBow);
     if (t->hImage) (void)hipHostFree(t->hImage);
     if (t->upStream) (void)hipStreamDestroy(t->upStream);
     if (t->evUp) (void)hipEventDestroy(t->evUp);
@@ -2421,9 +2424,10 @@ extern "C" int rumi_track_create(const RumiOrbConfig *cfg, int32_t max_points, i
     TRYA(dalloc(&t->dImage, t->imageBytes + 64)); TRYA(dalloc(&t->dBlk, t->blkBytes)); TRYA(dalloc(&t->dInvSigma2, 64));
     TRYA(dalloc(&t->dXw, C * 3)); TRYA(dalloc(&t->dObs, C * 2)); TRYA(dalloc(&t->dW, C)); TRYA(dalloc(&t->dIdx, C));
     TRYA(dalloc(&t->dOutC, C)); TRYA(dalloc(&t->dActive, C)); TRYA(dalloc(&t->dSeen, P)); TRYA(dalloc(&t->dBad, P)); TRYA(dalloc(&t->dLocal, P)); TRYA(dalloc(&t->dStaleIn, P)); TRYA(dalloc(&t->dStaleProj, P * 5)); TRYA(dalloc(&t->dChi, C));
-    TRYA(dalloc(&t->dWord, C)); TRYA(dalloc(&t->dNode, C)); TRYA(dalloc(&t->dWeight, C)); TRYA(dalloc(&t->dNN, 4));
+    TRYA(dalloc(&t->dBow, C * 16)); TRYA(dalloc(&t->dNN, 4));
+    t->dWeight = reinterpret_cast<double *>(t->dBow); t->dWord = reinterpret_cast<uint32_t *>(t->dBow + C * 8); t->dNode = t->dWord + C;
 #undef TRYA
-    if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&t->hBlk, t->blkBytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&t->hBow, C * 16, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&t->hImage, t->imageBytes + 64, hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithFlags(&t->upStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->evUp, hipEventDisableTiming) != hipSuccess) {
         rumi_track_destroy(t); return RUMI_E_NO_DEVICE;
@@ -2873,18 +2877,26 @@ extern "C" int rumi_track_reference_keyframe(RumiTracker *t, RumiVocabulary *voc
     if ((rc = run_search(m, MODE_BOW, nqe, fd, m->dQDesc, nullptr, nnratio, check_orientation, searched.data(), &nm)) != RUMI_OK) return rc;
     res->nmatches_motion = nm;
     std::memcpy(frame_mp, searched.data(), (size_t)n * 4);
-    // the per-feature transform for the host's mBowVec / mFeatVec (assembled there in feature order: rumi_voc_assemble)
-    HIP_TRY(hipMemcpyAsync(word_id, t->dWord, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(node_id, t->dNode, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(word_weight, t->dWeight, (size_t)n * 8, hipMemcpyDeviceToHost, nullptr));
-    if (nm < 15) { HIP_TRY(hipStreamSynchronize(nullptr)); return RUMI_OK; }     // TrackReferenceKeyFrame returns false here (:2335-2338)
+    // the per-feature transform for the host's mBowVec / mFeatVec (assembled there in feature order: rumi_voc_assemble): ONE copy of the block into
+    // pinned memory, queued BEHIND the pose chain (three copies into the caller's pageable arrays sat between the search and PoseOptimization)
+    const size_t C = (size_t)t->cap;
+    auto bow_out = [&]() {
+        std::memcpy(word_weight, t->hBow, (size_t)n * 8); std::memcpy(word_id, t->hBow + C * 8, (size_t)n * 4); std::memcpy(node_id, t->hBow + C * 12, (size_t)n * 4);
+    };
+    if (nm < 15) {                                          // TrackReferenceKeyFrame returns false here (:2335-2338)
+        HIP_TRY(hipMemcpy(t->hBow, t->dBow, C * 16, hipMemcpyDeviceToHost));
+        bow_out();
+        return RUMI_OK;
+    }
     const bool small = n <= kTrackLdsEdges;
     hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(1024), 0, nullptr, n, fd.keys, m->dFeatMp, m->dF[0], t->dInvSigma2, t->dXw, t->dObs, t->dW, t->dIdx, dB->start);
     if ((rc = rumi::pose_opt_device(dB->start, t->dXw, t->dObs, t->dW, m->dPose + 7, m->dPose, dB->Tout, t->dOutC, dB->nGood, t->dActive, t->dChi, small, nullptr)) != RUMI_OK) return rc;
     hipLaunchKernelGGL(k_track_discard, dim3(gC), dim3(256), 0, nullptr, t->dIdx, t->dOutC, m->dFeatMp, m->dI[1], dB);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->hBow, t->dBow, C * 16, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpyAsync(t->hBlk + t->oMp, m->dFeatMp, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpy(t->hBlk, t->dBlk, sizeof(TrackBlock), hipMemcpyDeviceToHost));
+    bow_out();
     const TrackBlock *hB = reinterpret_cast<const TrackBlock *>(t->hBlk);
     std::memcpy(res->Tcw_motion, hB->Tout, 28); std::memcpy(res->Tcw, hB->Tout, 28);
     res->ngood_motion = hB->nGood[0]; res->nmatches_map = hB->counters[0];

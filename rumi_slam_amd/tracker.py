@@ -2,6 +2,8 @@
 R/lib_src/Tracking.cc:2441-2607, 2996-3055) behind one call."""
 import ctypes as C
 
+import time
+
 import numpy as np
 
 from . import capi
@@ -177,9 +179,12 @@ class Tracker:
         mp = np.full(self.cap, -1, np.int32); dis = np.full(self.cap, -1, np.int32)
         word = np.zeros(self.cap, np.uint32); node = np.zeros(self.cap, np.uint32); wgt = np.zeros(self.cap, np.float64)
         res = RumiTrackResult()
-        capi.check(self._lib.rumi_track_reference_keyframe(self._h, voc._h, int(levelsup), capi.ptr(K4), capi.ptr(T), C.byref(kf_view.c), C.byref(kf_fv.c),
-                                                           capi.ptr(km), C.byref(P), float(nnratio), int(check_orientation), capi.ptr(word), capi.ptr(wgt),
-                                                           capi.ptr(node), capi.ptr(mp), capi.ptr(dis), C.byref(res)))
+        t0 = time.perf_counter()
+        rc = self._lib.rumi_track_reference_keyframe(self._h, voc._h, int(levelsup), capi.ptr(K4), capi.ptr(T), C.byref(kf_view.c), C.byref(kf_fv.c),
+                                                     capi.ptr(km), C.byref(P), float(nnratio), int(check_orientation), capi.ptr(word), capi.ptr(wgt),
+                                                     capi.ptr(node), capi.ptr(mp), capi.ptr(dis), C.byref(res))
+        self.last_call_s = time.perf_counter() - t0                    # the C entry alone (probes)
+        capi.check(rc)
         out = self._result(res, ("n", "mono_index", "nmatches_motion", "ngood_motion", "nmatches_map", "Tcw_motion"))
         k = res.n
         out.update(frame_mp=mp[:k].copy(), discarded=dis[:k].copy(), word_id=word[:k].copy(), word_weight=wgt[:k].copy(), node_id=node[:k].copy())

@@ -113,6 +113,7 @@ def measure(reps=60):
         trk.extract(img); t1 = time.perf_counter()
         m = trk.reference_keyframe(voc_big, K_TUM3, T, kview, kfv_big, kf_mp, pts, 4, 0.7, True); t2 = time.perf_counter()
         stage.setdefault("reference_keyframe", []).append(t2 - t1)
+        stage.setdefault("reference_keyframe_c_call", []).append(trk.last_call_s)
         return m["ngood_motion"], m["Tcw_motion"]
 
     def steps_refkf_small():
