@@ -2771,10 +2771,10 @@ extern "C" int rumi_local_ba_batch(RumiOptimizer *o, int32_t n_windows, RumiBaWi
             RumiBaWindow &W = win[batched[g0 + j]];
             args[j] = BawArgs{W.n_kf, W.kf_pose7, W.kf_fixed, W.n_mp, W.mp_pos3, W.n_edges, W.e_mp, W.e_kf, W.e_obs, W.e_inv_sigma2, W.K4, W.stop_flag, W.erase_out, W.stats};
         }
-        // two launch groups (from 8 windows on): the parent handle lends the first its stream and window table, one more child the second
-        { const int rc = need_children(cnt + 1); if (rc != RUMI_OK) return rc; }
-        RumiOptimizer *runners[2] = {o, o->workers[cnt]};
-        const int rc = baw_run(o, 0, cnt, args.data(), o->workers.data(), 0, 1, status.data(), runners, 2);
+        // launch groups (two from 8 windows on, three from 12: baw_run): the parent handle lends the first its stream and window table, further children the others
+        { const int rc = need_children(cnt + 3); if (rc != RUMI_OK) return rc; }
+        RumiOptimizer *runners[4] = {o, o->workers[cnt], o->workers[cnt + 1], o->workers[cnt + 2]};
+        const int rc = baw_run(o, 0, cnt, args.data(), o->workers.data(), 0, 1, status.data(), runners, 4);
         for (int j = 0; j < cnt; j++) win[batched[g0 + j]].status = status[j];
         if (rc != RUMI_OK && rc != RUMI_E_INVALID && rc != RUMI_E_CAPACITY) return rc;      // a HIP failure: nothing more to run
     }
