@@ -475,27 +475,6 @@ def main():
             line["value_h2d_d2h_inclusive"] = round(B * max(3, args.steps // 2) / dtd, 1)
             line["h2d_d2h_note"] = "host frames in (pinned), key-points + descriptors + counts + match indices out to pinned host buffers (%.1f MB per step back); every step ends synchronised" % ((hk.numel() * 4 + hd.numel() + hc.numel() * 4 + 3 * hm[0].numel() * 4) / 1e6)
             del hk, hd, hm, okp, odesc, mo
-            # ---- the queue behind the C ABI, ONE process (include/rumi_queue.h): host frames in, every shard's device holds the gathered records, host
-            # records out.  One shard = this GPU (its exchange is RCCL's ncclAllGather on one rank); two LOGICAL shards on this GPU for the sharded code path.
-            try:
-                from rumi_slam_amd.queue import RuminationQueue
-                ql = {}
-                nq = min(B, 512)
-                hq = [hostq[f].numpy() for f in range(nq)]
-                for shards in (1, 2):
-                    rq = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [local_rank] * shards, max_block=(nq + shards - 1) // shards, cap=cap)
-                    rec = np.zeros((nq, rq.record_bytes), np.uint8)
-                    rq.extract(hq, (0, 1000), out=rec)
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        rq.extract(hq, (0, 1000), out=rec)
-                    ql["%d_shard%s" % (shards, "s_logical" if shards > 1 else "")] = {"fps": round(3 * nq / (time.perf_counter() - t0), 1), "exchange": "RCCL all-gather" if rq.uses_rccl else "device-to-device copies",
-                                                                                     "last_ms": {k: round(v, 3) for k, v in rq.last_ms().items()}}
-                    rq.close()
-                line["queue_c_abi_one_process"] = dict(frames=nq, note="rumi_queue_extract: extraction only (no matching), pinned host frames in, pageable host records out", **ql)
-            except Exception as e:
-                line["queue_c_abi_one_process"] = {"error": str(e)}
-            del hostq
             # ---- one frame at a time through the drop-in host API (ORBextractor::operator(): host image in, host key-points out) ----
             ext1 = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, device=local_rank)
             for i in range(8):
@@ -565,6 +544,29 @@ def main():
             line["cpu_baseline"] = {"value": round(n / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": "%d of the same synthetic frames (extract + brute-force match), oracle/ (g++ -O2, scalar, 1 thread), %.1f s" % (n, cdt)}
             line.update(side_legs(args))
+        if world == 1 and not args.no_cpu and hostq is not None:
+            # (last of the N = 1 legs: RCCL's communicator leaves helper threads behind, and the one-frame host path measured after it ran at 2.8 k fps instead of 8 k)
+            # ---- the queue behind the C ABI, ONE process (include/rumi_queue.h): host frames in, every shard's device holds the gathered records, host
+            # records out.  One shard = this GPU (its exchange is RCCL's ncclAllGather on one rank); two LOGICAL shards on this GPU for the sharded code path.
+            try:
+                from rumi_slam_amd.queue import RuminationQueue
+                ql = {}
+                nq = min(B, 512)
+                hq = [hostq[f].numpy() for f in range(nq)]
+                for shards in (1, 2):
+                    rq = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [local_rank] * shards, max_block=(nq + shards - 1) // shards, cap=cap)
+                    rec = np.zeros((nq, rq.record_bytes), np.uint8)
+                    rq.extract(hq, (0, 1000), out=rec)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        rq.extract(hq, (0, 1000), out=rec)
+                    ql["%d_shard%s" % (shards, "s_logical" if shards > 1 else "")] = {"fps": round(3 * nq / (time.perf_counter() - t0), 1), "exchange": "RCCL all-gather" if rq.uses_rccl else "device-to-device copies",
+                                                                                     "last_ms": {k: round(v, 3) for k, v in rq.last_ms().items()}}
+                    rq.close()
+                line["queue_c_abi_one_process"] = dict(frames=nq, note="rumi_queue_extract: extraction only (no matching), pinned host frames in, pageable host records out", **ql)
+            except Exception as e:
+                line["queue_c_abi_one_process"] = {"error": str(e)}
+            del hostq
         emit(line)
     if world > 1:
         dist.destroy_process_group()
