@@ -2,8 +2,8 @@
  * rumi_queue.h — C ABI of the rumination queue on the GPUs of one node, driven from ONE process.
  *
  * What it replaces in the reference (R/ = /root/reference/src/rumi-slam/): the frames tracking could not use are collected and time-sorted by
- *   CloudImageSampler::GetImagesToProcess      R/lib_src/CloudImageSampler.cc:148-170   (host cv::Mats)
- * and handed on from System (R/lib_src/System.cc:1278); KFDSample runs ORBextractor::operator() on them one by one (R/lib_src/KFDSample.cc:113).
+ *   CloudImageSampler::TrackStep               R/lib_src/CloudImageSampler.cc:44, the sort at :148-170   (host cv::Mats in mvCurrentCloudProcessImages)
+ * and handed on by System::GetCloudProcessImages (R/lib_src/System.cc:1278); KFDSample runs ORBextractor::operator() on them one by one (R/lib_src/KFDSample.cc:113).
  * Here the queue of F frames is cut into contiguous blocks, one per device (block g = frames [g F / n, (g + 1) F / n): the result is already
  * time-ordered), every device extracts its block (rumi_orb_extract_batch_host_records: transfers overlapped with kernels), and ONE exchange step
  * follows: an all-gather of the fixed-capacity per-frame records over RCCL (ncclAllGather inside ncclGroupStart / ncclGroupEnd, one communicator

@@ -1,8 +1,8 @@
 // Drop-in helper for the rumination queue on the GPUs of one node (include/rumi_queue.h), in the reference's own types.
 //
-// Where it goes in the reference (R/ = /root/reference/src/rumi-slam/): CloudImageSampler::GetImagesToProcess (R/lib_src/CloudImageSampler.cc:148-170)
-// returns the time-sorted cv::Mats tracking could not use; KFDSample (R/lib_src/KFDSample.cc:113) runs `(*mpORBextractor)(im, cv::Mat(), keys, desc,
-// vLapping)` on them one at a time.  With this class the whole vector goes out in one call:
+// Where it goes in the reference (R/ = /root/reference/src/rumi-slam/): CloudImageSampler collects and time-sorts the images tracking could not use
+// (mvCurrentCloudProcessImages, R/lib_src/CloudImageSampler.cc:148-170); KFDSample (R/lib_src/KFDSample.cc:113,153) runs
+// `mpORBextractor->operator()(im, cv::Mat(), mvKeys, mDescriptors, vLapping)` on them one image per call.  With this class the whole vector goes out in one call:
 //
 //     static ORB_SLAM3::RuminationQueue queue(nFeatures, fScaleFactor, nLevels, fIniThFAST, fMinThFAST, {0, 1, 2, 3, 4, 5, 6, 7}, /*maxBlock*/ 128, 640, 480);
 //     std::vector<std::vector<cv::KeyPoint>> keys; std::vector<cv::Mat> descs;
