@@ -63,7 +63,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // one dword per row: the column tables are loaded once and the 2 x kResizeRows source-row loads are issued back to back.
 // No border pixels are written: the blur mirrors at the edges itself.
 // ------------------------------------------------------------------------------------------------
-constexpr int kResizeRows = 4;
+// (kResizeRows: 4 for the small levels, 8 for levels of 200 rows and more -- launch_resize)
+template <int kResizeRows>
 __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P, ImgSrc src,
                                                 const int16_t *__restrict__ coef, const RowTap *__restrict__ rowTab, int level, int32_t *__restrict__ clearWord) {
     if (clearWord && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *clearWord = 0;    // the call's error word (orb_host.hip)
@@ -1274,8 +1275,11 @@ __global__ __launch_bounds__(256, 7) void k_orient_desc(const DevParams *__restr
 // ---- launch wrappers (called from orb_host.hip) ----
 void launch_resize(const DevParams *dP, const DevParams &hP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, int level, int nframes,
                    hipStream_t st, int32_t *clearWord) {
-    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * kResizeRows - 1) / (4 * kResizeRows), nframes);
-    hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
+    static const int envRows = std::getenv("RUMI_RESIZE_ROWS") ? std::atoi(std::getenv("RUMI_RESIZE_ROWS")) : 0;
+    const int rows = envRows ? envRows : (hP.lv[level].h >= 200 ? 8 : 4);
+    dim3 g((hP.lv[level].w + 255) / 256, (hP.lv[level].h + 4 * rows - 1) / (4 * rows), nframes);
+    if (rows == 8) hipLaunchKernelGGL(k_resize<8>, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
+    else hipLaunchKernelGGL(k_resize<4>, g, dim3(256), 0, st, dP, src, coef, rowTab, level, clearWord);
 }
 void launch_pyramid_tiles(const DevParams *dP, ImgSrc src, const int16_t *coef, const RowTap *rowTab, const PyrTile *tiles, int ntiles, int bufBytes,
                           int tabEntries, int nframes, hipStream_t st, int32_t *clearWord, bool copyL0) {
