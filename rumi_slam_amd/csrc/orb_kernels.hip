@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
     // lane of every frame)
     const uint8_t *r0p[kResizeRows], *r1p[kResizeRows];
     uint32_t bh0[kResizeRows], bh1[kResizeRows];
-    bool live[kResizeRows];
+    bool live[kResizeRows], shared[kResizeRows];                  // shared: the row's first source row is the previous output row's second (scalar)
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) {
         const int oy = oyBase + r;
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         const RowTap t = rowTab[D.rowTab + (live[r] ? oy : 0)];
         r0p[r] = sb + (long long)t.r0 * sp; r1p[r] = sb + (long long)t.r1 * sp;
         bh0[r] = t.bh0; bh1[r] = t.bh1;
+        shared[r] = kResizeRows == 4 && r > 0 && r0p[r] == r1p[r - 1];       // (eight rows a lane: the branches cost 47 registers and the gain, measured)
     }
     const int sx0 = xofs[ox];
     // (the row's last dword may be partial: its surplus outputs come from the padded table entries and land in the row's padding)
@@ -102,10 +103,13 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
         const uint64_t ofs = reinterpret_cast<const U64 *>(xofs + ox)->v;
         const U64 *t8 = reinterpret_cast<const U64 *>(xa + 2 * ox);
         const uint64_t ta = t8[0].v, tb = t8[1].v;
+        // (at the usual scale factors five output rows in six start on the source row the row above ended on: that row is neither loaded
+        // nor filtered horizontally again -- the test is scalar, the branch is a real one)
         uint64_t s0[kResizeRows], s1[kResizeRows];
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
-            s0[r] = reinterpret_cast<const U64 *>(r0p[r] + wx0)->v;
+            s0[r] = 0;
+            if (!shared[r]) s0[r] = reinterpret_cast<const U64 *>(r0p[r] + wx0)->v;
             s1[r] = reinterpret_cast<const U64 *>(r1p[r] + wx0)->v;
         }
         // horizontal pass as a 2-element dot product: the two source bytes of an output are adjacent, v_perm_b32 spreads them into
@@ -121,17 +125,28 @@ __global__ __launch_bounds__(256) void k_resize(const DevParams *__restrict__ P,
             const uint64_t tt = i < 2 ? ta : tb;
             tap[i] = (uint32_t)(tt >> (32 * (i & 1)));
         }
+        uint32_t hPrev[4] = {0, 0, 0, 0};                              // horizontal results (>> 4) of the previous output row's second source row
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
             // vertical taps come pre-shifted: (b * x) >> 16 == mulhi(b << 16, x) for the non-negative operands here (b <= 2048, x <= 32 640)
+            uint32_t h0[4], h1[4];
+            if (shared[r]) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) h0[i] = hPrev[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(s0[r] >> 32), (uint32_t)s0[r], sel[i]);
+                    h0[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false) >> 4;
+                }
+            }
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(s0[r] >> 32), (uint32_t)s0[r], sel[i]);
                 const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(s1[r] >> 32), (uint32_t)s1[r], sel[i]);
-                const uint32_t q0 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p0), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                const uint32_t q1 = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false);
-                packed |= ((__umulhi(bh0[r], q0 >> 4) + __umulhi(bh1[r], q1 >> 4) + 2u) >> 2) << (8 * i);
+                h1[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p1), __builtin_bit_cast(v2u16, tap[i]), 0u, false) >> 4;
+                packed |= ((__umulhi(bh0[r], h0[i]) + __umulhi(bh1[r], h1[i]) + 2u) >> 2) << (8 * i);
+                hPrev[i] = h1[i];
             }
             if (live[r]) *reinterpret_cast<uint32_t *>(dbase + (long long)(oyBase + r) * D.pitch) = packed;
         }
