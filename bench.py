@@ -191,7 +191,8 @@ def one_process_queue(args):
     base = [synth_frame(1234 + i) for i in range(32)]
     frames = [base[i] if i < 32 else np.roll(base[i % 32], (7 * (i // 32), 11 * (i // 32)), (0, 1)) for i in range(F)]
     q = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [0] * N if logical else list(range(N)), max_block=(F + N - 1) // N, cap=args.nfeatures + 96)
-    rec = np.zeros((F, q.record_bytes), np.uint8)
+    import torch
+    rec = torch.zeros((F, q.record_bytes), dtype=torch.uint8).pin_memory().numpy()
     for _ in range(args.warmup):
         q.extract(frames, (0, 1000), out=rec)
     t0 = time.perf_counter()
@@ -560,15 +561,16 @@ def main():
                 hq = [hostq[f].numpy() for f in range(nq)]
                 for shards in (1, 2):
                     rq = RuminationQueue(args.nfeatures, 1.2, 8, 20, 7, [local_rank] * shards, max_block=(nq + shards - 1) // shards, cap=cap)
-                    rec = np.zeros((nq, rq.record_bytes), np.uint8)
-                    rq.extract(hq, (0, 1000), out=rec)
+                    rec = torch.zeros((nq, rq.record_bytes), dtype=torch.uint8).pin_memory().numpy()       # (pinned: the records arrive sub-chunk by sub-chunk under the kernels)
+                    for _ in range(4):                          # (a fresh pinned buffer is slow on its first use by each of the extractor's streams: 10 ms instead of 3.8)
+                        rq.extract(hq, (0, 1000), out=rec)
                     t0 = time.perf_counter()
                     for _ in range(3):
                         rq.extract(hq, (0, 1000), out=rec)
                     ql["%d_shard%s" % (shards, "s_logical" if shards > 1 else "")] = {"fps": round(3 * nq / (time.perf_counter() - t0), 1), "exchange": "RCCL all-gather" if rq.uses_rccl else "device-to-device copies",
                                                                                      "last_ms": {k: round(v, 3) for k, v in rq.last_ms().items()}}
                     rq.close()
-                line["queue_c_abi_one_process"] = dict(frames=nq, note="rumi_queue_extract: extraction only (no matching), pinned host frames in, pageable host records out", **ql)
+                line["queue_c_abi_one_process"] = dict(frames=nq, note="rumi_queue_extract: extraction only (no matching), pinned host frames in, host records out to pinned memory (every shard from its own device, under the kernels)", **ql)
             except Exception as e:
                 line["queue_c_abi_one_process"] = {"error": str(e)}
             del hostq

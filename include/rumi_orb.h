@@ -141,7 +141,8 @@ int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *imgs, int32_t 
                                 RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream);
 
 /* The same with ONE record per frame as output (the layout of rumi_orb_extract_batch_records_async): d_records [nframes][record_bytes] on the device,
- * h_records (may be NULL) the same bytes on the host.  What a shard of the rumination queue runs (rumi_queue.h). */
+ * h_records (may be NULL) the same bytes on the host: a pinned h_records receives every sub-chunk's records behind that sub-chunk's kernels, under the
+ * kernels of the next ones; a pageable one gets one copy at the end.  What a shard of the rumination queue runs (rumi_queue.h). */
 int rumi_orb_extract_batch_host_records(RumiOrb *h, const uint8_t *const *imgs, int32_t nframes, int32_t w, int32_t hgt, int32_t stride,
                                         int32_t lap0, int32_t lap1, void *d_records, int64_t record_bytes, int32_t cap, uint8_t *h_records,
                                         void *hip_stream);

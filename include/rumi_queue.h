@@ -44,12 +44,13 @@ int32_t rumi_queue_uses_rccl(const RumiQueue *q);
 
 /* The whole step: imgs[n_frames] host frames (8-bit grey, `stride` bytes per row, time order), lap0 / lap1 as ORBextractor::operator()'s
  * vLappingArea.  On return every shard's device holds the gathered records; d_gathered[g] (may be NULL as a whole) receives shard g's device pointer
- * (owned by the queue, valid until the next call); h_records (may be NULL): the n_frames records in queue order WITHOUT padding, copied from shard
- * 0's device.  Blocks until everything has arrived.  One host thread per shard feeds the transfers during the extraction; the exchange itself is
+ * (owned by the queue, valid until the next call); h_records (may be NULL): the n_frames records in queue order WITHOUT padding; every shard copies ITS block back
+ * from its own device during the extraction (N links instead of one; into PINNED memory sub-chunk by sub-chunk under the kernels, into pageable memory in one
+ * copy per shard).  Blocks until everything has arrived.  One host thread per shard feeds the transfers during the extraction; the exchange itself is
  * enqueued by the calling thread. */
 int rumi_queue_extract(RumiQueue *q, const uint8_t *const *imgs, int32_t n_frames, int32_t w, int32_t hgt, int32_t stride, int32_t lap0, int32_t lap1,
                        void **d_gathered, uint8_t *h_records);
-/* Times of the last call in ms: [0] extraction (slowest shard, wall), [1] exchange (wall, enqueue to completion), [2] copy to h_records, [3] total */
+/* Times of the last call in ms: [0] extraction (slowest shard, wall), [1] exchange (wall, enqueue to completion), [2] 0 (the copy to h_records is part of [0] since round 4), [3] total */
 int rumi_queue_last_ms(const RumiQueue *q, float ms[4]);
 
 #ifdef __cplusplus

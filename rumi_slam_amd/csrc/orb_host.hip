@@ -120,6 +120,9 @@ struct RumiOrb {
     int lastOutCap = 0;
     bool profiling = false;
     float stageMs[8] = {0};
+    // rumi_orb_extract_batch_host_records with a PINNED host destination: every sub-chunk's records follow its kernels to the host on the sub-chunk's
+    // own stream (rows [frame0, frame0 + n) of the record block), under the kernels of the sub-chunks behind it
+    uint8_t *mirrorHost = nullptr; const uint8_t *mirrorDev = nullptr; long long mirrorRow = 0;
     hipEvent_t ev[8] = {nullptr};
     // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
     hipStream_t sideStream = nullptr;
@@ -663,6 +666,8 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
                            (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
                            (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
+        if (h->mirrorHost)
+            HIP_TRY(hipMemcpyAsync(h->mirrorHost + (size_t)frame0 * h->mirrorRow, h->mirrorDev + (size_t)frame0 * h->mirrorRow, (size_t)n * h->mirrorRow, hipMemcpyDeviceToHost, s));
         return RUMI_OK;
     };
     if (resident) {
@@ -885,10 +890,18 @@ extern "C" int rumi_orb_extract_batch_host_records(RumiOrb *h, const uint8_t *co
     if (!d_records || cap < 1 || record_bytes < 8 + 60ll * cap || (record_bytes & 3)) { g_lastError = "rumi_orb_extract_batch_host_records: bad record size"; return RUMI_E_INVALID; }
     uint8_t *r = (uint8_t *)d_records;
     const OutLayout out{r + 8, record_bytes, r + 8 + (size_t)cap * sizeof(RumiKeyPoint), record_bytes, r, record_bytes};
-    return extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
-        if (h_records) HIP_TRY(hipMemcpyAsync(h_records, d_records, (size_t)nframes * record_bytes, hipMemcpyDeviceToHost, st));
+    // a pinned destination takes the records sub-chunk by sub-chunk behind the kernels (run_part); a pageable one (whose "asynchronous" copy would hold
+    // the enqueuing thread) gets them in one copy at the end
+    hipPointerAttribute_t attr{};
+    const bool pinnedOut = h && h_records && hipPointerGetAttributes(&attr, h_records) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (pinnedOut) { h->mirrorHost = h_records; h->mirrorDev = r; h->mirrorRow = record_bytes; }
+    const int rc = extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
+        if (h_records && !pinnedOut) HIP_TRY(hipMemcpyAsync(h_records, d_records, (size_t)nframes * record_bytes, hipMemcpyDeviceToHost, st));
         return RUMI_OK;
     });
+    if (h) { h->mirrorHost = nullptr; h->mirrorDev = nullptr; h->mirrorRow = 0; }
+    return rc;
 }
 
 // The handle's pinned staging buffer for a w x hgt frame, for a caller that lets its camera driver / decoder write the frame there (a cv::Mat

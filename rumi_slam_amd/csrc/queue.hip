@@ -170,7 +170,10 @@ extern "C" int rumi_queue_extract(RumiQueue *q, const uint8_t *const *imgs, int3
         // rows past the block are empty records (n = 0): only their 8-byte heads have to be cleared
         if (nb < q->per && hipMemset2DAsync(s.dOwn + (size_t)nb * q->rb, (size_t)q->rb, 0, 8, (size_t)(q->per - nb), s.stream) != hipSuccess) { s.rc = RUMI_E_NO_DEVICE; s.err = "memset failed"; return; }
         if (nb > 0) {
-            s.rc = rumi_orb_extract_batch_host_records(s.orb, imgs + b0, nb, w, hgt, stride, lap0, lap1, s.dOwn, q->rb, q->cap, nullptr, s.stream);
+            // the shard's records go back to the caller FROM THE SHARD'S OWN DEVICE (every device's link carries its share; a pinned destination
+            // receives them sub-chunk by sub-chunk under the kernels): nothing is copied back after the exchange
+            s.rc = rumi_orb_extract_batch_host_records(s.orb, imgs + b0, nb, w, hgt, stride, lap0, lap1, s.dOwn, q->rb, q->cap,
+                                                       h_records ? h_records + (size_t)b0 * q->rb : nullptr, s.stream);
             if (s.rc != RUMI_OK) s.err = rumi_last_error();
         }
         if (s.rc == RUMI_OK && hipStreamSynchronize(s.stream) != hipSuccess) { s.rc = RUMI_E_NO_DEVICE; s.err = "stream synchronisation failed"; }
@@ -212,16 +215,7 @@ extern "C" int rumi_queue_extract(RumiQueue *q, const uint8_t *const *imgs, int3
     }
     for (Shard &s : q->shards) { HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipStreamSynchronize(s.stream)); }
     const double t2 = now();
-    if (h_records) {
-        Shard &s = q->shards[0];
-        HIP_TRY(hipSetDevice(s.device));
-        for (int g = 0; g < n; g++) {
-            const int b0 = block_begin(n_frames, g, n), nb = block_begin(n_frames, g + 1, n) - b0;
-            if (nb > 0) HIP_TRY(hipMemcpyAsync(h_records + (size_t)b0 * q->rb, s.dAll + (size_t)g * blockBytes, (size_t)nb * q->rb, hipMemcpyDeviceToHost, s.stream));
-        }
-        HIP_TRY(hipStreamSynchronize(s.stream));
-    }
-    const double t3 = now();
+    const double t3 = now();                                // (the records reached h_records during the extraction: see work())
     if (d_gathered) for (int g = 0; g < n; g++) d_gathered[g] = q->shards[g].dAll;
     q->lastMs[0] = exMs; q->lastMs[1] = (float)(t2 - t1); q->lastMs[2] = (float)(t3 - t2); q->lastMs[3] = (float)(t3 - t0);
     return RUMI_OK;

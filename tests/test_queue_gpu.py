@@ -52,3 +52,35 @@ def test_queue_mirror_equals_the_single_extractor(shards):
         assert kp[i, :n].tobytes() == okp.tobytes() and np.array_equal(desc[i, :n], odesc)
     assert [q.row(F, f) for f in range(F)] == sorted(q.row(F, f) for f in range(F))
     print(q.last_ms())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [1, 2])
+def test_queue_records_reach_pinned_and_pageable_memory_alike(shards):
+    """The records go back from every shard's own device: into pinned memory sub-chunk by sub-chunk behind the kernels, into pageable memory in one copy per
+    shard.  Both must hold the same bytes as the gathered block on the device (a queue of several sub-chunks per shard, uneven last block)."""
+    import torch
+    from rumi_slam_amd.queue import RuminationQueue
+    F = 150
+    base = [synth_frame(1500 + i) for i in range(10)]
+    frames = [base[i % 10] if i < 10 else np.roll(base[i % 10], (3 * (i // 10), 5 * (i // 10)), (0, 1)) for i in range(F)]
+    q = RuminationQueue(1000, 1.2, 8, 20, 7, [0] * shards, max_block=(F + shards - 1) // shards)
+    pageable = np.zeros((F, q.record_bytes), np.uint8)
+    pinned = torch.zeros((F, q.record_bytes), dtype=torch.uint8).pin_memory().numpy()
+    _, dptr = q.extract(frames, out=pageable)
+    q.extract(frames, out=pinned)
+    assert np.array_equal(pageable, pinned)
+    counts = pageable[:, :8].copy().view(np.int32).reshape(F, 2)
+    assert counts[:, 0].min() > 500
+    # the gathered block of every shard (device memory): frame f at row q.row(F, f)
+    import ctypes as C
+    from rumi_slam_amd import capi
+    hip = C.CDLL("libamdhip64.so")
+    for g in range(shards):
+        blk = np.zeros((shards * q.block_capacity, q.record_bytes), np.uint8)
+        assert hip.hipMemcpy(C.c_void_p(blk.ctypes.data), C.c_void_p(dptr[g]), C.c_size_t(blk.nbytes), 2) == 0      # hipMemcpyDeviceToHost
+        for f in (0, 1, F // 2, F - 2, F - 1):
+            r = q.row(F, f)
+            n = int(counts[f, 0])
+            assert np.array_equal(blk[r, :8 + 28 * n], pinned[f, :8 + 28 * n])
+            assert np.array_equal(blk[r, 8 + 28 * q.cap:8 + 28 * q.cap + 32 * n], pinned[f, 8 + 28 * q.cap:8 + 28 * q.cap + 32 * n])
