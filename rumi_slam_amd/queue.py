@@ -59,13 +59,20 @@ class RuminationQueue:
     def extract(self, frames, lapping=(0, 1000), want_host=True, out=None):
         """frames: list of HxW u8 arrays (or one [F,H,W] array), time order.  Returns (records [F, record_bytes] u8 or None, device pointers of the
         gathered queue per shard)."""
-        fr = [np.ascontiguousarray(f, np.uint8) for f in frames]
-        F, (H, W) = len(fr), fr[0].shape
-        ptrs = (C.c_void_p * F)(*[f.ctypes.data for f in fr])
+        if isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8 and frames.strides[2] == 1:
+            F, H, W = frames.shape                                   # one array: the frame pointers by arithmetic (a list costs ~0.7 us per frame)
+            fr = [frames]
+            ptrs = frames.ctypes.data + np.arange(F, dtype=np.uint64) * np.uint64(frames.strides[0])
+            row_stride = frames.strides[1]
+        else:
+            fr = [f if (f.dtype == np.uint8 and f.flags.c_contiguous) else np.ascontiguousarray(f, np.uint8) for f in frames]
+            F, (H, W) = len(fr), fr[0].shape
+            ptrs = np.fromiter((f.__array_interface__["data"][0] for f in fr), np.uint64, F)
+            row_stride = fr[0].strides[0]
         dg = (C.c_void_p * self.n_shards)()
         rec = out if out is not None else (np.zeros((F, self.record_bytes), np.uint8) if want_host else None)
         assert rec is None or (rec.shape == (F, self.record_bytes) and rec.dtype == np.uint8 and rec.flags.c_contiguous)
-        capi.check(self._lib.rumi_queue_extract(self._h, C.cast(ptrs, C.c_void_p), F, W, H, fr[0].strides[0], int(lapping[0]), int(lapping[1]),
+        capi.check(self._lib.rumi_queue_extract(self._h, capi.ptr(ptrs), F, W, H, row_stride, int(lapping[0]), int(lapping[1]),
                                                 C.cast(dg, C.c_void_p), capi.ptr(rec) if rec is not None else None))
         return rec, [int(p or 0) for p in dg]
 

@@ -348,6 +348,20 @@ def test_local_ba_batch_equals_single_calls(opt):
             assert np.array_equal(s[1], g[1]) and np.array_equal(s[2], g[2]), f"window {i}, {workers} workers: values differ from the single call"
 
 
+def test_local_ba_batch_of_more_windows_than_one_launch_takes(opt):
+    """35 windows in one call: more than the 32 a launch group's table holds (the entry cuts the batch), the first cut runs as three launch groups;
+    every window bit for bit the single call, in the caller's order."""
+    cfgs = [dict(seed=500 + i, n_opt=3 + (i % 5), n_fixed=2, n_points=150 + 20 * (i % 4), outlier_frac=0.04 * (i % 2)) for i in range(35)]
+    probs = [ba_problem(**c) for c in cfgs]
+    wins = [(b["kf_pose"], b["kf_fixed"], b["mp_pos"], b["e_mp"], b["e_kf"], b["e_obs"], b["e_w"], b["K"]) for b in probs]
+    single = [opt.LocalBundleAdjustment(*w) for w in wins]
+    got = opt.LocalBundleAdjustmentBatch(wins, 1)
+    assert len(got) == len(wins)
+    for i, (s_, g) in enumerate(zip(single, got)):
+        assert np.array_equal(s_[0], g[0]) and np.array_equal(s_[3], g[3]), f"window {i}: stats / erase flags"
+        assert np.array_equal(s_[1], g[1]) and np.array_equal(s_[2], g[2]), f"window {i}: values differ from the single call"
+
+
 def test_local_ba_batch_windows_of_very_different_size(opt):
     """Windows of 6 to 29 optimised key-frames in ONE rumi_local_ba_batch call over several workers: the solve kernels of the larger windows need
     74-135 KB of dynamic LDS, which is an opt-in kept per FUNCTION, i.e. shared by all worker threads.  A worker with a small window must not
