@@ -477,7 +477,7 @@ def main():
                     a_.copy_(b_, non_blocking=True)
                 torch.cuda.synchronize()
                 return okp, odesc, ocnt, m
-            dtd, _ = timed(step_h2d_d2h, max(3, args.steps // 2), 1)
+            dtd, _ = timed(step_h2d_d2h, max(3, args.steps // 2), 5)      # (fresh pinned buffers are slow on their first use by each stream that copies into them)
             line["value_h2d_d2h_inclusive"] = round(B * max(3, args.steps // 2) / dtd, 1)
             line["h2d_d2h_note"] = "host frames in (pinned), key-points + descriptors + counts + match indices out to pinned host buffers (%.1f MB per step back); every step ends synchronised" % ((hk.numel() * 4 + hd.numel() + hc.numel() * 4 + 3 * hm[0].numel() * 4) / 1e6)
             del hk, hd, hm, okp, odesc, mo

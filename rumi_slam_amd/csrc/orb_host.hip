@@ -120,9 +120,9 @@ struct RumiOrb {
     int lastOutCap = 0;
     bool profiling = false;
     float stageMs[8] = {0};
-    // rumi_orb_extract_batch_host_records with a PINNED host destination: every sub-chunk's records follow its kernels to the host on the sub-chunk's
-    // own stream (rows [frame0, frame0 + n) of the record block), under the kernels of the sub-chunks behind it
-    uint8_t *mirrorHost = nullptr; const uint8_t *mirrorDev = nullptr; long long mirrorRow = 0;
+    // host entries with PINNED host destinations: every sub-chunk's output rows [frame0, frame0 + n) follow its kernels to the host on the sub-chunk's own
+    // stream, under the kernels of the sub-chunks behind it (one entry for the record layout, three for key-points / descriptors / counts)
+    struct Mirror { uint8_t *host; const uint8_t *dev; long long row; } mirror[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
     hipEvent_t ev[8] = {nullptr};
     // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree and joins before rBRIEF
     hipStream_t sideStream = nullptr;
@@ -666,8 +666,8 @@ static int extract_async_impl(RumiOrb *h, const void *d_imgs, int32_t nframes, i
                            (RumiKeyPoint *)((uint8_t *)d_kp + (size_t)frame0 * out.kpStride), out.kpStride,
                            (uint8_t *)d_desc + (size_t)frame0 * out.descStride, out.descStride, cap, n, s);
         if (timed) HIP_TRY(hipEventRecord(h->ev[7], s));
-        if (h->mirrorHost)
-            HIP_TRY(hipMemcpyAsync(h->mirrorHost + (size_t)frame0 * h->mirrorRow, h->mirrorDev + (size_t)frame0 * h->mirrorRow, (size_t)n * h->mirrorRow, hipMemcpyDeviceToHost, s));
+        for (const auto &mr : h->mirror)
+            if (mr.host) HIP_TRY(hipMemcpyAsync(mr.host + (size_t)frame0 * mr.row, mr.dev + (size_t)frame0 * mr.row, (size_t)n * mr.row, hipMemcpyDeviceToHost, s));
         return RUMI_OK;
     };
     if (resident) {
@@ -874,12 +874,29 @@ extern "C" int rumi_orb_extract_batch_host(RumiOrb *h, const uint8_t *const *img
                                            int32_t lap0, int32_t lap1, void *d_kp, void *d_desc, void *d_counts, int32_t cap,
                                            RumiKeyPoint *h_kp, uint8_t *h_desc, int32_t *h_counts, void *hip_stream) {
     const OutLayout out{d_kp, (long long)cap * (long long)sizeof(RumiKeyPoint), d_desc, (long long)cap * 32, d_counts, 8};
-    return extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
-        if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (h_kp) HIP_TRY(hipMemcpyAsync(h_kp, d_kp, (size_t)nframes * cap * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, st));
-        if (h_desc) HIP_TRY(hipMemcpyAsync(h_desc, d_desc, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, st));
+    // host arrays: one copy each at the end; optionally (pinned arrays) every sub-chunk's rows behind that sub-chunk's kernels (run_part)
+    // (MEASURED SLOWER for these three arrays, 4.4 MB per 64-frame sub-chunk: host frames in, everything out, 1024 frames a step: 101 k fps against 105-122 k
+    // with one copy each at the end -- the copies hold the sub-chunk streams while the uploads are the bottleneck.  Only with RUMI_ORB_MIRROR=2.  The record
+    // layout below gains 4 % from the same mechanism and has it by default.)
+    static const bool mirrorOn = std::getenv("RUMI_ORB_MIRROR") && std::atoi(std::getenv("RUMI_ORB_MIRROR")) == 2;
+    auto pinned = [](const void *p) {
+        hipPointerAttribute_t attr{};
+        const bool yes = mirrorOn && p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        return yes;
+    };
+    const bool pk = h && d_kp && pinned(h_kp), pd = h && d_desc && pinned(h_desc), pc = h && d_counts && pinned(h_counts);
+    if (pk) h->mirror[0] = {(uint8_t *)h_kp, (const uint8_t *)d_kp, out.kpStride};
+    if (pd) h->mirror[1] = {h_desc, (const uint8_t *)d_desc, out.descStride};
+    if (pc) h->mirror[2] = {(uint8_t *)h_counts, (const uint8_t *)d_counts, out.countsStride};
+    const int rc = extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
+        if (h_counts && !pc) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (h_kp && !pk) HIP_TRY(hipMemcpyAsync(h_kp, d_kp, (size_t)nframes * cap * sizeof(RumiKeyPoint), hipMemcpyDeviceToHost, st));
+        if (h_desc && !pd) HIP_TRY(hipMemcpyAsync(h_desc, d_desc, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, st));
         return RUMI_OK;
     });
+    if (h) for (auto &mr : h->mirror) mr = {nullptr, nullptr, 0};
+    return rc;
 }
 
 // The host-resident queue with ONE record per frame as output (the all-gather payload, rumi_orb_extract_batch_records_async's layout); h_records:
@@ -893,14 +910,15 @@ extern "C" int rumi_orb_extract_batch_host_records(RumiOrb *h, const uint8_t *co
     // a pinned destination takes the records sub-chunk by sub-chunk behind the kernels (run_part); a pageable one (whose "asynchronous" copy would hold
     // the enqueuing thread) gets them in one copy at the end
     hipPointerAttribute_t attr{};
-    const bool pinnedOut = h && h_records && hipPointerGetAttributes(&attr, h_records) == hipSuccess && attr.type == hipMemoryTypeHost;
+    static const bool mirrorOn = !(std::getenv("RUMI_ORB_MIRROR") && std::atoi(std::getenv("RUMI_ORB_MIRROR")) == 0);
+    const bool pinnedOut = mirrorOn && h && h_records && hipPointerGetAttributes(&attr, h_records) == hipSuccess && attr.type == hipMemoryTypeHost;
     (void)hipGetLastError();
-    if (pinnedOut) { h->mirrorHost = h_records; h->mirrorDev = r; h->mirrorRow = record_bytes; }
+    if (pinnedOut) h->mirror[0] = {h_records, r, record_bytes};
     const int rc = extract_batch_host_impl(h, imgs, nframes, w, hgt, stride, lap0, lap1, out, cap, hip_stream, [&](hipStream_t st) -> int {
         if (h_records && !pinnedOut) HIP_TRY(hipMemcpyAsync(h_records, d_records, (size_t)nframes * record_bytes, hipMemcpyDeviceToHost, st));
         return RUMI_OK;
     });
-    if (h) { h->mirrorHost = nullptr; h->mirrorDev = nullptr; h->mirrorRow = 0; }
+    if (h) h->mirror[0] = {nullptr, nullptr, 0};
     return rc;
 }
 

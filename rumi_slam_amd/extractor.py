@@ -130,7 +130,7 @@ class ORBextractor:
     def extract_batch_host(self, frames, vLappingArea=(0, 1000), cap=None, stream=None, to_host=False):
         """The rumination queue as the reference holds it: `frames` is a list of HOST images (numpy u8 [H,W], dense rows, one shape) or one
         host array / CPU tensor [B,H,W] (pinned memory is copied in place).  Transfers overlap the extraction (rumi_orb_extract_batch_host).
-        Returns the device tensors of ``extract_batch``; with to_host=True also numpy copies (kp, desc, counts) as a second tuple."""
+        Returns the device tensors of ``extract_batch``; with to_host=True (pageable arrays) or "pinned" also numpy copies (kp, desc, counts) as a second tuple."""
         import torch
         if hasattr(frames, "numpy") and not isinstance(frames, np.ndarray):      # CPU torch tensor (possibly pinned)
             assert not frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
@@ -150,7 +150,10 @@ class ORBextractor:
         desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
         counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
         hk = hd = hc = None
-        if to_host:
+        if to_host == "pinned":             # pinned host arrays (with RUMI_ORB_MIRROR=2 every sub-chunk's rows come back behind its kernels; measured slower)
+            hk = torch.zeros((B, cap, 28), dtype=torch.uint8).pin_memory().numpy().view(KP_DTYPE).reshape(B, cap)
+            hd, hc = torch.zeros((B, cap, 32), dtype=torch.uint8).pin_memory().numpy(), torch.zeros((B, 2), dtype=torch.int32).pin_memory().numpy()
+        elif to_host:
             hk, hd, hc = np.zeros((B, cap), KP_DTYPE), np.zeros((B, cap, 32), np.uint8), np.zeros((B, 2), np.int32)
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         capi.check(self._lib.rumi_orb_extract_batch_host(

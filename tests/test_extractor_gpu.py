@@ -255,7 +255,8 @@ def test_host_batch_bit_exact_300_frames(pinned):
     g, o = _pair(batch=B)
     frames = synth_batch(B, seed0=3000)
     src = torch.from_numpy(frames).pin_memory() if pinned else [frames[f] for f in range(B)]
-    (kp, desc, counts), (hk, hd, hc) = g.extract_batch_host(src, to_host=True)
+    # (pinned and pageable host outputs)
+    (kp, desc, counts), (hk, hd, hc) = g.extract_batch_host(src, to_host="pinned" if pinned else True)
     torch.cuda.synchronize()
     kp = kp.cpu().numpy(); desc = desc.cpu().numpy(); counts = counts.cpu().numpy()
     assert np.array_equal(counts, hc)
