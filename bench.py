@@ -480,6 +480,34 @@ def main():
             dtd, _ = timed(step_h2d_d2h, max(3, args.steps // 2), 5)      # (fresh pinned buffers are slow on their first use by each stream that copies into them)
             line["value_h2d_d2h_inclusive"] = round(B * max(3, args.steps // 2) / dtd, 1)
             line["h2d_d2h_note"] = "host frames in (pinned), key-points + descriptors + counts + match indices out to pinned host buffers (%.1f MB per step back); every step ends synchronised" % ((hk.numel() * 4 + hd.numel() + hc.numel() * 4 + 3 * hm[0].numel() * 4) / 1e6)
+            # ---- the same with the way back of step i under the uploads of step i + 1: two sets of device and pinned host buffers, the copies of a step on a
+            # stream of their own behind an event; a host consumer gets step i's results one step later
+            cb = torch.cuda.Stream(dev)
+            sets = [dict(okp=okp, odesc=odesc, ocnt=ocnt, mo=mo, hk=hk, hd=hd, hc=hc, hm=hm, done=torch.cuda.Event())]
+            sets.append(dict(okp=torch.empty_like(okp), odesc=torch.empty_like(odesc), ocnt=torch.zeros_like(ocnt), mo=[torch.empty_like(x) for x in mo],
+                             hk=torch.empty_like(hk).pin_memory(), hd=torch.empty_like(hd).pin_memory(), hc=torch.zeros_like(hc).pin_memory(),
+                             hm=[torch.empty_like(x).pin_memory() for x in hm], done=torch.cuda.Event()))
+            turn = [0]
+
+            def step_pipelined():
+                S = sets[turn[0] & 1]; turn[0] += 1
+                S["done"].synchronize()                      # the set's previous results have left (the consumer is done with the pinned buffers by then)
+                st_ = torch.cuda.current_stream(dev)
+                capi_.check(ext._lib.rumi_orb_extract_batch_host(ext._h, ptrs, B, W, H, hostq.stride(1), 0, 1000, S["okp"].data_ptr(), S["odesc"].data_ptr(), S["ocnt"].data_ptr(), cap,
+                                                                 None, None, None, st_.cuda_stream))
+                m = match_pairs(S["odesc"], S["ocnt"], S["mo"])
+                ready = torch.cuda.Event(); ready.record(st_)
+                with torch.cuda.stream(cb):
+                    cb.wait_event(ready)
+                    S["hk"].copy_(S["okp"], non_blocking=True); S["hd"].copy_(S["odesc"], non_blocking=True); S["hc"].copy_(S["ocnt"], non_blocking=True)
+                    for a_, b_ in zip(S["hm"], m):
+                        a_.copy_(b_, non_blocking=True)
+                    S["done"].record(cb)
+                return S["okp"], S["odesc"], S["ocnt"], m
+            dtp, _ = timed(step_pipelined, max(4, args.steps // 2), 6)
+            line["value_h2d_d2h_inclusive_pipelined"] = round(B * max(4, args.steps // 2) / dtp, 1)
+            line["h2d_d2h_pipelined_note"] = "the same bytes both ways, the copies back of step i on their own stream under the uploads of step i + 1 (two buffer sets; results one step late)"
+            del sets
             del hk, hd, hm, okp, odesc, mo
             # ---- one frame at a time through the drop-in host API (ORBextractor::operator(): host image in, host key-points out) ----
             ext1 = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, device=local_rank)
