@@ -28,7 +28,7 @@ for src, dst in (("prof_track/*/*kernel_stats.csv", TAG + "_track_frame_kernel_s
         print("missing", src)
 for src, dst in (("track_probe.log", TAG + "_track_frame_probe.txt"), ("lba_probe.log", TAG + "_lba_probe.txt"), ("bow_batch.log", TAG + "_bow_batch_probe.txt"),
                  ("pose_probe.log", TAG + "_pose_probe.txt"), ("rsq_probe.log", TAG + "_rsq_rcp_accuracy.txt"), ("bench_matrix.json", TAG + "_bench_matrix.json"),
-                 ("single_frame.log", TAG + "_single_frame_probe.txt"), ("bench_one_process.json", TAG + "_bench_line_one_process_queue.json"),
+                 ("single_frame.log", TAG + "_single_frame_probe.txt"), ("queue_probe.log", TAG + "_queue_probe.txt"), ("bench_one_process.json", TAG + "_bench_line_one_process_queue.json"),
                  ("test_queue_cc.log", TAG + "_queue_c_test.txt")):
     if os.path.exists(os.path.join(G, src)):
         txt = open(os.path.join(G, src)).read()

@@ -11,6 +11,7 @@ python tools/track_probe.py > $O/track_probe.log 2>&1
 python tools/single_frame_probe.py > $O/single_frame.log 2>&1
 RUMI_BENCH_LOGICAL_SHARDS=1 python bench.py --one-process --gpus 2 --steps 10 --warmup 3 --no-cpu > $O/bench_one_process.json 2> $O/bench_one_process.err
 python tools/lba_probe.py 20 12 28 > $O/lba_probe.log 2>&1
+python tools/queue_probe.py 512 2>&1 | grep shard > $O/queue_probe.log
 python tools/bow_batch_probe.py > $O/bow_batch.log 2>&1
 python tools/pose_probe.py > $O/pose_probe.log 2>&1
 tools/bin/rsq_probe > $O/rsq_probe.log 2>&1
